@@ -1,0 +1,792 @@
+/*
+ * compairr_hip.hip -- host side of libcompairr_hip.so: the C ABI declared in
+ * include/compairr_hip.h over the gfx950 kernels in kernels.h.
+ *
+ * No CPU fallback lives here: every entry point either runs on the HIP device
+ * or fails with an error code.
+ */
+#include "../../include/compairr_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace cmpr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+/* deterministic table contents; the result does not depend on them
+   (check_variant makes matches hash-independent, variants.cc:166-240) */
+struct SplitMix64 {
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next()
+  {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  }
+};
+
+template <typename T>
+struct DevBuf {
+  T     *p = nullptr;
+  size_t n = 0;
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct cmpr_context {
+  cmpr_options opt{};
+  int          device = 0;
+  int          cus = 256;
+  hipStream_t  stream = nullptr;
+  hipEvent_t   ev_start = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_stop = nullptr;
+  bool         events_valid = false;
+  std::string  err;
+
+  /* tunables */
+  int64_t blocks_per_cu = 8;
+  int64_t variant = 0;
+  int64_t bloom_log2_delta = 0;
+
+  /* Zobrist + patterns */
+  uint32_t          zpos = 0;
+  DevBuf<uint64_t>  zob, patterns;
+
+  /* set 2 + index */
+  bool              have_ref = false;
+  uint64_t          n2 = 0;
+  uint32_t          R2 = 0, longest2 = 0;
+  DevBuf<uint8_t>   res2;
+  DevBuf<uint64_t>  off2, cnt2, keys, bloom;
+  DevBuf<uint32_t>  v2, j2, rep2, vals;
+  uint64_t          slots = 0, bloom_words = 0;
+
+  /* set 1 tiles */
+  bool              have_q = false;
+  uint64_t          n1 = 0;
+  uint32_t          R1 = 0, ntiles = 0;
+  DevBuf<TileDesc>  tiles;
+  DevBuf<uint32_t>  qres, qv, qj, qrep;
+  DevBuf<uint64_t>  qcnt;
+  uint64_t          algorithmic_bytes = 0;
+  double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
+  std::vector<double> tot1, tot2;
+
+  /* per-launch scratch */
+  DevBuf<unsigned long long> matrix, stats;
+  DevBuf<double>             matrix_f64;
+  DevBuf<uint32_t>           tile_counter;
+  uint32_t                   launches = 0;
+};
+
+namespace {
+
+int fail(cmpr_context *c, int code, const std::string &msg)
+{
+  if (c)
+    c->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                        \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess)                                                       \
+      return fail((c), e_ == hipErrorOutOfMemory ? CMPR_ENOMEM : CMPR_EDEVICE,  \
+                  std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+template <typename T>
+int dev_alloc(cmpr_context *c, DevBuf<T> &b, size_t n)
+{
+  b.release();
+  if (n == 0)
+    n = 1;
+  HIP_TRY(c, hipMalloc((void **)&b.p, n * sizeof(T)));
+  b.n = n;
+  return CMPR_OK;
+}
+
+template <typename T>
+int dev_upload(cmpr_context *c, DevBuf<T> &b, const T *src, size_t n)
+{
+  int rc = dev_alloc(c, b, n);
+  if (rc)
+    return rc;
+  if (n)
+    HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return CMPR_OK;
+}
+
+int validate_options(const cmpr_options *o, std::string &why)
+{
+  if (!o) { why = "options is NULL"; return CMPR_EINVAL; }
+  if (o->alphabet_size != 20 && o->alphabet_size != 4) {
+    why = "alphabet_size must be 20 or 4"; return CMPR_EINVAL;
+  }
+  if (o->differences < 0) {
+    why = "Differences specified with -d or -differences cannot be negative.";
+    return CMPR_EINVAL;
+  }
+  if (o->indels && o->differences != 1) {
+    why = "Indels are only allowed when d=1"; return CMPR_EINVAL;
+  }
+  if (o->differences > 2) {
+    why = "d > 2 (the reference's all-against-all path, overlap.cc:286-359) is "
+          "not part of the GPU hot path";
+    return CMPR_EUNSUPPORTED;
+  }
+  if (o->score < CMPR_SCORE_PRODUCT || o->score > CMPR_SCORE_JACCARD) {
+    why = "unknown score"; return CMPR_EINVAL;
+  }
+  if (o->differences > 0 &&
+      (o->score == CMPR_SCORE_MH || o->score == CMPR_SCORE_JACCARD)) {
+    why = "The Morisita-Horn / Jaccard index is not defined when d>0";
+    return CMPR_EINVAL;
+  }
+  for (int k = 0; k < 7; k++)
+    if (o->reserved[k]) { why = "reserved option fields must be zero"; return CMPR_EINVAL; }
+  return CMPR_OK;
+}
+
+int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
+{
+  if (!s) { why = "set view is NULL"; return CMPR_EINVAL; }
+  if (s->n_repertoires == 0 && s->n > 0) { why = "n_repertoires is 0"; return CMPR_EINVAL; }
+  if (s->n >= 0xffffffc0ull) { why = "more than 2^32-64 sequences in one set"; return CMPR_EUNSUPPORTED; }
+  if (s->n == 0)
+    return CMPR_OK;
+  if (!s->offsets || !s->repertoire) { why = "offsets/repertoire is NULL"; return CMPR_EINVAL; }
+  if (!s->residues && s->offsets[s->n] > 0) { why = "residues is NULL"; return CMPR_EINVAL; }
+  if (!o.ignore_genes && (!s->v_gene || !s->j_gene)) { why = "v_gene/j_gene is NULL without ignore_genes"; return CMPR_EINVAL; }
+  if (!o.ignore_counts && !s->count) { why = "count is NULL without ignore_counts"; return CMPR_EINVAL; }
+  if (s->offsets[0] != 0) { why = "offsets[0] must be 0"; return CMPR_EINVAL; }
+  return CMPR_OK;
+}
+
+/* residue codes, gene and repertoire numbers in range; lengths >= 1 */
+int scan_view(const cmpr_options &o, const cmpr_set_view *s, uint32_t &longest,
+              std::vector<double> &rep_total, std::string &why)
+{
+  longest = 0;
+  rep_total.assign(s->n_repertoires, 0.0);
+  for (uint64_t i = 0; i < s->n; i++) {
+    if (s->offsets[i + 1] < s->offsets[i]) { why = "offsets not monotone"; return CMPR_EINVAL; }
+    uint64_t L = s->offsets[i + 1] - s->offsets[i];
+    if (L > 0xffffu) { why = "sequence longer than 65535 residues"; return CMPR_EUNSUPPORTED; }
+    longest = std::max<uint32_t>(longest, (uint32_t)L);
+    if (s->repertoire[i] >= s->n_repertoires) { why = "repertoire number out of range"; return CMPR_EINVAL; }
+    if (!o.ignore_genes &&
+        (s->v_gene[i] >= o.n_v_genes || s->j_gene[i] >= o.n_j_genes)) {
+      why = "gene number out of range"; return CMPR_EINVAL;
+    }
+    if (!o.ignore_counts && s->count[i] < 1) { why = "duplicate_count must be >= 1"; return CMPR_EINVAL; }
+    rep_total[s->repertoire[i]] += o.ignore_counts ? 1.0 : (double)s->count[i];
+  }
+  const uint64_t total = s->n ? s->offsets[s->n] : 0;
+  const uint8_t A = (uint8_t)o.alphabet_size;
+  for (uint64_t k = 0; k < total; k++)
+    if (s->residues[k] >= A) { why = "residue code out of range"; return CMPR_EINVAL; }
+  return CMPR_OK;
+}
+
+/* number of variants the reference enumerates for one query
+   (generate_variants, variants.cc:260-428) */
+uint64_t variants_of(const cmpr_options &o, const uint8_t *s, uint32_t L)
+{
+  const uint64_t A = (uint64_t)o.alphabet_size;
+  uint64_t n = 1;
+  if (o.differences >= 1) {
+    n += (A - 1) * L;
+    if (o.indels) {
+      if (L > 1) {
+        uint64_t runs = 1;
+        for (uint32_t p = 1; p < L; p++)
+          runs += s[p] != s[p - 1];
+        n += runs;
+      }
+      n += A + (A - 1) * (uint64_t)L;
+    }
+  }
+  if (o.differences >= 2)
+    n += (A - 1) * (A - 1) * (uint64_t)L * (L ? L - 1 : 0) / 2;
+  return n;
+}
+
+using ProbeFn = void (*)(const ProbeParams);
+
+ProbeFn select_kernel(const cmpr_options &o)
+{
+#define PICK(A_, D_, I_)                                                        \
+  (o.ignore_genes ? (ProbeFn)probe_kernel<A_, D_, I_, false>                    \
+                  : (ProbeFn)probe_kernel<A_, D_, I_, true>)
+  if (o.alphabet_size == 20) {
+    if (o.differences == 0) return PICK(20, 0, false);
+    if (o.differences == 1) return o.indels ? PICK(20, 1, true) : PICK(20, 1, false);
+    return PICK(20, 2, false);
+  }
+  if (o.differences == 0) return PICK(4, 0, false);
+  if (o.differences == 1) return o.indels ? PICK(4, 1, true) : PICK(4, 1, false);
+  return PICK(4, 2, false);
+#undef PICK
+}
+
+bool is_f64_score(const cmpr_options &o)
+{
+  return o.score == CMPR_SCORE_RATIO && !o.ignore_counts;
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------ */
+
+extern "C" int cmpr_abi_version(void)
+{
+  return CMPR_ABI_VERSION;
+}
+
+extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
+{
+  if (!out)
+    return fail(nullptr, CMPR_EINVAL, "out is NULL");
+  *out = nullptr;
+  std::string why;
+  int rc = validate_options(options, why);
+  if (rc)
+    return fail(nullptr, rc, why);
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, CMPR_EDEVICE,
+                std::string("no HIP device available: ") + hipGetErrorString(e));
+
+  cmpr_context *c = new (std::nothrow) cmpr_context();
+  if (!c)
+    return fail(nullptr, CMPR_ENOMEM, "out of host memory");
+  c->opt = *options;
+  if (options->device >= 0) {
+    if (options->device >= ndev) {
+      delete c;
+      return fail(nullptr, CMPR_EINVAL, "device ordinal out of range");
+    }
+    c->device = options->device;
+  } else {
+    (void)hipGetDevice(&c->device);
+  }
+#define CREATE_TRY(call)                                                        \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      std::string m = std::string(#call) + ": " + hipGetErrorString(e_);        \
+      cmpr_destroy(c);                                                          \
+      return fail(nullptr, CMPR_EDEVICE, m);                                    \
+    }                                                                           \
+  } while (0)
+  CREATE_TRY(hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  CREATE_TRY(hipGetDeviceProperties(&prop, c->device));
+  c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreate(&c->ev_start));
+  CREATE_TRY(hipEventCreate(&c->ev_k0));
+  CREATE_TRY(hipEventCreate(&c->ev_k1));
+  CREATE_TRY(hipEventCreate(&c->ev_stop));
+#undef CREATE_TRY
+  *out = c;
+  return CMPR_OK;
+}
+
+extern "C" void cmpr_destroy(cmpr_context *c)
+{
+  if (!c)
+    return;
+  (void)hipSetDevice(c->device);
+  if (c->stream)
+    (void)hipStreamSynchronize(c->stream);
+  c->zob.release(); c->patterns.release();
+  c->res2.release(); c->off2.release(); c->cnt2.release(); c->keys.release();
+  c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
+  c->vals.release();
+  c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
+  c->qrep.release(); c->qcnt.release();
+  c->matrix.release(); c->stats.release(); c->matrix_f64.release();
+  c->tile_counter.release();
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+  if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *cmpr_last_error(const cmpr_context *c)
+{
+  return c ? c->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" uint32_t cmpr_rows(const cmpr_context *c) { return c ? c->R1 : 0; }
+extern "C" uint32_t cmpr_cols(const cmpr_context *c) { return c ? c->R2 : 0; }
+
+extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value)
+{
+  if (!c || !name)
+    return CMPR_EINVAL;
+  std::string n(name);
+  if (n == "blocks_per_cu") {
+    if (value < 1 || value > 16)
+      return fail(c, CMPR_EINVAL, "blocks_per_cu must be 1..16");
+    c->blocks_per_cu = value;
+  } else if (n == "variant") {
+    c->variant = value;
+  } else if (n == "bloom_bits_log2_delta") {
+    if (value < -4 || value > 4)
+      return fail(c, CMPR_EINVAL, "bloom_bits_log2_delta must be -4..4");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set bloom_bits_log2_delta before cmpr_set_reference");
+    c->bloom_log2_delta = value;
+  } else {
+    return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
+  }
+  return CMPR_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* set 2: upload + index build on the device                            */
+/* ------------------------------------------------------------------ */
+
+extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
+                                  uint32_t longest_query)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  std::string why;
+  int rc = validate_view(c->opt, s, why);
+  if (rc)
+    return fail(c, rc, why);
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->have_ref = false;
+  c->have_q = false;
+
+  uint32_t longest = 0;
+  rc = scan_view(c->opt, s, longest, c->tot2, why);
+  if (rc)
+    return fail(c, rc, why);
+  c->longest2 = longest;
+  c->n2 = s->n;
+  c->R2 = s->n_repertoires;
+
+  /* Zobrist table for max(longest1, longest2) + 3 positions (overlap.cc:840) */
+  const uint32_t A = (uint32_t)c->opt.alphabet_size;
+  c->zpos = std::max(longest, longest_query) + EXTRA_POSITIONS;
+  const uint32_t n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+  const uint32_t n_j = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
+  {
+    std::vector<uint64_t> z((size_t)A * c->zpos + n_v + n_j);
+    SplitMix64 rng(0x636f6d7061697272ull);   /* "compairr" */
+    for (auto &x : z)
+      x = rng.next();
+    rc = dev_upload(c, c->zob, z.data(), z.size());
+    if (rc)
+      return rc;
+    /* 1024 patterns of 8 distinct bits (bloom_patterns_generate, bloompat.cc:36-52) */
+    std::vector<uint64_t> pat(PATTERN_COUNT);
+    for (auto &p : pat) {
+      p = 0;
+      for (uint32_t k = 0; k < PATTERN_K; k++) {
+        uint64_t bit;
+        do
+          bit = 1ull << (rng.next() & 63);
+        while (p & bit);
+        p |= bit;
+      }
+    }
+    rc = dev_upload(c, c->patterns, pat.data(), pat.size());
+    if (rc)
+      return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
+  }
+
+  /* records */
+  const uint64_t total = s->n ? s->offsets[s->n] : 0;
+  static const uint64_t zero_off[1] = {0};
+  if ((rc = dev_upload(c, c->res2, s->residues, (size_t)total))) return rc;
+  if ((rc = dev_upload(c, c->off2, s->n ? s->offsets : zero_off, (size_t)s->n + 1))) return rc;
+  if ((rc = dev_upload(c, c->rep2, s->repertoire, (size_t)s->n))) return rc;
+  if (!c->opt.ignore_genes) {
+    if ((rc = dev_upload(c, c->v2, s->v_gene, (size_t)s->n))) return rc;
+    if ((rc = dev_upload(c, c->j2, s->j_gene, (size_t)s->n))) return rc;
+  } else {
+    c->v2.release();
+    c->j2.release();
+  }
+  if (!c->opt.ignore_counts) {
+    if ((rc = dev_upload(c, c->cnt2, s->count, (size_t)s->n))) return rc;
+  } else {
+    c->cnt2.release();
+  }
+
+  /* table: smallest power of two with fill <= 70 % (hash_init, hashtable.cc:31-54);
+     Bloom: one byte per slot (bloom_init(tablesize), overlap.cc:863) */
+  c->slots = 1;
+  while (FILL_PERCENT * c->slots < 100 * s->n)
+    c->slots <<= 1;
+  uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
+  if (c->bloom_log2_delta > 0)
+    bloom_bytes <<= c->bloom_log2_delta;
+  else if (c->bloom_log2_delta < 0)
+    bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-c->bloom_log2_delta), 8);
+  if (bloom_bytes > (1ull << 32))
+    return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
+  c->bloom_words = bloom_bytes / 8;
+  if ((rc = dev_alloc(c, c->keys, (size_t)c->slots))) return rc;
+  if ((rc = dev_alloc(c, c->vals, (size_t)c->slots))) return rc;
+  if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->keys.p, 0xff, c->slots * sizeof(uint64_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
+
+  if (s->n) {
+    BuildParams B{};
+    B.zob = c->zob.p;
+    B.A = A;
+    B.zpos = c->zpos;
+    B.n_v = n_v;
+    B.use_genes = c->opt.ignore_genes ? 0u : 1u;
+    B.res = c->res2.p;
+    B.off = c->off2.p;
+    B.v = c->v2.p;
+    B.j = c->j2.p;
+    B.n = s->n;
+    B.keys = c->keys.p;
+    B.vals = c->vals.p;
+    B.slot_mask = c->slots - 1;
+    B.bloom = c->bloom.p;
+    B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
+    B.patterns = c->patterns.p;
+    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+    hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
+                       c->stream, B);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_ref = true;
+  return CMPR_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* set 1: sort by length, cut into 64-query tiles, upload               */
+/* ------------------------------------------------------------------ */
+
+extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  if (!c->have_ref)
+    return fail(c, CMPR_ESTATE, "cmpr_set_reference must be called first");
+  std::string why;
+  int rc = validate_view(c->opt, s, why);
+  if (rc)
+    return fail(c, rc, why);
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->have_q = false;
+
+  uint32_t longest = 0;
+  rc = scan_view(c->opt, s, longest, c->tot1, why);
+  if (rc)
+    return fail(c, rc, why);
+  if (longest + EXTRA_POSITIONS > c->zpos)
+    return fail(c, CMPR_EINVAL,
+                "query longer than the longest_query given to cmpr_set_reference");
+  c->n1 = s->n;
+  c->R1 = s->n_repertoires;
+
+  /* exact integer accumulation needs every cell < 2^64; a cell is at most
+     (sum of counts of its row repertoire) x (sum of counts of its column one) */
+  {
+    double m1 = 0, m2 = 0;
+    for (double x : c->tot1) m1 = std::max(m1, x);
+    for (double x : c->tot2) m2 = std::max(m2, x);
+    c->max_cell_bound = m1 * m2;
+    if (!is_f64_score(c->opt) && c->max_cell_bound >= 18446744073709551616.0 / 2)
+      return fail(c, CMPR_EUNSUPPORTED,
+                  "duplicate counts too large for exact 64-bit accumulation");
+  }
+
+  /* counting sort by length, longest first (heavy tiles are handed out first) */
+  std::vector<uint64_t> per_len((size_t)longest + 2, 0);
+  for (uint64_t i = 0; i < s->n; i++)
+    per_len[s->offsets[i + 1] - s->offsets[i]]++;
+  std::vector<uint64_t> tile_first((size_t)longest + 2, 0);   /* first tile of a length */
+  uint64_t ntiles = 0, res_words = 0;
+  std::vector<TileDesc> tiles;
+  for (int64_t L = longest; L >= 0; L--) {
+    tile_first[L] = ntiles;
+    const uint64_t cnt = per_len[L];
+    const uint64_t nt = (cnt + WAVE - 1) / WAVE;
+    const uint64_t words = ((uint64_t)L + 3) / 4;
+    for (uint64_t k = 0; k < nt; k++) {
+      TileDesc td;
+      td.len = (uint32_t)L;
+      td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
+      td.res_base = res_words;
+      res_words += words * WAVE;
+      tiles.push_back(td);
+    }
+    ntiles += nt;
+  }
+  if (ntiles * WAVE >= 0xffffffffull)
+    return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
+  c->ntiles = (uint32_t)ntiles;
+
+  const size_t slots = (size_t)ntiles * WAVE;
+  std::vector<uint32_t> qres((size_t)res_words, 0), qrep(slots, 0), qv, qj;
+  std::vector<uint64_t> qcnt;
+  if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
+  if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
+  std::vector<uint64_t> fill((size_t)longest + 2, 0);
+  uint64_t alg = 0;
+  for (uint64_t i = 0; i < s->n; i++) {
+    const uint64_t b = s->offsets[i];
+    const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+    const uint64_t k = fill[L]++;
+    const uint64_t tile = tile_first[L] + k / WAVE;
+    const uint32_t lane = (uint32_t)(k % WAVE);
+    const size_t slot = (size_t)tile * WAVE + lane;
+    qrep[slot] = s->repertoire[i];
+    if (!c->opt.ignore_genes) { qv[slot] = s->v_gene[i]; qj[slot] = s->j_gene[i]; }
+    if (!c->opt.ignore_counts) qcnt[slot] = s->count[i];
+    uint32_t *dst = qres.data() + tiles[tile].res_base + lane;
+    const uint8_t *src = s->residues + b;
+    for (uint32_t p = 0; p < L; p++)
+      dst[(size_t)(p >> 2) * WAVE] |= (uint32_t)src[p] << ((p & 3) * 8);
+    alg += (uint64_t)L + 20 + 8 * variants_of(c->opt, src, L);
+  }
+  c->algorithmic_bytes = alg;
+
+  if ((rc = dev_upload(c, c->tiles, tiles.data(), tiles.size()))) return rc;
+  if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
+  if ((rc = dev_upload(c, c->qrep, qrep.data(), qrep.size()))) return rc;
+  if (!c->opt.ignore_genes) {
+    if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
+    if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
+  }
+  if (!c->opt.ignore_counts)
+    if ((rc = dev_upload(c, c->qcnt, qcnt.data(), qcnt.size()))) return rc;
+
+  const size_t cells = (size_t)c->R1 * c->R2;
+  if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
+  if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
+  if ((rc = dev_alloc(c, c->stats, STAT_COUNT))) return rc;
+  if ((rc = dev_alloc(c, c->tile_counter, 1))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_q = true;
+  return CMPR_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* the per-query loop                                                    */
+/* ------------------------------------------------------------------ */
+
+namespace {
+
+/* enqueue: zero outputs, run the probe kernel over every tile.  `d_out` is the
+   integer matrix to fill (ours or the caller's). */
+int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
+{
+  const size_t cells = (size_t)c->R1 * c->R2;
+  HIP_TRY(c, hipEventRecord(c->ev_start, st));
+  HIP_TRY(c, hipMemsetAsync(d_out, 0, std::max<size_t>(cells, 1) * sizeof(unsigned long long), st));
+  if (is_f64_score(c->opt))
+    HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, std::max<size_t>(cells, 1) * sizeof(double), st));
+  HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * sizeof(unsigned long long), st));
+  HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, sizeof(uint32_t), st));
+  c->launches = 0;
+
+  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
+  if (c->ntiles > 0 && cells > 0) {
+    const uint32_t A = (uint32_t)c->opt.alphabet_size;
+    ProbeParams P{};
+    P.zob = c->zob.p;
+    P.zpos = c->zpos;
+    P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+    P.bloom = c->bloom.p;
+    P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
+    P.patterns = c->patterns.p;
+    P.keys = c->keys.p;
+    P.vals = c->vals.p;
+    P.slot_mask = c->slots - 1;
+    P.res2 = c->res2.p;
+    P.off2 = c->off2.p;
+    P.v2 = c->v2.p;
+    P.j2 = c->j2.p;
+    P.rep2 = c->rep2.p;
+    P.cnt2 = c->cnt2.p;
+    P.tiles = c->tiles.p;
+    P.qres = c->qres.p;
+    P.qv = c->qv.p;
+    P.qj = c->qj.p;
+    P.qrep = c->qrep.p;
+    P.qcnt = c->qcnt.p;
+    P.ntiles = c->ntiles;
+    P.first_tile = 0;
+    P.matrix = d_out;
+    P.matrix_f64 = c->matrix_f64.p;
+    P.R1 = c->R1;
+    P.R2 = c->R2;
+    P.score = c->opt.score;
+    P.ignore_counts = c->opt.ignore_counts;
+    P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
+    P.tile_counter = c->tile_counter.p;
+    P.stats = c->stats.p;
+
+    const size_t lds = ((size_t)A * c->zpos + PATTERN_COUNT) * sizeof(uint64_t) +
+                       (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
+                       WAVES_PER_BLOCK * sizeof(WaveQueue);
+    if (lds > 160 * 1024)
+      return fail(c, CMPR_EUNSUPPORTED,
+                  "sequences too long: Zobrist table does not fit the 160 KiB LDS");
+    ProbeFn fn = select_kernel(c->opt);
+    if (lds > 48 * 1024)
+      HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t waves_needed = c->ntiles;
+    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    grid = std::min<uint64_t>(grid, (waves_needed + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    grid = std::max<uint64_t>(grid, 1);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(BLOCK_THREADS), lds, st, P);
+    HIP_TRY(c, hipGetLastError());
+    c->launches = 1;
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_k1, st));
+  return CMPR_OK;
+}
+
+int check_ready(cmpr_context *c)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  if (!c->have_ref || !c->have_q)
+    return fail(c, CMPR_ESTATE, "cmpr_set_reference and cmpr_set_queries must be called first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  return CMPR_OK;
+}
+
+}  // namespace
+
+extern "C" int cmpr_overlap_matrix_device(cmpr_context *c, void *d_matrix, void *stream)
+{
+  int rc = check_ready(c);
+  if (rc)
+    return rc;
+  if (!d_matrix)
+    return fail(c, CMPR_EINVAL, "d_matrix is NULL");
+  if (is_f64_score(c->opt))
+    return fail(c, CMPR_EINVAL, "ratio score needs cmpr_overlap_matrix_f64");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  rc = enqueue_overlap(c, (unsigned long long *)d_matrix, st);
+  if (rc)
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev_stop, st));
+  c->events_valid = true;
+  if (!stream)
+    HIP_TRY(c, hipStreamSynchronize(st));
+  return CMPR_OK;
+}
+
+extern "C" int cmpr_overlap_matrix(cmpr_context *c, uint64_t *out)
+{
+  int rc = check_ready(c);
+  if (rc)
+    return rc;
+  if (!out)
+    return fail(c, CMPR_EINVAL, "matrix_out is NULL");
+  if (is_f64_score(c->opt))
+    return fail(c, CMPR_EINVAL, "ratio score needs cmpr_overlap_matrix_f64");
+  rc = enqueue_overlap(c, c->matrix.p, c->stream);
+  if (rc)
+    return rc;
+  const size_t cells = (size_t)c->R1 * c->R2;
+  if (cells)
+    HIP_TRY(c, hipMemcpyAsync(out, c->matrix.p, cells * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->events_valid = true;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CMPR_OK;
+}
+
+extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)
+{
+  int rc = check_ready(c);
+  if (rc)
+    return rc;
+  if (!out)
+    return fail(c, CMPR_EINVAL, "matrix_out is NULL");
+  rc = enqueue_overlap(c, c->matrix.p, c->stream);
+  if (rc)
+    return rc;
+  const size_t cells = (size_t)c->R1 * c->R2;
+  std::vector<unsigned long long> tmp(cells);
+  if (cells) {
+    if (is_f64_score(c->opt))
+      HIP_TRY(c, hipMemcpyAsync(out, c->matrix_f64.p, cells * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+    else
+      HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->matrix.p, cells * sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->events_valid = true;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!is_f64_score(c->opt)) {
+    const bool mean = c->opt.score == CMPR_SCORE_MEAN && !c->opt.ignore_counts;
+    for (size_t k = 0; k < cells; k++)
+      out[k] = mean ? (double)tmp[k] / 2 : (double)tmp[k];
+  }
+  return CMPR_OK;
+}
+
+extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
+{
+  if (!c || !out)
+    return CMPR_EINVAL;
+  if (!c->events_valid)
+    return fail(c, CMPR_ESTATE, "no overlap call has been made");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+  unsigned long long st[STAT_COUNT];
+  HIP_TRY(c, hipMemcpy(st, c->stats.p, sizeof st, hipMemcpyDeviceToHost));
+  float k_ms = 0, t_ms = 0;
+  HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
+  HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_start, c->ev_stop));
+  memset(out, 0, sizeof *out);
+  out->queries = c->n1;
+  out->variants = st[STAT_VARIANTS];
+  out->bloom_positive = st[STAT_BLOOM_POS];
+  out->hash_equal = st[STAT_HASH_EQ];
+  out->matches = st[STAT_MATCHES];
+  out->algorithmic_bytes = c->algorithmic_bytes;
+  out->kernel_ms = k_ms;
+  out->total_ms = t_ms;
+  out->kernel_launches = c->launches;
+  return CMPR_OK;
+}

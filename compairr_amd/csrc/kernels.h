@@ -1,0 +1,497 @@
+/*
+ * kernels.h -- hand-written HIP kernels for gfx950 (MI355X, wave64).
+ *
+ * Hot path of CompAIRR's --matrix command, rebuilt for the GPU:
+ *   index build  : hash every set-2 sequence, insert into hash table + Bloom
+ *                  (db_hash db.cc:903-916, hash_insert overlap.cc:63-128)
+ *   probe kernel : per query, enumerate every variant within distance d,
+ *                  Zobrist-hash it incrementally, test the Bloom filter, and
+ *                  for the few survivors walk the hash table, verify the hit
+ *                  exactly and add the score to the repertoire matrix
+ *                  (process_variants overlap.cc:253-284, generate_variants
+ *                  variants.cc:260-428, find_variant_matches overlap.cc:168-251,
+ *                  check_variant variants.cc:166-240, compute_score
+ *                  overlap.cc:144-166).
+ *
+ * Mapping: one query per LANE, 64 equal-length queries per wave ("tile").
+ * The variant loops (position p, replacement residue v) are then wave-uniform:
+ * the key of the replacement residue is a scalar (SGPR) operand, only the key
+ * of the query's own residue is a per-lane LDS lookup, and nothing diverges
+ * until a Bloom probe comes back positive.  Positives (~1 % of probes) are
+ * compacted with a wavefront ballot + prefix count into a per-wave LDS queue
+ * and verified 64 at a time, so the rare, long-latency hash-table walks never
+ * stall the probe stream.
+ */
+#ifndef COMPAIRR_AMD_KERNELS_H
+#define COMPAIRR_AMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "layout.h"
+
+namespace cmpr {
+
+/* ------------------------------------------------------------------ */
+/* small device helpers                                                 */
+/* ------------------------------------------------------------------ */
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+/* number of set bits of m below this lane */
+__device__ __forceinline__ uint32_t rank_below(uint64_t m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
+{
+  return h == EMPTY_KEY ? (h ^ 1ull) : h;
+}
+
+__device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
+{
+  /* high half, independent of the Bloom address bits (hashtable.h:36-41) */
+  return (uint32_t)((key >> 32) & mask);
+}
+
+/* ------------------------------------------------------------------ */
+/* index build                                                          */
+/* ------------------------------------------------------------------ */
+
+struct BuildParams {
+  const uint64_t *zob;
+  uint32_t        A;
+  uint32_t        zpos;
+  uint32_t        n_v;
+  uint32_t        use_genes;
+  const uint8_t  *res;
+  const uint64_t *off;
+  const uint32_t *v;
+  const uint32_t *j;
+  uint64_t        n;
+  uint64_t       *keys;
+  uint32_t       *vals;
+  uint64_t        slot_mask;
+  uint64_t       *bloom;
+  uint32_t        bloom_byte_mask;
+  uint32_t        pad;
+  const uint64_t *patterns;
+};
+
+/* One thread per set-2 sequence: Zobrist hash (zobrist.cc:74-88), claim the
+   first free slot of the probe chain with a 64-bit CAS (hash_insert,
+   overlap.cc:63-128: every entry is inserted, duplicates included), clear the
+   pattern bits in the Bloom word (bloom_set, bloompat.h:50-53). */
+__global__ void __launch_bounds__(BLOCK_THREADS)
+build_index_kernel(const BuildParams B)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if (i >= B.n)
+    return;
+  const uint64_t b = B.off[i];
+  const uint32_t L = (uint32_t)(B.off[i + 1] - b);
+  uint64_t h = 0;
+  if (B.use_genes) {
+    const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+    h = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+  }
+  for (uint32_t p = 0; p < L; p++)
+    h ^= B.zob[B.A * p + B.res[b + p]];
+
+  const uint64_t key = table_key(h);
+  uint64_t slot = table_home(key, B.slot_mask);
+  for (;;) {
+    unsigned long long prev =
+        atomicCAS((unsigned long long *)(B.keys + slot),
+                  (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+    if (prev == EMPTY_KEY)
+      break;
+    slot = (slot + 1) & B.slot_mask;
+  }
+  B.vals[slot] = (uint32_t)i;
+
+  const uint32_t boff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & B.bloom_byte_mask;
+  const uint64_t pat = B.patterns[(uint32_t)h & (PATTERN_COUNT - 1)];
+  atomicAnd((unsigned long long *)((char *)B.bloom + boff),
+            (unsigned long long)~pat);
+}
+
+/* ------------------------------------------------------------------ */
+/* probe kernel                                                         */
+/* ------------------------------------------------------------------ */
+
+constexpr int QCAP = 2 * WAVE;      /* per-wave queue of Bloom positives   */
+
+struct WaveQueue {
+  uint64_t hash[QCAP];
+  uint32_t slot[QCAP];   /* query: tile * 64 + lane                          */
+  uint32_t ca[QCAP];     /* kind | p1 << 3 | r1 << 24                        */
+  uint32_t cb[QCAP];     /* p2 | r2 << 24                                    */
+};
+
+__device__ __forceinline__ uint32_t pack_a(uint32_t kind, uint32_t p1, uint32_t r1)
+{
+  return kind | (p1 << 3) | (r1 << 24);
+}
+
+/* residue p of query `lane` of tile `td` */
+__device__ __forceinline__ uint32_t query_residue(const ProbeParams &P,
+                                                  const TileDesc &td,
+                                                  uint32_t lane, uint32_t p)
+{
+  uint32_t w = P.qres[td.res_base + (uint64_t)(p >> 2) * WAVE + lane];
+  return (w >> ((p & 3) * 8)) & 0xffu;
+}
+
+/* Exact test that the query with the variant applied IS the hit sequence --
+   restates check_variant (variants.cc:166-240) over the tile layout. */
+__device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
+                                    uint32_t lane, uint32_t ca, uint32_t cb,
+                                    uint32_t hit)
+{
+  const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
+  const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
+  const uint64_t tb = P.off2[hit];
+  const uint32_t M = (uint32_t)(P.off2[hit + 1] - tb);
+  const uint8_t *t = P.res2 + tb;
+  const uint32_t L = td.len;
+
+  if (kind == K_DEL) {
+    if (M + 1 != L)
+      return false;
+    for (uint32_t p = 0; p < p1; p++)
+      if (query_residue(P, td, lane, p) != t[p])
+        return false;
+    for (uint32_t p = p1 + 1; p < L; p++)
+      if (query_residue(P, td, lane, p) != t[p - 1])
+        return false;
+    return true;
+  }
+  if (kind == K_INS) {
+    if (M != L + 1 || t[p1] != r1)
+      return false;
+    for (uint32_t p = 0; p < p1; p++)
+      if (query_residue(P, td, lane, p) != t[p])
+        return false;
+    for (uint32_t p = p1; p < L; p++)
+      if (query_residue(P, td, lane, p) != t[p + 1])
+        return false;
+    return true;
+  }
+  /* same length: identical, one or two substitutions */
+  if (M != L)
+    return false;
+  if (kind == K_SUB && t[p1] != r1)
+    return false;
+  if (kind == K_SUB2 && (t[p1] != r1 || t[p2] != r2))
+    return false;
+  for (uint32_t p = 0; p < L; p++) {
+    if (kind != K_SAME && p == p1)
+      continue;
+    if (kind == K_SUB2 && p == p2)
+      continue;
+    if (query_residue(P, td, lane, p) != t[p])
+      return false;
+  }
+  return true;
+}
+
+struct LaneStats {
+  uint64_t variants;
+  uint32_t bloom_pos, hash_eq, matches;
+};
+
+/* Lane e of the wave resolves queue entry `e`: walk the probe chain
+   (find_variant_matches, overlap.cc:168-251), verify, score, accumulate. */
+template <bool GENES>
+__device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
+                              unsigned long long *mat_lds, LaneStats &st)
+{
+  const uint64_t key = table_key(q.hash[e]);
+  const uint32_t qs = q.slot[e];
+  const uint32_t ca = q.ca[e], cb = q.cb[e];
+  const TileDesc td = P.tiles[qs >> 6];
+  const uint32_t ql = qs & 63u;
+  uint64_t s = table_home(key, P.slot_mask);
+  for (;;) {
+    const uint64_t k = P.keys[s];
+    if (k == EMPTY_KEY)
+      break;
+    if (k == key) {
+      const uint32_t hit = P.vals[s];
+      st.hash_eq++;
+      bool ok = true;
+      if (GENES)
+        ok = (P.qv[qs] == P.v2[hit]) && (P.qj[qs] == P.j2[hit]);
+      if (ok && variant_matches_hit(P, td, ql, ca, cb, hit)) {
+        st.matches++;
+        const uint32_t cell = P.R2 * P.qrep[qs] + P.rep2[hit];
+        if (P.score == 1 /* ratio */ && !P.ignore_counts) {
+          unsafeAtomicAdd(P.matrix_f64 + cell,
+                          (double)P.qcnt[qs] / (double)P.cnt2[hit]);
+        } else {
+          unsigned long long sc = 1;
+          if (!P.ignore_counts) {
+            const unsigned long long f = P.qcnt[qs], g = P.cnt2[hit];
+            switch (P.score) {
+            case 2: case 6: sc = f < g ? f : g; break;       /* min, Jaccard */
+            case 3:         sc = f > g ? f : g; break;       /* max          */
+            case 4:         sc = f + g;         break;       /* 2 x mean     */
+            default:        sc = f * g;         break;       /* product, MH  */
+            }
+          }
+          if (mat_lds)
+            atomicAdd(mat_lds + cell, sc);
+          else
+            atomicAdd(P.matrix + cell, sc);
+        }
+      }
+    }
+    s = (s + 1) & P.slot_mask;
+  }
+}
+
+/* per-wave probing state */
+struct Prober {
+  const ProbeParams  &P;
+  const uint64_t     *pat_lds;
+  WaveQueue          &q;
+  unsigned long long *mat_lds;
+  uint32_t            lane;
+  uint32_t            qslot;     /* tile * 64 + lane                         */
+  int                 qn;        /* queue fill, wave-uniform, < 64 on entry  */
+  LaneStats           st;
+};
+
+template <bool GENES>
+__device__ __forceinline__ void drain_full(Prober &W)
+{
+  /* entries [qn-64, qn) -- all 64 lanes busy */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  W.qn -= WAVE;
+  resolve_entry<GENES>(W.P, W.q, W.qn + (int)W.lane, W.mat_lds, W.st);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+/* One Bloom probe per lane (bloom_get, bloompat.h:55-58) + queue push of the
+   positives.  `live` masks lanes whose variant does not exist (padding lanes,
+   replacement == original residue, repeated deletion). */
+template <bool GENES>
+__device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
+                                      uint32_t ca, uint32_t cb)
+{
+  const uint32_t boff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.P.bloom_byte_mask;
+  const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + boff);
+  const uint64_t pat = W.pat_lds[(uint32_t)hv & (PATTERN_COUNT - 1)];
+  const bool pos = live && ((word & pat) == 0);
+  W.st.variants += live ? 1ull : 0ull;
+  const uint64_t m = __ballot(pos);
+  if (m) {
+    if (pos) {
+      const int e = W.qn + (int)rank_below(m);
+      W.q.hash[e] = hv;
+      W.q.slot[e] = W.qslot;
+      W.q.ca[e] = ca;
+      W.q.cb[e] = cb;
+      W.st.bloom_pos++;
+    }
+    W.qn += __popcll(m);
+    if (W.qn >= WAVE)
+      drain_full<GENES>(W);
+  }
+}
+
+/*
+ * A: alphabet (20 aa / 4 nt); D: differences 0..2; INDELS: -i (D == 1);
+ * GENES: V/J hashed and compared (no -g).
+ *
+ * LDS: [A * zpos Zobrist position keys][1024 Bloom patterns]
+ *      [R1 * R2 matrix (optional)][one WaveQueue per wave]
+ *
+ * The replacement-residue loops are deliberately NOT unrolled: each probe()
+ * site carries an inlined queue drain, and memory-level parallelism comes
+ * from the 16-32 resident waves per CU (one 64-lane gather in flight each),
+ * which already exceeds what the memory system can retire.
+ */
+template <int A, int D, bool INDELS, bool GENES>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+probe_kernel(const ProbeParams P)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint64_t *zl = (uint64_t *)smem;
+  const uint32_t nz = (uint32_t)A * P.zpos;
+  uint64_t *pat_lds = zl + nz;
+  unsigned long long *mat_all = (unsigned long long *)(pat_lds + PATTERN_COUNT);
+  const uint32_t cells = P.R1 * P.R2;
+  WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
+
+  for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)
+    zl[i] = P.zob[i];
+  for (uint32_t i = threadIdx.x; i < PATTERN_COUNT; i += BLOCK_THREADS)
+    pat_lds[i] = P.patterns[i];
+  if (P.lds_matrix)
+    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
+      mat_all[i] = 0;
+  __syncthreads();
+
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x / WAVE;
+  Prober W{P, pat_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
+           lane, 0u, 0, {0ull, 0u, 0u, 0u}};
+  const uint64_t *zs = P.zob;            /* wave-uniform lookups: scalar loads */
+  const uint64_t *gene_keys = P.zob + nz;
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0)
+      t = atomicAdd(P.tile_counter, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= P.ntiles)
+      break;
+    t += P.first_tile;
+    const TileDesc td = P.tiles[t];
+    const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
+    const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
+    const uint32_t *qr = P.qres + td.res_base + lane;   /* + (p / 4) * 64 */
+    const bool valid = lane < nvalid;
+    W.qslot = t * WAVE + lane;
+
+    /* ---- hash of the query itself (zobrist_hash, zobrist.cc:74-88), and with
+            -i the two shifted hashes that seed the rolling indel enumeration
+            (zobrist_hash_delete_first :90-104, _insert_first :122-136) ---- */
+    uint64_t h = 0;
+    if (GENES)
+      h = gene_keys[P.qv[W.qslot]] ^ gene_keys[P.n_v + P.qj[W.qslot]];
+    uint64_t hdel = h, hins = h;
+    {
+      uint32_t w = 0;
+      for (uint32_t p = 0; p < L; p++) {
+        if ((p & 3u) == 0)
+          w = qr[(p >> 2) * WAVE];
+        const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+        h ^= zl[A * p + r];
+        if (INDELS) {
+          hins ^= zl[A * (p + 1) + r];
+          if (p > 0)
+            hdel ^= zl[A * (p - 1) + r];
+        }
+      }
+    }
+
+    /* ---- the unchanged sequence (generate_variants_0, variants.cc:260-268) */
+    probe<GENES>(W, h, valid, pack_a(K_SAME, 0, 0), 0);
+
+    if (D >= 1) {
+      /* ---- single substitutions (variants.cc:280-293) ---- */
+      uint32_t w = 0;
+      for (uint32_t p = 0; p < L; p++) {
+        if ((p & 3u) == 0)
+          w = qr[(p >> 2) * WAVE];
+        const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+        const uint64_t h1 = h ^ zl[A * p + r];
+        const uint64_t *zrow = zs + A * p;
+#pragma unroll 1
+        for (uint32_t v = 0; v < (uint32_t)A; v++)
+          probe<GENES>(W, h1 ^ zrow[v], valid && v != r, pack_a(K_SUB, p, v), 0);
+      }
+    }
+
+    if (INDELS) {
+      /* ---- deletions: one per run of equal residues, rolling hash
+              (variants.cc:301-325; none when L == 1) ---- */
+      if (L > 1) {
+        uint32_t w = 0, gone = 0;
+        uint64_t hd = hdel;
+#pragma unroll 1
+        for (uint32_t p = 0; p < L; p++) {
+          if ((p & 3u) == 0)
+            w = qr[(p >> 2) * WAVE];
+          const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+          const bool fresh = (p == 0) || (r != gone);
+          if (p > 0 && fresh)
+            hd ^= zl[A * (p - 1) + gone] ^ zl[A * (p - 1) + r];
+          probe<GENES>(W, hd, valid && fresh, pack_a(K_DEL, p, 0), 0);
+          gone = r;
+        }
+      }
+      /* ---- insertions: every residue in front of position 0, then behind
+              each position every residue that differs from it
+              (variants.cc:329-353) ---- */
+      {
+        uint64_t hi = hins;
+        uint32_t w = 0, r = 0xffu;
+        for (uint32_t ip = 0; ip <= L; ip++) {
+          if (ip > 0) {
+            const uint32_t p = ip - 1;
+            if ((p & 3u) == 0)
+              w = qr[(p >> 2) * WAVE];
+            r = (w >> ((p & 3u) * 8)) & 0xffu;
+            hi ^= zl[A * p + r] ^ zl[A * ip + r];
+          }
+          const uint64_t *zrow = zs + A * ip;
+#pragma unroll 1
+          for (uint32_t v = 0; v < (uint32_t)A; v++)
+            probe<GENES>(W, hi ^ zrow[v], valid && v != r, pack_a(K_INS, ip, v), 0);
+        }
+      }
+    }
+
+    if (D >= 2) {
+      /* ---- double substitutions p < q (variants.cc:370-399) ---- */
+      for (uint32_t p = 0; p + 1 < L; p++) {
+        const uint32_t rp = (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
+        const uint64_t hp = h ^ zl[A * p + rp];
+        for (uint32_t v = 0; v < (uint32_t)A; v++) {
+          const bool pv = valid && v != rp;
+          const uint64_t hpv = hp ^ zs[A * p + v];
+          const uint32_t ca = pack_a(K_SUB2, p, v);
+          uint32_t w = 0;
+          for (uint32_t qq = p + 1; qq < L; qq++) {
+            if ((qq & 3u) == 0 || qq == p + 1)
+              w = qr[(qq >> 2) * WAVE];
+            const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
+            const uint64_t hq = hpv ^ zl[A * qq + rq];
+            const uint64_t *zrow = zs + A * qq;
+#pragma unroll 1
+            for (uint32_t x = 0; x < (uint32_t)A; x++)
+              probe<GENES>(W, hq ^ zrow[x], pv && x != rq, ca, qq | (x << 24));
+          }
+        }
+      }
+    }
+  }
+
+  /* leftovers: fewer than 64 entries */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if ((int)lane < W.qn)
+    resolve_entry<GENES>(P, W.q, (int)lane, W.mat_lds, W.st);
+
+  /* statistics: wave reduction, one atomic per counter per wave */
+  {
+    unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,
+                                        W.st.hash_eq, W.st.matches};
+#pragma unroll
+    for (int k = 0; k < STAT_COUNT; k++) {
+      unsigned long long x = s[k];
+      for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_down(x, off, WAVE);
+      if (lane == 0 && x)
+        atomicAdd(P.stats + k, x);
+    }
+  }
+
+  if (P.lds_matrix) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS) {
+      const unsigned long long x = mat_all[i];
+      if (x)
+        atomicAdd(P.matrix + i, x);
+    }
+  }
+}
+
+}  // namespace cmpr
+#endif

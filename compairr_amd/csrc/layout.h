@@ -1,0 +1,97 @@
+/*
+ * layout.h -- device data layout shared by the kernels and the host side of
+ * libcompairr_hip.so.  gfx950 only; see DESIGN.md "Data layout in HBM".
+ */
+#ifndef COMPAIRR_AMD_LAYOUT_H
+#define COMPAIRR_AMD_LAYOUT_H
+
+#include <stdint.h>
+
+namespace cmpr {
+
+constexpr int      WAVE              = 64;
+constexpr int      BLOCK_THREADS     = 256;
+constexpr int      WAVES_PER_BLOCK   = BLOCK_THREADS / WAVE;
+
+/* Zobrist table: A * zpos position keys, then n_v V keys, then n_j J keys.
+   zpos = longest + 3 (insertion variants index position L, reference
+   MAX_INSERTS, compairr.h:111). */
+constexpr uint32_t EXTRA_POSITIONS   = 3;
+
+/* Blocked Bloom filter, one 64-bit word per block, k = 8 bits from one of
+   1024 precomputed patterns, inverted polarity (a cleared bit = present) so
+   that the membership test is (word & pattern) == 0 -- same geometry as
+   bloompat.h:22-58; the table contents are our own. */
+constexpr uint32_t PATTERN_BITS      = 10;
+constexpr uint32_t PATTERN_COUNT     = 1u << PATTERN_BITS;
+constexpr uint32_t PATTERN_K         = 8;
+
+/* Open-addressing table: 64-bit keys (the sequence hash), 32-bit payload (the
+   set-2 sequence number); an all-ones key marks a free slot (the reference
+   keeps a separate occupancy bitmap, hashtable.h:48-56). */
+constexpr uint64_t EMPTY_KEY         = ~0ull;
+constexpr uint32_t FILL_PERCENT      = 70;     /* hashtable.cc:24 */
+
+/* variant kinds, mutation_kind_enum of variants.h:56-63 */
+enum : uint32_t { K_SAME = 0, K_SUB = 1, K_DEL = 2, K_INS = 3, K_SUB2 = 4 };
+
+/* One tile = 64 queries of equal length, one per lane.  Residues are stored
+   four to a dword, position-major and lane-minor:
+     qres[res_base + (p / 4) * 64 + lane]  byte (p % 4)
+   so that one wave instruction reads four positions of all 64 queries as one
+   256-byte coalesced access. */
+struct TileDesc {
+  uint32_t len;       /* residues per query in this tile                    */
+  uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
+  uint64_t res_base;  /* dword offset of the tile's residues in qres         */
+};
+
+/* per-launch kernel arguments */
+struct ProbeParams {
+  /* Zobrist */
+  const uint64_t *zob;
+  uint32_t        zpos;
+  uint32_t        n_v;
+  /* Bloom */
+  const uint64_t *bloom;
+  uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
+  uint32_t        pad0;
+  const uint64_t *patterns;
+  /* hash table */
+  const uint64_t *keys;
+  const uint32_t *vals;
+  uint64_t        slot_mask;
+  /* set 2 records */
+  const uint8_t  *res2;
+  const uint64_t *off2;
+  const uint32_t *v2;
+  const uint32_t *j2;
+  const uint32_t *rep2;
+  const uint64_t *cnt2;
+  /* set 1 tiles */
+  const TileDesc *tiles;
+  const uint32_t *qres;
+  const uint32_t *qv;
+  const uint32_t *qj;
+  const uint32_t *qrep;
+  const uint64_t *qcnt;
+  uint32_t        ntiles;
+  uint32_t        first_tile;
+  /* output */
+  unsigned long long *matrix;      /* R1 * R2 integer sums                   */
+  double             *matrix_f64;  /* ratio score only                       */
+  uint32_t        R1, R2;
+  int32_t         score;
+  int32_t         ignore_counts;
+  int32_t         lds_matrix;      /* 1: privatise the matrix in LDS          */
+  int32_t         pad1;
+  /* work distribution + statistics */
+  uint32_t           *tile_counter;
+  unsigned long long *stats;       /* [variants, bloom+, hash==, matches]     */
+};
+
+enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
+       STAT_COUNT = 4 };
+
+}  // namespace cmpr
+#endif

@@ -1,0 +1,228 @@
+"""ctypes binding of the C ABI in ``include/compairr_hip.h``.
+
+There is deliberately no fallback: if ``libcompairr_hip.so`` has not been built
+(``make lib`` / ``__graft_entry__.build()``) or no HIP device is present, the
+calls fail loudly."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .sets import RepertoireSet
+
+SCORES = {"product": 0, "ratio": 1, "min": 2, "max": 3, "mean": 4, "mh": 5, "jaccard": 6}
+
+EXPORTS = [
+    "cmpr_abi_version", "cmpr_create", "cmpr_destroy", "cmpr_last_error",
+    "cmpr_set_reference", "cmpr_set_queries", "cmpr_overlap_matrix",
+    "cmpr_overlap_matrix_f64", "cmpr_overlap_matrix_device", "cmpr_get_stats",
+    "cmpr_rows", "cmpr_cols", "cmpr_set_tunable",
+]
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libcompairr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Options(C.Structure):
+    _fields_ = [("differences", C.c_int32), ("indels", C.c_int32),
+                ("ignore_genes", C.c_int32), ("ignore_counts", C.c_int32),
+                ("score", C.c_int32), ("alphabet_size", C.c_int32),
+                ("n_v_genes", C.c_uint32), ("n_j_genes", C.c_uint32),
+                ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class _SetView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("residues", C.c_void_p), ("offsets", C.c_void_p),
+                ("v_gene", C.c_void_p), ("j_gene", C.c_void_p),
+                ("repertoire", C.c_void_p), ("count", C.c_void_p),
+                ("n_repertoires", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("variants", C.c_uint64),
+                ("bloom_positive", C.c_uint64), ("hash_equal", C.c_uint64),
+                ("matches", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+@dataclass
+class Options:
+    differences: int = 0
+    indels: bool = False
+    ignore_genes: bool = False
+    ignore_counts: bool = False
+    score: str = "product"
+    nucleotides: bool = False
+    n_v_genes: int = 1
+    n_j_genes: int = 1
+    device: int = -1
+
+
+@dataclass
+class Stats:
+    queries: int
+    variants: int
+    bloom_positive: int
+    hash_equal: int
+    matches: int
+    algorithmic_bytes: int
+    kernel_ms: float
+    total_ms: float
+    kernel_launches: int
+
+
+def library_path() -> str:
+    env = os.environ.get("COMPAIRR_HIP_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                        "libcompairr_hip.so")
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    lib.cmpr_abi_version.restype = C.c_int
+    lib.cmpr_create.argtypes = [C.POINTER(_Options), C.POINTER(C.c_void_p)]
+    lib.cmpr_destroy.argtypes = [C.c_void_p]
+    lib.cmpr_destroy.restype = None
+    lib.cmpr_last_error.argtypes = [C.c_void_p]
+    lib.cmpr_last_error.restype = C.c_char_p
+    lib.cmpr_set_reference.argtypes = [C.c_void_p, C.POINTER(_SetView), C.c_uint32]
+    lib.cmpr_set_queries.argtypes = [C.c_void_p, C.POINTER(_SetView)]
+    lib.cmpr_overlap_matrix.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cmpr_overlap_matrix_f64.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cmpr_overlap_matrix_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cmpr_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    lib.cmpr_rows.argtypes = [C.c_void_p]
+    lib.cmpr_rows.restype = C.c_uint32
+    lib.cmpr_cols.argtypes = [C.c_void_p]
+    lib.cmpr_cols.restype = C.c_uint32
+    lib.cmpr_set_tunable.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    if lib.cmpr_abi_version() != 1:
+        raise RuntimeError("libcompairr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _view(s: RepertoireSet) -> _SetView:
+    v = _SetView()
+    v.n = s.n
+    v.residues = s.residues.ctypes.data
+    v.offsets = s.offsets.ctypes.data
+    v.v_gene = s.v_gene.ctypes.data
+    v.j_gene = s.j_gene.ctypes.data
+    v.repertoire = s.repertoire.ctypes.data
+    v.count = s.count.ctypes.data
+    v.n_repertoires = s.n_repertoires
+    return v
+
+
+class HipOverlap:
+    """One context of the C ABI: create -> set_reference -> set_queries ->
+    overlap_matrix*, mirroring the reference's overlap() around sim_thread
+    (/root/reference/src/overlap.cc:840-938)."""
+
+    def __init__(self, opt: Options):
+        self._lib = load_library()
+        o = _Options()
+        o.differences = opt.differences
+        o.indels = int(opt.indels)
+        o.ignore_genes = int(opt.ignore_genes)
+        o.ignore_counts = int(opt.ignore_counts)
+        o.score = SCORES[opt.score.lower()]
+        o.alphabet_size = 4 if opt.nucleotides else 20
+        o.n_v_genes = opt.n_v_genes
+        o.n_j_genes = opt.n_j_genes
+        o.device = opt.device
+        self.opt = opt
+        self._ctx = C.c_void_p()
+        rc = self._lib.cmpr_create(C.byref(o), C.byref(self._ctx))
+        if rc:
+            raise HipError(rc, self._lib.cmpr_last_error(None).decode())
+
+    def _check(self, rc: int) -> None:
+        if rc:
+            raise HipError(rc, self._lib.cmpr_last_error(self._ctx).decode())
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.cmpr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tunable(self, name: str, value: int) -> None:
+        self._check(self._lib.cmpr_set_tunable(self._ctx, name.encode(), value))
+
+    def set_reference(self, s: RepertoireSet, longest_query: int = 0) -> None:
+        v = _view(s)
+        self._check(self._lib.cmpr_set_reference(self._ctx, C.byref(v), longest_query))
+
+    def set_queries(self, s: RepertoireSet) -> None:
+        v = _view(s)
+        self._check(self._lib.cmpr_set_queries(self._ctx, C.byref(v)))
+
+    @property
+    def shape(self):
+        return (self._lib.cmpr_rows(self._ctx), self._lib.cmpr_cols(self._ctx))
+
+    def overlap_matrix(self) -> np.ndarray:
+        out = np.zeros(self.shape, dtype=np.uint64)
+        self._check(self._lib.cmpr_overlap_matrix(self._ctx, out.ctypes.data))
+        return out
+
+    def overlap_matrix_f64(self) -> np.ndarray:
+        out = np.zeros(self.shape, dtype=np.float64)
+        self._check(self._lib.cmpr_overlap_matrix_f64(self._ctx, out.ctypes.data))
+        return out
+
+    def overlap_matrix_device(self, d_matrix: int, stream: Optional[int] = None) -> None:
+        self._check(self._lib.cmpr_overlap_matrix_device(
+            self._ctx, C.c_void_p(d_matrix), C.c_void_p(stream or 0)))
+
+    def stats(self) -> Stats:
+        st = _Stats()
+        self._check(self._lib.cmpr_get_stats(self._ctx, C.byref(st)))
+        return Stats(st.queries, st.variants, st.bloom_positive, st.hash_equal,
+                     st.matches, st.algorithmic_bytes, st.kernel_ms, st.total_ms,
+                     st.kernel_launches)
+
+
+def overlap(set1: RepertoireSet, set2: RepertoireSet, opt: Options):
+    """Convenience: the whole path once; returns (cells as float64 in the
+    reference's units, Stats)."""
+    with HipOverlap(opt) as h:
+        h.set_reference(set2, set1.longest)
+        h.set_queries(set1)
+        m = h.overlap_matrix_f64()
+        return m, h.stats()

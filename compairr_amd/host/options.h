@@ -1,0 +1,71 @@
+/*
+ * options.h -- command line of the MI355X build of `compairr`.
+ *
+ * Same option table, defaults and validation rules as the reference program
+ * (/root/reference/src/compairr.cc:292-706) for the options on the --matrix
+ * path; commands and options outside that path are recognised and rejected
+ * with a clear message instead of being silently ignored.
+ */
+#ifndef COMPAIRR_AMD_OPTIONS_H
+#define COMPAIRR_AMD_OPTIONS_H
+
+#include <stdint.h>
+#include <cstdio>
+#include <string>
+
+namespace cmprhost {
+
+enum Score {
+  SCORE_PRODUCT = 0, SCORE_RATIO, SCORE_MIN, SCORE_MAX, SCORE_MEAN, SCORE_MH,
+  SCORE_JACCARD, SCORE_END
+};
+
+struct Options {
+  bool alternative = false;      /* -a */
+  bool cdr3 = false;             /* --cdr3 */
+  bool cluster = false;          /* -c (not on this path) */
+  bool deduplicate = false;      /* -z (not on this path) */
+  bool distance = false;         /* --distance (not on this path) */
+  bool existence = false;        /* -x (not on this path) */
+  bool help = false;             /* -h */
+  bool ignore_counts = false;    /* -f */
+  bool ignore_empty = false;     /* -e */
+  bool ignore_genes = false;     /* -g */
+  bool ignore_unknown = false;   /* -u */
+  bool indels = false;           /* -i */
+  bool matrix = false;           /* -m */
+  bool nucleotides = false;      /* -n */
+  bool no_matrix = false;        /* --no-matrix (not on this path) */
+  bool version = false;          /* -v */
+  const char *keep_columns = nullptr;  /* -k (not on this path) */
+  const char *log = nullptr;           /* -l */
+  const char *output = "-";            /* -o */
+  const char *pairs = nullptr;         /* -p (not on this path) */
+  const char *score_string = nullptr;  /* -s */
+  int64_t differences = 0;       /* -d */
+  int64_t score = SCORE_PRODUCT;
+  int64_t threads = 1;           /* -t (host threads; the loop runs on the GPU) */
+  int64_t device = -1;           /* --device N: HIP device ordinal (addition) */
+
+  const char *input1 = nullptr;
+  const char *input2 = nullptr;
+
+  int alphabet_size = 20;
+  const char *seq_header = "junction_aa";
+};
+
+/* Parses argv exactly as the reference does (getopt_long, each lowercase
+   option at most once, one command, argument counts, value checks).  Prints
+   the reference's messages and exits with status 1 on any error. */
+void parse_command_line(int argc, char **argv, Options &opt);
+
+void print_usage(FILE *f);
+void print_header(FILE *f);
+void print_options(FILE *f, const Options &opt, const char *backend_name);
+
+const char *score_description(int64_t score);
+
+[[noreturn]] void fatal(const char *msg);
+
+}  // namespace cmprhost
+#endif

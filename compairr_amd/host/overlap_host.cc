@@ -1,0 +1,244 @@
+/*
+ * overlap_host.cc -- see overlap_host.h.  Own code; the behaviour it keeps is
+ * cited per block from /root/reference/src/overlap.cc and compairr.cc.
+ */
+#include "overlap_host.h"
+
+#include <math.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+
+namespace cmprhost {
+
+namespace {
+
+FILE *open_output(const char *name)
+{
+  /* "-" = standard output (util.cc:156-170) */
+  if (strcmp(name, "-") == 0) {
+    int fd = dup(STDOUT_FILENO);
+    return fd < 0 ? nullptr : fdopen(fd, "w");
+  }
+  return fopen(name, "w");
+}
+
+void log_time(FILE *log, const char *prompt)
+{
+  char buf[100];
+  time_t now = time(nullptr);
+  size_t n = strftime(buf, sizeof buf, "%a %b %d %T %Z %Y", localtime(&now));
+  fprintf(log, "%s%s\n", prompt, n ? buf : "?");
+}
+
+struct RepertoireTotals {
+  std::vector<uint64_t> size, count;
+  std::vector<double>   sq_count;
+  std::vector<uint32_t> order;      /* display order: strcmp on the ids */
+};
+
+/* overlap.cc:627-667 */
+void totals_of(const RepertoireSet &s, RepertoireTotals &t)
+{
+  const size_t R = s.repertoires.names.size();
+  t.size.assign(R, 0);
+  t.count.assign(R, 0);
+  t.sq_count.assign(R, 0.0);
+  for (uint64_t i = 0; i < s.size(); i++) {
+    const uint32_t r = s.repertoire[i];
+    const uint64_t c = s.count[i];
+    t.size[r]++;
+    t.count[r] += c;
+    t.sq_count[r] += (double)(uint64_t)(c * c);
+  }
+  t.order.resize(R);
+  for (uint32_t i = 0; i < R; i++)
+    t.order[i] = i;
+  const std::vector<std::string> &names = s.repertoires.names;
+  std::sort(t.order.begin(), t.order.end(), [&names](uint32_t a, uint32_t b) {
+    return strcmp(names[a].c_str(), names[b].c_str()) < 0;
+  });
+}
+
+/* overlap.cc:669-697 */
+void log_repertoires(FILE *log, const RepertoireSet &s, const RepertoireTotals &t)
+{
+  const size_t R = t.order.size();
+  uint64_t sum_size = 0, sum_count = 0;
+  for (size_t i = 0; i < R; i++) {
+    sum_size += t.size[i];
+    sum_count += t.count[i];
+  }
+  int w1 = std::max(1, (int)(1 + floor(log10((double)R))));
+  int w2 = std::max(9, (int)(1 + floor(log10((double)sum_size))));
+  int w3 = std::max(5, (int)(1 + floor(log10((double)sum_count))));
+  if (R == 0) w1 = 1;
+  if (sum_size == 0) w2 = 9;
+  if (sum_count == 0) w3 = 5;
+  fprintf(log, "Repertoires in set:\n");
+  fprintf(log, "%*s %*s %*s %s\n", w1, "#", w2, "Sequences", w3, "Count", "Repertoire ID");
+  for (size_t i = 0; i < R; i++) {
+    const uint32_t r = t.order[i];
+    fprintf(log, "%*u %*lu %*lu %s\n", w1, (unsigned)(i + 1), w2,
+            (unsigned long)t.size[r], w3, (unsigned long)t.count[r],
+            s.repertoires.names[r].c_str());
+  }
+  fprintf(log, "\n");
+}
+
+/* show_matrix_value, overlap.cc:540-577 */
+double cell_value(const Options &o, double cell, const RepertoireTotals &t1,
+                  uint32_t s, const RepertoireTotals &t2, uint32_t t)
+{
+  if (o.score == SCORE_MH) {
+    double lx = t1.sq_count[s] / t1.count[s] / t1.count[s];
+    double ly = t2.sq_count[t] / t2.count[t] / t2.count[t];
+    double xy = 1.0 * t1.count[s] * t2.count[t];
+    return (2.0 * cell) / ((lx + ly) * xy);
+  }
+  if (o.score == SCORE_JACCARD) {
+    double sa = (double)t1.count[s], sb = (double)t2.count[t];
+    return cell / (sa + sb - cell);
+  }
+  return cell;
+}
+
+}  // namespace
+
+int compairr_main(int argc, char **argv, OverlapBackend &backend)
+{
+  Options o;
+  parse_command_line(argc, argv, o);
+
+  FILE *log = stderr;
+  if (o.log) {
+    log = fopen(o.log, "w");
+    if (!log)
+      fatal("Unable to open log file for writing.");
+  }
+  FILE *out = open_output(o.output);
+  if (!out)
+    fatal("Unable to open output file for writing.");
+
+  if (o.version || o.help) {
+    print_header(log);
+    if (o.help)
+      print_usage(stderr);
+    fclose(out);
+    if (log != stderr)
+      fclose(log);
+    return 0;
+  }
+
+  print_header(log);
+  log_time(log, "Start time:        ");
+  print_options(log, o, backend.name());
+  fprintf(log, "\n");
+
+  /* ---- read (overlap.cc:611-825) ---- */
+  GeneTables genes;
+  RepertoireSet set1, set2_storage;
+  RepertoireTotals tot1, tot2_storage;
+
+  fprintf(log, "Immune receptor repertoire set 1\n\n");
+  auto t0 = std::chrono::steady_clock::now();
+  read_airr_tsv(o.input1, o, genes, "1", log, set1);
+  auto t1 = std::chrono::steady_clock::now();
+  fprintf(log, "Reading sequences: %.9lfs\n\n",
+          std::chrono::duration<double>(t1 - t0).count());
+  totals_of(set1, tot1);
+  log_repertoires(log, set1, tot1);
+
+  fprintf(log, "Immune receptor repertoire set 2\n\n");
+  const bool same = !(o.input2 && strcmp(o.input1, o.input2));
+  if (!same) {
+    t0 = std::chrono::steady_clock::now();
+    read_airr_tsv(o.input2, o, genes, "2", log, set2_storage);
+    t1 = std::chrono::steady_clock::now();
+    fprintf(log, "Reading sequences: %.9lfs\n\n",
+            std::chrono::duration<double>(t1 - t0).count());
+    totals_of(set2_storage, tot2_storage);
+    if (set2_storage.repertoires.names.empty())
+      fatal("Repertoire set missing repertoire_id.");
+    log_repertoires(log, set2_storage, tot2_storage);
+  } else {
+    fprintf(log, "Set 2 is identical to set 1\n\n");
+    if (set1.repertoires.names.empty())
+      fatal("Repertoire set is missing repertoire_id.");
+  }
+  const RepertoireSet &set2 = same ? set1 : set2_storage;
+  const RepertoireTotals &tot2 = same ? tot1 : tot2_storage;
+
+  fprintf(log, "Unique V genes:    %lu\n", (unsigned long)genes.v.names.size());
+  fprintf(log, "Unique J genes:    %lu\n", (unsigned long)genes.j.names.size());
+
+  /* ---- the per-query loop, on the backend (overlap.cc:840-938) ---- */
+  const size_t R1 = set1.repertoires.names.size(), R2 = set2.repertoires.names.size();
+  std::vector<double> cells(R1 * R2, 0.0);
+  BackendReport rep;
+  std::string error;
+  if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error)) {
+    fprintf(stderr, "\nError: %s\n", error.c_str());
+    return 1;
+  }
+  fprintf(log, "Hashing sequences: 100%% (%.9lfs)\n", rep.seconds_index);
+  fprintf(log, "Query layout:      100%% (%.9lfs)\n", rep.seconds_queries);
+  fprintf(log, "Analysing:         100%% (%.9lfs)\n", rep.seconds_analysis);
+  if (!rep.device_name.empty()) {
+    const double s = rep.kernel_ms * 1e-3;
+    fprintf(log, "GPU:               %s\n", rep.device_name.c_str());
+    fprintf(log, "GPU kernel:        %.3f ms, %.3e query sequences/s, "
+                 "%.1f GB/s algorithmic\n",
+            rep.kernel_ms, s > 0 ? set1.size() / s : 0.0,
+            s > 0 ? rep.algorithmic_bytes / s * 1e-9 : 0.0);
+    fprintf(log, "GPU work:          %lu variants, %lu Bloom positives, "
+                 "%lu hash matches, %lu pairs\n",
+            (unsigned long)rep.variants, (unsigned long)rep.bloom_positive,
+            (unsigned long)rep.hash_equal, (unsigned long)rep.matches);
+  }
+
+  /* ---- print (overlap.cc:944-1039): rows/columns in strcmp order of the
+          ids, every value "\t%.10lg" ---- */
+  t0 = std::chrono::steady_clock::now();
+  if (o.alternative) {
+    fprintf(out, "#repertoire_id_1\trepertoire_id_2\tmatches\n");
+    for (size_t i = 0; i < R1; i++) {
+      const uint32_t s = tot1.order[i];
+      for (size_t j = 0; j < R2; j++) {
+        const uint32_t t = tot2.order[j];
+        fprintf(out, "%s\t%s", set1.repertoires.names[s].c_str(),
+                set2.repertoires.names[t].c_str());
+        fprintf(out, "\t%.10lg", cell_value(o, cells[R2 * s + t], tot1, s, tot2, t));
+        fprintf(out, "\n");
+      }
+    }
+  } else {
+    fprintf(out, "#");
+    for (size_t j = 0; j < R2; j++)
+      fprintf(out, "\t%s", set2.repertoires.names[tot2.order[j]].c_str());
+    fprintf(out, "\n");
+    for (size_t i = 0; i < R1; i++) {
+      const uint32_t s = tot1.order[i];
+      fprintf(out, "%s", set1.repertoires.names[s].c_str());
+      for (size_t j = 0; j < R2; j++) {
+        const uint32_t t = tot2.order[j];
+        fprintf(out, "\t%.10lg", cell_value(o, cells[R2 * s + t], tot1, s, tot2, t));
+      }
+      fprintf(out, "\n");
+    }
+  }
+  t1 = std::chrono::steady_clock::now();
+  fprintf(log, "Writing results:   100%% (%.9lfs)\n\n",
+          std::chrono::duration<double>(t1 - t0).count());
+  log_time(log, "End time:          ");
+
+  fclose(out);
+  if (log != stderr)
+    fclose(log);
+  return 0;
+}
+
+}  // namespace cmprhost

@@ -1,0 +1,184 @@
+/*
+ * compairr_hip.h -- C ABI of libcompairr_hip.so, the MI355X (gfx950) drop-in
+ * for CompAIRR's repertoire-overlap hot path.
+ *
+ * The reference has no FFI layer; its narrowest seam for this path is the
+ * launch of sim_thread inside overlap() (/root/reference/src/overlap.cc:926-936):
+ * everything before it (AIRR-TSV parse, db accessors) is the input, everything
+ * after it (matrix dump, overlap.cc:944-1039) the output.  The entry points
+ * below are what a binding at that seam needs; each cites the reference
+ * interface it replaces.  Plain pointers and sizes only, no C++/torch types.
+ *
+ * Threading: a context is used from one host thread at a time; distinct
+ * contexts are independent (no process-global state, unlike the file-static
+ * state at overlap.cc:24-53).
+ *
+ * Ownership: the caller owns every array it passes in and the output matrix;
+ * arrays may be freed as soon as the call that received them returns.  The
+ * library owns all device memory; nothing is retained after cmpr_destroy().
+ *
+ * Errors: every int-returning function returns 0 on success and a non-zero
+ * CMPR_E* code otherwise; cmpr_last_error() then gives the message.  The
+ * reference convention (fatal(): "\nError: %s\n" + exit(1), util.cc:84-88) is
+ * applied by the host program, not here.
+ */
+#ifndef COMPAIRR_HIP_H
+#define COMPAIRR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMPR_ABI_VERSION 1
+
+enum {
+  CMPR_OK          = 0,
+  CMPR_EINVAL      = 1,   /* illegal option / argument combination          */
+  CMPR_ENOMEM      = 2,   /* host or device allocation failed               */
+  CMPR_EDEVICE     = 3,   /* HIP runtime error (message has the HIP string) */
+  CMPR_EUNSUPPORTED= 4,   /* legal for the reference, not on this path      */
+  CMPR_ESTATE      = 5    /* calls out of order                             */
+};
+
+/* -s / --score, same numbering as the reference enum (compairr.h:125-135) */
+enum {
+  CMPR_SCORE_PRODUCT = 0,
+  CMPR_SCORE_RATIO   = 1,
+  CMPR_SCORE_MIN     = 2,
+  CMPR_SCORE_MAX     = 3,
+  CMPR_SCORE_MEAN    = 4,
+  CMPR_SCORE_MH      = 5,
+  CMPR_SCORE_JACCARD = 6
+};
+
+/*
+ * The process-global opt_* flags the loop reads (compairr.h:139-162), as a POD.
+ */
+typedef struct cmpr_options {
+  int32_t  differences;     /* opt_differences, 0..2 on this path             */
+  int32_t  indels;          /* opt_indels (requires differences == 1)         */
+  int32_t  ignore_genes;    /* opt_ignore_genes                               */
+  int32_t  ignore_counts;   /* opt_ignore_counts                              */
+  int32_t  score;           /* opt_score_int, CMPR_SCORE_*                    */
+  int32_t  alphabet_size;   /* alphabet_size: 20 (aa) or 4 (-n)               */
+  uint32_t n_v_genes;       /* db_get_v_gene_count() (db.cc:1018)             */
+  uint32_t n_j_genes;       /* db_get_j_gene_count() (db.cc:1023)             */
+  int32_t  device;          /* HIP device ordinal; -1 = current device        */
+  int32_t  reserved[7];     /* must be zero                                   */
+} cmpr_options;
+
+/*
+ * What the loop reads of a repertoire set through db_getsequence /
+ * db_getsequencelen / db_get_v_gene / db_get_j_gene / db_get_count /
+ * db_get_repertoire_id_no (db.cc:964-997), as structure-of-arrays in HOST
+ * memory.  Residues are the reference's codes (map_aa / map_nt, db.cc:33-71),
+ * not ASCII.
+ */
+typedef struct cmpr_set_view {
+  uint64_t        n;              /* number of sequences                      */
+  const uint8_t  *residues;       /* offsets[n] residue codes, concatenated   */
+  const uint64_t *offsets;        /* n + 1 entries, offsets[0] == 0           */
+  const uint32_t *v_gene;         /* n; may be NULL when ignore_genes         */
+  const uint32_t *j_gene;         /* n; may be NULL when ignore_genes         */
+  const uint32_t *repertoire;     /* n; values < n_repertoires                */
+  const uint64_t *count;          /* n; >= 1; may be NULL when ignore_counts  */
+  uint32_t        n_repertoires;
+  uint32_t        reserved;
+} cmpr_set_view;
+
+/* Work and timing of the last cmpr_overlap_* call. */
+typedef struct cmpr_stats {
+  uint64_t queries;            /* set-1 sequences processed                   */
+  uint64_t variants;           /* variant hashes probed against the Bloom     */
+  uint64_t bloom_positive;     /* probes that passed the Bloom filter         */
+  uint64_t hash_equal;         /* hash slots equal to a variant hash          */
+  uint64_t matches;            /* verified (query, hit) pairs                 */
+  uint64_t algorithmic_bytes;  /* sum over queries of (L + 20) + 8 * V(L)     */
+  double   kernel_ms;          /* HIP-event time of the probe kernel(s)       */
+  double   total_ms;           /* first launch -> matrix ready on the stream  */
+  uint32_t kernel_launches;
+  uint32_t reserved;
+} cmpr_stats;
+
+typedef struct cmpr_context cmpr_context;
+
+/* ABI version of the loaded library (== CMPR_ABI_VERSION it was built with). */
+int cmpr_abi_version(void);
+
+/*
+ * Create a context on one device.  Replaces the option globals + the
+ * zobrist_init() call (overlap.cc:840, zobrist.cc:28-67).
+ */
+int cmpr_create(const cmpr_options *options, cmpr_context **out);
+
+/* Frees device memory and the context (bloom_exit/hash_exit/zobrist_exit,
+   overlap.cc:1044-1049).  NULL is a no-op. */
+void cmpr_destroy(cmpr_context *ctx);
+
+/* Message of the last failed call on this context ("" if none).  With
+   ctx == NULL: message of the last failed cmpr_create() on this thread. */
+const char *cmpr_last_error(const cmpr_context *ctx);
+
+/*
+ * Upload set 2 and build its index on the device: per-sequence Zobrist hash
+ * (db_hash, db.cc:903-916), hash table + Bloom filter inserts (hash_init,
+ * bloom_init, hash_insert loop, overlap.cc:861-873).  Every entry is inserted,
+ * duplicates included.  `longest_query` is the longest set-1 sequence that
+ * will be submitted (the Zobrist table needs max(longest1, longest2) + 3
+ * positions, overlap.cc:840); pass 0 to size it from this set alone, in which
+ * case later longer queries make cmpr_set_queries() fail with CMPR_EINVAL.
+ */
+int cmpr_set_reference(cmpr_context *ctx, const cmpr_set_view *set2,
+                       uint32_t longest_query);
+
+/*
+ * Upload set 1 (the queries) and lay it out for the kernel.  After this call
+ * the queries are resident in HBM; cmpr_overlap_* may be called repeatedly.
+ * Passing the same view as set 2 gives the reference's one-file mode
+ * (overlap.cc:799-825).
+ */
+int cmpr_set_queries(cmpr_context *ctx, const cmpr_set_view *set1);
+
+/*
+ * The per-query loop (sim_thread / process_variants / find_variant_matches,
+ * overlap.cc:376-538, 253-284, 168-251).  Writes the R1 x R2 matrix,
+ * row = set-1 repertoire number, column = set-2 repertoire number
+ * (overlap.cc:222), as exact integer sums:
+ *   product, MH : sum of count1 * count2
+ *   min, Jaccard: sum of min;  max: sum of max;  -f: number of pairs
+ *   mean        : sum of (count1 + count2), i.e. TWICE the reference's cell
+ * The matrix is overwritten, not accumulated into.  Host-memory output.
+ * CMPR_SCORE_RATIO is not an integer sum: use cmpr_overlap_matrix_f64().
+ */
+int cmpr_overlap_matrix(cmpr_context *ctx, uint64_t *matrix_out);
+
+/* Same loop, double-precision cells; the only form that supports ratio
+   (order-dependent rounding, as in the threaded reference, overlap.cc:510-527). */
+int cmpr_overlap_matrix_f64(cmpr_context *ctx, double *matrix_out);
+
+/*
+ * Same loop, result left in DEVICE memory: `d_matrix` points to
+ * R1 * R2 uint64 on the context's device (e.g. a buffer a collective library
+ * will reduce across GPUs).  The kernels are enqueued on `stream`
+ * (a hipStream_t, NULL = the context's own stream) and the call returns
+ * without synchronising when `stream` is not NULL.
+ */
+int cmpr_overlap_matrix_device(cmpr_context *ctx, void *d_matrix, void *stream);
+
+/* Statistics of the last overlap call (synchronises the context's events). */
+int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);
+
+/* Sizes, for callers that allocate the matrix. */
+uint32_t cmpr_rows(const cmpr_context *ctx);      /* R1, after set_queries   */
+uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
+
+/* Tuning knobs (names are stable, unknown names -> CMPR_EINVAL):
+   "variant" (kernel variant id), "blocks_per_cu", "bloom_bits_log2_delta". */
+int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,57 @@
+"""Shared fixtures.  `-m "not gpu"` runs here on CPU (oracle vs golden vectors,
+host logic, C-ABI symbols); `-m gpu` runs on the MI355X box and goes through
+the C ABI of libcompairr_hip.so."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ARTIFACTS = [
+    "compairr_amd/lib/libcompairr_hip.so",
+    "bin/compairr",
+    "oracle/liboracle.so",
+    "tests/bin/compairr_oracle_cli",
+]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    missing = [a for a in ARTIFACTS if not os.path.exists(os.path.join(ROOT, a))]
+    if missing:
+        subprocess.run(["make", "-s", "-C", ROOT, "all"], check=True)
+
+
+def has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+GOLDEN_INPUTS = os.path.join(ROOT, "tests", "golden", "inputs")
+GOLDEN_EXPECTED = os.path.join(ROOT, "tests", "golden", "expected")
+
+
+def load_manifest():
+    with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as fh:
+        return json.load(fh)
+
+
+def run_cli(binary, case, timeout=120):
+    argv = [os.path.join(ROOT, binary), "-m"] + case["files"] + case["args"].split() + \
+           ["-l", os.devnull]
+    return subprocess.run(argv, cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def expected_of(case) -> bytes:
+    with open(os.path.join(GOLDEN_EXPECTED, case["name"] + ".tsv"), "rb") as fh:
+        return fh.read()

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs oracle/_ref/compairr (the unmodified reference program compiled from
+/root/reference by oracle/Makefile) on small inputs and records, per case, the
+argv, the input files, the exit status and the matrix it wrote to stdout.
+Inputs are (a) the reference's own test data files test/{seta,setb,setc}.tsv
+(data, copied verbatim), (b) hand-written edge-case TSVs defined below and
+(c) seeded random sets from compairr_amd.synth.
+
+Run from the repository root in the build container (needs /root/reference):
+    python tests/golden/make_golden.py
+The GPU box only ever reads the committed results.
+"""
+
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from compairr_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "compairr")
+REF_TEST = "/root/reference/test"
+INPUTS = os.path.join(HERE, "inputs")
+EXPECTED = os.path.join(HERE, "expected")
+
+HDR = "repertoire_id\tsequence_id\tduplicate_count\tv_call\tj_call\tjunction\tjunction_aa\n"
+
+
+def rows(lines, header=HDR, eol="\n"):
+    return header.replace("\n", eol) + "".join(l + eol for l in lines)
+
+
+EDGE_FILES = {
+    # CRLF line ends (db.cc:832-836)
+    "crlf.tsv": rows(["X1\ta\t2\tV1\tJ1\ttgtgct\tCASSL", "X2\tb\t3\tV1\tJ1\ttgtgca\tCASSV"], eol="\r\n"),
+    # lower-case residues, U in nucleotides (db.cc:33-71)
+    "lower.tsv": rows(["X1\ta\t2\tV1\tJ1\tugugcu\tcassl", "X1\tb\t5\tV1\tJ1\tTGTGCT\tCASSL",
+                       "X2\tc\t7\tV1\tJ1\ttgugca\tcAsSv"]),
+    # leading comment lines (db.cc:781-790)
+    "comments.tsv": "# a comment\n@another\n#\tthird\n" + rows(
+        ["X1\ta\t2\tV1\tJ1\ttgtgct\tCASSL", "X2\tb\t3\tV1\tJ1\ttgtgca\tCASSV"]),
+    # no repertoire_id column -> id "1"/"2" (overlap.cc:619,715; db.cc:505-508)
+    "norep.tsv": rows(["a\t2\tV1\tJ1\tCASSL", "b\t3\tV1\tJ1\tCASSV", "c\t4\tV2\tJ1\tCASSL"],
+                      header="sequence_id\tduplicate_count\tv_call\tj_call\tjunction_aa\n"),
+    # reordered + extra columns
+    "reorder.tsv": rows(["CASSL\tfoo\tJ1\t2\tX1\tV1\ta", "CASSV\tbar\tJ1\t3\tX2\tV1\tb",
+                         "CASSV\tbaz\tJ1\t11\tX1\tV1\tc"],
+                        header="junction_aa\textra\tj_call\tduplicate_count\trepertoire_id\tv_call\tsequence_id\n"),
+    # cdr3 / cdr3_aa columns (--cdr3)
+    "cdr3.tsv": rows(["X1\ta\t2\tV1\tJ1\tgctagc\tASSL\tCASSLF", "X2\tb\t3\tV1\tJ1\tgctagt\tASSV\tCASSVF",
+                      "X2\tc\t5\tV1\tJ1\tgctagc\tASSL\tCASSLW"],
+                     header="repertoire_id\tsequence_id\tduplicate_count\tv_call\tj_call\tcdr3\tcdr3_aa\tjunction_aa\n"),
+    # illegal symbols and empty sequences (-u, -e; db.cc:442-486)
+    "unknown.tsv": rows(["X1\ta\t2\tV1\tJ1\ttgt\tCASSL", "X1\tb\t3\tV1\tJ1\ttgn\tCAXSL",
+                         "X2\tc\t4\tV1\tJ1\ttgt\tCAS*L", "X2\td\t5\tV1\tJ1\t\t",
+                         "X2\te\t6\tV1\tJ1\ttgt\tCASSL", "X3\tf\t6\tV1\tJ1\ttgt\tCASSV"]),
+    # duplicates inside a repertoire, large counts (counts multiply)
+    "dups.tsv": rows(["X1\ta\t3000000\tV1\tJ1\ttgt\tCASSL", "X1\tb\t5\tV1\tJ1\ttgt\tCASSL",
+                      "X1\tc\t7\tV1\tJ1\ttgt\tCASSV", "X2\td\t4000000\tV1\tJ1\ttgt\tCASSL"]),
+    # display order is strcmp on ids: R1 < R10 < R2 (overlap.cc:130-142)
+    "order.tsv": rows(["R2\ta\t2\tV1\tJ1\ttgt\tCASSL", "R10\tb\t3\tV1\tJ1\ttgt\tCASSL",
+                       "R1\tc\t5\tV1\tJ1\ttgt\tCASSV", "R10\td\t7\tV1\tJ1\ttgt\tCASSV"]),
+    # indel corner cases: homopolymers, length 1, both ends (variants.cc:301-353)
+    "indel_a.tsv": rows(["P\ta\t1\tV1\tJ1\ta\tA", "P\tb\t2\tV1\tJ1\taa\tAA", "P\tc\t3\tV1\tJ1\taaa\tAAA",
+                         "P\td\t5\tV1\tJ1\taaaa\tAAAA", "Q\te\t7\tV1\tJ1\tca\tCA", "Q\tf\t11\tV1\tJ1\tac\tAC",
+                         "Q\tg\t13\tV1\tJ1\tc\tC", "Q\th\t17\tV1\tJ1\tcac\tCAC", "Q\ti\t19\tV1\tJ1\taca\tACA"]),
+    "indel_b.tsv": rows(["S\ta\t23\tV1\tJ1\taa\tAA", "S\tb\t29\tV1\tJ1\ta\tA", "T\tc\t31\tV1\tJ1\tcaa\tCAA",
+                         "T\td\t37\tV1\tJ1\taac\tAAC", "T\te\t41\tV1\tJ1\tcc\tCC", "S\tf\t43\tV1\tJ1\taaaaa\tAAAAA",
+                         "T\tg\t47\tV2\tJ1\taa\tAA", "S\th\t53\tV1\tJ2\tac\tAC"]),
+    # empty duplicate_count is legal only with -f (db.cc:545-571)
+    "nocount.tsv": rows(["X1\ta\t\tV1\tJ1\ttgt\tCASSL", "X2\tb\t\tV1\tJ1\ttgt\tCASSL", "X2\tc\t\tV1\tJ1\ttgt\tCASSV"]),
+    # no gene columns at all: legal with -g (db.cc:231-232)
+    "nogenes.tsv": rows(["X1\ta\t2\tCASSL", "X2\tb\t3\tCASSV", "X2\tc\t5\tCASSL"],
+                        header="repertoire_id\tsequence_id\tduplicate_count\tjunction_aa\n"),
+}
+
+
+def random_files():
+    """Seeded random inputs (c): aa/nt, several repertoires, planted neighbours."""
+    out = {}
+    for name, kw in {
+        "rand_aa_a.tsv": dict(n=700, seed=11, prefix="A", n_repertoires=5, pool_size=200),
+        "rand_aa_b.tsv": dict(n=600, seed=12, prefix="B", n_repertoires=4, pool_size=200),
+        "rand_nt_a.tsv": dict(n=300, seed=21, prefix="A", n_repertoires=3, pool_size=80, nucleotides=True),
+        "rand_nt_b.tsv": dict(n=250, seed=22, prefix="B", n_repertoires=3, pool_size=80, nucleotides=True),
+    }.items():
+        n = kw.pop("n")
+        seed = kw.pop("seed")
+        out[name] = (synth.make_set(n, seed, pool_seed=777, **kw), kw.get("nucleotides", False))
+    for name, kw in {
+        "tiny_aa_a.tsv": dict(n=120, seed=31, alphabet_size=20, letters=2, prefix="A"),
+        "tiny_aa_b.tsv": dict(n=100, seed=32, alphabet_size=20, letters=2, prefix="B"),
+        "tiny_nt_a.tsv": dict(n=150, seed=41, alphabet_size=4, letters=2, max_len=7, prefix="A"),
+        "tiny_nt_b.tsv": dict(n=130, seed=42, alphabet_size=4, letters=3, max_len=7, prefix="B"),
+    }.items():
+        n = kw.pop("n")
+        seed = kw.pop("seed")
+        out[name] = (synth.tiny_set(n, seed, **kw), kw["alphabet_size"] == 4)
+    return out
+
+
+def cases():
+    c = []
+
+    def add(name, args, files, note=""):
+        c.append({"name": name, "args": args, "files": files, "note": note})
+
+    # (a) the reference's own test + README examples + the survey's KAT table
+    add("ref_test_sh", "-d 1 -i", ["seta.tsv", "setb.tsv"], "test/test.sh:9, test/expected.tsv")
+    for k, (args, files) in enumerate([
+        ("-d 1", ["seta.tsv", "setb.tsv"]), ("", ["seta.tsv", "setb.tsv"]),
+        ("-d 1 -a", ["seta.tsv", "setb.tsv"]), ("-d 1 -g -n", ["seta.tsv", "setb.tsv"]),
+        ("-d 2 -n -g", ["seta.tsv", "setb.tsv"]), ("-d 1", ["setb.tsv"]),
+        ("-d 1 -s ratio -t 4", ["setb.tsv"]), ("-s jaccard", ["seta.tsv", "setb.tsv"]),
+        ("-s MH", ["setb.tsv"]), ("-d 3", ["seta.tsv", "setb.tsv"]),
+        ("-d 1", ["setb.tsv", "setb.tsv"]), ("-d 1 -i", ["seta.tsv", "setc.tsv"]),
+        ("-d 2", ["setb.tsv", "setc.tsv"]), ("-d 1 -f", ["seta.tsv", "setb.tsv"]),
+    ]):
+        add("ref_kat_%02d" % k, args, files)
+
+    # (b) edge inputs
+    add("edge_crlf", "-d 1", ["crlf.tsv", "lower.tsv"])
+    add("edge_lower_aa", "-d 1", ["lower.tsv"])
+    add("edge_lower_nt", "-d 1 -n", ["lower.tsv", "crlf.tsv"])
+    add("edge_comments", "-d 1 -i", ["comments.tsv", "crlf.tsv"])
+    add("edge_norep", "-d 1", ["norep.tsv", "crlf.tsv"])
+    add("edge_norep_both", "-d 1", ["norep.tsv", "norep.tsv"])
+    add("edge_norep_two", "", ["crlf.tsv", "norep.tsv"])
+    add("edge_reorder", "-d 1 -s min", ["reorder.tsv", "crlf.tsv"])
+    add("edge_cdr3_aa", "-d 1 --cdr3", ["cdr3.tsv"])
+    add("edge_cdr3_nt", "-d 1 --cdr3 -n", ["cdr3.tsv"])
+    add("edge_cdr3_junction", "-d 1", ["cdr3.tsv"])
+    add("edge_unknown_u_e", "-d 1 -u -e", ["unknown.tsv"])
+    add("edge_unknown_u_e_nt", "-d 1 -u -e -n", ["unknown.tsv", "crlf.tsv"])
+    add("edge_dups", "", ["dups.tsv"])
+    add("edge_dups_d1", "-d 1", ["dups.tsv", "dups.tsv"])
+    add("edge_dups_mh", "-s mh", ["dups.tsv"])
+    add("edge_order", "-d 1", ["order.tsv"])
+    add("edge_order_a", "-d 1 -a", ["order.tsv", "dups.tsv"])
+    add("edge_nocount_f", "-d 1 -f", ["nocount.tsv"])
+    add("edge_nogenes_g", "-d 1 -g", ["nogenes.tsv", "crlf.tsv"])
+    for score in ("product", "min", "max", "mean", "ratio"):
+        add("edge_indel_%s" % score, "-d 1 -i -s %s" % score, ["indel_a.tsv", "indel_b.tsv"])
+    add("edge_indel_self", "-d 1 -i", ["indel_a.tsv"])
+    add("edge_indel_nt", "-d 1 -i -n", ["indel_a.tsv", "indel_b.tsv"])
+    add("edge_indel_g", "-d 1 -i -g", ["indel_b.tsv", "indel_a.tsv"])
+    add("edge_indel_f", "-d 1 -i -f", ["indel_a.tsv", "indel_b.tsv"])
+    add("edge_indel_d2", "-d 2", ["indel_a.tsv", "indel_b.tsv"])
+    add("edge_indel_d0", "", ["indel_a.tsv", "indel_b.tsv"])
+
+    # errors: only the exit status is compared
+    add("err_illegal_char", "-d 1", ["unknown.tsv"], "exit 1")
+    add("err_empty_seq", "-d 1 -u", ["unknown.tsv"], "exit 1")
+    add("err_nocount", "-d 1", ["nocount.tsv"], "exit 1")
+    add("err_nogenes", "-d 1", ["nogenes.tsv"], "exit 1")
+    add("err_indel_d2", "-d 2 -i", ["seta.tsv", "setb.tsv"], "exit 1")
+    add("err_mh_d1", "-d 1 -s mh", ["seta.tsv", "setb.tsv"], "exit 1")
+    add("err_twice", "-d 1 -d 1", ["seta.tsv", "setb.tsv"], "exit 1")
+    add("err_score", "-s bogus", ["seta.tsv", "setb.tsv"], "exit 1")
+    add("err_missing_file", "-d 1", ["seta.tsv", "does_not_exist.tsv"], "exit 1")
+
+    # (c) random sets x option matrix
+    for fam, nt in (("rand_aa", False), ("rand_nt", True), ("tiny_aa", False), ("tiny_nt", True)):
+        a, b = "%s_a.tsv" % fam, "%s_b.tsv" % fam
+        n = " -n" if nt else ""
+        for d in ("", "-d 1", "-d 1 -i", "-d 2"):
+            tag = d.replace("-", "").replace(" ", "") or "d0"
+            for g in ("", " -g"):
+                add("%s_%s%s" % (fam, tag, "_g" if g else ""), (d + g + n).strip(), [a, b])
+            add("%s_%s_f" % (fam, tag), (d + " -f" + n).strip(), [a, b])
+            add("%s_%s_self" % (fam, tag), (d + n).strip(), [a])
+        for score in ("min", "max", "mean"):
+            add("%s_d1_%s" % (fam, score), ("-d 1 -s %s%s" % (score, n)).strip(), [a, b])
+        add("%s_jaccard" % fam, ("-s jaccard" + n).strip(), [a, b])
+        add("%s_mh" % fam, ("-s MH" + n).strip(), [a, b])
+        add("%s_mh_self" % fam, ("-s MH -a" + n).strip(), [b])
+        add("%s_d1_t3" % fam, ("-d 1 -i -t 3" + n).strip(), [a, b])
+    add("tiny_aa_d3", "-d 3", ["tiny_aa_a.tsv", "tiny_aa_b.tsv"], "d > 2: reference's brute-force path")
+    return c
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("build the reference first: make -C oracle ref")
+    shutil.rmtree(INPUTS, ignore_errors=True)
+    shutil.rmtree(EXPECTED, ignore_errors=True)
+    os.makedirs(INPUTS)
+    os.makedirs(EXPECTED)
+    for f in ("seta.tsv", "setb.tsv", "setc.tsv"):
+        shutil.copy(os.path.join(REF_TEST, f), os.path.join(INPUTS, f))
+    for name, text in EDGE_FILES.items():
+        with open(os.path.join(INPUTS, name), "w", newline="") as fh:
+            fh.write(text)
+    for name, (s, nt) in random_files().items():
+        # both junction and junction_aa columns are not needed: one file per alphabet
+        s.write_tsv(os.path.join(INPUTS, name), nucleotides=nt)
+
+    manifest = []
+    for case in cases():
+        argv = [REF, "-m"] + case["files"] + case["args"].split() + ["-l", os.devnull]
+        p = subprocess.run(argv, cwd=INPUTS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        entry = dict(case)
+        entry["exit"] = p.returncode
+        if p.returncode == 0:
+            with open(os.path.join(EXPECTED, case["name"] + ".tsv"), "wb") as fh:
+                fh.write(p.stdout)
+        elif not case["name"].startswith("err_"):
+            sys.exit("reference failed on %s: %s" % (case["name"], argv))
+        manifest.append(entry)
+    with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    print("%d cases written" % len(manifest))
+
+
+if __name__ == "__main__":
+    main()
