@@ -95,6 +95,14 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch (used by the tests and bench.py for device buffers, streams and
+    # torch.distributed) bundles its own libamdhip64 with the same SONAME; two HIP
+    # runtimes in one process do not both see the GPU.  Loading torch first
+    # makes this library bind to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(

@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+oracle on the same seeded inputs (bit-exact integer cells), against the golden
+vectors of the real reference (byte-exact TSV through bin/compairr), and --
+at sizes the oracle cannot reach in seconds -- through size-independent
+properties."""
+
+import numpy as np
+import pytest
+
+import _oracle
+from compairr_amd import HipOverlap, Options, synth
+from compairr_amd import hip as hipmod
+from conftest import expected_of, load_manifest, run_cli
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_manifest()
+FULL = dict(n_v_genes=synth.N_V, n_j_genes=synth.N_J)
+
+
+def gpu_cells(a, b, opt):
+    with HipOverlap(opt) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        if opt.score == "ratio" and not opt.ignore_counts:
+            return h.overlap_matrix_f64(), h.stats()
+        return h.overlap_matrix(), h.stats()
+
+
+def check(a, b, opt, threads=4):
+    got, st = gpu_cells(a, b, opt)
+    want, ost = _oracle.overlap(a, b, opt, threads=threads)
+    assert np.array_equal(got, _oracle.integer_cells(want, opt)), (opt, got, want)
+    assert st.matches == ost.matches
+    assert st.variants == ost.variants
+    return st
+
+
+# ---- golden vectors of the real reference, through the product binary ----
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_cli_matches_reference_golden(case):
+    p = run_cli("bin/compairr", case)
+    d = [int(x) for x in [case["args"].split()[i + 1] for i, a in
+                          enumerate(case["args"].split()) if a == "-d"][:1]]
+    if case["exit"] == 0 and d and d[0] > 2:
+        # the reference's all-against-all path (overlap.cc:286-359) is out of scope
+        assert p.returncode == 1 and b"d > 2" in p.stderr
+        return
+    if case["exit"] != 0:
+        assert p.returncode == case["exit"]
+        return
+    assert p.returncode == 0, p.stderr.decode()
+    if "ratio" in case["args"]:
+        # order-dependent floating-point sum also inside the reference
+        got = [l.split(b"\t") for l in p.stdout.splitlines()]
+        exp = [l.split(b"\t") for l in expected_of(case).splitlines()]
+        assert got[0] == exp[0]
+        for g, e in zip(got[1:], exp[1:]):
+            assert g[0] == e[0]
+            assert np.allclose([float(x) for x in g[1:]], [float(x) for x in e[1:]],
+                               rtol=1e-9, atol=0)
+        return
+    assert p.stdout == expected_of(case)
+
+
+# ---- HIP vs oracle on seeded inputs, option matrix ----
+
+@pytest.mark.parametrize("d,indels", [(0, False), (1, False), (1, True), (2, False)])
+@pytest.mark.parametrize("nt", [False, True])
+def test_tiny_adversarial_sets(d, indels, nt):
+    """2-3 letter alphabets: homopolymer runs, many exact duplicates, length-1
+    sequences, every sequence has many neighbours."""
+    A = 4 if nt else 20
+    for seed in range(12):
+        x = synth.tiny_set(300, seed, alphabet_size=A, letters=2 + seed % 2, max_len=7)
+        y = synth.tiny_set(257, seed + 500, alphabet_size=A, letters=2 + seed % 2, max_len=7)
+        o = Options(differences=d, indels=indels, nucleotides=nt, n_v_genes=2, n_j_genes=2,
+                    ignore_genes=(seed % 3 == 0), ignore_counts=(seed % 5 == 0),
+                    score=["product", "min", "max", "mean"][seed % 4])
+        check(x, y, o)
+        check(x, x, o)          # one-file mode: self pairs count
+
+
+@pytest.mark.parametrize("d,indels,n", [(0, False, 200000), (1, False, 100000),
+                                        (1, True, 60000), (2, False, 3000)])
+def test_synthetic_aa(d, indels, n):
+    a = synth.make_set(n, 1, prefix="A", pool_size=n // 4)
+    b = synth.make_set(n + 777, 2, prefix="B", pool_size=n // 4)
+    st = check(a, b, Options(differences=d, indels=indels, **FULL), threads=8)
+    assert st.matches > 0 and st.bloom_positive > 0 and st.hash_equal >= st.matches
+
+
+@pytest.mark.parametrize("d,indels,n", [(0, False, 100000), (1, False, 50000),
+                                        (1, True, 30000), (2, False, 4000)])
+def test_synthetic_nt(d, indels, n):
+    a = synth.make_set(n, 3, prefix="A", pool_size=n // 4, nucleotides=True)
+    b = synth.make_set(n + 13, 4, prefix="B", pool_size=n // 4, nucleotides=True)
+    st = check(a, b, Options(differences=d, indels=indels, nucleotides=True,
+                             ignore_genes=True, **FULL), threads=8)
+    assert st.matches > 0
+
+
+@pytest.mark.parametrize("score", ["product", "min", "max", "mean"])
+@pytest.mark.parametrize("f", [False, True])
+def test_scores(score, f):
+    a = synth.make_set(30000, 5, prefix="A", pool_size=5000)
+    b = synth.make_set(30000, 6, prefix="B", pool_size=5000)
+    check(a, b, Options(differences=1, indels=True, score=score, ignore_counts=f, **FULL))
+
+
+def test_ratio_within_tolerance():
+    a = synth.make_set(30000, 5, prefix="A", pool_size=5000)
+    b = synth.make_set(30000, 6, prefix="B", pool_size=5000)
+    o = Options(differences=1, score="ratio", **FULL)
+    got, _ = gpu_cells(a, b, o)
+    want, _ = _oracle.overlap(a, b, o)
+    # floating-point sum, order-dependent in the reference too (overlap.cc:510-527)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
+def test_mh_and_jaccard_sums_d0():
+    a = synth.make_set(50000, 7, prefix="A", pool_size=5000)
+    b = synth.make_set(50000, 8, prefix="B", pool_size=5000)
+    for s in ("mh", "jaccard"):
+        check(a, b, Options(differences=0, score=s, **FULL))
+
+
+def test_many_repertoires_uses_global_atomics():
+    """R1 x R2 > 2048 cells: the matrix is no longer privatised in LDS."""
+    a = synth.make_set(40000, 9, prefix="A", pool_size=5000, n_repertoires=70)
+    b = synth.make_set(40000, 10, prefix="B", pool_size=5000, n_repertoires=64)
+    assert a.n_repertoires * b.n_repertoires > 2048
+    check(a, b, Options(differences=1, indels=True, **FULL))
+
+
+def test_ragged_and_empty():
+    o = Options(differences=1, indels=True, **FULL)
+    a = synth.make_set(1000, 1, prefix="A", pool_size=1000)
+    b = synth.make_set(1, 2, prefix="B", pool_size=1000)
+    check(a, b, o)                     # one reference sequence
+    check(b, a, o)                     # one query
+    e = synth.make_set(0, 1)
+    with HipOverlap(o) as h:
+        h.set_reference(a, 0)
+        h.set_queries(e)               # no queries: 0 x R2 matrix
+        assert h.overlap_matrix().shape == (0, a.n_repertoires)
+    # 63 / 64 / 65 queries of one length: tile padding
+    for n in (63, 64, 65, 129):
+        q = a.subset(np.flatnonzero(a.lengths == 15)[:n])
+        check(q, a, o)
+
+
+def test_long_sequences():
+    rng = np.random.default_rng(5)
+    n, L = 300, 200
+    res = rng.integers(0, 4, size=n * L, dtype=np.uint8)
+    for k in range(1, n, 2):           # plant neighbours of the previous sequence
+        res[k * L:(k + 1) * L] = res[(k - 1) * L:k * L]
+        res[k * L + int(rng.integers(0, L))] ^= 1
+    from compairr_amd.sets import NT, RepertoireSet
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    s = RepertoireSet(res, offs, np.zeros(n, np.uint32), np.zeros(n, np.uint32),
+                      (np.arange(n) % 3).astype(np.uint32), np.full(n, 2, np.uint64),
+                      ["a", "b", "c"], ["V"], ["J"], NT)
+    o = Options(differences=1, indels=True, nucleotides=True, n_v_genes=1, n_j_genes=1)
+    st = check(s, s, o)
+    assert st.matches >= n + 2 * (n // 2)
+
+
+def test_errors_through_the_abi():
+    a = synth.make_set(100, 1)
+    with HipOverlap(Options(differences=1, **FULL)) as h:
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_queries(a)           # before set_reference
+        assert e.value.code == 5
+        h.set_reference(a, 0)
+        with pytest.raises(hipmod.HipError):
+            h.set_reference(a.subset(slice(0, 10)), 0) or h.set_queries(
+                synth.make_set(10, 1, nucleotides=True))   # longer than announced
+    with HipOverlap(Options(differences=1, score="ratio", **FULL)) as h:
+        h.set_reference(a, a.longest)
+        h.set_queries(a)
+        with pytest.raises(hipmod.HipError):
+            h.overlap_matrix()         # ratio needs the f64 entry point
+
+
+def test_repeatable_and_device_output():
+    import torch
+    a = synth.make_set(50000, 1, prefix="A")
+    b = synth.make_set(50000, 2, prefix="B")
+    o = Options(differences=1, **FULL)
+    with HipOverlap(o) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        m1 = h.overlap_matrix()
+        m2 = h.overlap_matrix()
+        assert np.array_equal(m1, m2)
+        t = torch.zeros(m1.size, dtype=torch.int64, device="cuda")
+        s = torch.cuda.current_stream()
+        h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(t.cpu().numpy().astype(np.uint64).reshape(m1.shape), m1)
+
+
+# ---- full-size properties (BASELINE configs; no oracle at this size) ----
+
+def test_full_size_properties_1m():
+    """config 2/3 shape at 1M: symmetry (swap the sets -> transposed matrix),
+    query-shard linearity, monotonicity in d, and the d = 0 self-comparison
+    known answer."""
+    n = 1_000_000
+    a = synth.make_set(n, 1, prefix="A")
+    b = synth.make_set(n, 2, prefix="B")
+    o1 = Options(differences=1, **FULL)
+    mab, st = gpu_cells(a, b, o1)
+    mba, _ = gpu_cells(b, a, o1)
+    assert np.array_equal(mab, mba.T)
+    assert st.variants == int((1 + 19 * a.lengths).sum())
+    # linearity over query shards (what the multi-GPU path relies on)
+    parts = [gpu_cells(a.subset(slice(k * n // 3, (k + 1) * n // 3)), b, o1)[0] for k in range(3)]
+    # shard repertoire numbering is the full set's (subset keeps it)
+    assert np.array_equal(sum(parts), mab)
+    m0, _ = gpu_cells(a, b, Options(differences=0, **FULL))
+    assert (mab >= m0).all() and mab.sum() > m0.sum() > 0
+    # d = 0, -f, self: every cell counts pairs of identical (seq, V, J) entries
+    of = Options(differences=0, ignore_counts=True, **FULL)
+    ms, _ = gpu_cells(a, a, of)
+    assert np.trace(ms) >= n and np.array_equal(ms, ms.T)
