@@ -18,7 +18,7 @@ HOST_CORE = compairr_amd/host/airr_tsv.cc compairr_amd/host/options.cc compairr_
 HOST_SRC = $(HOST_CORE) compairr_amd/host/hip_backend.cc
 HOST_HDR = $(wildcard compairr_amd/host/*.h) include/compairr_hip.h
 KERN_SRC = compairr_amd/csrc/compairr_hip.hip
-KERN_HDR = compairr_amd/csrc/kernels.h compairr_amd/csrc/layout.h include/compairr_hip.h
+KERN_HDR = compairr_amd/csrc/kernels.h compairr_amd/csrc/kernels_sliced.h compairr_amd/csrc/layout.h include/compairr_hip.h
 
 all: lib cli oracle
 

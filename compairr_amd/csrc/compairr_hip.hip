@@ -7,6 +7,7 @@
  */
 #include "../../include/compairr_hip.h"
 #include "kernels.h"
+#include "kernels_sliced.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -62,8 +63,19 @@ struct cmpr_context {
 
   /* tunables */
   int64_t blocks_per_cu = 8;
-  int64_t variant = 0;
+  int64_t variant = 1;            /* 0: one global Bloom; 1: LDS-staged slices */
   int64_t bloom_log2_delta = 0;
+  int64_t class_residues = -1;    /* -1: choose from the data                  */
+  int64_t chunk_tiles = 32;
+  int64_t slice_words_log2 = SLICE_WORDS_LOG2;
+
+  /* sliced Bloom layout (variant 1) */
+  bool                  sliced = false;
+  SliceGeom             geom{};
+  std::vector<uint32_t> ctab;     /* host copy of the class tables             */
+  DevBuf<uint32_t>      d_ctab;
+  DevBuf<Chunk>         chunks;
+  uint32_t              nchunks = 0;
 
   /* Zobrist + patterns */
   uint32_t          zpos = 0;
@@ -232,7 +244,37 @@ uint64_t variants_of(const cmpr_options &o, const uint8_t *s, uint32_t L)
   return n;
 }
 
+/* host twin of class_key() in kernels.h */
+uint32_t class_key_host(const SliceGeom &g, const std::vector<uint32_t> &t, uint32_t A,
+                        bool genes, const uint8_t *s, uint32_t L, uint32_t v, uint32_t j,
+                        uint32_t k)
+{
+  uint32_t ck = t[L];
+  if (genes)
+    ck ^= t[g.off_cv + v] ^ t[g.off_cj + j];
+  if (L > 0)
+    for (uint32_t i = 0; i < k; i++)
+      ck ^= t[g.off_cr + i * A + s[class_pos(L, i)]];
+  return ck;
+}
+
 using ProbeFn = void (*)(const ProbeParams);
+
+ProbeFn select_sliced_kernel(const cmpr_options &o)
+{
+#define PICK(A_, D_, I_)                                                        \
+  (o.ignore_genes ? (ProbeFn)probe_sliced_kernel<A_, D_, I_, false>             \
+                  : (ProbeFn)probe_sliced_kernel<A_, D_, I_, true>)
+  if (o.alphabet_size == 20) {
+    if (o.differences == 0) return PICK(20, 0, false);
+    if (o.differences == 1) return o.indels ? PICK(20, 1, true) : PICK(20, 1, false);
+    return PICK(20, 2, false);
+  }
+  if (o.differences == 0) return PICK(4, 0, false);
+  if (o.differences == 1) return o.indels ? PICK(4, 1, true) : PICK(4, 1, false);
+  return PICK(4, 2, false);
+#undef PICK
+}
 
 ProbeFn select_kernel(const cmpr_options &o)
 {
@@ -312,6 +354,19 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipEventCreate(&c->ev_k1));
   CREATE_TRY(hipEventCreate(&c->ev_stop));
 #undef CREATE_TRY
+  /* environment overrides of the tunables (for the CLI, which has no flag) */
+  if (const char *e = getenv("COMPAIRR_HIP_VARIANT"))
+    c->variant = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("COMPAIRR_HIP_SLICE_WORDS_LOG2")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 13)
+      c->slice_words_log2 = v;
+  }
+  if (const char *e = getenv("COMPAIRR_HIP_CLASS_RESIDUES")) {
+    int v = atoi(e);
+    if (v >= -1 && v <= (int)MAX_CLASS_RES)
+      c->class_residues = v;
+  }
   *out = c;
   return CMPR_OK;
 }
@@ -330,7 +385,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
-  c->tile_counter.release();
+  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
@@ -357,7 +412,27 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_EINVAL, "blocks_per_cu must be 1..16");
     c->blocks_per_cu = value;
   } else if (n == "variant") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "variant must be 0 or 1");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set variant before cmpr_set_reference");
     c->variant = value;
+  } else if (n == "class_residues") {
+    if (value < -1 || value > (int64_t)MAX_CLASS_RES)
+      return fail(c, CMPR_EINVAL, "class_residues must be -1..3");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
+    c->class_residues = value;
+  } else if (n == "slice_words_log2") {
+    if (value < 1 || value > 13)
+      return fail(c, CMPR_EINVAL, "slice_words_log2 must be 1..13");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set slice_words_log2 before cmpr_set_reference");
+    c->slice_words_log2 = value;
+  } else if (n == "chunk_tiles") {
+    if (value < 1 || value > 4096)
+      return fail(c, CMPR_EINVAL, "chunk_tiles must be 1..4096");
+    c->chunk_tiles = value;
   } else if (n == "bloom_bits_log2_delta") {
     if (value < -4 || value > 4)
       return fail(c, CMPR_EINVAL, "bloom_bits_log2_delta must be -4..4");
@@ -458,6 +533,55 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   if (bloom_bytes > (1ull << 32))
     return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
   c->bloom_words = bloom_bytes / 8;
+
+  /* ---- variant 1: cut the filter into class-keyed slices (layout.h) ---- */
+  c->sliced = c->variant == 1;
+  if (c->sliced) {
+    SliceGeom &g = c->geom;
+    uint32_t wl = 0;
+    while ((1ull << (wl + 1)) <= c->bloom_words && wl + 1 <= (uint32_t)c->slice_words_log2)
+      wl++;
+    g.words_log2 = wl;
+    g.smask = (uint32_t)(c->bloom_words >> wl) - 1;
+    g.ncl = c->zpos + 1;
+    g.off_cv = g.ncl;
+    g.off_cj = g.off_cv + n_v;
+    g.off_cr = g.off_cj + n_j;
+    c->ctab.assign((size_t)g.off_cr + MAX_CLASS_RES * A, 0);
+    SplitMix64 crng(0x736c69636573ull);     /* "slices" */
+    for (auto &x : c->ctab)
+      x = (uint32_t)(crng.next() >> 32);
+    /* k = fewest class residues that spread set 2 evenly over the slices */
+    const uint64_t S = (uint64_t)g.smask + 1;
+    uint32_t best_k = 0;
+    if (c->class_residues >= 0) {
+      best_k = (uint32_t)c->class_residues;
+    } else if (S > 1 && s->n > 0) {
+      double best_max = -1;
+      std::vector<uint32_t> pop;
+      for (uint32_t k = 0; k <= MAX_CLASS_RES; k++) {
+        pop.assign((size_t)S, 0);
+        for (uint64_t i = 0; i < s->n; i++) {
+          const uint64_t b = s->offsets[i];
+          const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+          pop[class_key_host(g, c->ctab, A, !c->opt.ignore_genes, s->residues + b, L,
+                             c->opt.ignore_genes ? 0 : s->v_gene[i],
+                             c->opt.ignore_genes ? 0 : s->j_gene[i], k) & g.smask]++;
+        }
+        const double mx = *std::max_element(pop.begin(), pop.end());
+        const double mean = (double)s->n / (double)S;
+        if (best_max < 0 || mx < best_max) {
+          best_max = mx;
+          best_k = k;
+        }
+        if (mx <= 2.0 * mean + 64)
+          break;
+      }
+    }
+    g.k = best_k;
+    if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
+    g.ctab = c->d_ctab.p;
+  }
   if ((rc = dev_alloc(c, c->keys, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->vals, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
@@ -482,6 +606,8 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.bloom = c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.patterns = c->patterns.p;
+    B.sliced = c->sliced ? 1u : 0u;
+    B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
                        c->stream, B);
@@ -531,44 +657,101 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
                   "duplicate counts too large for exact 64-bit accumulation");
   }
 
-  /* counting sort by length, longest first (heavy tiles are handed out first) */
-  std::vector<uint64_t> per_len((size_t)longest + 2, 0);
-  for (uint64_t i = 0; i < s->n; i++)
-    per_len[s->offsets[i + 1] - s->offsets[i]]++;
-  std::vector<uint64_t> tile_first((size_t)longest + 2, 0);   /* first tile of a length */
+  /* Counting sort into groups of equal (slice, length): slices ascending,
+     inside a slice longest first.  Variant 0 has one slice.  Every group is
+     cut into 64-query tiles. */
+  const uint32_t A = (uint32_t)c->opt.alphabet_size;
+  const uint64_t S = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
+  const uint64_t per_slice = (uint64_t)longest + 1;
+  std::vector<uint32_t> group_of((size_t)s->n);
+  std::vector<uint64_t> per_group((size_t)(S * per_slice), 0);
+  for (uint64_t i = 0; i < s->n; i++) {
+    const uint64_t b = s->offsets[i];
+    const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+    uint32_t slice = 0;
+    if (c->sliced)
+      slice = class_key_host(c->geom, c->ctab, A, !c->opt.ignore_genes, s->residues + b, L,
+                             c->opt.ignore_genes ? 0 : s->v_gene[i],
+                             c->opt.ignore_genes ? 0 : s->j_gene[i], c->geom.k) &
+              c->geom.smask;
+    const uint64_t g = (uint64_t)slice * per_slice + (longest - L);
+    group_of[i] = (uint32_t)g;
+    per_group[g]++;
+  }
+  if (S * per_slice >= 0xffffffffull)
+    return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
+  std::vector<uint64_t> tile_first((size_t)(S * per_slice), 0);
   uint64_t ntiles = 0, res_words = 0;
   std::vector<TileDesc> tiles;
-  for (int64_t L = longest; L >= 0; L--) {
-    tile_first[L] = ntiles;
-    const uint64_t cnt = per_len[L];
-    const uint64_t nt = (cnt + WAVE - 1) / WAVE;
-    const uint64_t words = ((uint64_t)L + 3) / 4;
-    for (uint64_t k = 0; k < nt; k++) {
-      TileDesc td;
-      td.len = (uint32_t)L;
-      td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
-      td.res_base = res_words;
-      res_words += words * WAVE;
-      tiles.push_back(td);
+  std::vector<Chunk> chunks;
+  std::vector<uint64_t> chunk_work;
+  for (uint64_t slice = 0; slice < S; slice++) {
+    const uint64_t slice_first = ntiles;
+    for (uint64_t gl = 0; gl < per_slice; gl++) {
+      const uint64_t g = slice * per_slice + gl;
+      const uint64_t L = longest - gl;
+      tile_first[g] = ntiles;
+      const uint64_t cnt = per_group[g];
+      const uint64_t nt = (cnt + WAVE - 1) / WAVE;
+      const uint64_t words = (L + 3) / 4;
+      for (uint64_t k = 0; k < nt; k++) {
+        TileDesc td;
+        td.len = (uint32_t)L;
+        td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
+        td.res_base = res_words;
+        td.slice = (uint32_t)slice;
+        td.pad = 0;
+        res_words += words * WAVE;
+        tiles.push_back(td);
+      }
+      ntiles += nt;
     }
-    ntiles += nt;
+    if (c->sliced)
+      for (uint64_t t0 = slice_first; t0 < ntiles; t0 += (uint64_t)c->chunk_tiles) {
+        Chunk ck;
+        ck.slice = (uint32_t)slice;
+        ck.first_tile = (uint32_t)t0;
+        ck.ntiles = (uint32_t)std::min<uint64_t>((uint64_t)c->chunk_tiles, ntiles - t0);
+        ck.pad = 0;
+        uint64_t work = 0;
+        for (uint32_t t = 0; t < ck.ntiles; t++)
+          work += (uint64_t)(tiles[t0 + t].len + 1) * tiles[t0 + t].nvalid;
+        chunks.push_back(ck);
+        chunk_work.push_back(work);
+      }
   }
   if (ntiles * WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
   c->ntiles = (uint32_t)ntiles;
+  if (c->sliced) {
+    /* heaviest chunks first: the tail of the launch is made of light ones */
+    std::vector<uint32_t> order(chunks.size());
+    for (uint32_t i = 0; i < order.size(); i++)
+      order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      return chunk_work[x] > chunk_work[y];
+    });
+    std::vector<Chunk> sorted(chunks.size());
+    for (size_t i = 0; i < order.size(); i++)
+      sorted[i] = chunks[order[i]];
+    c->nchunks = (uint32_t)sorted.size();
+    if ((rc = dev_upload(c, c->chunks, sorted.data(), sorted.size()))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
 
   const size_t slots = (size_t)ntiles * WAVE;
   std::vector<uint32_t> qres((size_t)res_words, 0), qrep(slots, 0), qv, qj;
   std::vector<uint64_t> qcnt;
   if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
   if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
-  std::vector<uint64_t> fill((size_t)longest + 2, 0);
+  std::vector<uint64_t> fill((size_t)(S * per_slice), 0);
   uint64_t alg = 0;
   for (uint64_t i = 0; i < s->n; i++) {
     const uint64_t b = s->offsets[i];
     const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-    const uint64_t k = fill[L]++;
-    const uint64_t tile = tile_first[L] + k / WAVE;
+    const uint64_t g = group_of[i];
+    const uint64_t k = fill[g]++;
+    const uint64_t tile = tile_first[g] + k / WAVE;
     const uint32_t lane = (uint32_t)(k % WAVE);
     const size_t slot = (size_t)tile * WAVE + lane;
     qrep[slot] = s->repertoire[i];
@@ -657,20 +840,27 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
     P.tile_counter = c->tile_counter.p;
     P.stats = c->stats.p;
+    P.geom = c->geom;
+    P.chunks = c->chunks.p;
+    P.nchunks = c->nchunks;
 
-    const size_t lds = ((size_t)A * c->zpos + PATTERN_COUNT) * sizeof(uint64_t) +
-                       (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
-                       WAVES_PER_BLOCK * sizeof(WaveQueue);
+    size_t lds = ((size_t)A * c->zpos + PATTERN_COUNT) * sizeof(uint64_t) +
+                 (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
+                 WAVES_PER_BLOCK * sizeof(WaveQueue);
+    if (c->sliced)
+      lds += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
+             MAX_CLASS_RES * A * sizeof(uint32_t) + 16;
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    ProbeFn fn = select_kernel(c->opt);
+    ProbeFn fn = c->sliced ? select_sliced_kernel(c->opt) : select_kernel(c->opt);
     if (lds > 48 * 1024)
       HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t waves_needed = c->ntiles;
     uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
-    grid = std::min<uint64_t>(grid, (waves_needed + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks
+                                              : ((uint64_t)c->ntiles + WAVES_PER_BLOCK - 1) /
+                                                    WAVES_PER_BLOCK);
     grid = std::max<uint64_t>(grid, 1);
     hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(BLOCK_THREADS), lds, st, P);
     HIP_TRY(c, hipGetLastError());

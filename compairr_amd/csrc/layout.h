@@ -44,6 +44,45 @@ struct TileDesc {
   uint32_t len;       /* residues per query in this tile                    */
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
   uint64_t res_base;  /* dword offset of the tile's residues in qres         */
+  uint32_t slice;     /* Bloom slice of every query of the tile (sliced mode) */
+  uint32_t pad;
+};
+
+/* Sliced Bloom layout (kernel variant 1).  The filter is cut into S = 2^s
+   slices of 2^w words; a sequence's slice is NOT taken from its Zobrist hash
+   but from a "class key" that is invariant under most single edits:
+       ckey = CL[len] ^ CV[v] ^ CJ[j] ^ CR[0][seq[m_0]] ^ ... ^ CR[k-1][seq[m_k-1]]
+       slice = ckey & (S - 1),   m_i = (len / 2 + i) % len
+   so every substitution variant of a query that does not touch one of the k
+   class positions lives in the query's own slice.  Queries are grouped by
+   slice, a workgroup stages that 2^w-word slice into LDS once and answers
+   those probes from LDS; only variants that change the class (substitution at
+   a class position, indels) go to the filter in HBM.  The word inside a slice
+   and the bit pattern still come from the Zobrist hash. */
+constexpr uint32_t MAX_CLASS_RES     = 3;
+constexpr uint32_t SLICE_WORDS_LOG2  = 11;     /* 2048 words = 16 KiB per slice */
+
+struct SliceGeom {
+  uint32_t smask;          /* S - 1                                          */
+  uint32_t words_log2;     /* w                                              */
+  uint32_t k;              /* class residues, 0..MAX_CLASS_RES               */
+  uint32_t ncl;            /* entries of CL (lengths 0..ncl-1)               */
+  /* class tables, u32 each: CL[ncl] | CV[n_v] | CJ[n_j] | CR[MAX_CLASS_RES][A] */
+  const uint32_t *ctab;
+  uint32_t off_cv, off_cj, off_cr, pad;
+};
+
+__host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i)
+{
+  return len ? (len / 2 + i) % len : 0;
+}
+
+/* one block-level work item of the sliced kernel: tiles of one slice */
+struct Chunk {
+  uint32_t slice;
+  uint32_t first_tile;
+  uint32_t ntiles;
+  uint32_t pad;
 };
 
 /* per-launch kernel arguments */
@@ -85,6 +124,11 @@ struct ProbeParams {
   int32_t         ignore_counts;
   int32_t         lds_matrix;      /* 1: privatise the matrix in LDS          */
   int32_t         pad1;
+  /* sliced mode */
+  SliceGeom       geom;
+  const Chunk    *chunks;
+  uint32_t        nchunks;
+  uint32_t        pad2;
   /* work distribution + statistics */
   uint32_t           *tile_counter;
   unsigned long long *stats;       /* [variants, bloom+, hash==, matches]     */

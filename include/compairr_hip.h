@@ -174,8 +174,16 @@ int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);
 uint32_t cmpr_rows(const cmpr_context *ctx);      /* R1, after set_queries   */
 uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
 
-/* Tuning knobs (names are stable, unknown names -> CMPR_EINVAL):
-   "variant" (kernel variant id), "blocks_per_cu", "bloom_bits_log2_delta". */
+/* Tuning knobs (unknown names -> CMPR_EINVAL).  Results never depend on them.
+     "variant"               0: one Bloom filter probed in HBM; 1 (default):
+                             class-keyed 16 KiB slices staged in LDS
+     "blocks_per_cu"         resident workgroups per CU the grid is sized for
+     "bloom_bits_log2_delta" filter size = hash-table slots bytes << delta
+     "class_residues"        -1 (default: from the data) or 0..3
+     "slice_words_log2"      log2 of 64-bit words per slice (default 11)
+     "chunk_tiles"           tiles per workgroup work item (default 32)
+   "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
+   must be set before cmpr_set_reference(). */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

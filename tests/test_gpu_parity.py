@@ -18,8 +18,10 @@ CASES = load_manifest()
 FULL = dict(n_v_genes=synth.N_V, n_j_genes=synth.N_J)
 
 
-def gpu_cells(a, b, opt):
+def gpu_cells(a, b, opt, tun=None):
     with HipOverlap(opt) as h:
+        for k, v in (tun or {}).items():
+            h.set_tunable(k, v)
         h.set_reference(b, a.longest)
         h.set_queries(a)
         if opt.score == "ratio" and not opt.ignore_counts:
@@ -27,12 +29,28 @@ def gpu_cells(a, b, opt):
         return h.overlap_matrix(), h.stats()
 
 
-def check(a, b, opt, threads=4):
-    got, st = gpu_cells(a, b, opt)
+# kernel variants / layouts every parity case is run under: the un-sliced filter
+# in HBM, the default LDS-staged slices, and deliberately tiny slices (64 B,
+# 3 class residues) so that small inputs still spread over many slices and
+# exercise every class-changing variant
+LAYOUTS = {
+    "hbm": {"variant": 0},
+    "lds": {"variant": 1},
+    "lds_tiny_k3": {"variant": 1, "slice_words_log2": 3, "class_residues": 3, "chunk_tiles": 2},
+    "lds_tiny_k1": {"variant": 1, "slice_words_log2": 4, "class_residues": 1, "chunk_tiles": 3},
+    "lds_tiny_k0": {"variant": 1, "slice_words_log2": 5, "class_residues": 0},
+}
+
+
+def check(a, b, opt, threads=4, layouts=LAYOUTS):
     want, ost = _oracle.overlap(a, b, opt, threads=threads)
-    assert np.array_equal(got, _oracle.integer_cells(want, opt)), (opt, got, want)
-    assert st.matches == ost.matches
-    assert st.variants == ost.variants
+    want = _oracle.integer_cells(want, opt)
+    st = None
+    for name, tun in layouts.items():
+        got, st = gpu_cells(a, b, opt, tun)
+        assert np.array_equal(got, want), (name, opt, got, want)
+        assert st.matches == ost.matches, name
+        assert st.variants == ost.variants, name
     return st
 
 
