@@ -64,9 +64,11 @@ struct cmpr_context {
   /* tunables */
   int64_t blocks_per_cu = 8;
   int64_t variant = 1;            /* 0: one global Bloom; 1: LDS-staged slices */
-  int64_t bloom_log2_delta = 0;
+  int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
-  int64_t chunk_tiles = 32;
+  int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
+  int64_t waves_per_block = 8;
+  int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
   int64_t slice_words_log2 = SLICE_WORDS_LOG2;
 
   /* sliced Bloom layout (variant 1) */
@@ -89,6 +91,7 @@ struct cmpr_context {
   DevBuf<uint64_t>  off2, cnt2, keys, bloom;
   DevBuf<uint32_t>  v2, j2, rep2, vals;
   uint64_t          slots = 0, bloom_words = 0;
+  uint32_t          pat_hi_shift = PATTERN_BITS;
 
   /* set 1 tiles */
   bool              have_q = false;
@@ -260,11 +263,12 @@ uint32_t class_key_host(const SliceGeom &g, const std::vector<uint32_t> &t, uint
 
 using ProbeFn = void (*)(const ProbeParams);
 
-ProbeFn select_sliced_kernel(const cmpr_options &o)
+template <int NW>
+ProbeFn select_sliced_kernel_nw(const cmpr_options &o)
 {
 #define PICK(A_, D_, I_)                                                        \
-  (o.ignore_genes ? (ProbeFn)probe_sliced_kernel<A_, D_, I_, false>             \
-                  : (ProbeFn)probe_sliced_kernel<A_, D_, I_, true>)
+  (o.ignore_genes ? (ProbeFn)probe_sliced_kernel<A_, D_, I_, false, NW>         \
+                  : (ProbeFn)probe_sliced_kernel<A_, D_, I_, true, NW>)
   if (o.alphabet_size == 20) {
     if (o.differences == 0) return PICK(20, 0, false);
     if (o.differences == 1) return o.indels ? PICK(20, 1, true) : PICK(20, 1, false);
@@ -274,6 +278,15 @@ ProbeFn select_sliced_kernel(const cmpr_options &o)
   if (o.differences == 1) return o.indels ? PICK(4, 1, true) : PICK(4, 1, false);
   return PICK(4, 2, false);
 #undef PICK
+}
+
+ProbeFn select_sliced_kernel(const cmpr_options &o, int nw)
+{
+  switch (nw) {
+  case 4:  return select_sliced_kernel_nw<4>(o);
+  case 16: return select_sliced_kernel_nw<16>(o);
+  default: return select_sliced_kernel_nw<8>(o);
+  }
 }
 
 ProbeFn select_kernel(const cmpr_options &o)
@@ -430,9 +443,15 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_ESTATE, "set slice_words_log2 before cmpr_set_reference");
     c->slice_words_log2 = value;
   } else if (n == "chunk_tiles") {
-    if (value < 1 || value > 4096)
-      return fail(c, CMPR_EINVAL, "chunk_tiles must be 1..4096");
+    if (value < 0 || value > 4096)
+      return fail(c, CMPR_EINVAL, "chunk_tiles must be 0..4096");
     c->chunk_tiles = value;
+  } else if (n == "debug") {
+    c->debug = value;
+  } else if (n == "waves_per_block") {
+    if (value != 4 && value != 8 && value != 16)
+      return fail(c, CMPR_EINVAL, "waves_per_block must be 4, 8 or 16");
+    c->waves_per_block = value;
   } else if (n == "bloom_bits_log2_delta") {
     if (value < -4 || value > 4)
       return fail(c, CMPR_EINVAL, "bloom_bits_log2_delta must be -4..4");
@@ -483,17 +502,20 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     rc = dev_upload(c, c->zob, z.data(), z.size());
     if (rc)
       return rc;
-    /* 1024 patterns of 8 distinct bits (bloom_patterns_generate, bloompat.cc:36-52) */
+    /* 1024 x 2 half patterns, 4 distinct bits each (the reference draws 1024
+       patterns of 8 distinct bits, bloom_patterns_generate, bloompat.cc:36-52) */
     std::vector<uint64_t> pat(PATTERN_COUNT);
     for (auto &p : pat) {
-      p = 0;
-      for (uint32_t k = 0; k < PATTERN_K; k++) {
-        uint64_t bit;
-        do
-          bit = 1ull << (rng.next() & 63);
-        while (p & bit);
-        p |= bit;
-      }
+      uint32_t half[2] = {0, 0};
+      for (int hsel = 0; hsel < 2; hsel++)
+        for (uint32_t k = 0; k < PATTERN_K / 2; k++) {
+          uint32_t bit;
+          do
+            bit = 1u << (rng.next() & 31);
+          while (half[hsel] & bit);
+          half[hsel] |= bit;
+        }
+      p = ((uint64_t)half[1] << 32) | half[0];
     }
     rc = dev_upload(c, c->patterns, pat.data(), pat.size());
     if (rc)
@@ -526,10 +548,15 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   while (FILL_PERCENT * c->slots < 100 * s->n)
     c->slots <<= 1;
   uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
-  if (c->bloom_log2_delta > 0)
-    bloom_bytes <<= c->bloom_log2_delta;
-  else if (c->bloom_log2_delta < 0)
-    bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-c->bloom_log2_delta), 8);
+  /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
+     whatever the total), so it takes 4 bytes per table slot: with the 2^20
+     pattern space that leaves almost only true positives for the table walk. */
+  const int64_t delta = c->bloom_log2_delta == -100 ? (c->variant == 1 ? 2 : 0)
+                                                    : c->bloom_log2_delta;
+  if (delta > 0)
+    bloom_bytes <<= delta;
+  else if (delta < 0)
+    bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 8);
   if (bloom_bytes > (1ull << 32))
     return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
   c->bloom_words = bloom_bytes / 8;
@@ -574,13 +601,21 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
           best_max = mx;
           best_k = k;
         }
-        if (mx <= 2.0 * mean + 64)
+        if (mx <= 3.0 * mean + 64)
           break;
       }
     }
     g.k = best_k;
     if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
     g.ctab = c->d_ctab.p;
+  }
+  {
+    /* high half pattern: the 10 hash bits above the word-address bits */
+    uint32_t wbits = 0;
+    const uint64_t words = c->sliced ? (1ull << c->geom.words_log2) : c->bloom_words;
+    while ((1ull << wbits) < words)
+      wbits++;
+    c->pat_hi_shift = std::min<uint32_t>(PATTERN_BITS + wbits, 64 - PATTERN_BITS);
   }
   if ((rc = dev_alloc(c, c->keys, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->vals, (size_t)c->slots))) return rc;
@@ -607,6 +642,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.patterns = c->patterns.p;
     B.sliced = c->sliced ? 1u : 0u;
+    B.pat_hi_shift = c->pat_hi_shift;
     B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
@@ -681,6 +717,8 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if (S * per_slice >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
   std::vector<uint64_t> tile_first((size_t)(S * per_slice), 0);
+  const uint64_t chunk_tiles =
+      c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : 8 * (uint64_t)c->waves_per_block;
   uint64_t ntiles = 0, res_words = 0;
   std::vector<TileDesc> tiles;
   std::vector<Chunk> chunks;
@@ -707,11 +745,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
       ntiles += nt;
     }
     if (c->sliced)
-      for (uint64_t t0 = slice_first; t0 < ntiles; t0 += (uint64_t)c->chunk_tiles) {
+      for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
         Chunk ck;
         ck.slice = (uint32_t)slice;
         ck.first_tile = (uint32_t)t0;
-        ck.ntiles = (uint32_t)std::min<uint64_t>((uint64_t)c->chunk_tiles, ntiles - t0);
+        ck.ntiles = (uint32_t)std::min<uint64_t>(chunk_tiles, ntiles - t0);
         ck.pad = 0;
         uint64_t work = 0;
         for (uint32_t t = 0; t < ck.ntiles; t++)
@@ -813,6 +851,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
     P.bloom = c->bloom.p;
     P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
+    P.pat_hi_shift = c->pat_hi_shift;
     P.patterns = c->patterns.p;
     P.keys = c->keys.p;
     P.vals = c->vals.p;
@@ -843,26 +882,31 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.geom = c->geom;
     P.chunks = c->chunks.p;
     P.nchunks = c->nchunks;
+    P.debug = (uint32_t)c->debug;
 
+    const int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
     size_t lds = ((size_t)A * c->zpos + PATTERN_COUNT) * sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
-                 WAVES_PER_BLOCK * sizeof(WaveQueue);
+                 (size_t)nw * sizeof(WaveQueue);
     if (c->sliced)
       lds += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
              MAX_CLASS_RES * A * sizeof(uint32_t) + 16;
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    ProbeFn fn = c->sliced ? select_sliced_kernel(c->opt) : select_kernel(c->opt);
+    ProbeFn fn = c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
     if (lds > 48 * 1024)
       HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint64_t grid = (uint64_t)c->cus * (uint64_t)c->blocks_per_cu;
+    /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
+    uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
+    per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
+    uint64_t grid = (uint64_t)c->cus * per_cu;
     grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks
                                               : ((uint64_t)c->ntiles + WAVES_PER_BLOCK - 1) /
                                                     WAVES_PER_BLOCK);
     grid = std::max<uint64_t>(grid, 1);
-    hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(BLOCK_THREADS), lds, st, P);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3((uint32_t)nw * WAVE), lds, st, P);
     HIP_TRY(c, hipGetLastError());
     c->launches = 1;
   }

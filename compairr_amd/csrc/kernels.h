@@ -51,6 +51,18 @@ __host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
   return h == EMPTY_KEY ? (h ^ 1ull) : h;
 }
 
+/* 8-bit pattern of a hash: low-dword half from table entry (h & 1023), high-dword
+   half from entry ((h >> hi_shift) & 1023); `pat` is the 1024 x u64 table in LDS
+   or HBM (entry = high half << 32 | low half) */
+__device__ __forceinline__ uint64_t pattern_of(const uint64_t *pat, uint64_t h,
+                                               uint32_t hi_shift)
+{
+  const uint32_t *t = (const uint32_t *)pat;
+  const uint32_t lo = t[2u * ((uint32_t)h & (PATTERN_COUNT - 1))];
+  const uint32_t hi = t[2u * ((uint32_t)(h >> hi_shift) & (PATTERN_COUNT - 1)) + 1u];
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
 {
   /* high half, independent of the Bloom address bits (hashtable.h:36-41) */
@@ -78,6 +90,8 @@ struct BuildParams {
   uint64_t       *bloom;
   uint32_t        bloom_byte_mask;
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
+  uint32_t        pat_hi_shift;
+  uint32_t        pad;
   const uint64_t *patterns;
   SliceGeom       geom;
 };
@@ -137,7 +151,7 @@ build_index_kernel(const BuildParams B)
     boff = ((uint64_t)slice << (B.geom.words_log2 + 3)) +
            (((uint32_t)(h >> (PATTERN_BITS - 3))) & (((1u << B.geom.words_log2) - 1u) << 3));
   }
-  const uint64_t pat = B.patterns[(uint32_t)h & (PATTERN_COUNT - 1)];
+  const uint64_t pat = pattern_of(B.patterns, h, B.pat_hi_shift);
   atomicAnd((unsigned long long *)((char *)B.bloom + boff),
             (unsigned long long)~pat);
 }
@@ -308,7 +322,7 @@ __device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
 {
   const uint32_t boff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.P.bloom_byte_mask;
   const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + boff);
-  const uint64_t pat = W.pat_lds[(uint32_t)hv & (PATTERN_COUNT - 1)];
+  const uint64_t pat = pattern_of(W.pat_lds, hv, W.P.pat_hi_shift);
   const bool pos = live && ((word & pat) == 0);
   W.st.variants += live ? 1ull : 0ull;
   const uint64_t m = __ballot(pos);

@@ -5,18 +5,22 @@
  * -> hash-table walk -> exact verify -> matrix accumulate; reference:
  * overlap.cc:253-284, variants.cc:260-428, bloompat.h:40-58, overlap.cc:168-251),
  * but the Bloom filter is laid out so that the probes of one query land in a
- * 16 KiB slice chosen by the query's class key (layout.h, "Sliced Bloom
+ * 32 KiB slice chosen by the query's class key (layout.h, "Sliced Bloom
  * layout").  A workgroup takes a chunk of tiles that share a slice, copies the
- * slice HBM -> LDS with coalesced 16-byte loads, and its four waves answer
- * every class-preserving probe (for d = 1 substitutions: all but the k class
- * positions, i.e. ~93 % at k = 1) from LDS.  Class-changing variants
- * (substitution at a class position, insertions, deletions) compute their own
- * slice and probe the filter in HBM, exactly as variant 0 does.
+ * slice HBM -> LDS, and its waves answer every class-preserving probe (for
+ * d = 1 substitutions: all but the k class positions, ~93 % at k = 1) from
+ * LDS.  Class-changing variants (substitution at a class position, insertions,
+ * deletions) compute their own slice and probe the filter in HBM.
  *
- * The replacement-residue keys of a position are fetched once per position
- * into one VGPR pair (lane r holds the key of residue r) and broadcast with
- * v_readlane, so the inner loop has no memory access besides the two LDS
- * reads of the probe itself (filter word, bit pattern).
+ * Probing is done a ROW at a time (one position, all A replacement residues),
+ * in two phases:
+ *   1. fully unrolled, branch-free: A hashes, A filter words and A patterns
+ *      are read back to back (LDS reads or HBM loads all in flight together)
+ *      and reduced to one per-lane bit mask of Bloom-positive residues;
+ *   2. a short loop pops the set bits (usually 0-3 per lane) and compacts the
+ *      positives of the wave into the LDS queue with a ballot + prefix count.
+ * The replacement-residue keys of a position are fetched once per row into one
+ * VGPR pair (lane r holds the key of residue r) and broadcast with v_readlane.
  */
 #ifndef COMPAIRR_AMD_KERNELS_SLICED_H
 #define COMPAIRR_AMD_KERNELS_SLICED_H
@@ -37,12 +41,14 @@ struct SProber {
   const ProbeParams  &P;
   const uint64_t     *pat_lds;
   const uint64_t     *slice_lds;
-  const uint32_t     *cr_lds;      /* CR[MAX_CLASS_RES][A]                    */
   WaveQueue          &q;
   unsigned long long *mat_lds;
   uint32_t            lane;
   uint32_t            qslot;
   uint32_t            wmask_bytes; /* (slice_words - 1) << 3                  */
+  uint32_t            slice_shift; /* log2(bytes per slice)                   */
+  uint32_t            smask;
+  uint32_t            pat_hi_shift;
   uint32_t            tile_slice;
   int                 qn;
   LaneStats           st;
@@ -66,46 +72,87 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
     if (W.qn >= WAVE) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       W.qn -= WAVE;
-      resolve_entry<GENES>(W.P, W.q, W.qn + (int)W.lane, W.mat_lds, W.st);
+      if (!(W.P.debug & DBG_SKIP_RESOLVE))
+        resolve_entry<GENES>(W.P, W.q, W.qn + (int)W.lane, W.mat_lds, W.st);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
 }
 
-/* class-preserving variant: filter word from the LDS copy of the slice */
-template <bool GENES>
-__device__ __forceinline__ void probe_lds(SProber &W, uint64_t hv, bool live,
-                                          uint32_t ca, uint32_t cb)
+__device__ __forceinline__ bool bloom_hit(uint64_t word, uint64_t pat)
 {
-  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-  const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
-  const uint64_t pat = W.pat_lds[(uint32_t)hv & (PATTERN_COUNT - 1)];
-  W.st.variants += live ? 1ull : 0ull;
-  s_push<GENES>(W, live && ((word & pat) == 0), hv, ca, cb);
+  return (word & pat) == 0;            /* inverted polarity, bloompat.h:55-58 */
 }
 
-/* class-changing variant: `dk` = XOR of the class-key terms that differ */
-template <bool GENES>
-__device__ __forceinline__ void probe_hbm(SProber &W, uint64_t hv, uint32_t dk,
-                                          bool live, uint32_t ca, uint32_t cb)
+/* phase 1, class-preserving row: filter words from the LDS copy of the slice */
+template <int A>
+__device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint64_t zrow)
 {
-  const uint32_t vslice = (W.tile_slice ^ dk) & W.P.geom.smask;
-  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-  const uint64_t off = ((uint64_t)vslice << (W.P.geom.words_log2 + 3)) + woff;
-  const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + off);
-  const uint64_t pat = W.pat_lds[(uint32_t)hv & (PATTERN_COUNT - 1)];
-  W.st.variants += live ? 1ull : 0ull;
-  s_push<GENES>(W, live && ((word & pat) == 0), hv, ca, cb);
+  uint32_t mask = 0;
+#pragma unroll
+  for (int v = 0; v < A; v++) {
+    const uint64_t hv = h1 ^ readlane64(zrow, v);
+    const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+    const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
+    const uint64_t pat = pattern_of(W.pat_lds, hv, W.pat_hi_shift);
+    mask |= bloom_hit(word, pat) ? (1u << v) : 0u;
+  }
+  return mask;
+}
+
+/* phase 1, class-changing row: slice of residue v = own slice ^ dk_lane ^ crow[v]
+   (crow: lane v holds the class-key term of replacement residue v) */
+template <int A>
+__device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint64_t zrow,
+                                            uint32_t dk_lane, uint32_t crow)
+{
+  uint64_t word[A];
+  uint64_t hv[A];
+#pragma unroll
+  for (int v = 0; v < A; v++) {
+    hv[v] = h1 ^ readlane64(zrow, v);
+    const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)crow, v);
+    const uint32_t vslice = (W.tile_slice ^ dk_lane ^ cv) & W.smask;
+    const uint32_t woff = ((uint32_t)(hv[v] >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+    const uint64_t off = ((uint64_t)vslice << W.slice_shift) + woff;
+    word[v] = *(const uint64_t *)((const char *)W.P.bloom + off);
+  }
+  uint32_t mask = 0;
+#pragma unroll
+  for (int v = 0; v < A; v++) {
+    const uint64_t pat = pattern_of(W.pat_lds, hv[v], W.pat_hi_shift);
+    mask |= bloom_hit(word[v], pat) ? (1u << v) : 0u;
+  }
+  return mask;
+}
+
+/* phase 2: pop the set bits of `mask`, queue the positives.  zl_row = LDS keys
+   of this position (A entries); the residue goes into ca (RES_IN_A) or cb. */
+template <bool GENES, bool RES_IN_A>
+__device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
+                                         const uint64_t *zl_row, uint32_t ca, uint32_t cb)
+{
+  if (W.P.debug & DBG_SKIP_EMIT)
+    mask = 0;
+  while (__ballot(mask != 0)) {
+    const bool pos = mask != 0;
+    const uint32_t v = pos ? (uint32_t)__ffs((int)mask) - 1u : 0u;
+    const uint64_t hv = h1 ^ zl_row[v];
+    s_push<GENES>(W, pos, hv, RES_IN_A ? (ca | (v << 24)) : ca,
+                  RES_IN_A ? cb : (cb | (v << 24)));
+    mask &= mask - 1u;
+  }
 }
 
 /*
  * LDS: [A * zpos Zobrist keys][1024 patterns][R1 * R2 matrix (optional)]
- *      [4 WaveQueues][2^w-word Bloom slice][CR tables][chunk broadcast]
+ *      [NW WaveQueues][2^w-word Bloom slice][CR tables][chunk broadcast]
  */
-template <int A, int D, bool INDELS, bool GENES>
-__global__ void __launch_bounds__(BLOCK_THREADS)
+template <int A, int D, bool INDELS, bool GENES, int NW>
+__global__ void __launch_bounds__(NW * WAVE)
 probe_sliced_kernel(const ProbeParams P)
 {
+  constexpr uint32_t NT = NW * WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
   uint64_t *zl = (uint64_t *)smem;
   const uint32_t nz = (uint32_t)A * P.zpos;
@@ -113,35 +160,37 @@ probe_sliced_kernel(const ProbeParams P)
   unsigned long long *mat_all = (unsigned long long *)(pat_lds + PATTERN_COUNT);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
-  uint64_t *slice_lds = (uint64_t *)(queues + WAVES_PER_BLOCK);
+  uint64_t *slice_lds = (uint64_t *)(queues + NW);
   const uint32_t slice_words = 1u << P.geom.words_log2;
   uint32_t *cr_lds = (uint32_t *)(slice_lds + slice_words);
   uint32_t *bcast = cr_lds + MAX_CLASS_RES * A;
 
-  for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)
+  for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[i];
-  for (uint32_t i = threadIdx.x; i < PATTERN_COUNT; i += BLOCK_THREADS)
+  for (uint32_t i = threadIdx.x; i < PATTERN_COUNT; i += NT)
     pat_lds[i] = P.patterns[i];
   if (P.lds_matrix)
-    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
+    for (uint32_t i = threadIdx.x; i < cells; i += NT)
       mat_all[i] = 0;
-  for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += BLOCK_THREADS)
+  for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += NT)
     cr_lds[i] = P.geom.ctab[P.geom.off_cr + i];
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t K = P.geom.k;
-  SProber W{P, pat_lds, slice_lds, cr_lds, queues[wave],
-            P.lds_matrix ? mat_all : nullptr, lane, 0u,
-            (slice_words - 1u) << 3, 0u, 0, {0ull, 0u, 0u, 0u}};
+  SProber W{P, pat_lds, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
+            lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
+            P.pat_hi_shift, 0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *gene_keys = P.zob + nz;
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
 
   for (;;) {
     /* ---- next chunk: tiles of one slice; stage that slice into LDS ---- */
     __syncthreads();                       /* everyone is done with the old slice */
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
       bcast[0] = atomicAdd(P.tile_counter, 1u);
+      bcast[1] = 0;                        /* tiles of the chunk handed out so far */
+    }
     __syncthreads();
     const uint32_t item = bcast[0];
     if (item >= P.nchunks)
@@ -149,19 +198,26 @@ probe_sliced_kernel(const ProbeParams P)
     const Chunk ck = P.chunks[item];
     {
       const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
-      for (uint32_t i = threadIdx.x; i < slice_words; i += BLOCK_THREADS)
+      for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
         slice_lds[i] = src[i];
     }
     __syncthreads();
     W.tile_slice = ck.slice;
 
-    for (uint32_t t = ck.first_tile + wave; t < ck.first_tile + ck.ntiles;
-         t += WAVES_PER_BLOCK) {
+    for (;;) {
+      uint32_t tk = 0;
+      if (lane == 0)
+        tk = atomicAdd(&bcast[1], 1u);
+      tk = __builtin_amdgcn_readfirstlane(tk);
+      if (tk >= ck.ntiles)
+        break;
+      const uint32_t t = ck.first_tile + tk;
       const TileDesc td = P.tiles[t];
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t *qr = P.qres + td.res_base + lane;
       const bool valid = lane < nvalid;
+      const uint32_t vmask = valid ? ~0u : 0u;
       W.qslot = t * WAVE + lane;
       auto res_at = [&](uint32_t p) -> uint32_t {
         return (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
@@ -200,21 +256,33 @@ probe_sliced_kernel(const ProbeParams P)
           c = c || (i < K && m[i] == p);
         return c;
       };
-      /* class-key change of replacing residue r by v at position p */
-      auto sub_delta = [&](uint32_t p, uint32_t r, uint32_t v) -> uint32_t {
+      /* class-key terms of position p: of residue `r` (per lane) and, as a
+         row, of every replacement residue (lane v holds the term of v) */
+      auto class_terms = [&](uint32_t p, uint32_t r, uint32_t &crow) -> uint32_t {
         uint32_t dk = 0;
+        crow = 0;
 #pragma unroll
         for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
-          if (i < K && m[i] == p)
-            dk ^= cr_lds[i * A + r] ^ cr_lds[i * A + v];
+          if (i < K && m[i] == p) {
+            dk ^= cr_lds[i * A + r];
+            crow ^= cr_lds[i * A + zlane];
+          }
         return dk;
       };
 
-      /* ---- the unchanged sequence ---- */
-      probe_lds<GENES>(W, h, valid, pack_a(K_SAME, 0, 0), 0);
+      uint64_t nvar = 1;
+
+      /* ---- the unchanged sequence (variants.cc:260-268) ---- */
+      {
+        const uint32_t woff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+        const uint64_t word = *(const uint64_t *)((const char *)slice_lds + woff);
+        const uint64_t pat = pattern_of(pat_lds, h, W.pat_hi_shift);
+        s_push<GENES>(W, valid && bloom_hit(word, pat), h, pack_a(K_SAME, 0, 0), 0);
+      }
 
       if (D >= 1) {
         /* ---- single substitutions (variants.cc:280-293) ---- */
+        nvar += (uint64_t)(A - 1) * L;
         uint32_t w = 0;
         for (uint32_t p = 0; p < L; p++) {
           if ((p & 3u) == 0)
@@ -222,23 +290,23 @@ probe_sliced_kernel(const ProbeParams P)
           const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
           const uint64_t h1 = h ^ zl[A * p + r];
           const uint64_t zrow = zl[A * p + zlane];
+          uint32_t mask = 0;
           if (!is_class_pos(p)) {
-#pragma unroll 2
-            for (uint32_t v = 0; v < (uint32_t)A; v++)
-              probe_lds<GENES>(W, h1 ^ readlane64(zrow, v), valid && v != r,
-                               pack_a(K_SUB, p, v), 0);
-          } else {
-#pragma unroll 1
-            for (uint32_t v = 0; v < (uint32_t)A; v++)
-              probe_hbm<GENES>(W, h1 ^ readlane64(zrow, v), sub_delta(p, r, v),
-                               valid && v != r, pack_a(K_SUB, p, v), 0);
+            if (!(P.debug & DBG_SKIP_LDS_ROWS))
+              mask = row_lds<A>(W, h1, zrow);
+          } else if (!(P.debug & DBG_SKIP_HBM_ROWS)) {
+            uint32_t crow;
+            const uint32_t dk = class_terms(p, r, crow);
+            mask = row_hbm<A>(W, h1, zrow, dk, crow);
           }
+          mask &= vmask & ~(1u << r);              /* the original residue is no variant */
+          emit_row<GENES, true>(W, mask, h1, zl + A * p, pack_a(K_SUB, p, 0), 0);
         }
       }
 
       if (INDELS) {
         /* Indel variants change the length, hence the class: their slice is
-           tile_slice ^ (CL[L] ^ CL[L'] ^ old class residues ^ new class residues). */
+           own ^ CL[L] ^ CL[L'] ^ old class residues ^ new class residues. */
         const uint32_t cl_L = P.geom.ctab[L];
         uint32_t cbase = 0;                      /* XOR_i CR[i][s[m_i(L)]] */
 #pragma unroll
@@ -247,7 +315,9 @@ probe_sliced_kernel(const ProbeParams P)
             cbase ^= cr_lds[i * A + res_at(m[i])];
 
         /* ---- deletions (variants.cc:301-325): u = s without position p,
-                u[x] = x < p ? s[x] : s[x + 1], length L - 1 ---- */
+                u[x] = x < p ? s[x] : s[x + 1]; one per run of equal residues.
+                Blocks of up to 32 positions: phase 1 rolls the hash and gathers
+                the filter words, phase 2 replays the roll for the positives. */
         if (L > 1) {
           const uint32_t dl = cl_L ^ P.geom.ctab[L - 1] ^ cbase;
           uint32_t md[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
@@ -260,27 +330,54 @@ probe_sliced_kernel(const ProbeParams P)
               hi[i] = cr_lds[i * A + res_at(md[i] + 1)];
             }
           }
-          uint32_t w = 0, gone = 0;
           uint64_t hd = hdel;
-#pragma unroll 1
-          for (uint32_t p = 0; p < L; p++) {
-            if ((p & 3u) == 0)
-              w = qr[(p >> 2) * WAVE];
-            const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
-            const bool fresh = (p == 0) || (r != gone);
-            if (p > 0 && fresh)
-              hd ^= zl[A * (p - 1) + gone] ^ zl[A * (p - 1) + r];
-            uint32_t dk = dl;
+          uint32_t gone = 0;
+          for (uint32_t p0 = 0; p0 < L; p0 += 32) {
+            const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
+            const uint64_t hd0 = hd;
+            const uint32_t gone0 = gone;
+            uint32_t mask = 0, w = 0;
+#pragma unroll 4
+            for (uint32_t p = p0; p < pe; p++) {
+              if ((p & 3u) == 0 || p == p0)
+                w = qr[(p >> 2) * WAVE];
+              const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+              const bool fresh = (p == 0) || (r != gone);
+              if (p > 0 && fresh)
+                hd ^= zl[A * (p - 1) + gone] ^ zl[A * (p - 1) + r];
+              uint32_t dk = dl;
 #pragma unroll
-            for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
-              dk ^= md[i] < p ? lo[i] : hi[i];
-            probe_hbm<GENES>(W, hd, dk, valid && fresh, pack_a(K_DEL, p, 0), 0);
-            gone = r;
+              for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+                dk ^= md[i] < p ? lo[i] : hi[i];
+              const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
+              const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+              const uint64_t word = *(const uint64_t *)((const char *)P.bloom +
+                                                        ((uint64_t)vslice << W.slice_shift) + woff);
+              const uint64_t pat = pattern_of(pat_lds, hd, W.pat_hi_shift);
+              nvar += fresh ? 1u : 0u;
+              mask |= (fresh && bloom_hit(word, pat)) ? (1u << (p - p0)) : 0u;
+              gone = r;
+            }
+            mask &= vmask;
+            if (__ballot(mask != 0)) {
+              uint64_t hr = hd0;
+              uint32_t g = gone0;
+#pragma unroll 1
+              for (uint32_t p = p0; p < pe; p++) {
+                const uint32_t r = res_at(p);
+                if (p > 0 && r != g)
+                  hr ^= zl[A * (p - 1) + g] ^ zl[A * (p - 1) + r];
+                s_push<GENES>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
+                g = r;
+              }
+            }
           }
         }
+
         /* ---- insertions (variants.cc:329-353): u = s with v put in front of
                 position ip, u[x] = x < ip ? s[x] : x == ip ? v : s[x - 1] ---- */
         {
+          nvar += (uint64_t)A + (uint64_t)(A - 1) * L;
           const uint32_t dl = cl_L ^ P.geom.ctab[L + 1] ^ cbase;
           uint32_t mi[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
 #pragma unroll
@@ -304,38 +401,41 @@ probe_sliced_kernel(const ProbeParams P)
               r = (w >> ((p & 3u) * 8)) & 0xffu;
               hi_hash ^= zl[A * p + r] ^ zl[A * ip + r];
             }
-            uint32_t dk0 = dl;
+            uint32_t dk0 = dl, crow = 0;
 #pragma unroll
             for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
-              if (i < K && mi[i] != ip)
-                dk0 ^= mi[i] < ip ? lo[i] : hi[i];
+              if (i < K) {
+                if (mi[i] == ip)
+                  crow ^= cr_lds[i * A + zlane];          /* u[mi] = v */
+                else
+                  dk0 ^= mi[i] < ip ? lo[i] : hi[i];
+              }
             const uint64_t zrow = zl[A * ip + zlane];
-#pragma unroll 1
-            for (uint32_t v = 0; v < (uint32_t)A; v++) {
-              uint32_t dk = dk0;
-#pragma unroll
-              for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
-                if (i < K && mi[i] == ip)
-                  dk ^= cr_lds[i * A + v];
-              probe_hbm<GENES>(W, hi_hash ^ readlane64(zrow, v), dk, valid && v != r,
-                               pack_a(K_INS, ip, v), 0);
-            }
+            uint32_t mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow);
+            mask &= vmask;
+            if (ip > 0)
+              mask &= ~(1u << r);                         /* v != s[ip - 1] */
+            emit_row<GENES, true>(W, mask, hi_hash, zl + A * ip, pack_a(K_INS, ip, 0), 0);
           }
         }
       }
 
       if (D >= 2) {
         /* ---- double substitutions p < q (variants.cc:370-399) ---- */
+        nvar += (uint64_t)(A - 1) * (A - 1) * ((uint64_t)L * (L ? L - 1 : 0) / 2);
         for (uint32_t p = 0; p + 1 < L; p++) {
           const uint32_t rp = res_at(p);
           const uint64_t hp = h ^ zl[A * p + rp];
           const uint64_t zrow_p = zl[A * p + zlane];
+          uint32_t crow_p;
+          const uint32_t dk_p = class_terms(p, rp, crow_p);
           const bool cp = is_class_pos(p);
+#pragma unroll 1
           for (uint32_t v = 0; v < (uint32_t)A; v++) {
-            const bool pv = valid && v != rp;
+            const uint32_t pv = (valid && v != rp) ? ~0u : 0u;
             const uint64_t hpv = hp ^ readlane64(zrow_p, v);
             const uint32_t ca = pack_a(K_SUB2, p, v);
-            const uint32_t dkp = cp ? sub_delta(p, rp, v) : 0u;
+            const uint32_t dk_pv = dk_p ^ (uint32_t)__builtin_amdgcn_readlane((int)crow_p, (int)v);
             uint32_t w = 0;
             for (uint32_t qq = p + 1; qq < L; qq++) {
               if ((qq & 3u) == 0 || qq == p + 1)
@@ -343,22 +443,22 @@ probe_sliced_kernel(const ProbeParams P)
               const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
               const uint64_t hq = hpv ^ zl[A * qq + rq];
               const uint64_t zrow_q = zl[A * qq + zlane];
+              uint32_t mask;
               if (!cp && !is_class_pos(qq)) {
-#pragma unroll 2
-                for (uint32_t x = 0; x < (uint32_t)A; x++)
-                  probe_lds<GENES>(W, hq ^ readlane64(zrow_q, x), pv && x != rq, ca,
-                                   qq | (x << 24));
+                mask = row_lds<A>(W, hq, zrow_q);
               } else {
-#pragma unroll 1
-                for (uint32_t x = 0; x < (uint32_t)A; x++)
-                  probe_hbm<GENES>(W, hq ^ readlane64(zrow_q, x),
-                                   dkp ^ sub_delta(qq, rq, x), pv && x != rq, ca,
-                                   qq | (x << 24));
+                uint32_t crow_q;
+                const uint32_t dk_q = class_terms(qq, rq, crow_q);
+                mask = row_hbm<A>(W, hq, zrow_q, dk_pv ^ dk_q, crow_q);
               }
+              mask &= pv & ~(1u << rq);
+              emit_row<GENES, false>(W, mask, hq, zl + A * qq, ca, qq);
             }
           }
         }
       }
+
+      W.st.variants += valid ? nvar : 0ull;
     }
   }
 
@@ -382,7 +482,7 @@ probe_sliced_kernel(const ProbeParams P)
 
   if (P.lds_matrix) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS) {
+    for (uint32_t i = threadIdx.x; i < cells; i += NT) {
       const unsigned long long x = mat_all[i];
       if (x)
         atomicAdd(P.matrix + i, x);

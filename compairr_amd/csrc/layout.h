@@ -18,10 +18,14 @@ constexpr int      WAVES_PER_BLOCK   = BLOCK_THREADS / WAVE;
    MAX_INSERTS, compairr.h:111). */
 constexpr uint32_t EXTRA_POSITIONS   = 3;
 
-/* Blocked Bloom filter, one 64-bit word per block, k = 8 bits from one of
-   1024 precomputed patterns, inverted polarity (a cleared bit = present) so
-   that the membership test is (word & pattern) == 0 -- same geometry as
-   bloompat.h:22-58; the table contents are our own. */
+/* Blocked Bloom filter, one 64-bit word per block, k = 8 bits per key, inverted
+   polarity (a cleared bit = present) so that the membership test is
+   (word & pattern) == 0 -- the geometry of bloompat.h:22-58.  The reference
+   draws the 8 bits from ONE table of 1024 patterns, which floors its false
+   positive rate at (keys per word) / 1024; here the pattern is the union of
+   two independent half patterns -- 4 bits of the low dword chosen by hash
+   bits 0..9, 4 bits of the high dword chosen by 10 other hash bits -- i.e.
+   2^20 distinct patterns from the same 8 KiB of table. */
 constexpr uint32_t PATTERN_BITS      = 10;
 constexpr uint32_t PATTERN_COUNT     = 1u << PATTERN_BITS;
 constexpr uint32_t PATTERN_K         = 8;
@@ -60,7 +64,7 @@ struct TileDesc {
    a class position, indels) go to the filter in HBM.  The word inside a slice
    and the bit pattern still come from the Zobrist hash. */
 constexpr uint32_t MAX_CLASS_RES     = 3;
-constexpr uint32_t SLICE_WORDS_LOG2  = 11;     /* 2048 words = 16 KiB per slice */
+constexpr uint32_t SLICE_WORDS_LOG2  = 12;     /* 4096 words = 32 KiB per slice */
 
 struct SliceGeom {
   uint32_t smask;          /* S - 1                                          */
@@ -94,7 +98,7 @@ struct ProbeParams {
   /* Bloom */
   const uint64_t *bloom;
   uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
-  uint32_t        pad0;
+  uint32_t        pat_hi_shift;      /* hash bits [s, s+10) pick the high half pattern */
   const uint64_t *patterns;
   /* hash table */
   const uint64_t *keys;
@@ -128,11 +132,15 @@ struct ProbeParams {
   SliceGeom       geom;
   const Chunk    *chunks;
   uint32_t        nchunks;
-  uint32_t        pad2;
+  uint32_t        debug;           /* ablation switches, 0 in production      */
   /* work distribution + statistics */
   uint32_t           *tile_counter;
   unsigned long long *stats;       /* [variants, bloom+, hash==, matches]     */
 };
+
+/* ProbeParams::debug bits: timing experiments only, results become wrong */
+enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
+                  DBG_SKIP_LDS_ROWS = 8 };
 
 enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
        STAT_COUNT = 4 };

@@ -176,12 +176,14 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
 
 /* Tuning knobs (unknown names -> CMPR_EINVAL).  Results never depend on them.
      "variant"               0: one Bloom filter probed in HBM; 1 (default):
-                             class-keyed 16 KiB slices staged in LDS
+                             class-keyed 32 KiB slices staged in LDS
      "blocks_per_cu"         resident workgroups per CU the grid is sized for
-     "bloom_bits_log2_delta" filter size = hash-table slots bytes << delta
+     "bloom_bits_log2_delta" filter bytes = hash-table slots << delta
+                             (default 0 for variant 0, +2 for variant 1)
      "class_residues"        -1 (default: from the data) or 0..3
-     "slice_words_log2"      log2 of 64-bit words per slice (default 11)
-     "chunk_tiles"           tiles per workgroup work item (default 32)
+     "slice_words_log2"      log2 of 64-bit words per slice (default 12)
+     "chunk_tiles"           tiles per workgroup work item (default 8 x waves)
+     "waves_per_block"       4, 8 (default) or 16 waves per workgroup (variant 1)
    "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
    must be set before cmpr_set_reference(). */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
