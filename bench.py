@@ -77,6 +77,7 @@ def main():
     import torch
     import torch.distributed as dist
     from compairr_amd import HipOverlap, Options, synth
+    from compairr_amd.dist import allreduce_matrix
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -111,14 +112,14 @@ def main():
     h.set_queries(qry)
     t_layout = time.time() - t0
     R1, R2 = h.shape
+    layout = h.layout()
     # every rank must use the same R1 x R2 (16 x 16 for the synthetic law)
     matrix = torch.zeros(R1 * R2, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream()
 
     def step():
         h.overlap_matrix_device(matrix.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_reduce(matrix)            # RCCL sum over xGMI, R1*R2 int64
+        allreduce_matrix(matrix)               # RCCL sum over xGMI, R1*R2 int64 (no-op at N=1)
 
     kernel_ms = []
     for _ in range(args.warmup):
@@ -196,6 +197,7 @@ def main():
                        "sharding": "queries sharded per GPU, reference index replicated, "
                                    "one RCCL all-reduce of the matrix" if world > 1 else "single GPU",
                        "matrix_checksum": synth.checksum(result_matrix),
+                       "layout": layout,
                        "setup_seconds": {"generate": round(t_gen, 2), "index_build+upload": round(t_index, 3),
                                          "query_layout+upload": round(t_layout, 3)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -464,6 +464,32 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
   return CMPR_OK;
 }
 
+extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *value)
+{
+  if (!c || !name || !value)
+    return CMPR_EINVAL;
+  std::string n(name);
+  if (n == "variant") *value = c->variant;
+  else if (n == "blocks_per_cu") *value = c->blocks_per_cu;
+  else if (n == "bloom_bits_log2_delta") {
+    *value = 0;
+    for (uint64_t b = std::max<uint64_t>(c->slots, 8); b < c->bloom_words * 8; b <<= 1)
+      (*value)++;
+  }
+  else if (n == "class_residues") *value = c->sliced && c->have_ref ? (int64_t)c->geom.k : c->class_residues;
+  else if (n == "slice_words_log2") *value = c->sliced && c->have_ref ? (int64_t)c->geom.words_log2 : c->slice_words_log2;
+  else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
+  else if (n == "waves_per_block") *value = c->waves_per_block;
+  else if (n == "debug") *value = c->debug;
+  else if (n == "slices") *value = c->sliced ? (int64_t)c->geom.smask + 1 : 1;
+  else if (n == "tiles") *value = c->ntiles;
+  else if (n == "chunks") *value = c->nchunks;
+  else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
+  else
+    return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
+  return CMPR_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* set 2: upload + index build on the device                            */
 /* ------------------------------------------------------------------ */
@@ -596,12 +622,14 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
                              c->opt.ignore_genes ? 0 : s->j_gene[i], k) & g.smask]++;
         }
         const double mx = *std::max_element(pop.begin(), pop.end());
-        const double mean = (double)s->n / (double)S;
         if (best_max < 0 || mx < best_max) {
           best_max = mx;
           best_k = k;
         }
-        if (mx <= 3.0 * mean + 64)
+        /* every class residue costs one HBM-probed row per query, so take the
+           fewest that still leave the fullest slice >= 12 filter bits per key
+           (fill <= 0.49, false-positive rate <= 3e-3 there, far less elsewhere) */
+        if (mx * 12.0 <= (double)(64ull << g.words_log2))
           break;
       }
     }

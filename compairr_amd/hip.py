@@ -21,7 +21,7 @@ EXPORTS = [
     "cmpr_abi_version", "cmpr_create", "cmpr_destroy", "cmpr_last_error",
     "cmpr_set_reference", "cmpr_set_queries", "cmpr_overlap_matrix",
     "cmpr_overlap_matrix_f64", "cmpr_overlap_matrix_device", "cmpr_get_stats",
-    "cmpr_rows", "cmpr_cols", "cmpr_set_tunable",
+    "cmpr_rows", "cmpr_cols", "cmpr_set_tunable", "cmpr_get_tunable",
 ]
 
 
@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.cmpr_cols.argtypes = [C.c_void_p]
     lib.cmpr_cols.restype = C.c_uint32
     lib.cmpr_set_tunable.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.cmpr_get_tunable.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     if lib.cmpr_abi_version() != 1:
         raise RuntimeError("libcompairr_hip.so ABI version mismatch")
     _lib = lib
@@ -191,6 +192,17 @@ class HipOverlap:
 
     def set_tunable(self, name: str, value: int) -> None:
         self._check(self._lib.cmpr_set_tunable(self._ctx, name.encode(), value))
+
+    def get_tunable(self, name: str) -> int:
+        v = C.c_int64()
+        self._check(self._lib.cmpr_get_tunable(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def layout(self) -> dict:
+        return {k: self.get_tunable(k) for k in
+                ("variant", "slices", "slice_words_log2", "class_residues",
+                 "bloom_bits_log2_delta", "waves_per_block", "chunk_tiles",
+                 "tiles", "chunks", "query_slots")}
 
     def set_reference(self, s: RepertoireSet, longest_query: int = 0) -> None:
         v = _view(s)

@@ -188,6 +188,11 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
    must be set before cmpr_set_reference(). */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 
+/* Current value of a tunable (for the data-dependent ones, the value in effect
+   after cmpr_set_reference / cmpr_set_queries), plus the read-only names
+   "slices", "tiles", "chunks" and "query_slots" (tiles x 64, padding included). */
+int cmpr_get_tunable(cmpr_context *ctx, const char *name, int64_t *value);
+
 #ifdef __cplusplus
 }
 #endif
