@@ -81,7 +81,7 @@ struct cmpr_context {
 
   /* Zobrist + patterns */
   uint32_t          zpos = 0;
-  DevBuf<uint64_t>  zob, patterns;
+  DevBuf<uint64_t>  zob;
 
   /* set 2 + index */
   bool              have_ref = false;
@@ -391,7 +391,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   (void)hipSetDevice(c->device);
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
-  c->zob.release(); c->patterns.release();
+  c->zob.release();
   c->res2.release(); c->off2.release(); c->cnt2.release(); c->keys.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->vals.release();
@@ -528,24 +528,6 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     rc = dev_upload(c, c->zob, z.data(), z.size());
     if (rc)
       return rc;
-    /* 1024 x 2 half patterns, 4 distinct bits each (the reference draws 1024
-       patterns of 8 distinct bits, bloom_patterns_generate, bloompat.cc:36-52) */
-    std::vector<uint64_t> pat(PATTERN_COUNT);
-    for (auto &p : pat) {
-      uint32_t half[2] = {0, 0};
-      for (int hsel = 0; hsel < 2; hsel++)
-        for (uint32_t k = 0; k < PATTERN_K / 2; k++) {
-          uint32_t bit;
-          do
-            bit = 1u << (rng.next() & 31);
-          while (half[hsel] & bit);
-          half[hsel] |= bit;
-        }
-      p = ((uint64_t)half[1] << 32) | half[0];
-    }
-    rc = dev_upload(c, c->patterns, pat.data(), pat.size());
-    if (rc)
-      return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
   }
 
@@ -668,7 +650,6 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.slot_mask = c->slots - 1;
     B.bloom = c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
-    B.patterns = c->patterns.p;
     B.sliced = c->sliced ? 1u : 0u;
     B.pat_hi_shift = c->pat_hi_shift;
     B.geom = c->geom;
@@ -880,7 +861,6 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.bloom = c->bloom.p;
     P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     P.pat_hi_shift = c->pat_hi_shift;
-    P.patterns = c->patterns.p;
     P.keys = c->keys.p;
     P.vals = c->vals.p;
     P.slot_mask = c->slots - 1;
@@ -913,7 +893,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.debug = (uint32_t)c->debug;
 
     const int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
-    size_t lds = ((size_t)A * c->zpos + PATTERN_COUNT) * sizeof(uint64_t) +
+    size_t lds = (size_t)A * c->zpos * sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)nw * sizeof(WaveQueue);
     if (c->sliced)

@@ -51,15 +51,17 @@ __host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
   return h == EMPTY_KEY ? (h ^ 1ull) : h;
 }
 
-/* 8-bit pattern of a hash: low-dword half from table entry (h & 1023), high-dword
-   half from entry ((h >> hi_shift) & 1023); `pat` is the 1024 x u64 table in LDS
-   or HBM (entry = high half << 32 | low half) */
-__device__ __forceinline__ uint64_t pattern_of(const uint64_t *pat, uint64_t h,
-                                               uint32_t hi_shift)
+/* Bit pattern of a hash, computed, not looked up: two bits of the low dword
+   from hash bits [0,5) and [5,10), two bits of the high dword from hash bits
+   [s,s+5) and [s+5,s+10).  (The reference reads one of 1024 precomputed 8-bit
+   patterns, bloompat.h:45-48; at the >= 32 filter bits per key this build uses,
+   4 bits from a 2^20 pattern space give a lower false-positive rate than 8 bits
+   from a 2^10 space, and cost two random LDS reads less per probe.) */
+__host__ __device__ __forceinline__ uint64_t pattern_of(uint64_t h, uint32_t hi_shift)
 {
-  const uint32_t *t = (const uint32_t *)pat;
-  const uint32_t lo = t[2u * ((uint32_t)h & (PATTERN_COUNT - 1))];
-  const uint32_t hi = t[2u * ((uint32_t)(h >> hi_shift) & (PATTERN_COUNT - 1)) + 1u];
+  const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> hi_shift);
+  const uint32_t lo = (1u << (a & 31u)) | (1u << ((a >> 5) & 31u));
+  const uint32_t hi = (1u << (b & 31u)) | (1u << ((b >> 5) & 31u));
   return ((uint64_t)hi << 32) | lo;
 }
 
@@ -92,7 +94,6 @@ struct BuildParams {
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
   uint32_t        pat_hi_shift;
   uint32_t        pad;
-  const uint64_t *patterns;
   SliceGeom       geom;
 };
 
@@ -151,7 +152,7 @@ build_index_kernel(const BuildParams B)
     boff = ((uint64_t)slice << (B.geom.words_log2 + 3)) +
            (((uint32_t)(h >> (PATTERN_BITS - 3))) & (((1u << B.geom.words_log2) - 1u) << 3));
   }
-  const uint64_t pat = pattern_of(B.patterns, h, B.pat_hi_shift);
+  const uint64_t pat = pattern_of(h, B.pat_hi_shift);
   atomicAnd((unsigned long long *)((char *)B.bloom + boff),
             (unsigned long long)~pat);
 }
@@ -294,7 +295,6 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
 /* per-wave probing state */
 struct Prober {
   const ProbeParams  &P;
-  const uint64_t     *pat_lds;
   WaveQueue          &q;
   unsigned long long *mat_lds;
   uint32_t            lane;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
 {
   const uint32_t boff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.P.bloom_byte_mask;
   const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + boff);
-  const uint64_t pat = pattern_of(W.pat_lds, hv, W.P.pat_hi_shift);
+  const uint64_t pat = pattern_of(hv, W.P.pat_hi_shift);
   const bool pos = live && ((word & pat) == 0);
   W.st.variants += live ? 1ull : 0ull;
   const uint64_t m = __ballot(pos);
@@ -345,8 +345,8 @@ __device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
  * A: alphabet (20 aa / 4 nt); D: differences 0..2; INDELS: -i (D == 1);
  * GENES: V/J hashed and compared (no -g).
  *
- * LDS: [A * zpos Zobrist position keys][1024 Bloom patterns]
- *      [R1 * R2 matrix (optional)][one WaveQueue per wave]
+ * LDS: [A * zpos Zobrist position keys][R1 * R2 matrix (optional)]
+ *      [one WaveQueue per wave]
  *
  * The replacement-residue loops are deliberately NOT unrolled: each probe()
  * site carries an inlined queue drain, and memory-level parallelism comes
@@ -360,15 +360,12 @@ probe_kernel(const ProbeParams P)
   extern __shared__ __align__(16) unsigned char smem[];
   uint64_t *zl = (uint64_t *)smem;
   const uint32_t nz = (uint32_t)A * P.zpos;
-  uint64_t *pat_lds = zl + nz;
-  unsigned long long *mat_all = (unsigned long long *)(pat_lds + PATTERN_COUNT);
+  unsigned long long *mat_all = (unsigned long long *)(zl + nz);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
 
   for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)
     zl[i] = P.zob[i];
-  for (uint32_t i = threadIdx.x; i < PATTERN_COUNT; i += BLOCK_THREADS)
-    pat_lds[i] = P.patterns[i];
   if (P.lds_matrix)
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
       mat_all[i] = 0;
@@ -376,7 +373,7 @@ probe_kernel(const ProbeParams P)
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
-  Prober W{P, pat_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
+  Prober W{P, queues[wave], P.lds_matrix ? mat_all : nullptr,
            lane, 0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *zs = P.zob;            /* wave-uniform lookups: scalar loads */
   const uint64_t *gene_keys = P.zob + nz;

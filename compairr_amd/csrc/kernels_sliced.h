@@ -14,9 +14,9 @@
  *
  * Probing is done a ROW at a time (one position, all A replacement residues),
  * in two phases:
- *   1. fully unrolled, branch-free: A hashes, A filter words and A patterns
- *      are read back to back (LDS reads or HBM loads all in flight together)
- *      and reduced to one per-lane bit mask of Bloom-positive residues;
+ *   1. fully unrolled, branch-free: A hashes, their A filter words (LDS reads
+ *      or HBM loads, all in flight together) and A computed bit patterns are
+ *      reduced to one per-lane bit mask of Bloom-positive residues;
  *   2. a short loop pops the set bits (usually 0-3 per lane) and compacts the
  *      positives of the wave into the LDS queue with a ballot + prefix count.
  * The replacement-residue keys of a position are fetched once per row into one
@@ -39,7 +39,6 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t x, uint32_t l)
 /* per-wave state of the sliced kernel */
 struct SProber {
   const ProbeParams  &P;
-  const uint64_t     *pat_lds;
   const uint64_t     *slice_lds;
   WaveQueue          &q;
   unsigned long long *mat_lds;
@@ -94,7 +93,7 @@ __device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint6
     const uint64_t hv = h1 ^ readlane64(zrow, v);
     const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
     const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
-    const uint64_t pat = pattern_of(W.pat_lds, hv, W.pat_hi_shift);
+    const uint64_t pat = pattern_of(hv, W.pat_hi_shift);
     mask |= bloom_hit(word, pat) ? (1u << v) : 0u;
   }
   return mask;
@@ -120,7 +119,7 @@ __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint6
   uint32_t mask = 0;
 #pragma unroll
   for (int v = 0; v < A; v++) {
-    const uint64_t pat = pattern_of(W.pat_lds, hv[v], W.pat_hi_shift);
+    const uint64_t pat = pattern_of(hv[v], W.pat_hi_shift);
     mask |= bloom_hit(word[v], pat) ? (1u << v) : 0u;
   }
   return mask;
@@ -145,7 +144,7 @@ __device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
 }
 
 /*
- * LDS: [A * zpos Zobrist keys][1024 patterns][R1 * R2 matrix (optional)]
+ * LDS: [A * zpos Zobrist keys][R1 * R2 matrix (optional)]
  *      [NW WaveQueues][2^w-word Bloom slice][CR tables][chunk broadcast]
  */
 template <int A, int D, bool INDELS, bool GENES, int NW>
@@ -156,8 +155,7 @@ probe_sliced_kernel(const ProbeParams P)
   extern __shared__ __align__(16) unsigned char smem[];
   uint64_t *zl = (uint64_t *)smem;
   const uint32_t nz = (uint32_t)A * P.zpos;
-  uint64_t *pat_lds = zl + nz;
-  unsigned long long *mat_all = (unsigned long long *)(pat_lds + PATTERN_COUNT);
+  unsigned long long *mat_all = (unsigned long long *)(zl + nz);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
   uint64_t *slice_lds = (uint64_t *)(queues + NW);
@@ -167,8 +165,6 @@ probe_sliced_kernel(const ProbeParams P)
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[i];
-  for (uint32_t i = threadIdx.x; i < PATTERN_COUNT; i += NT)
-    pat_lds[i] = P.patterns[i];
   if (P.lds_matrix)
     for (uint32_t i = threadIdx.x; i < cells; i += NT)
       mat_all[i] = 0;
@@ -178,7 +174,7 @@ probe_sliced_kernel(const ProbeParams P)
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t K = P.geom.k;
-  SProber W{P, pat_lds, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
+  SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
             P.pat_hi_shift, 0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *gene_keys = P.zob + nz;
@@ -276,7 +272,7 @@ probe_sliced_kernel(const ProbeParams P)
       {
         const uint32_t woff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & W.wmask_bytes;
         const uint64_t word = *(const uint64_t *)((const char *)slice_lds + woff);
-        const uint64_t pat = pattern_of(pat_lds, h, W.pat_hi_shift);
+        const uint64_t pat = pattern_of(h, W.pat_hi_shift);
         s_push<GENES>(W, valid && bloom_hit(word, pat), h, pack_a(K_SAME, 0, 0), 0);
       }
 
@@ -353,7 +349,7 @@ probe_sliced_kernel(const ProbeParams P)
               const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
               const uint64_t word = *(const uint64_t *)((const char *)P.bloom +
                                                         ((uint64_t)vslice << W.slice_shift) + woff);
-              const uint64_t pat = pattern_of(pat_lds, hd, W.pat_hi_shift);
+              const uint64_t pat = pattern_of(hd, W.pat_hi_shift);
               nvar += fresh ? 1u : 0u;
               mask |= (fresh && bloom_hit(word, pat)) ? (1u << (p - p0)) : 0u;
               gone = r;

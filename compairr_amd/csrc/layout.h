@@ -18,17 +18,15 @@ constexpr int      WAVES_PER_BLOCK   = BLOCK_THREADS / WAVE;
    MAX_INSERTS, compairr.h:111). */
 constexpr uint32_t EXTRA_POSITIONS   = 3;
 
-/* Blocked Bloom filter, one 64-bit word per block, k = 8 bits per key, inverted
-   polarity (a cleared bit = present) so that the membership test is
-   (word & pattern) == 0 -- the geometry of bloompat.h:22-58.  The reference
-   draws the 8 bits from ONE table of 1024 patterns, which floors its false
-   positive rate at (keys per word) / 1024; here the pattern is the union of
-   two independent half patterns -- 4 bits of the low dword chosen by hash
-   bits 0..9, 4 bits of the high dword chosen by 10 other hash bits -- i.e.
-   2^20 distinct patterns from the same 8 KiB of table. */
-constexpr uint32_t PATTERN_BITS      = 10;
-constexpr uint32_t PATTERN_COUNT     = 1u << PATTERN_BITS;
-constexpr uint32_t PATTERN_K         = 8;
+/* Blocked Bloom filter, one 64-bit word per block, inverted polarity (a cleared
+   bit = present) so that the membership test is (word & pattern) == 0 -- the
+   block geometry of bloompat.h:22-58.  The reference sets 8 bits per key taken
+   from ONE table of 1024 patterns, which floors its false-positive rate at
+   (keys per word) / 1024; this build sets 4 bits per key computed directly from
+   20 hash bits (kernels.h pattern_of): a 2^20 pattern space and no table. */
+constexpr uint32_t PATTERN_BITS      = 10;     /* hash bits [0,10): low half pattern;
+                                                  word address starts at bit 10      */
+constexpr uint32_t PATTERN_K         = 4;
 
 /* Open-addressing table: 64-bit keys (the sequence hash), 32-bit payload (the
    set-2 sequence number); an all-ones key marks a free slot (the reference
@@ -99,7 +97,6 @@ struct ProbeParams {
   const uint64_t *bloom;
   uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
   uint32_t        pat_hi_shift;      /* hash bits [s, s+10) pick the high half pattern */
-  const uint64_t *patterns;
   /* hash table */
   const uint64_t *keys;
   const uint32_t *vals;
