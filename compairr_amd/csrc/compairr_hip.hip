@@ -66,6 +66,8 @@ struct cmpr_context {
   int64_t variant = 1;            /* 0: one global Bloom; 1: LDS-staged slices */
   int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
+  int64_t heavy_threshold = -1;   /* class population above which it is split;
+                                     -1: from the slice size, 0: every class   */
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
@@ -247,20 +249,6 @@ uint64_t variants_of(const cmpr_options &o, const uint8_t *s, uint32_t L)
   return n;
 }
 
-/* host twin of class_key() in kernels.h */
-uint32_t class_key_host(const SliceGeom &g, const std::vector<uint32_t> &t, uint32_t A,
-                        bool genes, const uint8_t *s, uint32_t L, uint32_t v, uint32_t j,
-                        uint32_t k)
-{
-  uint32_t ck = t[L];
-  if (genes)
-    ck ^= t[g.off_cv + v] ^ t[g.off_cj + j];
-  if (L > 0)
-    for (uint32_t i = 0; i < k; i++)
-      ck ^= t[g.off_cr + i * A + s[class_pos(L, i)]];
-  return ck;
-}
-
 using ProbeFn = void (*)(const ProbeParams);
 
 template <int NW>
@@ -436,6 +424,12 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
     c->class_residues = value;
+  } else if (n == "heavy_threshold") {
+    if (value < -1)
+      return fail(c, CMPR_EINVAL, "heavy_threshold must be >= -1");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set heavy_threshold before cmpr_set_reference");
+    c->heavy_threshold = value;
   } else if (n == "slice_words_log2") {
     if (value < 1 || value > 13)
       return fail(c, CMPR_EINVAL, "slice_words_log2 must be 1..13");
@@ -481,6 +475,13 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->waves_per_block;
   else if (n == "debug") *value = c->debug;
+  else if (n == "heavy_threshold") *value = c->heavy_threshold;
+  else if (n == "heavy_buckets") {
+    *value = 0;
+    if (c->sliced && c->have_ref)
+      for (uint32_t w = 0; w < HEAVY_WORDS; w++)
+        *value += __builtin_popcount(c->ctab[c->geom.off_hv + w]);
+  }
   else if (n == "slices") *value = c->sliced ? (int64_t)c->geom.smask + 1 : 1;
   else if (n == "tiles") *value = c->ntiles;
   else if (n == "chunks") *value = c->nchunks;
@@ -582,40 +583,67 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     g.off_cv = g.ncl;
     g.off_cj = g.off_cv + n_v;
     g.off_cr = g.off_cj + n_j;
-    c->ctab.assign((size_t)g.off_cr + MAX_CLASS_RES * A, 0);
+    g.off_hv = g.off_cr + MAX_CLASS_RES * A;
+    c->ctab.assign((size_t)g.off_hv + HEAVY_WORDS, 0);
     SplitMix64 crng(0x736c69636573ull);     /* "slices" */
-    for (auto &x : c->ctab)
-      x = (uint32_t)(crng.next() >> 32);
-    /* k = fewest class residues that spread set 2 evenly over the slices */
+    for (size_t i = 0; i < g.off_hv; i++)
+      c->ctab[i] = (uint32_t)(crng.next() >> 32);
+    const bool genes = !c->opt.ignore_genes;
     const uint64_t S = (uint64_t)g.smask + 1;
-    uint32_t best_k = 0;
-    if (c->class_residues >= 0) {
-      best_k = (uint32_t)c->class_residues;
-    } else if (S > 1 && s->n > 0) {
-      double best_max = -1;
-      std::vector<uint32_t> pop;
-      for (uint32_t k = 0; k <= MAX_CLASS_RES; k++) {
-        pop.assign((size_t)S, 0);
-        for (uint64_t i = 0; i < s->n; i++) {
-          const uint64_t b = s->offsets[i];
-          const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-          pop[class_key_host(g, c->ctab, A, !c->opt.ignore_genes, s->residues + b, L,
-                             c->opt.ignore_genes ? 0 : s->v_gene[i],
-                             c->opt.ignore_genes ? 0 : s->j_gene[i], k) & g.smask]++;
+    const double slice_bits = (double)(64ull << g.words_log2);
+    /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
+       bits per key, false-positive rate <= 6e-3 there and far less elsewhere */
+    const double slice_cap = slice_bits / 12.0;
+    g.k = 0;
+    if (S > 1 && s->n > 0) {
+      /* population of every (length, V, J) class bucket */
+      std::vector<uint32_t> bucket((size_t)1 << HEAVY_BUCKETS_LOG2, 0);
+      std::vector<uint32_t> base_of((size_t)s->n);
+      for (uint64_t i = 0; i < s->n; i++) {
+        const uint32_t L = (uint32_t)(s->offsets[i + 1] - s->offsets[i]);
+        const uint32_t b = class_base(c->ctab.data(), g, genes, L, genes ? s->v_gene[i] : 0,
+                                      genes ? s->j_gene[i] : 0);
+        base_of[i] = b;
+        bucket[b >> (32 - HEAVY_BUCKETS_LOG2)]++;
+      }
+      /* heavy = would take more than half of a slice's budget on its own */
+      const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold : slice_cap / 2;
+      bool any_heavy = false;
+      for (uint32_t b = 0; b < bucket.size(); b++)
+        if ((double)bucket[b] > thr) {
+          c->ctab[g.off_hv + (b >> 5)] |= 1u << (b & 31);
+          any_heavy = true;
         }
-        const double mx = *std::max_element(pop.begin(), pop.end());
-        if (best_max < 0 || mx < best_max) {
-          best_max = mx;
-          best_k = k;
+      if (c->class_residues >= 0) {
+        g.k = (uint32_t)c->class_residues;
+      } else if (any_heavy) {
+        /* K = fewest class residues that bring the fullest slice under the cap;
+           every one costs the heavy queries one HBM-probed row */
+        double best_max = -1;
+        uint32_t best_k = 1;
+        std::vector<uint32_t> pop;
+        for (uint32_t k = 1; k <= MAX_CLASS_RES; k++) {
+          pop.assign((size_t)S, 0);
+          for (uint64_t i = 0; i < s->n; i++) {
+            const uint64_t b = s->offsets[i];
+            const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+            uint32_t ck = base_of[i];
+            if (L > 0 && class_is_heavy(c->ctab.data(), g, ck))
+              for (uint32_t r = 0; r < k; r++)
+                ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r)]];
+            pop[ck & g.smask]++;
+          }
+          const double mx = *std::max_element(pop.begin(), pop.end());
+          if (best_max < 0 || mx < best_max) {
+            best_max = mx;
+            best_k = k;
+          }
+          if (mx <= slice_cap)
+            break;
         }
-        /* every class residue costs one HBM-probed row per query, so take the
-           fewest that still leave the fullest slice >= 12 filter bits per key
-           (fill <= 0.49, false-positive rate <= 3e-3 there, far less elsewhere) */
-        if (mx * 12.0 <= (double)(64ull << g.words_log2))
-          break;
+        g.k = best_k;
       }
     }
-    g.k = best_k;
     if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
     g.ctab = c->d_ctab.p;
   }
@@ -706,20 +734,23 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
      inside a slice longest first.  Variant 0 has one slice.  Every group is
      cut into 64-query tiles. */
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
-  const uint64_t S = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
+  const uint64_t S = c->sliced ? 2 * ((uint64_t)c->geom.smask + 1) : 1;   /* (slice, heavy) */
   const uint64_t per_slice = (uint64_t)longest + 1;
   std::vector<uint32_t> group_of((size_t)s->n);
   std::vector<uint64_t> per_group((size_t)(S * per_slice), 0);
   for (uint64_t i = 0; i < s->n; i++) {
     const uint64_t b = s->offsets[i];
     const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-    uint32_t slice = 0;
-    if (c->sliced)
-      slice = class_key_host(c->geom, c->ctab, A, !c->opt.ignore_genes, s->residues + b, L,
-                             c->opt.ignore_genes ? 0 : s->v_gene[i],
-                             c->opt.ignore_genes ? 0 : s->j_gene[i], c->geom.k) &
-              c->geom.smask;
-    const uint64_t g = (uint64_t)slice * per_slice + (longest - L);
+    uint64_t sh = 0;
+    if (c->sliced) {
+      bool heavy = false;
+      const bool genes = !c->opt.ignore_genes;
+      const uint32_t slice = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b, L,
+                                          genes ? s->v_gene[i] : 0, genes ? s->j_gene[i] : 0,
+                                          &heavy) & c->geom.smask;
+      sh = 2 * (uint64_t)slice + (heavy ? 1 : 0);
+    }
+    const uint64_t g = sh * per_slice + (longest - L);
     group_of[i] = (uint32_t)g;
     per_group[g]++;
   }
@@ -732,10 +763,12 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   std::vector<TileDesc> tiles;
   std::vector<Chunk> chunks;
   std::vector<uint64_t> chunk_work;
-  for (uint64_t slice = 0; slice < S; slice++) {
+  for (uint64_t sh = 0; sh < S; sh++) {
+    const uint64_t slice = c->sliced ? sh / 2 : 0;
+    const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
     const uint64_t slice_first = ntiles;
     for (uint64_t gl = 0; gl < per_slice; gl++) {
-      const uint64_t g = slice * per_slice + gl;
+      const uint64_t g = sh * per_slice + gl;
       const uint64_t L = longest - gl;
       tile_first[g] = ntiles;
       const uint64_t cnt = per_group[g];
@@ -747,7 +780,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
         td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
         td.res_base = res_words;
         td.slice = (uint32_t)slice;
-        td.pad = 0;
+        td.k = tile_k;
         res_words += words * WAVE;
         tiles.push_back(td);
       }
@@ -898,7 +931,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
                  (size_t)nw * sizeof(WaveQueue);
     if (c->sliced)
       lds += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
-             MAX_CLASS_RES * A * sizeof(uint32_t) + 16;
+             MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16;
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");

@@ -97,21 +97,6 @@ struct BuildParams {
   SliceGeom       geom;
 };
 
-/* class key of a sequence (layout.h "Sliced Bloom layout"); same function on
-   the host for the queries (class_key_host in compairr_hip.hip) */
-__device__ __forceinline__ uint32_t class_key(const SliceGeom &g, uint32_t A,
-                                              bool genes, const uint8_t *s,
-                                              uint32_t L, uint32_t v, uint32_t j)
-{
-  uint32_t ck = g.ctab[L];
-  if (genes)
-    ck ^= g.ctab[g.off_cv + v] ^ g.ctab[g.off_cj + j];
-  if (L > 0)
-    for (uint32_t i = 0; i < g.k; i++)
-      ck ^= g.ctab[g.off_cr + i * A + s[class_pos(L, i)]];
-  return ck;
-}
-
 /* One thread per set-2 sequence: Zobrist hash (zobrist.cc:74-88), claim the
    first free slot of the probe chain with a 64-bit CAS (hash_insert,
    overlap.cc:63-128: every entry is inserted, duplicates included), clear the
@@ -146,9 +131,9 @@ build_index_kernel(const BuildParams B)
 
   uint64_t boff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & B.bloom_byte_mask;
   if (B.sliced) {
-    const uint32_t slice = class_key(B.geom, B.A, B.use_genes != 0, B.res + b, L,
-                                     B.use_genes ? B.v[i] : 0u,
-                                     B.use_genes ? B.j[i] : 0u) & B.geom.smask;
+    const uint32_t slice = class_key_of(B.geom.ctab, B.geom, B.A, B.use_genes != 0,
+                                        B.res + b, L, B.use_genes ? B.v[i] : 0u,
+                                        B.use_genes ? B.j[i] : 0u, nullptr) & B.geom.smask;
     boff = ((uint64_t)slice << (B.geom.words_log2 + 3)) +
            (((uint32_t)(h >> (PATTERN_BITS - 3))) & (((1u << B.geom.words_log2) - 1u) << 3));
   }

@@ -100,10 +100,12 @@ __device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint6
 }
 
 /* phase 1, class-changing row: slice of residue v = own slice ^ dk_lane ^ crow[v]
-   (crow: lane v holds the class-key term of replacement residue v) */
+   (crow: lane v holds the class-key term of replacement residue v; it applies
+   only to lanes whose variant class is split: crow_enable = all ones / zero) */
 template <int A>
 __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint64_t zrow,
-                                            uint32_t dk_lane, uint32_t crow)
+                                            uint32_t dk_lane, uint32_t crow,
+                                            uint32_t crow_enable = ~0u)
 {
   uint64_t word[A];
   uint64_t hv[A];
@@ -111,7 +113,7 @@ __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint6
   for (int v = 0; v < A; v++) {
     hv[v] = h1 ^ readlane64(zrow, v);
     const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)crow, v);
-    const uint32_t vslice = (W.tile_slice ^ dk_lane ^ cv) & W.smask;
+    const uint32_t vslice = (W.tile_slice ^ dk_lane ^ (cv & crow_enable)) & W.smask;
     const uint32_t woff = ((uint32_t)(hv[v] >> (PATTERN_BITS - 3))) & W.wmask_bytes;
     const uint64_t off = ((uint64_t)vslice << W.slice_shift) + woff;
     word[v] = *(const uint64_t *)((const char *)W.P.bloom + off);
@@ -161,7 +163,8 @@ probe_sliced_kernel(const ProbeParams P)
   uint64_t *slice_lds = (uint64_t *)(queues + NW);
   const uint32_t slice_words = 1u << P.geom.words_log2;
   uint32_t *cr_lds = (uint32_t *)(slice_lds + slice_words);
-  uint32_t *bcast = cr_lds + MAX_CLASS_RES * A;
+  uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;     /* heavy-class bitmap */
+  uint32_t *bcast = hv_lds + HEAVY_WORDS;
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[i];
@@ -170,10 +173,13 @@ probe_sliced_kernel(const ProbeParams P)
       mat_all[i] = 0;
   for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += NT)
     cr_lds[i] = P.geom.ctab[P.geom.off_cr + i];
+  if (INDELS)
+    for (uint32_t i = threadIdx.x; i < HEAVY_WORDS; i += NT)
+      hv_lds[i] = P.geom.ctab[P.geom.off_hv + i];
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
-  const uint32_t K = P.geom.k;
+  const uint32_t KH = P.geom.k;           /* class residues of heavy classes */
   SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
             P.pat_hi_shift, 0u, 0, {0ull, 0u, 0u, 0u}};
@@ -211,6 +217,7 @@ probe_sliced_kernel(const ProbeParams P)
       const TileDesc td = P.tiles[t];
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
+      const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
       const uint32_t *qr = P.qres + td.res_base + lane;
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
@@ -301,10 +308,19 @@ probe_sliced_kernel(const ProbeParams P)
       }
 
       if (INDELS) {
-        /* Indel variants change the length, hence the class: their slice is
-           own ^ CL[L] ^ CL[L'] ^ old class residues ^ new class residues. */
+        /* Indel variants change the length, hence the class:
+             ckey' = base ^ CL[L] ^ CL[L'] ^ (heavy(base') ? class residues of the variant : 0)
+           while the tile's slice is ckey = base ^ (K ? class residues of the query : 0). */
         const uint32_t cl_L = P.geom.ctab[L];
-        uint32_t cbase = 0;                      /* XOR_i CR[i][s[m_i(L)]] */
+        uint32_t base = cl_L;
+        if (GENES)
+          base ^= P.geom.ctab[P.geom.off_cv + P.qv[W.qslot]] ^
+                  P.geom.ctab[P.geom.off_cj + P.qj[W.qslot]];
+        auto heavy_of = [&](uint32_t bs) -> uint32_t {
+          const uint32_t b = bs >> (32 - HEAVY_BUCKETS_LOG2);
+          return (KH > 0 && ((hv_lds[b >> 5] >> (b & 31u)) & 1u)) ? ~0u : 0u;
+        };
+        uint32_t cbase = 0;                      /* XOR_i CR[i][s[m_i(L)]], heavy tiles */
 #pragma unroll
         for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
           if (i < K && L > 0)
@@ -315,15 +331,17 @@ probe_sliced_kernel(const ProbeParams P)
                 Blocks of up to 32 positions: phase 1 rolls the hash and gathers
                 the filter words, phase 2 replays the roll for the positives. */
         if (L > 1) {
-          const uint32_t dl = cl_L ^ P.geom.ctab[L - 1] ^ cbase;
+          const uint32_t dlen = cl_L ^ P.geom.ctab[L - 1];
+          const uint32_t hv = heavy_of(base ^ dlen);          /* is the variant's class split? */
+          const uint32_t dl = dlen ^ cbase;
           uint32_t md[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
 #pragma unroll
           for (uint32_t i = 0; i < MAX_CLASS_RES; i++) {
             md[i] = class_pos(L - 1, i);
             lo[i] = hi[i] = 0;
-            if (i < K) {
-              lo[i] = cr_lds[i * A + res_at(md[i])];
-              hi[i] = cr_lds[i * A + res_at(md[i] + 1)];
+            if (i < KH) {
+              lo[i] = cr_lds[i * A + res_at(md[i])] & hv;
+              hi[i] = cr_lds[i * A + res_at(md[i] + 1)] & hv;
             }
           }
           uint64_t hd = hdel;
@@ -374,17 +392,19 @@ probe_sliced_kernel(const ProbeParams P)
                 position ip, u[x] = x < ip ? s[x] : x == ip ? v : s[x - 1] ---- */
         {
           nvar += (uint64_t)A + (uint64_t)(A - 1) * L;
-          const uint32_t dl = cl_L ^ P.geom.ctab[L + 1] ^ cbase;
+          const uint32_t dlen = cl_L ^ P.geom.ctab[L + 1];
+          const uint32_t hv = heavy_of(base ^ dlen);
+          const uint32_t dl = dlen ^ cbase;
           uint32_t mi[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
 #pragma unroll
           for (uint32_t i = 0; i < MAX_CLASS_RES; i++) {
             mi[i] = class_pos(L + 1, i);
             lo[i] = hi[i] = 0;
-            if (i < K) {
+            if (i < KH) {
               if (mi[i] < L)
-                lo[i] = cr_lds[i * A + res_at(mi[i])];
+                lo[i] = cr_lds[i * A + res_at(mi[i])] & hv;
               if (mi[i] >= 1)
-                hi[i] = cr_lds[i * A + res_at(mi[i] - 1)];
+                hi[i] = cr_lds[i * A + res_at(mi[i] - 1)] & hv;
             }
           }
           uint64_t hi_hash = hins;
@@ -400,14 +420,14 @@ probe_sliced_kernel(const ProbeParams P)
             uint32_t dk0 = dl, crow = 0;
 #pragma unroll
             for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
-              if (i < K) {
+              if (i < KH) {
                 if (mi[i] == ip)
                   crow ^= cr_lds[i * A + zlane];          /* u[mi] = v */
                 else
                   dk0 ^= mi[i] < ip ? lo[i] : hi[i];
               }
             const uint64_t zrow = zl[A * ip + zlane];
-            uint32_t mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow);
+            uint32_t mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
             mask &= vmask;
             if (ip > 0)
               mask &= ~(1u << r);                         /* v != s[ip - 1] */

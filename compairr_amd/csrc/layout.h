@@ -47,36 +47,76 @@ struct TileDesc {
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
   uint64_t res_base;  /* dword offset of the tile's residues in qres         */
   uint32_t slice;     /* Bloom slice of every query of the tile (sliced mode) */
-  uint32_t pad;
+  uint32_t k;         /* class residues of the tile's queries: 0 (light) or K  */
 };
 
 /* Sliced Bloom layout (kernel variant 1).  The filter is cut into S = 2^s
    slices of 2^w words; a sequence's slice is NOT taken from its Zobrist hash
    but from a "class key" that is invariant under most single edits:
-       ckey = CL[len] ^ CV[v] ^ CJ[j] ^ CR[0][seq[m_0]] ^ ... ^ CR[k-1][seq[m_k-1]]
+       base  = CL[len] ^ CV[v] ^ CJ[j]
+       ckey  = base ^ (heavy(base) ? CR[0][seq[m_0]] ^ ... ^ CR[K-1][seq[m_K-1]] : 0)
        slice = ckey & (S - 1),   m_i = (len / 2 + i) % len
-   so every substitution variant of a query that does not touch one of the k
-   class positions lives in the query's own slice.  Queries are grouped by
-   slice, a workgroup stages that 2^w-word slice into LDS once and answers
-   those probes from LDS; only variants that change the class (substitution at
-   a class position, indels) go to the filter in HBM.  The word inside a slice
-   and the bit pattern still come from the Zobrist hash. */
-constexpr uint32_t MAX_CLASS_RES     = 3;
-constexpr uint32_t SLICE_WORDS_LOG2  = 12;     /* 4096 words = 32 KiB per slice */
+   heavy(base) is one bit of a 65536-bucket bitmap filled from set 2: a
+   (len, V, J) class that alone would overfill a slice is split over up to
+   20^K slices by K "class residues" from the middle of the sequence; all
+   other ("light") classes are not split.  Hence every substitution variant
+   of a light query, and every substitution variant of a heavy query that does
+   not touch a class position, lives in the query's own slice.  Queries are
+   grouped by slice, a workgroup stages that slice into LDS once and answers
+   those probes from LDS; only variants that change the class key go to the
+   filter in HBM.  The word inside a slice and the bit pattern still come from
+   the Zobrist hash. */
+constexpr uint32_t MAX_CLASS_RES      = 3;
+constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
+constexpr uint32_t HEAVY_BUCKETS_LOG2 = 16;
+constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
 
 struct SliceGeom {
   uint32_t smask;          /* S - 1                                          */
   uint32_t words_log2;     /* w                                              */
-  uint32_t k;              /* class residues, 0..MAX_CLASS_RES               */
+  uint32_t k;              /* K: class residues of heavy classes, 0..3       */
   uint32_t ncl;            /* entries of CL (lengths 0..ncl-1)               */
-  /* class tables, u32 each: CL[ncl] | CV[n_v] | CJ[n_j] | CR[MAX_CLASS_RES][A] */
+  /* class tables, u32 each:
+     CL[ncl] | CV[n_v] | CJ[n_j] | CR[MAX_CLASS_RES][A] | heavy bitmap[HEAVY_WORDS] */
   const uint32_t *ctab;
-  uint32_t off_cv, off_cj, off_cr, pad;
+  uint32_t off_cv, off_cj, off_cr, off_hv;
 };
 
 __host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i)
 {
   return len ? (len / 2 + i) % len : 0;
+}
+
+/* `t` = the class tables (host vector or device pointer, same layout) */
+__host__ __device__ inline uint32_t class_base(const uint32_t *t, const SliceGeom &g,
+                                               bool genes, uint32_t L, uint32_t v, uint32_t j)
+{
+  uint32_t b = t[L];
+  if (genes)
+    b ^= t[g.off_cv + v] ^ t[g.off_cj + j];
+  return b;
+}
+
+__host__ __device__ inline bool class_is_heavy(const uint32_t *t, const SliceGeom &g,
+                                               uint32_t base)
+{
+  const uint32_t b = base >> (32 - HEAVY_BUCKETS_LOG2);
+  return (t[g.off_hv + (b >> 5)] >> (b & 31u)) & 1u;
+}
+
+__host__ __device__ inline uint32_t class_key_of(const uint32_t *t, const SliceGeom &g,
+                                                 uint32_t A, bool genes, const uint8_t *s,
+                                                 uint32_t L, uint32_t v, uint32_t j,
+                                                 bool *heavy_out)
+{
+  uint32_t ck = class_base(t, g, genes, L, v, j);
+  const bool heavy = g.k > 0 && class_is_heavy(t, g, ck);
+  if (heavy && L > 0)
+    for (uint32_t i = 0; i < g.k; i++)
+      ck ^= t[g.off_cr + i * A + s[class_pos(L, i)]];
+  if (heavy_out)
+    *heavy_out = heavy;
+  return ck;
 }
 
 /* one block-level work item of the sliced kernel: tiles of one slice */

@@ -36,9 +36,17 @@ def gpu_cells(a, b, opt, tun=None):
 LAYOUTS = {
     "hbm": {"variant": 0},
     "lds": {"variant": 1},
-    "lds_tiny_k3": {"variant": 1, "slice_words_log2": 3, "class_residues": 3, "chunk_tiles": 2},
-    "lds_tiny_k1": {"variant": 1, "slice_words_log2": 4, "class_residues": 1, "chunk_tiles": 3},
+    # every class split by 3 / 1 class residues, 64-byte slices
+    "lds_tiny_k3": {"variant": 1, "slice_words_log2": 3, "class_residues": 3, "chunk_tiles": 2,
+                    "heavy_threshold": 0},
+    "lds_tiny_k1": {"variant": 1, "slice_words_log2": 4, "class_residues": 1, "chunk_tiles": 3,
+                    "heavy_threshold": 0},
+    # no class split at all
     "lds_tiny_k0": {"variant": 1, "slice_words_log2": 5, "class_residues": 0},
+    # light and heavy classes mixed (classes with more than 2 sequences are split)
+    "lds_tiny_mixed": {"variant": 1, "slice_words_log2": 3, "class_residues": 2,
+                       "heavy_threshold": 2, "waves_per_block": 4},
+    "lds_mixed_auto": {"variant": 1, "slice_words_log2": 6, "waves_per_block": 16},
 }
 
 
