@@ -79,6 +79,7 @@ struct cmpr_context {
   std::vector<uint32_t> ctab;     /* host copy of the class tables             */
   DevBuf<uint32_t>      d_ctab;
   DevBuf<Chunk>         chunks;
+  DevBuf<uint32_t>      tile_list;
   uint32_t              nchunks = 0;
 
   /* Zobrist + patterns */
@@ -386,7 +387,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
-  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release();
+  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
@@ -763,6 +764,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   std::vector<TileDesc> tiles;
   std::vector<Chunk> chunks;
   std::vector<uint64_t> chunk_work;
+  std::vector<uint32_t> tile_list;              /* chunk -> tile ids */
+  std::vector<std::vector<uint32_t>> sibling[2];
+  if (c->sliced && c->opt.indels)
+    for (int k = 0; k < 2; k++)
+      sibling[k].resize((size_t)c->geom.smask + 1);
   for (uint64_t sh = 0; sh < S; sh++) {
     const uint64_t slice = c->sliced ? sh / 2 : 0;
     const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
@@ -786,20 +792,61 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
       }
       ntiles += nt;
     }
-    if (c->sliced)
+    if (c->sliced) {
+      /* main pass: the tiles of this slice, any length */
       for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
         Chunk ck;
         ck.slice = (uint32_t)slice;
-        ck.first_tile = (uint32_t)t0;
+        ck.first_tile = (uint32_t)tile_list.size();
         ck.ntiles = (uint32_t)std::min<uint64_t>(chunk_tiles, ntiles - t0);
-        ck.pad = 0;
+        ck.pass = 0;
         uint64_t work = 0;
-        for (uint32_t t = 0; t < ck.ntiles; t++)
+        for (uint32_t t = 0; t < ck.ntiles; t++) {
           work += (uint64_t)(tiles[t0 + t].len + 1) * tiles[t0 + t].nvalid;
+          tile_list.push_back((uint32_t)(t0 + t));
+        }
         chunks.push_back(ck);
         chunk_work.push_back(work);
       }
+      /* indel passes: file every tile under the sibling slice its insertion /
+         deletion variants fall into (own ^ CL[L] ^ CL[L+-1]) */
+      if (c->opt.indels)
+        for (uint64_t gl = 0; gl < per_slice; gl++) {
+          const uint64_t g = sh * per_slice + gl;
+          const uint64_t L = longest - gl;
+          const uint64_t nt = (per_group[g] + WAVE - 1) / WAVE;
+          for (uint32_t pass = 1; pass <= 2; pass++) {
+            if (pass == 2 && L < 2)
+              continue;
+            const uint32_t dlen = c->ctab[L] ^ c->ctab[pass == 1 ? L + 1 : L - 1];
+            std::vector<uint32_t> &dst =
+                sibling[pass - 1][((uint32_t)slice ^ dlen) & c->geom.smask];
+            for (uint64_t t = 0; t < nt; t++)
+              dst.push_back((uint32_t)(tile_first[g] + t));
+          }
+        }
+    }
   }
+  if (c->sliced && c->opt.indels)
+    for (uint32_t pass = 1; pass <= 2; pass++)
+      for (size_t T = 0; T < sibling[pass - 1].size(); T++) {
+        const std::vector<uint32_t> &src = sibling[pass - 1][T];
+        for (size_t t0 = 0; t0 < src.size(); t0 += chunk_tiles) {
+          Chunk ck;
+          ck.slice = (uint32_t)T;
+          ck.first_tile = (uint32_t)tile_list.size();
+          ck.ntiles = (uint32_t)std::min<size_t>(chunk_tiles, src.size() - t0);
+          ck.pass = pass;
+          uint64_t work = 0;
+          for (uint32_t t = 0; t < ck.ntiles; t++) {
+            const TileDesc &td = tiles[src[t0 + t]];
+            work += (uint64_t)(pass == 1 ? td.len + 2 : 2) * td.nvalid;
+            tile_list.push_back(src[t0 + t]);
+          }
+          chunks.push_back(ck);
+          chunk_work.push_back(work);
+        }
+      }
   if (ntiles * WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
   c->ntiles = (uint32_t)ntiles;
@@ -816,6 +863,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
       sorted[i] = chunks[order[i]];
     c->nchunks = (uint32_t)sorted.size();
     if ((rc = dev_upload(c, c->chunks, sorted.data(), sorted.size()))) return rc;
+    if ((rc = dev_upload(c, c->tile_list, tile_list.data(), tile_list.size()))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
 
@@ -922,6 +970,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.stats = c->stats.p;
     P.geom = c->geom;
     P.chunks = c->chunks.p;
+    P.tile_list = c->tile_list.p;
     P.nchunks = c->nchunks;
     P.debug = (uint32_t)c->debug;
 

@@ -204,7 +204,7 @@ probe_sliced_kernel(const ProbeParams P)
         slice_lds[i] = src[i];
     }
     __syncthreads();
-    W.tile_slice = ck.slice;
+    const uint32_t pass = ck.pass;         /* 0 main, 1 insertions, 2 deletions */
 
     for (;;) {
       uint32_t tk = 0;
@@ -213,11 +213,12 @@ probe_sliced_kernel(const ProbeParams P)
       tk = __builtin_amdgcn_readfirstlane(tk);
       if (tk >= ck.ntiles)
         break;
-      const uint32_t t = ck.first_tile + tk;
+      const uint32_t t = P.tile_list[ck.first_tile + tk];
       const TileDesc td = P.tiles[t];
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
+      W.tile_slice = __builtin_amdgcn_readfirstlane(td.slice);
       const uint32_t *qr = P.qres + td.res_base + lane;
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
@@ -273,17 +274,17 @@ probe_sliced_kernel(const ProbeParams P)
         return dk;
       };
 
-      uint64_t nvar = 1;
+      uint64_t nvar = pass == 0 ? 1 : 0;
 
       /* ---- the unchanged sequence (variants.cc:260-268) ---- */
-      {
+      if (pass == 0) {
         const uint32_t woff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & W.wmask_bytes;
         const uint64_t word = *(const uint64_t *)((const char *)slice_lds + woff);
         const uint64_t pat = pattern_of(h, W.pat_hi_shift);
         s_push<GENES>(W, valid && bloom_hit(word, pat), h, pack_a(K_SAME, 0, 0), 0);
       }
 
-      if (D >= 1) {
+      if (D >= 1 && pass == 0) {
         /* ---- single substitutions (variants.cc:280-293) ---- */
         nvar += (uint64_t)(A - 1) * L;
         uint32_t w = 0;
@@ -311,6 +312,16 @@ probe_sliced_kernel(const ProbeParams P)
         /* Indel variants change the length, hence the class:
              ckey' = base ^ CL[L] ^ CL[L'] ^ (heavy(base') ? class residues of the variant : 0)
            while the tile's slice is ckey = base ^ (K ? class residues of the query : 0). */
+        /* Most insertion variants of a tile fall into ONE other slice, the
+           "sibling" own ^ CL[L] ^ CL[L+1] (all of them when neither class is
+           split; for split classes those rows that leave the class residues in
+           place), and most deletion variants into own ^ CL[L] ^ CL[L-1].  The
+           host schedules the indel rows as separate passes over the tiles of one
+           (slice, length) group with that sibling slice staged in LDS; a lane
+           whose variant lands elsewhere probes the filter in HBM. */
+        const bool do_del = pass == 2;
+        const bool do_ins = pass == 1;
+        const uint32_t staged = ck.slice;
         const uint32_t cl_L = P.geom.ctab[L];
         uint32_t base = cl_L;
         if (GENES)
@@ -330,7 +341,7 @@ probe_sliced_kernel(const ProbeParams P)
                 u[x] = x < p ? s[x] : s[x + 1]; one per run of equal residues.
                 Blocks of up to 32 positions: phase 1 rolls the hash and gathers
                 the filter words, phase 2 replays the roll for the positives. */
-        if (L > 1) {
+        if (L > 1 && do_del) {
           const uint32_t dlen = cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hv = heavy_of(base ^ dlen);          /* is the variant's class split? */
           const uint32_t dl = dlen ^ cbase;
@@ -365,8 +376,12 @@ probe_sliced_kernel(const ProbeParams P)
                 dk ^= md[i] < p ? lo[i] : hi[i];
               const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
               const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-              const uint64_t word = *(const uint64_t *)((const char *)P.bloom +
-                                                        ((uint64_t)vslice << W.slice_shift) + woff);
+              uint64_t word;
+              if (vslice == staged)
+                word = *(const uint64_t *)((const char *)slice_lds + woff);
+              else
+                word = *(const uint64_t *)((const char *)P.bloom +
+                                           ((uint64_t)vslice << W.slice_shift) + woff);
               const uint64_t pat = pattern_of(hd, W.pat_hi_shift);
               nvar += fresh ? 1u : 0u;
               mask |= (fresh && bloom_hit(word, pat)) ? (1u << (p - p0)) : 0u;
@@ -390,7 +405,7 @@ probe_sliced_kernel(const ProbeParams P)
 
         /* ---- insertions (variants.cc:329-353): u = s with v put in front of
                 position ip, u[x] = x < ip ? s[x] : x == ip ? v : s[x - 1] ---- */
-        {
+        if (do_ins) {
           nvar += (uint64_t)A + (uint64_t)(A - 1) * L;
           const uint32_t dlen = cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hv = heavy_of(base ^ dlen);
@@ -418,16 +433,29 @@ probe_sliced_kernel(const ProbeParams P)
               hi_hash ^= zl[A * p + r] ^ zl[A * ip + r];
             }
             uint32_t dk0 = dl, crow = 0;
+            bool v_on_class_pos = false;
 #pragma unroll
             for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
               if (i < KH) {
-                if (mi[i] == ip)
+                if (mi[i] == ip) {
                   crow ^= cr_lds[i * A + zlane];          /* u[mi] = v */
-                else
+                  v_on_class_pos = true;
+                } else {
                   dk0 ^= mi[i] < ip ? lo[i] : hi[i];
+                }
               }
             const uint64_t zrow = zl[A * ip + zlane];
-            uint32_t mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
+            /* rows that put v on a class position spread over up to A slices */
+            const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == staged;
+            uint32_t mask = 0;
+            if (__ballot(in_lds)) {
+              const uint32_t ml = row_lds<A>(W, hi_hash, zrow);
+              mask = in_lds ? ml : 0u;
+            }
+            if (__ballot(!in_lds)) {
+              if (!in_lds)
+                mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
+            }
             mask &= vmask;
             if (ip > 0)
               mask &= ~(1u << r);                         /* v != s[ip - 1] */
@@ -436,7 +464,7 @@ probe_sliced_kernel(const ProbeParams P)
         }
       }
 
-      if (D >= 2) {
+      if (D >= 2 && pass == 0) {
         /* ---- double substitutions p < q (variants.cc:370-399) ---- */
         nvar += (uint64_t)(A - 1) * (A - 1) * ((uint64_t)L * (L ? L - 1 : 0) / 2);
         for (uint32_t p = 0; p + 1 < L; p++) {

@@ -121,10 +121,12 @@ __host__ __device__ inline uint32_t class_key_of(const uint32_t *t, const SliceG
 
 /* one block-level work item of the sliced kernel: tiles of one slice */
 struct Chunk {
-  uint32_t slice;
-  uint32_t first_tile;
+  uint32_t slice;        /* slice to stage in LDS                            */
+  uint32_t first_tile;   /* index into ProbeParams::tile_list                */
   uint32_t ntiles;
-  uint32_t pad;
+  uint32_t pass;         /* 0: all rows of the tiles' own slice; 1: insertion
+                            rows, 2: deletion rows, with the
+                            sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
 };
 
 /* per-launch kernel arguments */
@@ -168,6 +170,7 @@ struct ProbeParams {
   /* sliced mode */
   SliceGeom       geom;
   const Chunk    *chunks;
+  const uint32_t *tile_list;       /* chunk c covers tiles tile_list[first .. first+n) */
   uint32_t        nchunks;
   uint32_t        debug;           /* ablation switches, 0 in production      */
   /* work distribution + statistics */
