@@ -49,15 +49,64 @@ def parse_args():
     return p.parse_args()
 
 
-def cpu_baseline(ref, queries, opt, sample):
-    """Reference algorithm on the host cores (rank 0, N = 1 only): the oracle
-    port (oracle/liboracle.so), all cores, on the first `sample` queries of the
-    workload against the full reference set.  Returns (dict, matrix, sample_set)."""
+def _opt_argv(args):
+    argv = ["-d", str(args.differences)]
+    if args.indels:
+        argv.append("-i")
+    if args.nucleotides:
+        argv.append("-n")
+    if args.ignore_genes:
+        argv.append("-g")
+    return argv
+
+
+def cpu_baseline(ref, queries, opt, sample, args):
+    """The reference algorithm on this box's host cores (rank 0, N = 1 only), on a
+    bounded sample: the first `sample` queries of the workload against the full
+    reference set.
+
+    kind "reference": the unmodified reference program (oracle/_ref/compairr,
+    compiled from /root/reference by oracle/Makefile and shipped as a binary)
+    is fed the sample as AIRR TSV files and its own 'Analysing:' log time is
+    taken -- exactly the per-query loop, overlap.cc:906-938.
+    kind "port": the oracle port (oracle/liboracle.so) when the binary is absent.
+    Returns (dict, integer matrix, sample set)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 256))
+    threads = max(1, min(cores, 256))           # the reference caps -t at 256
     q = queries.subset(slice(0, sample))
+    exe = os.path.join(ROOT, "oracle", "_ref", "compairr")
+    if os.path.exists(exe):
+        import re
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="cmpr_bench_") as tmp:
+            fq, fr = os.path.join(tmp, "q.tsv"), os.path.join(tmp, "r.tsv")
+            q.write_tsv_fast(fq, args.nucleotides)
+            ref.write_tsv_fast(fr, args.nucleotides)
+            log, out = os.path.join(tmp, "log"), os.path.join(tmp, "out.tsv")
+            t0 = time.time()
+            p = subprocess.run([exe, "-m", fq, fr, "-t", str(threads), "-l", log, "-o", out]
+                               + _opt_argv(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            if p.returncode == 0:
+                text = open(log).read()
+                sec = float(re.search(r"Analysing:\s+100% \(([0-9.]+)s\)", text).group(1))
+                rows = [l.rstrip("\n").split("\t") for l in open(out)]
+                cols = rows[0][1:]
+                cell = {(r[0], cid): float(x) for r in rows[1:] for cid, x in zip(cols, r[1:])}
+                m = np.zeros((q.n_repertoires, ref.n_repertoires))
+                for i, a in enumerate(q.repertoire_ids):
+                    for j, b in enumerate(ref.repertoire_ids):
+                        m[i, j] = cell.get((a, b), 0.0)
+                return ({"value": q.n / sec, "unit": "query sequences/s", "cores": threads,
+                         "kind": "reference",
+                         "sample": "CompAIRR 1.13.0 binary (oracle/_ref), -t %d, first %d queries "
+                                   "of the workload vs all %d reference sequences; its own "
+                                   "'Analysing:' time %.2f s (whole run incl. TSV parse %.1f s)"
+                                   % (threads, q.n, ref.n, sec, wall)},
+                        m, q, "%.10g")
     m, st = _oracle.overlap(q, ref, opt, threads=threads)
     rate = q.n / st.seconds_analysis if st.seconds_analysis > 0 else 0.0
     return ({"value": rate, "unit": "query sequences/s", "cores": threads, "kind": "port",
@@ -65,7 +114,7 @@ def cpu_baseline(ref, queries, opt, sample):
                        "per-query loop only (reference 'Analysing:' region) %.2f s, "
                        "index build %.2f s excluded" % (q.n, ref.n, st.seconds_analysis,
                                                         st.seconds_index)},
-            _oracle.integer_cells(m, opt), q)
+            _oracle.integer_cells(m, opt).astype(np.float64), q, None)
 
 
 def main():
@@ -154,17 +203,20 @@ def main():
         baseline = None
         parity = None
         if world == 1 and args.cpu_sample >= 0:
-            per_q = {0: 3e7, 1: 2.5e5, 2: 2e3}[args.differences] / (2 if args.indels else 1)
-            sample = args.cpu_sample or int(min(args.queries,
-                                                max(1000, per_q * 20 * (os.cpu_count() or 1) / 8)))
-            baseline, want, q = cpu_baseline(ref, qry, opt, sample)
-            # the same sample on the GPU must give the same cells, bit for bit
+            # ~10-30 s of CPU work: single-core rates of the reference loop
+            per_q = {0: 3e7, 1: 2.3e5, 2: 2.6e3}[args.differences] / (2 if args.indels else 1)
+            sample = args.cpu_sample or int(min(args.queries, max(1000, per_q * 20)))
+            baseline, want, q, fmt = cpu_baseline(ref, qry, opt, sample, args)
+            # the same sample on the GPU must give the same cells: bit for bit against
+            # the port, digit for digit (the reference prints %.10lg) against the binary
             h.set_queries(q)
-            got = h.overlap_matrix()
-            parity = bool(np.array_equal(got[:want.shape[0]], want))
+            got = h.overlap_matrix().astype(np.float64)
+            if fmt:
+                got = np.vectorize(lambda x: float(fmt % x))(got)
+            parity = bool(np.array_equal(got, want))
             if not parity:
-                print("PARITY FAILURE: HIP matrix differs from the CPU oracle on the sample",
-                      file=sys.stderr)
+                print("PARITY FAILURE: HIP matrix differs from the CPU %s on the sample"
+                      % baseline["kind"], file=sys.stderr)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

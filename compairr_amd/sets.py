@@ -74,6 +74,32 @@ class RepertoireSet:
                              list(self.repertoire_ids), self.v_names, self.j_names,
                              self.alphabet)
 
+    def write_tsv_fast(self, path: str, nucleotides: bool = False) -> None:
+        """Same columns as write_tsv (minus sequence_id), vectorised with pyarrow:
+        10M sequences in seconds.  Used by bench.py to feed the real reference."""
+        import pyarrow as pa
+        import pyarrow.csv as pc
+        col = "junction" if nucleotides else "junction_aa"
+        lut = np.frombuffer(self.alphabet.encode(), dtype=np.uint8)
+        seq = pa.Array.from_buffers(pa.large_utf8(), self.n,
+                                    [None, pa.py_buffer(self.offsets.astype(np.int64)),
+                                     pa.py_buffer(lut[self.residues])])
+
+        def names(idx, table):
+            return pa.DictionaryArray.from_arrays(pa.array(idx.astype(np.int32)),
+                                                  pa.array(table)).dictionary_decode()
+
+        vn = self.v_names or ["V%d" % k for k in range(int(self.v_gene.max(initial=0)) + 1)]
+        jn = self.j_names or ["J%d" % k for k in range(int(self.j_gene.max(initial=0)) + 1)]
+        tbl = pa.table({"repertoire_id": names(self.repertoire, self.repertoire_ids),
+                        "duplicate_count": pa.array(self.count.astype(np.int64)),
+                        "v_call": names(self.v_gene, vn), "j_call": names(self.j_gene, jn),
+                        col: seq})
+        with open(path, "wb") as fh:
+            fh.write(("\t".join(tbl.column_names) + "\n").encode())
+            pc.write_csv(tbl, fh, write_options=pc.WriteOptions(
+                include_header=False, delimiter="\t", quoting_style="none"))
+
     def write_tsv(self, path: str, nucleotides: bool = False, cdr3: bool = False,
                   crlf: bool = False) -> None:
         """AIRR rearrangement TSV with the columns the path needs."""
