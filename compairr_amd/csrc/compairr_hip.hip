@@ -438,8 +438,10 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_ESTATE, "set slice_words_log2 before cmpr_set_reference");
     c->slice_words_log2 = value;
   } else if (n == "chunk_tiles") {
-    if (value < 0 || value > 4096)
-      return fail(c, CMPR_EINVAL, "chunk_tiles must be 0..4096");
+    if (value < 0 || value > 512)
+      return fail(c, CMPR_EINVAL, "chunk_tiles must be 0..512");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set chunk_tiles before cmpr_set_queries");
     c->chunk_tiles = value;
   } else if (n == "debug") {
     c->debug = value;
@@ -980,7 +982,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
                  (size_t)nw * sizeof(WaveQueue);
     if (c->sliced)
       lds += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
-             MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16;
+             MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
+             (size_t)(c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block) * sizeof(TileRef);
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");

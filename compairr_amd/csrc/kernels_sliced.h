@@ -93,8 +93,7 @@ __device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint6
     const uint64_t hv = h1 ^ readlane64(zrow, v);
     const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
     const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
-    const uint64_t pat = pattern_of(hv, W.pat_hi_shift);
-    mask |= bloom_hit(word, pat) ? (1u << v) : 0u;
+    mask |= bloom_hit(word, pattern_of(hv, W.pat_hi_shift)) ? (1u << v) : 0u;
   }
   return mask;
 }
@@ -107,22 +106,31 @@ __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint6
                                             uint32_t dk_lane, uint32_t crow,
                                             uint32_t crow_enable = ~0u)
 {
-  uint64_t word[A];
-  uint64_t hv[A];
-#pragma unroll
-  for (int v = 0; v < A; v++) {
-    hv[v] = h1 ^ readlane64(zrow, v);
-    const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)crow, v);
-    const uint32_t vslice = (W.tile_slice ^ dk_lane ^ (cv & crow_enable)) & W.smask;
-    const uint32_t woff = ((uint32_t)(hv[v] >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-    const uint64_t off = ((uint64_t)vslice << W.slice_shift) + woff;
-    word[v] = *(const uint64_t *)((const char *)W.P.bloom + off);
-  }
+  /* batches of at most 10 loads in flight: enough to cover the latency, and the
+     register footprint stays under the 128 VGPRs that 4 waves per SIMD allow */
+  constexpr int B = A > 10 ? 10 : A;
   uint32_t mask = 0;
 #pragma unroll
-  for (int v = 0; v < A; v++) {
-    const uint64_t pat = pattern_of(hv[v], W.pat_hi_shift);
-    mask |= bloom_hit(word[v], pat) ? (1u << v) : 0u;
+  for (int v0 = 0; v0 < A; v0 += B) {
+    uint64_t word[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const int v = v0 + k;
+      const uint64_t hv = h1 ^ readlane64(zrow, v);
+      const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)crow, v);
+      const uint32_t vslice = (W.tile_slice ^ dk_lane ^ (cv & crow_enable)) & W.smask;
+      const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+      const uint64_t off = ((uint64_t)vslice << W.slice_shift) + woff;
+      word[k] = *(const uint64_t *)((const char *)W.P.bloom + off);
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      /* the hash is recomputed (2 readlane + 2 xor) rather than kept live
+         across the loads */
+      const uint64_t hv = h1 ^ readlane64(zrow, v0 + k);
+      mask |= bloom_hit(word[k], pattern_of(hv, W.pat_hi_shift)) ? (1u << (v0 + k)) : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   return mask;
 }
@@ -145,12 +153,46 @@ __device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
   }
 }
 
+/* tile descriptor + tile number, staged in LDS per chunk */
+struct TileRef {
+  TileDesc td;
+  uint32_t t;
+  uint32_t pad;
+};
+
+/* The residues of a tile, streamed one dword (4 positions x 64 lanes) ahead of
+   use so that the HBM/L2 latency of the next dword hides behind the rows of
+   the current one. */
+struct ResStream {
+  const uint32_t *qr;      /* + (p / 4) * 64 */
+  uint32_t        L;
+  uint32_t        cur, nxt;
+  __device__ __forceinline__ void start(const uint32_t *q, uint32_t len)
+  {
+    qr = q;
+    L = len;
+    cur = 0;
+    nxt = len ? q[0] : 0u;
+  }
+  /* residue at position p; positions must be visited in increasing order */
+  __device__ __forceinline__ uint32_t at(uint32_t p)
+  {
+    if ((p & 3u) == 0) {
+      cur = nxt;
+      if (p + 4 < L)
+        nxt = qr[((p >> 2) + 1) * WAVE];
+    }
+    return (cur >> ((p & 3u) * 8)) & 0xffu;
+  }
+};
+
 /*
  * LDS: [A * zpos Zobrist keys][R1 * R2 matrix (optional)]
- *      [NW WaveQueues][2^w-word Bloom slice][CR tables][chunk broadcast]
+ *      [NW WaveQueues][2^w-word Bloom slice][CR tables][heavy bitmap]
+ *      [chunk broadcast][tile descriptors of the chunk]
  */
 template <int A, int D, bool INDELS, bool GENES, int NW>
-__global__ void __launch_bounds__(NW * WAVE)
+__global__ void __launch_bounds__(NW * WAVE, 4)
 probe_sliced_kernel(const ProbeParams P)
 {
   constexpr uint32_t NT = NW * WAVE;
@@ -165,6 +207,7 @@ probe_sliced_kernel(const ProbeParams P)
   uint32_t *cr_lds = (uint32_t *)(slice_lds + slice_words);
   uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;     /* heavy-class bitmap */
   uint32_t *bcast = hv_lds + HEAVY_WORDS;
+  TileRef *tref_lds = (TileRef *)(bcast + 4);           /* chunk_cap entries */
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[i];
@@ -202,6 +245,11 @@ probe_sliced_kernel(const ProbeParams P)
       const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
       for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
         slice_lds[i] = src[i];
+      for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT) {
+        const uint32_t t = P.tile_list[ck.first_tile + i];
+        tref_lds[i].td = P.tiles[t];
+        tref_lds[i].t = t;
+      }
     }
     __syncthreads();
     const uint32_t pass = ck.pass;         /* 0 main, 1 insertions, 2 deletions */
@@ -213,8 +261,8 @@ probe_sliced_kernel(const ProbeParams P)
       tk = __builtin_amdgcn_readfirstlane(tk);
       if (tk >= ck.ntiles)
         break;
-      const uint32_t t = P.tile_list[ck.first_tile + tk];
-      const TileDesc td = P.tiles[t];
+      const uint32_t t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
+      const TileDesc td = tref_lds[tk].td;
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
@@ -229,16 +277,15 @@ probe_sliced_kernel(const ProbeParams P)
 
       /* ---- query hash (zobrist.cc:74-88) and, with -i, the two shifted
               hashes of the rolling indel enumeration (:90-104, :122-136) ---- */
+      ResStream rs;
+      rs.start(qr, L);
       uint64_t h = 0;
       if (GENES)
         h = gene_keys[P.qv[W.qslot]] ^ gene_keys[P.n_v + P.qj[W.qslot]];
       uint64_t hdel = h, hins = h;
       {
-        uint32_t w = 0;
         for (uint32_t p = 0; p < L; p++) {
-          if ((p & 3u) == 0)
-            w = qr[(p >> 2) * WAVE];
-          const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+          const uint32_t r = rs.at(p);
           h ^= zl[A * p + r];
           if (INDELS) {
             hins ^= zl[A * (p + 1) + r];
@@ -287,11 +334,9 @@ probe_sliced_kernel(const ProbeParams P)
       if (D >= 1 && pass == 0) {
         /* ---- single substitutions (variants.cc:280-293) ---- */
         nvar += (uint64_t)(A - 1) * L;
-        uint32_t w = 0;
+        rs.start(qr, L);
         for (uint32_t p = 0; p < L; p++) {
-          if ((p & 3u) == 0)
-            w = qr[(p >> 2) * WAVE];
-          const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
+          const uint32_t r = rs.at(p);
           const uint64_t h1 = h ^ zl[A * p + r];
           const uint64_t zrow = zl[A * p + zlane];
           uint32_t mask = 0;
@@ -423,13 +468,12 @@ probe_sliced_kernel(const ProbeParams P)
             }
           }
           uint64_t hi_hash = hins;
-          uint32_t w = 0, r = 0xffu;
+          uint32_t r = 0xffu;
+          rs.start(qr, L);
           for (uint32_t ip = 0; ip <= L; ip++) {
             if (ip > 0) {
               const uint32_t p = ip - 1;
-              if ((p & 3u) == 0)
-                w = qr[(p >> 2) * WAVE];
-              r = (w >> ((p & 3u) * 8)) & 0xffu;
+              r = rs.at(p);
               hi_hash ^= zl[A * p + r] ^ zl[A * ip + r];
             }
             uint32_t dk0 = dl, crow = 0;
