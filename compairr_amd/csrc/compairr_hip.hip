@@ -694,6 +694,121 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   return CMPR_OK;
 }
 
+extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
+{
+  if (!c || !out)
+    return CMPR_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  *out = 0;
+  const uint32_t A = (uint32_t)c->opt.alphabet_size;
+  const uint32_t n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+  DevBuf<unsigned long long> d_count;
+  DevBuf<uint8_t> res;
+  DevBuf<uint64_t> off, keys;
+  DevBuf<uint32_t> v, j, rep, vals;
+  struct Cleanup {
+    DevBuf<unsigned long long> &a; DevBuf<uint8_t> &b; DevBuf<uint64_t> &c1, &c2;
+    DevBuf<uint32_t> &d1, &d2, &d3, &d4;
+    ~Cleanup() { a.release(); b.release(); c1.release(); c2.release();
+                 d1.release(); d2.release(); d3.release(); d4.release(); }
+  } cleanup{d_count, res, off, keys, v, j, rep, vals};
+  int rc;
+  if ((rc = dev_alloc(c, d_count, 1))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), c->stream));
+
+  DupParams D{};
+  D.A = A;
+  D.n_v = n_v;
+  D.use_genes = c->opt.ignore_genes ? 0u : 1u;
+  D.count = d_count.p;
+  if (!s) {
+    if (!c->have_ref)
+      return fail(c, CMPR_ESTATE, "cmpr_set_reference must be called first");
+    D.zob = c->zob.p;
+    D.zpos = c->zpos;
+    D.res = c->res2.p; D.off = c->off2.p; D.v = c->v2.p; D.j = c->j2.p; D.rep = c->rep2.p;
+    D.n = c->n2;
+    D.keys = c->keys.p; D.vals = c->vals.p; D.slot_mask = c->slots - 1;
+  } else {
+    std::string why;
+    if ((rc = validate_view(c->opt, s, why)))
+      return fail(c, rc, why);
+    uint32_t longest = 0;
+    std::vector<double> tot;
+    if ((rc = scan_view(c->opt, s, longest, tot, why)))
+      return fail(c, rc, why);
+    /* own Zobrist keys when no reference set is resident or it is too short */
+    DevBuf<uint64_t> zob_own;
+    struct Z { DevBuf<uint64_t> &z; ~Z() { z.release(); } } zclean{zob_own};
+    uint32_t zpos = c->zpos;
+    const uint64_t *zob = c->zob.p;
+    if (!c->have_ref || longest + EXTRA_POSITIONS > c->zpos) {
+      zpos = longest + EXTRA_POSITIONS;
+      const uint32_t n_j = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
+      std::vector<uint64_t> z((size_t)A * zpos + n_v + n_j);
+      SplitMix64 rng(0x6475706c69636174ull);
+      for (auto &x : z)
+        x = rng.next();
+      if ((rc = dev_upload(c, zob_own, z.data(), z.size()))) return rc;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      zob = zob_own.p;
+    }
+    const uint64_t total = s->n ? s->offsets[s->n] : 0;
+    static const uint64_t zero_off[1] = {0};
+    if ((rc = dev_upload(c, res, s->residues, (size_t)total))) return rc;
+    if ((rc = dev_upload(c, off, s->n ? s->offsets : zero_off, (size_t)s->n + 1))) return rc;
+    if ((rc = dev_upload(c, rep, s->repertoire, (size_t)s->n))) return rc;
+    if (!c->opt.ignore_genes) {
+      if ((rc = dev_upload(c, v, s->v_gene, (size_t)s->n))) return rc;
+      if ((rc = dev_upload(c, j, s->j_gene, (size_t)s->n))) return rc;
+    }
+    uint64_t slots = 1;
+    while (FILL_PERCENT * slots < 100 * s->n)
+      slots <<= 1;
+    if ((rc = dev_alloc(c, keys, (size_t)slots))) return rc;
+    if ((rc = dev_alloc(c, vals, (size_t)slots))) return rc;
+    HIP_TRY(c, hipMemsetAsync(keys.p, 0xff, slots * sizeof(uint64_t), c->stream));
+    DevBuf<uint64_t> scratch_bloom;               /* build_index_kernel wants a filter */
+    struct Sb { DevBuf<uint64_t> &z; ~Sb() { z.release(); } } sbclean{scratch_bloom};
+    if ((rc = dev_alloc(c, scratch_bloom, 1))) return rc;
+    if (s->n) {
+      BuildParams B{};
+      B.zob = zob; B.A = A; B.zpos = zpos; B.n_v = n_v; B.use_genes = D.use_genes;
+      B.res = res.p; B.off = off.p; B.v = v.p; B.j = j.p; B.n = s->n;
+      B.keys = keys.p; B.vals = vals.p; B.slot_mask = slots - 1;
+      B.bloom = scratch_bloom.p; B.bloom_byte_mask = 0; B.sliced = 0;
+      B.pat_hi_shift = PATTERN_BITS;
+      const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+      hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
+      HIP_TRY(c, hipGetLastError());
+    }
+    D.zob = zob; D.zpos = zpos;
+    D.res = res.p; D.off = off.p; D.v = v.p; D.j = j.p; D.rep = rep.p;
+    D.n = s->n;
+    D.keys = keys.p; D.vals = vals.p; D.slot_mask = slots - 1;
+    if (D.n) {
+      const uint32_t grid = (uint32_t)((D.n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+      hipLaunchKernelGGL(count_duplicates_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, D);
+      HIP_TRY(c, hipGetLastError());
+    }
+    unsigned long long hc = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hc, d_count.p, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = hc;
+    return CMPR_OK;
+  }
+  if (D.n) {
+    const uint32_t grid = (uint32_t)((D.n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+    hipLaunchKernelGGL(count_duplicates_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+  }
+  unsigned long long hc = 0;
+  HIP_TRY(c, hipMemcpyAsync(&hc, d_count.p, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *out = hc;
+  return CMPR_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* set 1: sort by length, cut into 64-query tiles, upload               */
 /* ------------------------------------------------------------------ */

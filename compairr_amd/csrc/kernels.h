@@ -142,6 +142,70 @@ build_index_kernel(const BuildParams B)
             (unsigned long long)~pat);
 }
 
+/* Exact duplicates inside one set: entry i counts when an entry j < i of the
+   same repertoire has the same sequence (and V/J unless -g) -- what hash_insert
+   reports while indexing (overlap.cc:76-115) and check_duplicates() sums
+   (overlap.cc:579-605).  The reference finds j because it inserts in input
+   order; here the table is built in parallel, so every same-key entry of the
+   probe chain is inspected and "earlier" is decided by the index. */
+struct DupParams {
+  const uint64_t *zob;
+  uint32_t        A, zpos, n_v, use_genes;
+  const uint8_t  *res;
+  const uint64_t *off;
+  const uint32_t *v, *j, *rep;
+  uint64_t        n;
+  const uint64_t *keys;
+  const uint32_t *vals;
+  uint64_t        slot_mask;
+  unsigned long long *count;
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+count_duplicates_kernel(const DupParams B)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  bool dup = false;
+  if (i < B.n) {
+    const uint64_t b = B.off[i];
+    const uint32_t L = (uint32_t)(B.off[i + 1] - b);
+    uint64_t h = 0;
+    if (B.use_genes) {
+      const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+      h = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+    }
+    for (uint32_t p = 0; p < L; p++)
+      h ^= B.zob[B.A * p + B.res[b + p]];
+    const uint64_t key = table_key(h);
+    uint64_t slot = table_home(key, B.slot_mask);
+    for (;;) {
+      const uint64_t k = B.keys[slot];
+      if (k == EMPTY_KEY)
+        break;
+      if (k == key) {
+        const uint64_t o = B.vals[slot];
+        if (o < i && B.rep[o] == B.rep[i] &&
+            (!B.use_genes || (B.v[o] == B.v[i] && B.j[o] == B.j[i]))) {
+          const uint64_t ob = B.off[o];
+          if ((uint32_t)(B.off[o + 1] - ob) == L) {
+            bool same = true;
+            for (uint32_t p = 0; p < L && same; p++)
+              same = B.res[ob + p] == B.res[b + p];
+            if (same) {
+              dup = true;
+              break;
+            }
+          }
+        }
+      }
+      slot = (slot + 1) & B.slot_mask;
+    }
+  }
+  const uint64_t m = __ballot(dup);
+  if (m && lane_id() == 0)
+    atomicAdd(B.count, (unsigned long long)__popcll(m));
+}
+
 /* ------------------------------------------------------------------ */
 /* probe kernel                                                         */
 /* ------------------------------------------------------------------ */

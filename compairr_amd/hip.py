@@ -22,6 +22,7 @@ EXPORTS = [
     "cmpr_set_reference", "cmpr_set_queries", "cmpr_overlap_matrix",
     "cmpr_overlap_matrix_f64", "cmpr_overlap_matrix_device", "cmpr_get_stats",
     "cmpr_rows", "cmpr_cols", "cmpr_set_tunable", "cmpr_get_tunable",
+    "cmpr_count_duplicates",
 ]
 
 
@@ -121,6 +122,7 @@ def load_library() -> C.CDLL:
     lib.cmpr_overlap_matrix_f64.argtypes = [C.c_void_p, C.c_void_p]
     lib.cmpr_overlap_matrix_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cmpr_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    lib.cmpr_count_duplicates.argtypes = [C.c_void_p, C.POINTER(_SetView), C.POINTER(C.c_uint64)]
     lib.cmpr_rows.argtypes = [C.c_void_p]
     lib.cmpr_rows.restype = C.c_uint32
     lib.cmpr_cols.argtypes = [C.c_void_p]
@@ -229,6 +231,14 @@ class HipOverlap:
     def overlap_matrix_device(self, d_matrix: int, stream: Optional[int] = None) -> None:
         self._check(self._lib.cmpr_overlap_matrix_device(
             self._ctx, C.c_void_p(d_matrix), C.c_void_p(stream or 0)))
+
+    def count_duplicates(self, s: Optional[RepertoireSet] = None) -> int:
+        """Exact duplicates inside `s` (None: the resident reference set)."""
+        out = C.c_uint64()
+        v = _view(s) if s is not None else None
+        self._check(self._lib.cmpr_count_duplicates(
+            self._ctx, C.byref(v) if v is not None else None, C.byref(out)))
+        return out.value
 
     def stats(self) -> Stats:
         st = _Stats()

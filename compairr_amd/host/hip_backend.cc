@@ -28,6 +28,7 @@ struct Api {
   int (*overlap_matrix)(cmpr_context *, uint64_t *) = nullptr;
   int (*overlap_matrix_f64)(cmpr_context *, double *) = nullptr;
   int (*get_stats)(cmpr_context *, cmpr_stats *) = nullptr;
+  int (*count_duplicates)(cmpr_context *, const cmpr_set_view *, uint64_t *) = nullptr;
 };
 
 template <typename F>
@@ -75,7 +76,7 @@ public:
                const RepertoireSet &set2, bool same, std::vector<double> &cells,
                BackendReport &rep, std::string &error) override
   {
-    (void)same;
+    same_ = same;
     cmpr_options co;
     memset(&co, 0, sizeof co);
     co.differences = (int32_t)std::min<int64_t>(o.differences, INT32_MAX);
@@ -108,6 +109,21 @@ private:
       error = api_.last_error(ctx);
       return false;
     }
+    /* duplicate warnings: set 2 from the resident index; set 1 only when it is a
+       different file (check_duplicates, overlap.cc:846-851) */
+    uint64_t dups = 0;
+    if (api_.count_duplicates(ctx, nullptr, &dups)) {
+      error = api_.last_error(ctx);
+      return false;
+    }
+    rep.dup_set2 = dups;
+    if (!same_) {
+      if (api_.count_duplicates(ctx, &v1, &dups)) {
+        error = api_.last_error(ctx);
+        return false;
+      }
+      rep.dup_set1 = dups;
+    }
     rep.seconds_index = since(t0);
     t0 = std::chrono::steady_clock::now();
     if (api_.set_queries(ctx, &v1)) {
@@ -135,6 +151,7 @@ private:
   }
 
   Api api_;
+  bool same_ = false;
 };
 
 }  // namespace
@@ -176,7 +193,8 @@ OverlapBackend *make_hip_backend(const char *argv0, std::string &error)
       !bind(api.handle, "cmpr_set_queries", api.set_queries, error) ||
       !bind(api.handle, "cmpr_overlap_matrix", api.overlap_matrix, error) ||
       !bind(api.handle, "cmpr_overlap_matrix_f64", api.overlap_matrix_f64, error) ||
-      !bind(api.handle, "cmpr_get_stats", api.get_stats, error)) {
+      !bind(api.handle, "cmpr_get_stats", api.get_stats, error) ||
+      !bind(api.handle, "cmpr_count_duplicates", api.count_duplicates, error)) {
     dlclose(api.handle);
     return nullptr;
   }

@@ -184,7 +184,14 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
     fprintf(stderr, "\nError: %s\n", error.c_str());
     return 1;
   }
+  /* the reference's duplicate warnings (overlap.cc:846-851, 872-873) */
+  if (rep.dup_set1 > 0)
+    fprintf(log, "Warning: %lu duplicates detected in repertoire set 1\n",
+            (unsigned long)rep.dup_set1);
   fprintf(log, "Hashing sequences: 100%% (%.9lfs)\n", rep.seconds_index);
+  if (rep.dup_set2 > 0)
+    fprintf(log, "Warning: %lu duplicates detected in repertoire set 2\n",
+            (unsigned long)rep.dup_set2);
   fprintf(log, "Query layout:      100%% (%.9lfs)\n", rep.seconds_queries);
   fprintf(log, "Analysing:         100%% (%.9lfs)\n", rep.seconds_analysis);
   if (!rep.device_name.empty()) {

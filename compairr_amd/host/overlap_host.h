@@ -19,6 +19,7 @@ struct BackendReport {
   double   seconds_analysis = 0;  /* the per-query loop (reference: "Analysing:") */
   double   kernel_ms = 0;
   uint64_t variants = 0, bloom_positive = 0, hash_equal = 0, matches = 0;
+  uint64_t dup_set1 = 0, dup_set2 = 0;   /* exact duplicates (overlap.cc:850,872) */
   uint64_t algorithmic_bytes = 0;
   std::string device_name;
 };

@@ -167,6 +167,18 @@ int cmpr_overlap_matrix_f64(cmpr_context *ctx, double *matrix_out);
  */
 int cmpr_overlap_matrix_device(cmpr_context *ctx, void *d_matrix, void *stream);
 
+/*
+ * Exact duplicates inside one set: the number the reference reports as
+ * "Warning: N duplicates detected in repertoire set K" -- sequences that repeat
+ * an earlier one of the same repertoire with the same V, J (unless
+ * ignore_genes) and residues (hash_insert's return value summed,
+ * overlap.cc:76-115, 579-605, 865-873).  set == NULL: the resident reference
+ * set (needs cmpr_set_reference); otherwise `set` is uploaded and indexed in a
+ * temporary table that is freed before returning.  Does not disturb the
+ * resident sets.
+ */
+int cmpr_count_duplicates(cmpr_context *ctx, const cmpr_set_view *set, uint64_t *out);
+
 /* Statistics of the last overlap call (synchronises the context's events). */
 int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);
 

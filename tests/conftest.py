@@ -45,11 +45,16 @@ def load_manifest():
         return json.load(fh)
 
 
-def run_cli(binary, case, timeout=120):
+def run_cli(binary, case, timeout=120, log=None):
     argv = [os.path.join(ROOT, binary), "-m"] + case["files"] + case["args"].split() + \
-           ["-l", os.devnull]
+           ["-l", log or os.devnull]
     return subprocess.run(argv, cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, timeout=timeout)
+
+
+def warnings_of(logfile):
+    with open(logfile, errors="replace") as fh:
+        return [l.rstrip("\n") for l in fh if l.startswith("Warning:")]
 
 
 def expected_of(case) -> bytes:

@@ -204,10 +204,16 @@ def main():
 
     manifest = []
     for case in cases():
-        argv = [REF, "-m"] + case["files"] + case["args"].split() + ["-l", os.devnull]
+        logf = os.path.join(HERE, "_log.tmp")
+        argv = [REF, "-m"] + case["files"] + case["args"].split() + ["-l", logf]
         p = subprocess.run(argv, cwd=INPUTS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         entry = dict(case)
         entry["exit"] = p.returncode
+        # the duplicate warnings of the log are part of the contract
+        entry["warnings"] = [l.rstrip("\n") for l in open(logf, errors="replace")
+                             if l.startswith("Warning:")] if os.path.exists(logf) else []
+        if os.path.exists(logf):
+            os.remove(logf)
         if p.returncode == 0:
             with open(os.path.join(EXPECTED, case["name"] + ".tsv"), "wb") as fh:
                 fh.write(p.stdout)

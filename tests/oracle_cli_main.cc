@@ -61,6 +61,8 @@ public:
     rep.bloom_positive = st.bloom_positive;
     rep.hash_equal = st.hash_equal;
     rep.matches = st.matches;
+    rep.dup_set1 = st.dup_set1;
+    rep.dup_set2 = st.dup_set2;
     return true;
   }
 };

@@ -10,7 +10,7 @@ import pytest
 import _oracle
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
-from conftest import expected_of, load_manifest, run_cli
+from conftest import expected_of, load_manifest, run_cli, warnings_of
 
 pytestmark = pytest.mark.gpu
 
@@ -65,8 +65,9 @@ def check(a, b, opt, threads=4, layouts=LAYOUTS):
 # ---- golden vectors of the real reference, through the product binary ----
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_cli_matches_reference_golden(case):
-    p = run_cli("bin/compairr", case)
+def test_cli_matches_reference_golden(case, tmp_path):
+    log = str(tmp_path / "log.txt")
+    p = run_cli("bin/compairr", case, log=log)
     d = [int(x) for x in [case["args"].split()[i + 1] for i, a in
                           enumerate(case["args"].split()) if a == "-d"][:1]]
     if case["exit"] == 0 and d and d[0] > 2:
@@ -77,6 +78,7 @@ def test_cli_matches_reference_golden(case):
         assert p.returncode == case["exit"]
         return
     assert p.returncode == 0, p.stderr.decode()
+    assert warnings_of(log) == case["warnings"]      # duplicate counts, exact (log parity)
     if "ratio" in case["args"]:
         # order-dependent floating-point sum also inside the reference
         got = [l.split(b"\t") for l in p.stdout.splitlines()]
@@ -192,6 +194,34 @@ def test_long_sequences():
     o = Options(differences=1, indels=True, nucleotides=True, n_v_genes=1, n_j_genes=1)
     st = check(s, s, o)
     assert st.matches >= n + 2 * (n // 2)
+
+
+def test_duplicate_counts_match_the_reference_algorithm():
+    """hash_insert's duplicate count (overlap.cc:76-115) on the GPU: set 2 from the
+    resident index, set 1 from a temporary one."""
+    for seed, genes in ((1, True), (2, False)):
+        a = synth.make_set(40000, 10 + seed, prefix="A", pool_size=2000, n_repertoires=3)
+        b = synth.make_set(50000, 20 + seed, prefix="B", pool_size=2000, n_repertoires=2)
+        o = Options(differences=1, ignore_genes=not genes, **FULL)
+        _, ost = _oracle.overlap(a, b, o)
+        assert ost.dup_set1 > 0 and ost.dup_set2 > 0
+        for tun in LAYOUTS.values():
+            with HipOverlap(o) as h:
+                for k, v in tun.items():
+                    h.set_tunable(k, v)
+                h.set_reference(b, a.longest)
+                assert h.count_duplicates() == ost.dup_set2
+                assert h.count_duplicates(a) == ost.dup_set1
+                h.set_queries(a)                     # resident sets untouched
+                assert h.overlap_matrix().sum() > 0
+        with HipOverlap(o) as h:                     # no reference resident
+            assert h.count_duplicates(a) == ost.dup_set1
+    t = synth.tiny_set(500, 3, letters=2, max_len=4)
+    o = Options(differences=0, n_v_genes=2, n_j_genes=2)
+    _, ost = _oracle.overlap(t, t, o)
+    with HipOverlap(o) as h:
+        h.set_reference(t, 0)
+        assert h.count_duplicates() == ost.dup_set2 > 100
 
 
 def test_errors_through_the_abi():
