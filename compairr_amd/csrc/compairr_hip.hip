@@ -91,10 +91,11 @@ struct cmpr_context {
   uint64_t          n2 = 0;
   uint32_t          R2 = 0, longest2 = 0;
   DevBuf<uint8_t>   res2;
-  DevBuf<uint64_t>  off2, cnt2, keys, bloom;
-  DevBuf<uint32_t>  v2, j2, rep2, vals;
+  DevBuf<uint64_t>  off2, cnt2, bloom;
+  DevBuf<uint32_t>  v2, j2, rep2;
+  DevBuf<Slot>      table;
+  DevBuf<RefRec>    rec2;
   uint64_t          slots = 0, bloom_words = 0;
-  uint32_t          pat_hi_shift = PATTERN_BITS;
 
   /* set 1 tiles */
   bool              have_q = false;
@@ -381,9 +382,9 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
   c->zob.release();
-  c->res2.release(); c->off2.release(); c->cnt2.release(); c->keys.release();
+  c->res2.release(); c->off2.release(); c->cnt2.release(); c->table.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
-  c->vals.release();
+  c->rec2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
@@ -650,18 +651,9 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
     g.ctab = c->d_ctab.p;
   }
-  {
-    /* high half pattern: the 10 hash bits above the word-address bits */
-    uint32_t wbits = 0;
-    const uint64_t words = c->sliced ? (1ull << c->geom.words_log2) : c->bloom_words;
-    while ((1ull << wbits) < words)
-      wbits++;
-    c->pat_hi_shift = std::min<uint32_t>(PATTERN_BITS + wbits, 64 - PATTERN_BITS);
-  }
-  if ((rc = dev_alloc(c, c->keys, (size_t)c->slots))) return rc;
-  if ((rc = dev_alloc(c, c->vals, (size_t)c->slots))) return rc;
+  if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->keys.p, 0xff, c->slots * sizeof(uint64_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
 
   if (s->n) {
@@ -676,17 +668,29 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.v = c->v2.p;
     B.j = c->j2.p;
     B.n = s->n;
-    B.keys = c->keys.p;
-    B.vals = c->vals.p;
+    B.table = c->table.p;
     B.slot_mask = c->slots - 1;
     B.bloom = c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.sliced = c->sliced ? 1u : 0u;
-    B.pat_hi_shift = c->pat_hi_shift;
     B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
                        c->stream, B);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if ((rc = dev_alloc(c, c->rec2, (size_t)s->n))) return rc;
+  if (s->n) {
+    PackParams K{};
+    K.off = c->off2.p;
+    K.cnt = c->opt.ignore_counts ? nullptr : c->cnt2.p;
+    K.v = c->opt.ignore_genes ? nullptr : c->v2.p;
+    K.j = c->opt.ignore_genes ? nullptr : c->j2.p;
+    K.rep = c->rep2.p;
+    K.n = s->n;
+    K.out = c->rec2.p;
+    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, K);
     HIP_TRY(c, hipGetLastError());
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -704,14 +708,15 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
   const uint32_t n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
   DevBuf<unsigned long long> d_count;
   DevBuf<uint8_t> res;
-  DevBuf<uint64_t> off, keys;
-  DevBuf<uint32_t> v, j, rep, vals;
+  DevBuf<uint64_t> off;
+  DevBuf<uint32_t> v, j, rep;
+  DevBuf<Slot> table;
   struct Cleanup {
-    DevBuf<unsigned long long> &a; DevBuf<uint8_t> &b; DevBuf<uint64_t> &c1, &c2;
-    DevBuf<uint32_t> &d1, &d2, &d3, &d4;
-    ~Cleanup() { a.release(); b.release(); c1.release(); c2.release();
-                 d1.release(); d2.release(); d3.release(); d4.release(); }
-  } cleanup{d_count, res, off, keys, v, j, rep, vals};
+    DevBuf<unsigned long long> &a; DevBuf<uint8_t> &b; DevBuf<uint64_t> &c1;
+    DevBuf<uint32_t> &d1, &d2, &d3; DevBuf<Slot> &e;
+    ~Cleanup() { a.release(); b.release(); c1.release();
+                 d1.release(); d2.release(); d3.release(); e.release(); }
+  } cleanup{d_count, res, off, v, j, rep, table};
   int rc;
   if ((rc = dev_alloc(c, d_count, 1))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), c->stream));
@@ -728,7 +733,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     D.zpos = c->zpos;
     D.res = c->res2.p; D.off = c->off2.p; D.v = c->v2.p; D.j = c->j2.p; D.rep = c->rep2.p;
     D.n = c->n2;
-    D.keys = c->keys.p; D.vals = c->vals.p; D.slot_mask = c->slots - 1;
+    D.table = c->table.p; D.slot_mask = c->slots - 1;
   } else {
     std::string why;
     if ((rc = validate_view(c->opt, s, why)))
@@ -765,9 +770,8 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     uint64_t slots = 1;
     while (FILL_PERCENT * slots < 100 * s->n)
       slots <<= 1;
-    if ((rc = dev_alloc(c, keys, (size_t)slots))) return rc;
-    if ((rc = dev_alloc(c, vals, (size_t)slots))) return rc;
-    HIP_TRY(c, hipMemsetAsync(keys.p, 0xff, slots * sizeof(uint64_t), c->stream));
+    if ((rc = dev_alloc(c, table, (size_t)slots))) return rc;
+    HIP_TRY(c, hipMemsetAsync(table.p, 0xff, slots * sizeof(Slot), c->stream));
     DevBuf<uint64_t> scratch_bloom;               /* build_index_kernel wants a filter */
     struct Sb { DevBuf<uint64_t> &z; ~Sb() { z.release(); } } sbclean{scratch_bloom};
     if ((rc = dev_alloc(c, scratch_bloom, 1))) return rc;
@@ -775,9 +779,8 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
       BuildParams B{};
       B.zob = zob; B.A = A; B.zpos = zpos; B.n_v = n_v; B.use_genes = D.use_genes;
       B.res = res.p; B.off = off.p; B.v = v.p; B.j = j.p; B.n = s->n;
-      B.keys = keys.p; B.vals = vals.p; B.slot_mask = slots - 1;
+      B.table = table.p; B.slot_mask = slots - 1;
       B.bloom = scratch_bloom.p; B.bloom_byte_mask = 0; B.sliced = 0;
-      B.pat_hi_shift = PATTERN_BITS;
       const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
       hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
       HIP_TRY(c, hipGetLastError());
@@ -785,7 +788,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     D.zob = zob; D.zpos = zpos;
     D.res = res.p; D.off = off.p; D.v = v.p; D.j = j.p; D.rep = rep.p;
     D.n = s->n;
-    D.keys = keys.p; D.vals = vals.p; D.slot_mask = slots - 1;
+    D.table = table.p; D.slot_mask = slots - 1;
     if (D.n) {
       const uint32_t grid = (uint32_t)((D.n + BLOCK_THREADS - 1) / BLOCK_THREADS);
       hipLaunchKernelGGL(count_duplicates_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, D);
@@ -1058,9 +1061,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
     P.bloom = c->bloom.p;
     P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
-    P.pat_hi_shift = c->pat_hi_shift;
-    P.keys = c->keys.p;
-    P.vals = c->vals.p;
+    P.table = c->table.p;
     P.slot_mask = c->slots - 1;
     P.res2 = c->res2.p;
     P.off2 = c->off2.p;
@@ -1068,6 +1069,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.j2 = c->j2.p;
     P.rep2 = c->rep2.p;
     P.cnt2 = c->cnt2.p;
+    P.rec2 = c->rec2.p;
     P.tiles = c->tiles.p;
     P.qres = c->qres.p;
     P.qv = c->qv.p;

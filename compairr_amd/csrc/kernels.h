@@ -51,15 +51,16 @@ __host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
   return h == EMPTY_KEY ? (h ^ 1ull) : h;
 }
 
-/* Bit pattern of a hash, computed, not looked up: two bits of the low dword
-   from hash bits [0,5) and [5,10), two bits of the high dword from hash bits
-   [s,s+5) and [s+5,s+10).  (The reference reads one of 1024 precomputed 8-bit
-   patterns, bloompat.h:45-48; at the >= 32 filter bits per key this build uses,
-   4 bits from a 2^20 pattern space give a lower false-positive rate than 8 bits
-   from a 2^10 space, and cost two random LDS reads less per probe.) */
-__host__ __device__ __forceinline__ uint64_t pattern_of(uint64_t h, uint32_t hi_shift)
+/* Bit pattern of a hash, computed, not looked up: two bits of the low dword of
+   the filter word picked by hash bits [0,5) and [5,10), two bits of the high
+   dword picked by hash bits [32,37) and [37,42).  (The reference reads one of
+   1024 precomputed 8-bit patterns, bloompat.h:45-48; at the >= 32 filter bits
+   per key this build uses, 4 bits from a 2^20 pattern space give a lower
+   false-positive rate than 8 bits from a 2^10 space, and cost two random LDS
+   reads less per probe.) */
+__host__ __device__ __forceinline__ uint64_t pattern_of(uint64_t h)
 {
-  const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> hi_shift);
+  const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
   const uint32_t lo = (1u << (a & 31u)) | (1u << ((a >> 5) & 31u));
   const uint32_t hi = (1u << (b & 31u)) | (1u << ((b >> 5) & 31u));
   return ((uint64_t)hi << 32) | lo;
@@ -86,14 +87,12 @@ struct BuildParams {
   const uint32_t *v;
   const uint32_t *j;
   uint64_t        n;
-  uint64_t       *keys;
-  uint32_t       *vals;
+  Slot           *table;
   uint64_t        slot_mask;
   uint64_t       *bloom;
   uint32_t        bloom_byte_mask;
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
-  uint32_t        pat_hi_shift;
-  uint32_t        pad;
+  uint32_t        pad[2];
   SliceGeom       geom;
 };
 
@@ -121,13 +120,13 @@ build_index_kernel(const BuildParams B)
   uint64_t slot = table_home(key, B.slot_mask);
   for (;;) {
     unsigned long long prev =
-        atomicCAS((unsigned long long *)(B.keys + slot),
+        atomicCAS((unsigned long long *)&B.table[slot].key,
                   (unsigned long long)EMPTY_KEY, (unsigned long long)key);
     if (prev == EMPTY_KEY)
       break;
     slot = (slot + 1) & B.slot_mask;
   }
-  B.vals[slot] = (uint32_t)i;
+  B.table[slot].val = (uint32_t)i;
 
   uint64_t boff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & B.bloom_byte_mask;
   if (B.sliced) {
@@ -137,7 +136,7 @@ build_index_kernel(const BuildParams B)
     boff = ((uint64_t)slice << (B.geom.words_log2 + 3)) +
            (((uint32_t)(h >> (PATTERN_BITS - 3))) & (((1u << B.geom.words_log2) - 1u) << 3));
   }
-  const uint64_t pat = pattern_of(h, B.pat_hi_shift);
+  const uint64_t pat = pattern_of(h);
   atomicAnd((unsigned long long *)((char *)B.bloom + boff),
             (unsigned long long)~pat);
 }
@@ -155,8 +154,7 @@ struct DupParams {
   const uint64_t *off;
   const uint32_t *v, *j, *rep;
   uint64_t        n;
-  const uint64_t *keys;
-  const uint32_t *vals;
+  const Slot     *table;
   uint64_t        slot_mask;
   unsigned long long *count;
 };
@@ -179,11 +177,12 @@ count_duplicates_kernel(const DupParams B)
     const uint64_t key = table_key(h);
     uint64_t slot = table_home(key, B.slot_mask);
     for (;;) {
-      const uint64_t k = B.keys[slot];
+      const Slot sl = B.table[slot];
+      const uint64_t k = sl.key;
       if (k == EMPTY_KEY)
         break;
       if (k == key) {
-        const uint64_t o = B.vals[slot];
+        const uint64_t o = sl.val;
         if (o < i && B.rep[o] == B.rep[i] &&
             (!B.use_genes || (B.v[o] == B.v[i] && B.j[o] == B.j[i]))) {
           const uint64_t ob = B.off[o];
@@ -204,6 +203,30 @@ count_duplicates_kernel(const DupParams B)
   const uint64_t m = __ballot(dup);
   if (m && lane_id() == 0)
     atomicAdd(B.count, (unsigned long long)__popcll(m));
+}
+
+/* SoA -> one 32-byte record per set-2 sequence (layout.h RefRec) */
+struct PackParams {
+  const uint64_t *off, *cnt;
+  const uint32_t *v, *j, *rep;
+  uint64_t        n;
+  RefRec         *out;
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+pack_records_kernel(const PackParams B)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if (i >= B.n)
+    return;
+  RefRec r;
+  r.off = B.off[i];
+  r.len = (uint32_t)(B.off[i + 1] - r.off);
+  r.cnt = B.cnt ? B.cnt[i] : 1ull;
+  r.v = B.v ? B.v[i] : 0u;
+  r.j = B.j ? B.j[i] : 0u;
+  r.rep = B.rep[i];
+  B.out[i] = r;
 }
 
 /* ------------------------------------------------------------------ */
@@ -234,56 +257,47 @@ __device__ __forceinline__ uint32_t query_residue(const ProbeParams &P,
 }
 
 /* Exact test that the query with the variant applied IS the hit sequence --
-   restates check_variant (variants.cc:166-240) over the tile layout. */
+   restates check_variant (variants.cc:166-240) over the tile layout.  Written
+   without early exits: position x of the hit is compared with the residue the
+   variant must have there, all loads of the loop are independent and stay in
+   flight together (an early-exit loop costs one memory round trip per residue). */
 __device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
                                     uint32_t lane, uint32_t ca, uint32_t cb,
-                                    uint32_t hit)
+                                    const RefRec &rec)
 {
   const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
   const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
-  const uint64_t tb = P.off2[hit];
-  const uint32_t M = (uint32_t)(P.off2[hit + 1] - tb);
-  const uint8_t *t = P.res2 + tb;
+  const uint32_t M = rec.len;
   const uint32_t L = td.len;
-
-  if (kind == K_DEL) {
-    if (M + 1 != L)
-      return false;
-    for (uint32_t p = 0; p < p1; p++)
-      if (query_residue(P, td, lane, p) != t[p])
-        return false;
-    for (uint32_t p = p1 + 1; p < L; p++)
-      if (query_residue(P, td, lane, p) != t[p - 1])
-        return false;
-    return true;
-  }
-  if (kind == K_INS) {
-    if (M != L + 1 || t[p1] != r1)
-      return false;
-    for (uint32_t p = 0; p < p1; p++)
-      if (query_residue(P, td, lane, p) != t[p])
-        return false;
-    for (uint32_t p = p1; p < L; p++)
-      if (query_residue(P, td, lane, p) != t[p + 1])
-        return false;
-    return true;
-  }
-  /* same length: identical, one or two substitutions */
-  if (M != L)
+  const uint8_t *t = P.res2 + rec.off;
+  /* expected length of the hit */
+  const uint32_t want = kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L);
+  if (M != want)
     return false;
-  if (kind == K_SUB && t[p1] != r1)
-    return false;
-  if (kind == K_SUB2 && (t[p1] != r1 || t[p2] != r2))
-    return false;
-  for (uint32_t p = 0; p < L; p++) {
-    if (kind != K_SAME && p == p1)
-      continue;
-    if (kind == K_SUB2 && p == p2)
-      continue;
-    if (query_residue(P, td, lane, p) != t[p])
-      return false;
+  uint32_t bad = 0;
+#pragma unroll 4
+  for (uint32_t x = 0; x < M; x++) {
+    /* query position that lands on x, or "the new residue" */
+    uint32_t qp = x;
+    bool is_new = false;
+    uint32_t newres = r1;
+    if (kind == K_DEL) {
+      qp = x < p1 ? x : x + 1;
+    } else if (kind == K_INS) {
+      is_new = x == p1;
+      qp = x < p1 ? x : x - 1;
+    } else if (kind == K_SUB) {
+      is_new = x == p1;
+    } else if (kind == K_SUB2) {
+      is_new = x == p1 || x == p2;
+      newres = x == p1 ? r1 : r2;
+    }
+    if (qp >= L)
+      qp = L ? L - 1 : 0;                       /* only when is_new; keeps the load in range */
+    const uint32_t expect = is_new ? newres : query_residue(P, td, lane, qp);
+    bad |= expect ^ (uint32_t)t[x];
   }
-  return true;
+  return bad == 0;
 }
 
 struct LaneStats {
@@ -292,7 +306,8 @@ struct LaneStats {
 };
 
 /* Lane e of the wave resolves queue entry `e`: walk the probe chain
-   (find_variant_matches, overlap.cc:168-251), verify, score, accumulate. */
+   (find_variant_matches, overlap.cc:168-251), verify, score, accumulate.
+   The chain is read four slots at a time (independent loads). */
 template <bool GENES>
 __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
                               unsigned long long *mat_lds, LaneStats &st)
@@ -300,29 +315,45 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
   const uint64_t key = table_key(q.hash[e]);
   const uint32_t qs = q.slot[e];
   const uint32_t ca = q.ca[e], cb = q.cb[e];
+  /* everything of the query that a match needs is fetched now, next to the
+     first table read, not after it: one memory round trip less per match */
   const TileDesc td = P.tiles[qs >> 6];
   const uint32_t ql = qs & 63u;
+  const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
+  const uint32_t q_rep = P.qrep[qs];
+  const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
   uint64_t s = table_home(key, P.slot_mask);
   for (;;) {
-    const uint64_t k = P.keys[s];
-    if (k == EMPTY_KEY)
-      break;
-    if (k == key) {
-      const uint32_t hit = P.vals[s];
+    Slot k[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      k[i] = P.table[(s + i) & P.slot_mask];
+    bool end = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (end)
+        break;
+      if (k[i].key == EMPTY_KEY) {
+        end = true;
+        break;
+      }
+      if (k[i].key != key)
+        continue;
+      const uint32_t hit = k[i].val;
+      const RefRec rec = P.rec2[hit];
       st.hash_eq++;
       bool ok = true;
       if (GENES)
-        ok = (P.qv[qs] == P.v2[hit]) && (P.qj[qs] == P.j2[hit]);
-      if (ok && variant_matches_hit(P, td, ql, ca, cb, hit)) {
+        ok = (q_v == rec.v) && (q_j == rec.j);
+      if (ok && variant_matches_hit(P, td, ql, ca, cb, rec)) {
         st.matches++;
-        const uint32_t cell = P.R2 * P.qrep[qs] + P.rep2[hit];
+        const uint32_t cell = P.R2 * q_rep + rec.rep;
         if (P.score == 1 /* ratio */ && !P.ignore_counts) {
-          unsafeAtomicAdd(P.matrix_f64 + cell,
-                          (double)P.qcnt[qs] / (double)P.cnt2[hit]);
+          unsafeAtomicAdd(P.matrix_f64 + cell, (double)q_cnt / (double)rec.cnt);
         } else {
           unsigned long long sc = 1;
           if (!P.ignore_counts) {
-            const unsigned long long f = P.qcnt[qs], g = P.cnt2[hit];
+            const unsigned long long f = q_cnt, g = rec.cnt;
             switch (P.score) {
             case 2: case 6: sc = f < g ? f : g; break;       /* min, Jaccard */
             case 3:         sc = f > g ? f : g; break;       /* max          */
@@ -337,7 +368,9 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
         }
       }
     }
-    s = (s + 1) & P.slot_mask;
+    if (end)
+      break;
+    s = (s + 4) & P.slot_mask;
   }
 }
 
@@ -371,7 +404,7 @@ __device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
 {
   const uint32_t boff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.P.bloom_byte_mask;
   const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + boff);
-  const uint64_t pat = pattern_of(hv, W.P.pat_hi_shift);
+  const uint64_t pat = pattern_of(hv);
   const bool pos = live && ((word & pat) == 0);
   W.st.variants += live ? 1ull : 0ull;
   const uint64_t m = __ballot(pos);

@@ -47,7 +47,6 @@ struct SProber {
   uint32_t            wmask_bytes; /* (slice_words - 1) << 3                  */
   uint32_t            slice_shift; /* log2(bytes per slice)                   */
   uint32_t            smask;
-  uint32_t            pat_hi_shift;
   uint32_t            tile_slice;
   int                 qn;
   LaneStats           st;
@@ -80,7 +79,11 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
 
 __device__ __forceinline__ bool bloom_hit(uint64_t word, uint64_t pat)
 {
-  return (word & pat) == 0;            /* inverted polarity, bloompat.h:55-58 */
+  /* inverted polarity, bloompat.h:55-58: (word & pat) == 0, as one and + one
+     and-or + one 32-bit compare */
+  const uint32_t t = ((uint32_t)word & (uint32_t)pat) |
+                     ((uint32_t)(word >> 32) & (uint32_t)(pat >> 32));
+  return t == 0;
 }
 
 /* phase 1, class-preserving row: filter words from the LDS copy of the slice */
@@ -93,7 +96,7 @@ __device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint6
     const uint64_t hv = h1 ^ readlane64(zrow, v);
     const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
     const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
-    mask |= bloom_hit(word, pattern_of(hv, W.pat_hi_shift)) ? (1u << v) : 0u;
+    mask |= bloom_hit(word, pattern_of(hv)) ? (1u << v) : 0u;
   }
   return mask;
 }
@@ -128,7 +131,7 @@ __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint6
       /* the hash is recomputed (2 readlane + 2 xor) rather than kept live
          across the loads */
       const uint64_t hv = h1 ^ readlane64(zrow, v0 + k);
-      mask |= bloom_hit(word[k], pattern_of(hv, W.pat_hi_shift)) ? (1u << (v0 + k)) : 0u;
+      mask |= bloom_hit(word[k], pattern_of(hv)) ? (1u << (v0 + k)) : 0u;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -187,8 +190,8 @@ struct ResStream {
 };
 
 /*
- * LDS: [A * zpos Zobrist keys][R1 * R2 matrix (optional)]
- *      [NW WaveQueues][2^w-word Bloom slice][CR tables][heavy bitmap]
+ * LDS: [2^w-word Bloom slice][A * zpos Zobrist keys][R1 * R2 matrix (optional)]
+ *      [NW WaveQueues][CR tables][heavy bitmap]
  *      [chunk broadcast][tile descriptors of the chunk]
  */
 template <int A, int D, bool INDELS, bool GENES, int NW>
@@ -197,14 +200,15 @@ probe_sliced_kernel(const ProbeParams P)
 {
   constexpr uint32_t NT = NW * WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
-  uint64_t *zl = (uint64_t *)smem;
+  /* the Bloom slice sits at LDS address 0: its reads need no base add */
+  uint64_t *slice_lds = (uint64_t *)smem;
+  const uint32_t slice_words = 1u << P.geom.words_log2;
+  uint64_t *zl = slice_lds + slice_words;
   const uint32_t nz = (uint32_t)A * P.zpos;
   unsigned long long *mat_all = (unsigned long long *)(zl + nz);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
-  uint64_t *slice_lds = (uint64_t *)(queues + NW);
-  const uint32_t slice_words = 1u << P.geom.words_log2;
-  uint32_t *cr_lds = (uint32_t *)(slice_lds + slice_words);
+  uint32_t *cr_lds = (uint32_t *)(queues + NW);
   uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;     /* heavy-class bitmap */
   uint32_t *bcast = hv_lds + HEAVY_WORDS;
   TileRef *tref_lds = (TileRef *)(bcast + 4);           /* chunk_cap entries */
@@ -225,7 +229,7 @@ probe_sliced_kernel(const ProbeParams P)
   const uint32_t KH = P.geom.k;           /* class residues of heavy classes */
   SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
-            P.pat_hi_shift, 0u, 0, {0ull, 0u, 0u, 0u}};
+            0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *gene_keys = P.zob + nz;
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
 
@@ -327,7 +331,7 @@ probe_sliced_kernel(const ProbeParams P)
       if (pass == 0) {
         const uint32_t woff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & W.wmask_bytes;
         const uint64_t word = *(const uint64_t *)((const char *)slice_lds + woff);
-        const uint64_t pat = pattern_of(h, W.pat_hi_shift);
+        const uint64_t pat = pattern_of(h);
         s_push<GENES>(W, valid && bloom_hit(word, pat), h, pack_a(K_SAME, 0, 0), 0);
       }
 
@@ -427,7 +431,7 @@ probe_sliced_kernel(const ProbeParams P)
               else
                 word = *(const uint64_t *)((const char *)P.bloom +
                                            ((uint64_t)vslice << W.slice_shift) + woff);
-              const uint64_t pat = pattern_of(hd, W.pat_hi_shift);
+              const uint64_t pat = pattern_of(hd);
               nvar += fresh ? 1u : 0u;
               mask |= (fresh && bloom_hit(word, pat)) ? (1u << (p - p0)) : 0u;
               gone = r;

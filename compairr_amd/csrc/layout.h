@@ -24,13 +24,20 @@ constexpr uint32_t EXTRA_POSITIONS   = 3;
    from ONE table of 1024 patterns, which floors its false-positive rate at
    (keys per word) / 1024; this build sets 4 bits per key computed directly from
    20 hash bits (kernels.h pattern_of): a 2^20 pattern space and no table. */
-constexpr uint32_t PATTERN_BITS      = 10;     /* hash bits [0,10): low half pattern;
+constexpr uint32_t PATTERN_BITS      = 10;     /* hash bits [0,10) and [32,42): pattern;
                                                   word address starts at bit 10      */
 constexpr uint32_t PATTERN_K         = 4;
 
-/* Open-addressing table: 64-bit keys (the sequence hash), 32-bit payload (the
-   set-2 sequence number); an all-ones key marks a free slot (the reference
-   keeps a separate occupancy bitmap, hashtable.h:48-56). */
+/* Open-addressing table: 64-bit key (the sequence hash) and 32-bit payload (the
+   set-2 sequence number) side by side in one 16-byte slot, so that a probe
+   reads key and payload with one access; an all-ones key marks a free slot
+   (the reference keeps three arrays: hash_values, hash_data and an occupancy
+   bitmap, hashtable.h:22-29,48-72). */
+struct Slot {
+  uint64_t key;
+  uint32_t val;
+  uint32_t pad;
+};
 constexpr uint64_t EMPTY_KEY         = ~0ull;
 constexpr uint32_t FILL_PERCENT      = 70;     /* hashtable.cc:24 */
 
@@ -129,6 +136,16 @@ struct Chunk {
                             sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
 };
 
+/* One set-2 sequence as the verification step reads it: one 32-byte record
+   (two 16-byte loads) instead of six scattered loads from the SoA arrays. */
+struct RefRec {
+  uint64_t off;       /* first residue in res2                              */
+  uint64_t cnt;       /* duplicate_count (1 with -f)                        */
+  uint32_t len;
+  uint32_t v, j;      /* 0 with -g                                          */
+  uint32_t rep;
+};
+
 /* per-launch kernel arguments */
 struct ProbeParams {
   /* Zobrist */
@@ -138,10 +155,9 @@ struct ProbeParams {
   /* Bloom */
   const uint64_t *bloom;
   uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
-  uint32_t        pat_hi_shift;      /* hash bits [s, s+10) pick the high half pattern */
+  uint32_t        pad0;
   /* hash table */
-  const uint64_t *keys;
-  const uint32_t *vals;
+  const Slot     *table;
   uint64_t        slot_mask;
   /* set 2 records */
   const uint8_t  *res2;
@@ -150,6 +166,7 @@ struct ProbeParams {
   const uint32_t *j2;
   const uint32_t *rep2;
   const uint64_t *cnt2;
+  const RefRec   *rec2;
   /* set 1 tiles */
   const TileDesc *tiles;
   const uint32_t *qres;
