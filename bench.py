@@ -131,7 +131,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is taken even at world
+    # size 1, so that `--gpus 1` launched that way exercises the same code as N > 1
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1 and args.gpus == 1, \
@@ -174,7 +177,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -182,12 +185,12 @@ def main():
         step()
         kernel_ms.append(h.stats().kernel_ms)   # HIP events on the kernel's stream
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     st = h.stats()
@@ -264,7 +267,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
