@@ -367,7 +367,7 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   }
   if (const char *e = getenv("COMPAIRR_HIP_CLASS_RESIDUES")) {
     int v = atoi(e);
-    if (v >= -1 && v <= (int)MAX_CLASS_RES)
+    if (v >= -1 && v <= (int)max_class_res((uint32_t)c->opt.alphabet_size))
       c->class_residues = v;
   }
   *out = c;
@@ -421,8 +421,8 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_ESTATE, "set variant before cmpr_set_reference");
     c->variant = value;
   } else if (n == "class_residues") {
-    if (value < -1 || value > (int64_t)MAX_CLASS_RES)
-      return fail(c, CMPR_EINVAL, "class_residues must be -1..3");
+    if (value < -1 || value > (int64_t)max_class_res((uint32_t)c->opt.alphabet_size))
+      return fail(c, CMPR_EINVAL, "class_residues must be -1..3 (amino acids) / -1..8 (nucleotides)");
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
     c->class_residues = value;
@@ -626,7 +626,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
         double best_max = -1;
         uint32_t best_k = 1;
         std::vector<uint32_t> pop;
-        for (uint32_t k = 1; k <= MAX_CLASS_RES; k++) {
+        for (uint32_t k = 1; k <= max_class_res(A); k++) {
           pop.assign((size_t)S, 0);
           for (uint64_t i = 0; i < s->n; i++) {
             const uint64_t b = s->offsets[i];

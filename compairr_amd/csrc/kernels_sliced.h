@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_sliced_kernel(const ProbeParams P)
 {
   constexpr uint32_t NT = NW * WAVE;
+  constexpr uint32_t MCR = max_class_res(A);   /* unrolled class-residue loops */
   extern __shared__ __align__(16) unsigned char smem[];
   /* the Bloom slice sits at LDS address 0: its reads need no base add */
   uint64_t *slice_lds = (uint64_t *)smem;
@@ -300,14 +301,14 @@ probe_sliced_kernel(const ProbeParams P)
       }
 
       /* class positions of this length (wave-uniform) */
-      uint32_t m[MAX_CLASS_RES];
+      uint32_t m[MCR];
 #pragma unroll
-      for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+      for (uint32_t i = 0; i < MCR; i++)
         m[i] = class_pos(L, i);
       auto is_class_pos = [&](uint32_t p) -> bool {
         bool c = false;
 #pragma unroll
-        for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+        for (uint32_t i = 0; i < MCR; i++)
           c = c || (i < K && m[i] == p);
         return c;
       };
@@ -317,7 +318,7 @@ probe_sliced_kernel(const ProbeParams P)
         uint32_t dk = 0;
         crow = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+        for (uint32_t i = 0; i < MCR; i++)
           if (i < K && m[i] == p) {
             dk ^= cr_lds[i * A + r];
             crow ^= cr_lds[i * A + zlane];
@@ -382,7 +383,7 @@ probe_sliced_kernel(const ProbeParams P)
         };
         uint32_t cbase = 0;                      /* XOR_i CR[i][s[m_i(L)]], heavy tiles */
 #pragma unroll
-        for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+        for (uint32_t i = 0; i < MCR; i++)
           if (i < K && L > 0)
             cbase ^= cr_lds[i * A + res_at(m[i])];
 
@@ -394,9 +395,9 @@ probe_sliced_kernel(const ProbeParams P)
           const uint32_t dlen = cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hv = heavy_of(base ^ dlen);          /* is the variant's class split? */
           const uint32_t dl = dlen ^ cbase;
-          uint32_t md[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
+          uint32_t md[MCR], lo[MCR], hi[MCR];
 #pragma unroll
-          for (uint32_t i = 0; i < MAX_CLASS_RES; i++) {
+          for (uint32_t i = 0; i < MCR; i++) {
             md[i] = class_pos(L - 1, i);
             lo[i] = hi[i] = 0;
             if (i < KH) {
@@ -421,7 +422,7 @@ probe_sliced_kernel(const ProbeParams P)
                 hd ^= zl[A * (p - 1) + gone] ^ zl[A * (p - 1) + r];
               uint32_t dk = dl;
 #pragma unroll
-              for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+              for (uint32_t i = 0; i < MCR; i++)
                 dk ^= md[i] < p ? lo[i] : hi[i];
               const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
               const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
@@ -459,9 +460,9 @@ probe_sliced_kernel(const ProbeParams P)
           const uint32_t dlen = cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hv = heavy_of(base ^ dlen);
           const uint32_t dl = dlen ^ cbase;
-          uint32_t mi[MAX_CLASS_RES], lo[MAX_CLASS_RES], hi[MAX_CLASS_RES];
+          uint32_t mi[MCR], lo[MCR], hi[MCR];
 #pragma unroll
-          for (uint32_t i = 0; i < MAX_CLASS_RES; i++) {
+          for (uint32_t i = 0; i < MCR; i++) {
             mi[i] = class_pos(L + 1, i);
             lo[i] = hi[i] = 0;
             if (i < KH) {
@@ -483,7 +484,7 @@ probe_sliced_kernel(const ProbeParams P)
             uint32_t dk0 = dl, crow = 0;
             bool v_on_class_pos = false;
 #pragma unroll
-            for (uint32_t i = 0; i < MAX_CLASS_RES; i++)
+            for (uint32_t i = 0; i < MCR; i++)
               if (i < KH) {
                 if (mi[i] == ip) {
                   crow ^= cr_lds[i * A + zlane];          /* u[mi] = v */

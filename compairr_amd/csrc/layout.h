@@ -73,7 +73,9 @@ struct TileDesc {
    those probes from LDS; only variants that change the class key go to the
    filter in HBM.  The word inside a slice and the bit pattern still come from
    the Zobrist hash. */
-constexpr uint32_t MAX_CLASS_RES      = 3;
+constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 3 for aa (20^3 splits),
+                                                 K <= 8 for nt (4^8 splits)            */
+__host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 3u; }
 constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
 constexpr uint32_t HEAVY_BUCKETS_LOG2 = 16;
 constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
@@ -81,7 +83,7 @@ constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
 struct SliceGeom {
   uint32_t smask;          /* S - 1                                          */
   uint32_t words_log2;     /* w                                              */
-  uint32_t k;              /* K: class residues of heavy classes, 0..3       */
+  uint32_t k;              /* K: class residues of heavy classes               */
   uint32_t ncl;            /* entries of CL (lengths 0..ncl-1)               */
   /* class tables, u32 each:
      CL[ncl] | CV[n_v] | CJ[n_j] | CR[MAX_CLASS_RES][A] | heavy bitmap[HEAVY_WORDS] */

@@ -50,10 +50,20 @@ LAYOUTS = {
 }
 
 
-def check(a, b, opt, threads=4, layouts=LAYOUTS):
+# nucleotides only: up to 8 class residues (4^8 splits)
+NT_LAYOUTS = dict(LAYOUTS)
+NT_LAYOUTS["lds_tiny_k8"] = {"variant": 1, "slice_words_log2": 3, "class_residues": 8,
+                             "heavy_threshold": 0, "chunk_tiles": 5}
+NT_LAYOUTS["lds_tiny_k5_mixed"] = {"variant": 1, "slice_words_log2": 4, "class_residues": 5,
+                                   "heavy_threshold": 3}
+
+
+def check(a, b, opt, threads=4, layouts=None):
     want, ost = _oracle.overlap(a, b, opt, threads=threads)
     want = _oracle.integer_cells(want, opt)
     st = None
+    if layouts is None:
+        layouts = NT_LAYOUTS if opt.nucleotides else LAYOUTS
     for name, tun in layouts.items():
         got, st = gpu_cells(a, b, opt, tun)
         assert np.array_equal(got, want), (name, opt, got, want)
