@@ -156,6 +156,22 @@ __device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
   }
 }
 
+/* one probe, class-preserving: filter word from the staged slice */
+__device__ __forceinline__ bool probe_one_lds(const SProber &W, uint64_t hv)
+{
+  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
+  return bloom_hit(word, pattern_of(hv));
+}
+
+/* address of the filter word of a class-changing variant (dk = class-key delta) */
+__device__ __forceinline__ const uint64_t *hbm_word(const SProber &W, uint64_t hv, uint32_t dk)
+{
+  const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
+  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  return (const uint64_t *)((const char *)W.P.bloom + ((uint64_t)vslice << W.slice_shift) + woff);
+}
+
 /* tile descriptor + tile number, staged in LDS per chunk */
 struct TileRef {
   TileDesc td;
@@ -340,6 +356,60 @@ probe_sliced_kernel(const ProbeParams P)
         /* ---- single substitutions (variants.cc:280-293) ---- */
         nvar += (uint64_t)(A - 1) * L;
         rs.start(qr, L);
+        if constexpr (A == 4) {
+          /* Nucleotides: a row has only 3 variants, so 16 positions are probed
+             per block -- the three OTHER residues of each lane, (r + k) & 3, so
+             that no probe is wasted on the original -- and their positives
+             share one 48-bit mask and one compaction loop. */
+          for (uint32_t p0 = 0; p0 < L; p0 += 16) {
+            uint64_t mask = 0;
+#pragma unroll 2
+            for (uint32_t jj = 0; jj < 16; jj++) {
+              const uint32_t p = p0 + jj;
+              if (p < L) {
+                const uint32_t r = rs.at(p);
+                const uint64_t *zp = zl + 4 * p;
+                const uint64_t h1 = h ^ zp[r];
+                if (!is_class_pos(p)) {
+#pragma unroll
+                  for (uint32_t k = 1; k <= 3; k++) {
+                    const uint64_t hv = h1 ^ zp[(r + k) & 3u];
+                    mask |= probe_one_lds(W, hv) ? (1ull << (3 * jj + k - 1)) : 0ull;
+                  }
+                } else {
+                  uint32_t crow;
+                  const uint32_t dk_r = class_terms(p, r, crow);
+                  uint64_t word[3];
+#pragma unroll
+                  for (uint32_t k = 1; k <= 3; k++) {
+                    const uint32_t v = (r + k) & 3u;
+                    uint32_t dk_v;
+                    (void)crow;
+                    dk_v = class_terms(p, v, crow);
+                    word[k - 1] = *hbm_word(W, h1 ^ zp[v], dk_r ^ dk_v);
+                  }
+#pragma unroll
+                  for (uint32_t k = 1; k <= 3; k++) {
+                    const uint64_t hv = h1 ^ zp[(r + k) & 3u];
+                    mask |= bloom_hit(word[k - 1], pattern_of(hv)) ? (1ull << (3 * jj + k - 1)) : 0ull;
+                  }
+                }
+              }
+            }
+            if (!valid || (P.debug & DBG_SKIP_EMIT))
+              mask = 0;
+            while (__ballot(mask != 0)) {
+              const bool pos = mask != 0;
+              const uint32_t b = pos ? (uint32_t)__ffsll((long long)mask) - 1u : 0u;
+              const uint32_t p = p0 + b / 3u;
+              const uint32_t r = res_at(p < L ? p : 0);
+              const uint32_t v = (r + b % 3u + 1u) & 3u;
+              const uint64_t hv = h ^ zl[4 * p + r] ^ zl[4 * p + v];
+              s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+              mask &= mask - 1ull;
+            }
+          }
+        } else
         for (uint32_t p = 0; p < L; p++) {
           const uint32_t r = rs.at(p);
           const uint64_t h1 = h ^ zl[A * p + r];
@@ -516,6 +586,72 @@ probe_sliced_kernel(const ProbeParams P)
       if (D >= 2 && pass == 0) {
         /* ---- double substitutions p < q (variants.cc:370-399) ---- */
         nvar += (uint64_t)(A - 1) * (A - 1) * ((uint64_t)L * (L ? L - 1 : 0) / 2);
+        if constexpr (A == 4) {
+          /* Nucleotides: both substitutions enumerate the three OTHER residues of
+             the lane ((r + k) & 3), so none of the 9 (instead of 16) probes per
+             position pair is masked; the second position runs in blocks of 16
+             that share one 48-bit mask and one compaction loop. */
+          for (uint32_t p = 0; p + 1 < L; p++) {
+            const uint32_t rp = res_at(p);
+            const uint64_t hp = h ^ zl[4 * p + rp];
+            const bool cp = is_class_pos(p);
+            uint32_t crow_unused;
+            const uint32_t dk_rp = cp ? class_terms(p, rp, crow_unused) : 0u;
+#pragma unroll 1
+            for (uint32_t kp = 1; kp <= 3; kp++) {
+              const uint32_t vp = (rp + kp) & 3u;
+              const uint64_t hpv = hp ^ zl[4 * p + vp];
+              const uint32_t ca = pack_a(K_SUB2, p, vp);
+              const uint32_t dk_pv = cp ? (dk_rp ^ class_terms(p, vp, crow_unused)) : 0u;
+              for (uint32_t q0 = p + 1; q0 < L; q0 += 16) {
+                uint64_t mask = 0;
+                uint32_t w = 0;
+#pragma unroll 2
+                for (uint32_t jj = 0; jj < 16; jj++) {
+                  const uint32_t qq = q0 + jj;
+                  if (qq < L) {
+                    if ((qq & 3u) == 0 || jj == 0)
+                      w = qr[(qq >> 2) * WAVE];
+                    const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
+                    const uint64_t *zq = zl + 4 * qq;
+                    const uint64_t hq = hpv ^ zq[rq];
+                    if (!cp && !is_class_pos(qq)) {
+#pragma unroll
+                      for (uint32_t k = 1; k <= 3; k++)
+                        mask |= probe_one_lds(W, hq ^ zq[(rq + k) & 3u])
+                                    ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    } else {
+                      const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
+                      uint64_t word[3];
+#pragma unroll
+                      for (uint32_t k = 1; k <= 3; k++) {
+                        const uint32_t x = (rq + k) & 3u;
+                        word[k - 1] = *hbm_word(W, hq ^ zq[x],
+                                                dk_pv ^ dk_rq ^ class_terms(qq, x, crow_unused));
+                      }
+#pragma unroll
+                      for (uint32_t k = 1; k <= 3; k++)
+                        mask |= bloom_hit(word[k - 1], pattern_of(hq ^ zq[(rq + k) & 3u]))
+                                    ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    }
+                  }
+                }
+                if (!valid || (P.debug & DBG_SKIP_EMIT))
+                  mask = 0;
+                while (__ballot(mask != 0)) {
+                  const bool pos = mask != 0;
+                  const uint32_t b = pos ? (uint32_t)__ffsll((long long)mask) - 1u : 0u;
+                  const uint32_t qq = q0 + b / 3u;
+                  const uint32_t rq = res_at(qq < L ? qq : 0);
+                  const uint32_t x = (rq + b % 3u + 1u) & 3u;
+                  const uint64_t hv = hpv ^ zl[4 * qq + rq] ^ zl[4 * qq + x];
+                  s_push<GENES>(W, pos, hv, ca, qq | (x << 24));
+                  mask &= mask - 1ull;
+                }
+              }
+            }
+          }
+        } else
         for (uint32_t p = 0; p + 1 < L; p++) {
           const uint32_t rp = res_at(p);
           const uint64_t hp = h ^ zl[A * p + rp];
