@@ -10,6 +10,7 @@
 #include "kernels_sliced.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,7 @@ struct cmpr_context {
   int64_t variant = 1;            /* 0: one global Bloom; 1: LDS-staged slices */
   int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
+  int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
   int64_t heavy_threshold = -1;   /* class population above which it is split;
                                      -1: from the slice size, 0: every class   */
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
@@ -104,6 +106,7 @@ struct cmpr_context {
   DevBuf<TileDesc>  tiles;
   DevBuf<uint32_t>  qres, qv, qj, qrep;
   DevBuf<uint64_t>  qcnt;
+  DevBuf<uint16_t>  qlen;
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;
@@ -386,7 +389,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
-  c->qrep.release(); c->qcnt.release();
+  c->qrep.release(); c->qcnt.release(); c->qlen.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
   c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -426,6 +429,12 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
     c->class_residues = value;
+  } else if (n == "class_anchor") {
+    if (value < -1 || value > 65535)
+      return fail(c, CMPR_EINVAL, "class_anchor must be -1..65535");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set class_anchor before cmpr_set_reference");
+    c->class_anchor = value;
   } else if (n == "heavy_threshold") {
     if (value < -1)
       return fail(c, CMPR_EINVAL, "heavy_threshold must be >= -1");
@@ -480,6 +489,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "waves_per_block") *value = c->waves_per_block;
   else if (n == "debug") *value = c->debug;
   else if (n == "heavy_threshold") *value = c->heavy_threshold;
+  else if (n == "class_anchor") *value = c->sliced && c->have_ref ? (int64_t)c->geom.c0 : c->class_anchor;
   else if (n == "heavy_buckets") {
     *value = 0;
     if (c->sliced && c->have_ref)
@@ -599,6 +609,64 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
        bits per key, false-positive rate <= 6e-3 there and far less elsewhere */
     const double slice_cap = slice_bits / 12.0;
     g.k = 0;
+    /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
+       (<= 5th-percentile length of set 2) and be informative (a conserved
+       position splits nothing); the closer to the start, the more insertion /
+       deletion variants keep their class residues in place.  So: the first
+       window of max_class_res positions whose residue entropy in set 2 is at
+       least 70 % of the maximum. */
+    {
+      std::vector<uint64_t> hist((size_t)longest + 2, 0);
+      for (uint64_t i = 0; i < s->n; i++)
+        hist[s->offsets[i + 1] - s->offsets[i]]++;
+      uint64_t acc = 0;
+      uint32_t l5 = longest;
+      for (uint32_t L = 0; L <= longest; L++) {
+        acc += hist[L];
+        if (acc * 20 >= s->n) {
+          l5 = L;
+          break;
+        }
+      }
+      const uint32_t mcr = max_class_res(A);
+      g.c0 = 0;
+      if (l5 > mcr && s->n > 0) {
+        const uint32_t npos = l5;
+        std::vector<uint64_t> cnt((size_t)npos * A, 0);
+        const uint64_t stride = std::max<uint64_t>(1, s->n / 200000);   /* a sample is enough */
+        for (uint64_t i = 0; i < s->n; i += stride) {
+          const uint64_t b = s->offsets[i];
+          const uint32_t L = (uint32_t)std::min<uint64_t>(s->offsets[i + 1] - b, npos);
+          for (uint32_t p = 0; p < L; p++)
+            cnt[(size_t)p * A + s->residues[b + p]]++;
+        }
+        std::vector<double> ent(npos, 0.0);
+        for (uint32_t p = 0; p < npos; p++) {
+          double tot = 0;
+          for (uint32_t r = 0; r < A; r++)
+            tot += (double)cnt[(size_t)p * A + r];
+          for (uint32_t r = 0; r < A && tot > 0; r++) {
+            const double q = (double)cnt[(size_t)p * A + r] / tot;
+            if (q > 0)
+              ent[p] -= q * std::log2(q);
+          }
+        }
+        const double need = 0.7 * std::log2((double)A);
+        uint32_t best = (l5 - mcr) / 2;
+        for (uint32_t c0 = 0; c0 + mcr <= npos; c0++) {
+          bool ok = true;
+          for (uint32_t i = 0; i < mcr; i++)
+            ok = ok && ent[c0 + i] >= need;
+          if (ok) {
+            best = c0;
+            break;
+          }
+        }
+        g.c0 = best;
+      }
+      if (c->class_anchor >= 0)
+        g.c0 = (uint32_t)c->class_anchor;
+    }
     if (S > 1 && s->n > 0) {
       /* population of every (length, V, J) class bucket */
       std::vector<uint32_t> bucket((size_t)1 << HEAVY_BUCKETS_LOG2, 0);
@@ -634,7 +702,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
             uint32_t ck = base_of[i];
             if (L > 0 && class_is_heavy(c->ctab.data(), g, ck))
               for (uint32_t r = 0; r < k; r++)
-                ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r)]];
+                ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r, g.c0)]];
             pop[ck & g.smask]++;
           }
           const double mx = *std::max_element(pop.begin(), pop.end());
@@ -889,14 +957,59 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if (c->sliced && c->opt.indels)
     for (int k = 0; k < 2; k++)
       sibling[k].resize((size_t)c->geom.smask + 1);
+  /* Without -i, queries long enough to contain all class positions unwrapped
+     (len >= c0 + K) may share a tile with queries of other lengths: inside a
+     (slice, heavy) group they are laid out longest first and cut every 64,
+     whatever their lengths; the kernel masks each lane by its own length.
+     This keeps the padding small when there are many slices and lengths
+     (100M references x 49 nucleotide lengths = 1.6M groups).  Shorter queries,
+     and all queries with -i (the indel passes stage one sibling slice per
+     length), keep one tile group per length. */
+  const bool mixed_ok = c->sliced && !c->opt.indels;
+  const uint64_t min_mixed = mixed_ok ? (uint64_t)c->geom.c0 + c->geom.k : ~0ull;
+  std::vector<uint64_t> slot_base((size_t)(S * per_slice), 0);
   for (uint64_t sh = 0; sh < S; sh++) {
     const uint64_t slice = c->sliced ? sh / 2 : 0;
     const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
     const uint64_t slice_first = ntiles;
+    /* mixed-length tiles */
+    {
+      uint64_t n_long = 0;
+      for (uint64_t gl = 0; gl < per_slice; gl++) {
+        const uint64_t L = longest - gl;
+        if (L < min_mixed)
+          break;
+        const uint64_t g = sh * per_slice + gl;
+        slot_base[g] = ntiles * WAVE + n_long;
+        tile_first[g] = ntiles + n_long / WAVE;
+        n_long += per_group[g];
+      }
+      uint64_t gl = 0, seen = 0;        /* group that holds element k * 64 */
+      for (uint64_t k = 0; k * WAVE < n_long; k++) {
+        while (seen + per_group[sh * per_slice + gl] <= k * WAVE) {
+          seen += per_group[sh * per_slice + gl];
+          gl++;
+        }
+        const uint64_t L = longest - gl;              /* longest query of the tile */
+        TileDesc td;
+        td.len = (uint32_t)L;
+        td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, n_long - k * WAVE);
+        td.res_base = res_words;
+        td.slice = (uint32_t)slice;
+        td.k = tile_k;
+        res_words += ((L + 3) / 4) * WAVE;
+        tiles.push_back(td);
+      }
+      ntiles += (n_long + WAVE - 1) / WAVE;
+    }
+    /* one tile group per length */
     for (uint64_t gl = 0; gl < per_slice; gl++) {
       const uint64_t g = sh * per_slice + gl;
       const uint64_t L = longest - gl;
+      if (L >= min_mixed)
+        continue;
       tile_first[g] = ntiles;
+      slot_base[g] = ntiles * WAVE;
       const uint64_t cnt = per_group[g];
       const uint64_t nt = (cnt + WAVE - 1) / WAVE;
       const uint64_t words = (L + 3) / 4;
@@ -990,6 +1103,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   const size_t slots = (size_t)ntiles * WAVE;
   std::vector<uint32_t> qres((size_t)res_words, 0), qrep(slots, 0), qv, qj;
   std::vector<uint64_t> qcnt;
+  std::vector<uint16_t> qlen(slots, 0);
   if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
   if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
   std::vector<uint64_t> fill((size_t)(S * per_slice), 0);
@@ -998,10 +1112,10 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     const uint64_t b = s->offsets[i];
     const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
     const uint64_t g = group_of[i];
-    const uint64_t k = fill[g]++;
-    const uint64_t tile = tile_first[g] + k / WAVE;
-    const uint32_t lane = (uint32_t)(k % WAVE);
-    const size_t slot = (size_t)tile * WAVE + lane;
+    const size_t slot = (size_t)(slot_base[g] + fill[g]++);
+    const uint64_t tile = slot / WAVE;
+    const uint32_t lane = (uint32_t)(slot % WAVE);
+    qlen[slot] = (uint16_t)L;
     qrep[slot] = s->repertoire[i];
     if (!c->opt.ignore_genes) { qv[slot] = s->v_gene[i]; qj[slot] = s->j_gene[i]; }
     if (!c->opt.ignore_counts) qcnt[slot] = s->count[i];
@@ -1016,6 +1130,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_upload(c, c->tiles, tiles.data(), tiles.size()))) return rc;
   if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
   if ((rc = dev_upload(c, c->qrep, qrep.data(), qrep.size()))) return rc;
+  if ((rc = dev_upload(c, c->qlen, qlen.data(), qlen.size()))) return rc;
   if (!c->opt.ignore_genes) {
     if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
     if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
@@ -1076,6 +1191,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qj = c->qj.p;
     P.qrep = c->qrep.p;
     P.qcnt = c->qcnt.p;
+    P.qlen = c->qlen.p;
     P.ntiles = c->ntiles;
     P.first_tile = 0;
     P.matrix = d_out;

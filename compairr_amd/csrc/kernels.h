@@ -262,13 +262,12 @@ __device__ __forceinline__ uint32_t query_residue(const ProbeParams &P,
    variant must have there, all loads of the loop are independent and stay in
    flight together (an early-exit loop costs one memory round trip per residue). */
 __device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
-                                    uint32_t lane, uint32_t ca, uint32_t cb,
+                                    uint32_t lane, uint32_t L, uint32_t ca, uint32_t cb,
                                     const RefRec &rec)
 {
   const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
   const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
   const uint32_t M = rec.len;
-  const uint32_t L = td.len;
   const uint8_t *t = P.res2 + rec.off;
   /* expected length of the hit */
   const uint32_t want = kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L);
@@ -321,6 +320,7 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
   const uint32_t ql = qs & 63u;
   const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
   const uint32_t q_rep = P.qrep[qs];
+  const uint32_t q_len = P.qlen[qs];           /* own length (tiles may mix lengths) */
   const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
   uint64_t s = table_home(key, P.slot_mask);
   for (;;) {
@@ -345,7 +345,7 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
       bool ok = true;
       if (GENES)
         ok = (q_v == rec.v) && (q_j == rec.j);
-      if (ok && variant_matches_hit(P, td, ql, ca, cb, rec)) {
+      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
         st.matches++;
         const uint32_t cell = P.R2 * q_rep + rec.rep;
         if (P.score == 1 /* ratio */ && !P.ignore_counts) {

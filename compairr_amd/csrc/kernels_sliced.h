@@ -292,6 +292,8 @@ probe_sliced_kernel(const ProbeParams P)
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
       W.qslot = t * WAVE + lane;
+      /* own length: tiles without -i may mix lengths (L = the longest one) */
+      const uint32_t Ll = valid ? (uint32_t)P.qlen[W.qslot] : 0u;
       auto res_at = [&](uint32_t p) -> uint32_t {
         return (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
       };
@@ -307,7 +309,7 @@ probe_sliced_kernel(const ProbeParams P)
       {
         for (uint32_t p = 0; p < L; p++) {
           const uint32_t r = rs.at(p);
-          h ^= zl[A * p + r];
+          h ^= p < Ll ? zl[A * p + r] : 0ull;
           if (INDELS) {
             hins ^= zl[A * (p + 1) + r];
             if (p > 0)
@@ -320,7 +322,7 @@ probe_sliced_kernel(const ProbeParams P)
       uint32_t m[MCR];
 #pragma unroll
       for (uint32_t i = 0; i < MCR; i++)
-        m[i] = class_pos(L, i);
+        m[i] = class_pos(L, i, P.geom.c0);
       auto is_class_pos = [&](uint32_t p) -> bool {
         bool c = false;
 #pragma unroll
@@ -354,7 +356,7 @@ probe_sliced_kernel(const ProbeParams P)
 
       if (D >= 1 && pass == 0) {
         /* ---- single substitutions (variants.cc:280-293) ---- */
-        nvar += (uint64_t)(A - 1) * L;
+        nvar += (uint64_t)(A - 1) * Ll;
         rs.start(qr, L);
         if constexpr (A == 4) {
           /* Nucleotides: a row has only 3 variants, so 16 positions are probed
@@ -370,11 +372,12 @@ probe_sliced_kernel(const ProbeParams P)
                 const uint32_t r = rs.at(p);
                 const uint64_t *zp = zl + 4 * p;
                 const uint64_t h1 = h ^ zp[r];
+                const bool act = p < Ll;
                 if (!is_class_pos(p)) {
 #pragma unroll
                   for (uint32_t k = 1; k <= 3; k++) {
                     const uint64_t hv = h1 ^ zp[(r + k) & 3u];
-                    mask |= probe_one_lds(W, hv) ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    mask |= (act && probe_one_lds(W, hv)) ? (1ull << (3 * jj + k - 1)) : 0ull;
                   }
                 } else {
                   uint32_t crow;
@@ -391,7 +394,8 @@ probe_sliced_kernel(const ProbeParams P)
 #pragma unroll
                   for (uint32_t k = 1; k <= 3; k++) {
                     const uint64_t hv = h1 ^ zp[(r + k) & 3u];
-                    mask |= bloom_hit(word[k - 1], pattern_of(hv)) ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    mask |= (act && bloom_hit(word[k - 1], pattern_of(hv)))
+                                ? (1ull << (3 * jj + k - 1)) : 0ull;
                   }
                 }
               }
@@ -423,7 +427,7 @@ probe_sliced_kernel(const ProbeParams P)
             const uint32_t dk = class_terms(p, r, crow);
             mask = row_hbm<A>(W, h1, zrow, dk, crow);
           }
-          mask &= vmask & ~(1u << r);              /* the original residue is no variant */
+          mask &= (p < Ll ? ~0u : 0u) & ~(1u << r);      /* not past the lane's own end, not the original residue */
           emit_row<GENES, true>(W, mask, h1, zl + A * p, pack_a(K_SUB, p, 0), 0);
         }
       }
@@ -468,7 +472,7 @@ probe_sliced_kernel(const ProbeParams P)
           uint32_t md[MCR], lo[MCR], hi[MCR];
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++) {
-            md[i] = class_pos(L - 1, i);
+            md[i] = class_pos(L - 1, i, P.geom.c0);
             lo[i] = hi[i] = 0;
             if (i < KH) {
               lo[i] = cr_lds[i * A + res_at(md[i])] & hv;
@@ -533,7 +537,7 @@ probe_sliced_kernel(const ProbeParams P)
           uint32_t mi[MCR], lo[MCR], hi[MCR];
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++) {
-            mi[i] = class_pos(L + 1, i);
+            mi[i] = class_pos(L + 1, i, P.geom.c0);
             lo[i] = hi[i] = 0;
             if (i < KH) {
               if (mi[i] < L)
@@ -585,7 +589,7 @@ probe_sliced_kernel(const ProbeParams P)
 
       if (D >= 2 && pass == 0) {
         /* ---- double substitutions p < q (variants.cc:370-399) ---- */
-        nvar += (uint64_t)(A - 1) * (A - 1) * ((uint64_t)L * (L ? L - 1 : 0) / 2);
+        nvar += (uint64_t)(A - 1) * (A - 1) * ((uint64_t)Ll * (Ll ? Ll - 1 : 0) / 2);
         if constexpr (A == 4) {
           /* Nucleotides: both substitutions enumerate the three OTHER residues of
              the lane ((r + k) & 3), so none of the 9 (instead of 16) probes per
@@ -615,10 +619,11 @@ probe_sliced_kernel(const ProbeParams P)
                     const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
                     const uint64_t *zq = zl + 4 * qq;
                     const uint64_t hq = hpv ^ zq[rq];
+                    const bool act = qq < Ll;            /* implies p < Ll */
                     if (!cp && !is_class_pos(qq)) {
 #pragma unroll
                       for (uint32_t k = 1; k <= 3; k++)
-                        mask |= probe_one_lds(W, hq ^ zq[(rq + k) & 3u])
+                        mask |= (act && probe_one_lds(W, hq ^ zq[(rq + k) & 3u]))
                                     ? (1ull << (3 * jj + k - 1)) : 0ull;
                     } else {
                       const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
@@ -631,7 +636,7 @@ probe_sliced_kernel(const ProbeParams P)
                       }
 #pragma unroll
                       for (uint32_t k = 1; k <= 3; k++)
-                        mask |= bloom_hit(word[k - 1], pattern_of(hq ^ zq[(rq + k) & 3u]))
+                        mask |= (act && bloom_hit(word[k - 1], pattern_of(hq ^ zq[(rq + k) & 3u])))
                                     ? (1ull << (3 * jj + k - 1)) : 0ull;
                     }
                   }
@@ -680,7 +685,7 @@ probe_sliced_kernel(const ProbeParams P)
                 const uint32_t dk_q = class_terms(qq, rq, crow_q);
                 mask = row_hbm<A>(W, hq, zrow_q, dk_pv ^ dk_q, crow_q);
               }
-              mask &= pv & ~(1u << rq);
+              mask &= pv & (qq < Ll ? ~0u : 0u) & ~(1u << rq);
               emit_row<GENES, false>(W, mask, hq, zl + A * qq, ca, qq);
             }
           }

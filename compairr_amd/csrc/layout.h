@@ -50,7 +50,7 @@ enum : uint32_t { K_SAME = 0, K_SUB = 1, K_DEL = 2, K_INS = 3, K_SUB2 = 4 };
    so that one wave instruction reads four positions of all 64 queries as one
    256-byte coalesced access. */
 struct TileDesc {
-  uint32_t len;       /* residues per query in this tile                    */
+  uint32_t len;       /* residues of the longest query of the tile          */
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
   uint64_t res_base;  /* dword offset of the tile's residues in qres         */
   uint32_t slice;     /* Bloom slice of every query of the tile (sliced mode) */
@@ -62,11 +62,12 @@ struct TileDesc {
    but from a "class key" that is invariant under most single edits:
        base  = CL[len] ^ CV[v] ^ CJ[j]
        ckey  = base ^ (heavy(base) ? CR[0][seq[m_0]] ^ ... ^ CR[K-1][seq[m_K-1]] : 0)
-       slice = ckey & (S - 1),   m_i = (len / 2 + i) % len
+       slice = ckey & (S - 1),   m_i = (c0 + i) % len
    heavy(base) is one bit of a 65536-bucket bitmap filled from set 2: a
    (len, V, J) class that alone would overfill a slice is split over up to
-   20^K slices by K "class residues" from the middle of the sequence; all
-   other ("light") classes are not split.  Hence every substitution variant
+   20^K slices by K "class residues" at the fixed positions c0 .. c0+K-1 (c0
+   is picked from set 2's length distribution so that they lie inside almost
+   every sequence); all other ("light") classes are not split.  Hence every substitution variant
    of a light query, and every substitution variant of a heavy query that does
    not touch a class position, lives in the query's own slice.  Queries are
    grouped by slice, a workgroup stages that slice into LDS once and answers
@@ -89,11 +90,13 @@ struct SliceGeom {
      CL[ncl] | CV[n_v] | CJ[n_j] | CR[MAX_CLASS_RES][A] | heavy bitmap[HEAVY_WORDS] */
   const uint32_t *ctab;
   uint32_t off_cv, off_cj, off_cr, off_hv;
+  uint32_t c0;             /* first class position                          */
+  uint32_t pad;
 };
 
-__host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i)
+__host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i, uint32_t c0)
 {
-  return len ? (len / 2 + i) % len : 0;
+  return len ? (c0 + i) % len : 0;
 }
 
 /* `t` = the class tables (host vector or device pointer, same layout) */
@@ -122,7 +125,7 @@ __host__ __device__ inline uint32_t class_key_of(const uint32_t *t, const SliceG
   const bool heavy = g.k > 0 && class_is_heavy(t, g, ck);
   if (heavy && L > 0)
     for (uint32_t i = 0; i < g.k; i++)
-      ck ^= t[g.off_cr + i * A + s[class_pos(L, i)]];
+      ck ^= t[g.off_cr + i * A + s[class_pos(L, i, g.c0)]];
   if (heavy_out)
     *heavy_out = heavy;
   return ck;
@@ -176,6 +179,7 @@ struct ProbeParams {
   const uint32_t *qj;
   const uint32_t *qrep;
   const uint64_t *qcnt;
+  const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
   uint32_t        ntiles;
   uint32_t        first_tile;
   /* output */
