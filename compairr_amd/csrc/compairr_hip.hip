@@ -72,6 +72,8 @@ struct cmpr_context {
                                      -1: from the slice size, 0: every class   */
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
+  int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  bool    waves_per_block_forced = false;
   int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
   int64_t slice_words_log2 = SLICE_WORDS_LOG2;
 
@@ -81,7 +83,8 @@ struct cmpr_context {
   std::vector<uint32_t> ctab;     /* host copy of the class tables             */
   DevBuf<uint32_t>      d_ctab;
   DevBuf<Chunk>         chunks;
-  DevBuf<uint32_t>      tile_list;
+  DevBuf<uint32_t>      tile_list, small_tiles;
+  uint32_t              nsmall = 0;
   uint32_t              nchunks = 0;
 
   /* Zobrist + patterns */
@@ -391,7 +394,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
-  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release();
+  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
@@ -455,10 +458,17 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     c->chunk_tiles = value;
   } else if (n == "debug") {
     c->debug = value;
+  } else if (n == "small_slice_tiles") {
+    if (value < 0 || value > 64)
+      return fail(c, CMPR_EINVAL, "small_slice_tiles must be 0..64");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set small_slice_tiles before cmpr_set_queries");
+    c->small_slice_tiles = value;
   } else if (n == "waves_per_block") {
     if (value != 4 && value != 8 && value != 16)
       return fail(c, CMPR_EINVAL, "waves_per_block must be 4, 8 or 16");
     c->waves_per_block = value;
+    c->waves_per_block_forced = true;
   } else if (n == "bloom_bits_log2_delta") {
     if (value < -4 || value > 4)
       return fail(c, CMPR_EINVAL, "bloom_bits_log2_delta must be -4..4");
@@ -499,6 +509,8 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "slices") *value = c->sliced ? (int64_t)c->geom.smask + 1 : 1;
   else if (n == "tiles") *value = c->ntiles;
   else if (n == "chunks") *value = c->nchunks;
+  else if (n == "small_tiles") *value = c->nsmall;
+  else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
   else
     return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
@@ -953,6 +965,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   std::vector<Chunk> chunks;
   std::vector<uint64_t> chunk_work;
   std::vector<uint32_t> tile_list;              /* chunk -> tile ids */
+  std::vector<uint32_t> small_tiles;            /* wave-phase tiles */
   std::vector<std::vector<uint32_t>> sibling[2];
   if (c->sliced && c->opt.indels)
     for (int k = 0; k < 2; k++)
@@ -1026,7 +1039,13 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
       ntiles += nt;
     }
     if (c->sliced) {
-      /* main pass: the tiles of this slice, any length */
+      /* main pass: the tiles of this slice, any length.  A slice with very few
+         query tiles is not worth a workgroup + a staged copy: its tiles go to the
+         list that single waves work through, probing the slice in HBM / L2. */
+      if (!c->opt.indels && ntiles - slice_first <= (uint64_t)c->small_slice_tiles) {
+        for (uint64_t t = slice_first; t < ntiles; t++)
+          small_tiles.push_back((uint32_t)t);
+      } else
       for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
         Chunk ck;
         ck.slice = (uint32_t)slice;
@@ -1097,6 +1116,12 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     c->nchunks = (uint32_t)sorted.size();
     if ((rc = dev_upload(c, c->chunks, sorted.data(), sorted.size()))) return rc;
     if ((rc = dev_upload(c, c->tile_list, tile_list.data(), tile_list.size()))) return rc;
+    /* longest first, like the chunks */
+    std::stable_sort(small_tiles.begin(), small_tiles.end(), [&](uint32_t x, uint32_t y) {
+      return tiles[x].len > tiles[y].len;
+    });
+    c->nsmall = (uint32_t)small_tiles.size();
+    if ((rc = dev_upload(c, c->small_tiles, small_tiles.data(), small_tiles.size()))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
 
@@ -1142,7 +1167,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
   if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
   if ((rc = dev_alloc(c, c->stats, STAT_COUNT))) return rc;
-  if ((rc = dev_alloc(c, c->tile_counter, 1))) return rc;
+  if ((rc = dev_alloc(c, c->tile_counter, 2))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
   return CMPR_OK;
@@ -1164,7 +1189,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   if (is_f64_score(c->opt))
     HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, std::max<size_t>(cells, 1) * sizeof(double), st));
   HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * sizeof(unsigned long long), st));
-  HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, sizeof(uint32_t), st));
+  HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, 2 * sizeof(uint32_t), st));
   c->launches = 0;
 
   HIP_TRY(c, hipEventRecord(c->ev_k0, st));
@@ -1206,10 +1231,17 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.geom = c->geom;
     P.chunks = c->chunks.p;
     P.tile_list = c->tile_list.p;
+    P.small_tiles = c->small_tiles.p;
+    P.nsmall = c->nsmall;
     P.nchunks = c->nchunks;
     P.debug = (uint32_t)c->debug;
 
-    const int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
+    /* workgroups of 8 waves share one staged slice; when the chunks are short
+       (many slices, few queries each) 4 waves keep more of them busy */
+    int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
+    if (c->sliced && !c->waves_per_block_forced && c->nchunks > 0 &&
+        (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
+      nw = 4;
     size_t lds = (size_t)A * c->zpos * sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)nw * sizeof(WaveQueue);
@@ -1228,7 +1260,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
     per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
     uint64_t grid = (uint64_t)c->cus * per_cu;
-    grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks
+    grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks + ((uint64_t)c->nsmall + nw - 1) / nw
                                               : ((uint64_t)c->ntiles + WAVES_PER_BLOCK - 1) /
                                                     WAVES_PER_BLOCK);
     grid = std::max<uint64_t>(grid, 1);

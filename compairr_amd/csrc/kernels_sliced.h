@@ -164,6 +164,19 @@ __device__ __forceinline__ bool probe_one_lds(const SProber &W, uint64_t hv)
   return bloom_hit(word, pattern_of(hv));
 }
 
+/* one probe of the tile's own slice: LDS copy when staged, else where it lies */
+__device__ __forceinline__ bool probe_one_own(const SProber &W, uint64_t hv, bool staged)
+{
+  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  uint64_t word;
+  if (staged)
+    word = *(const uint64_t *)((const char *)W.slice_lds + woff);
+  else
+    word = *(const uint64_t *)((const char *)W.P.bloom +
+                               ((uint64_t)W.tile_slice << W.slice_shift) + woff);
+  return bloom_hit(word, pattern_of(hv));
+}
+
 /* address of the filter word of a class-changing variant (dk = class-key delta) */
 __device__ __forceinline__ const uint64_t *hbm_word(const SProber &W, uint64_t hv, uint32_t dk)
 {
@@ -250,40 +263,70 @@ probe_sliced_kernel(const ProbeParams P)
   const uint64_t *gene_keys = P.zob + nz;
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
 
+  /* Two kinds of work.  Block phase: chunks (several tiles that need the same
+     slice) are claimed by the whole workgroup, which stages the slice in LDS.
+     Wave phase: tiles whose slice holds too few queries to be worth a
+     workgroup (many slices, few queries) are claimed one at a time by single
+     waves and probe their slice where it lies, in HBM / L2. */
+  bool block_phase = true;
   for (;;) {
-    /* ---- next chunk: tiles of one slice; stage that slice into LDS ---- */
-    __syncthreads();                       /* everyone is done with the old slice */
-    if (threadIdx.x == 0) {
-      bcast[0] = atomicAdd(P.tile_counter, 1u);
-      bcast[1] = 0;                        /* tiles of the chunk handed out so far */
-    }
-    __syncthreads();
-    const uint32_t item = bcast[0];
-    if (item >= P.nchunks)
-      break;
-    const Chunk ck = P.chunks[item];
-    {
-      const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
-      for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
-        slice_lds[i] = src[i];
-      for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT) {
-        const uint32_t t = P.tile_list[ck.first_tile + i];
-        tref_lds[i].td = P.tiles[t];
-        tref_lds[i].t = t;
+    Chunk ck;
+    ck.slice = 0;
+    ck.first_tile = 0;
+    ck.ntiles = 0;
+    ck.pass = 0;
+    if (block_phase) {
+      /* ---- next chunk: tiles of one slice; stage that slice into LDS ---- */
+      __syncthreads();                     /* everyone is done with the old slice */
+      if (threadIdx.x == 0) {
+        bcast[0] = atomicAdd(P.tile_counter, 1u);
+        bcast[1] = 0;                      /* tiles of the chunk handed out so far */
+      }
+      __syncthreads();
+      const uint32_t item = bcast[0];
+      if (item >= P.nchunks) {
+        block_phase = false;               /* the same for every thread of the block */
+      } else {
+        ck = P.chunks[item];
+        const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
+        for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
+          slice_lds[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT) {
+          const uint32_t t = P.tile_list[ck.first_tile + i];
+          tref_lds[i].td = P.tiles[t];
+          tref_lds[i].t = t;
+        }
+        __syncthreads();
       }
     }
-    __syncthreads();
+    const bool staged = block_phase;       /* own-slice probes: LDS or HBM */
     const uint32_t pass = ck.pass;         /* 0 main, 1 insertions, 2 deletions */
 
+    bool all_done = false;
     for (;;) {
-      uint32_t tk = 0;
-      if (lane == 0)
-        tk = atomicAdd(&bcast[1], 1u);
-      tk = __builtin_amdgcn_readfirstlane(tk);
-      if (tk >= ck.ntiles)
-        break;
-      const uint32_t t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
-      const TileDesc td = tref_lds[tk].td;
+      uint32_t t;
+      TileDesc td;
+      if (block_phase) {
+        uint32_t tk = 0;
+        if (lane == 0)
+          tk = atomicAdd(&bcast[1], 1u);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= ck.ntiles)
+          break;
+        t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
+        td = tref_lds[tk].td;
+      } else {
+        uint32_t i = 0;
+        if (lane == 0)
+          i = atomicAdd(P.tile_counter + 1, 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= P.nsmall) {
+          all_done = true;
+          break;
+        }
+        t = P.small_tiles[i];
+        td = P.tiles[t];
+      }
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
@@ -347,12 +390,8 @@ probe_sliced_kernel(const ProbeParams P)
       uint64_t nvar = pass == 0 ? 1 : 0;
 
       /* ---- the unchanged sequence (variants.cc:260-268) ---- */
-      if (pass == 0) {
-        const uint32_t woff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-        const uint64_t word = *(const uint64_t *)((const char *)slice_lds + woff);
-        const uint64_t pat = pattern_of(h);
-        s_push<GENES>(W, valid && bloom_hit(word, pat), h, pack_a(K_SAME, 0, 0), 0);
-      }
+      if (pass == 0)
+        s_push<GENES>(W, valid && probe_one_own(W, h, staged), h, pack_a(K_SAME, 0, 0), 0);
 
       if (D >= 1 && pass == 0) {
         /* ---- single substitutions (variants.cc:280-293) ---- */
@@ -377,7 +416,7 @@ probe_sliced_kernel(const ProbeParams P)
 #pragma unroll
                   for (uint32_t k = 1; k <= 3; k++) {
                     const uint64_t hv = h1 ^ zp[(r + k) & 3u];
-                    mask |= (act && probe_one_lds(W, hv)) ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    mask |= (act && probe_one_own(W, hv, staged)) ? (1ull << (3 * jj + k - 1)) : 0ull;
                   }
                 } else {
                   uint32_t crow;
@@ -421,7 +460,7 @@ probe_sliced_kernel(const ProbeParams P)
           uint32_t mask = 0;
           if (!is_class_pos(p)) {
             if (!(P.debug & DBG_SKIP_LDS_ROWS))
-              mask = row_lds<A>(W, h1, zrow);
+              mask = staged ? row_lds<A>(W, h1, zrow) : row_hbm<A>(W, h1, zrow, 0u, 0u);
           } else if (!(P.debug & DBG_SKIP_HBM_ROWS)) {
             uint32_t crow;
             const uint32_t dk = class_terms(p, r, crow);
@@ -445,7 +484,7 @@ probe_sliced_kernel(const ProbeParams P)
            whose variant lands elsewhere probes the filter in HBM. */
         const bool do_del = pass == 2;
         const bool do_ins = pass == 1;
-        const uint32_t staged = ck.slice;
+        const uint32_t sibling = ck.slice;     /* the slice staged for this pass */
         const uint32_t cl_L = P.geom.ctab[L];
         uint32_t base = cl_L;
         if (GENES)
@@ -501,7 +540,7 @@ probe_sliced_kernel(const ProbeParams P)
               const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
               const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
               uint64_t word;
-              if (vslice == staged)
+              if (vslice == sibling)
                 word = *(const uint64_t *)((const char *)slice_lds + woff);
               else
                 word = *(const uint64_t *)((const char *)P.bloom +
@@ -569,7 +608,7 @@ probe_sliced_kernel(const ProbeParams P)
               }
             const uint64_t zrow = zl[A * ip + zlane];
             /* rows that put v on a class position spread over up to A slices */
-            const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == staged;
+            const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == sibling;
             uint32_t mask = 0;
             if (__ballot(in_lds)) {
               const uint32_t ml = row_lds<A>(W, hi_hash, zrow);
@@ -623,7 +662,7 @@ probe_sliced_kernel(const ProbeParams P)
                     if (!cp && !is_class_pos(qq)) {
 #pragma unroll
                       for (uint32_t k = 1; k <= 3; k++)
-                        mask |= (act && probe_one_lds(W, hq ^ zq[(rq + k) & 3u]))
+                        mask |= (act && probe_one_own(W, hq ^ zq[(rq + k) & 3u], staged))
                                     ? (1ull << (3 * jj + k - 1)) : 0ull;
                     } else {
                       const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
@@ -679,7 +718,7 @@ probe_sliced_kernel(const ProbeParams P)
               const uint64_t zrow_q = zl[A * qq + zlane];
               uint32_t mask;
               if (!cp && !is_class_pos(qq)) {
-                mask = row_lds<A>(W, hq, zrow_q);
+                mask = staged ? row_lds<A>(W, hq, zrow_q) : row_hbm<A>(W, hq, zrow_q, 0u, 0u);
               } else {
                 uint32_t crow_q;
                 const uint32_t dk_q = class_terms(qq, rq, crow_q);
@@ -694,6 +733,8 @@ probe_sliced_kernel(const ProbeParams P)
 
       W.st.variants += valid ? nvar : 0ull;
     }
+    if (all_done)
+      break;
   }
 
   /* leftovers: fewer than 64 entries */

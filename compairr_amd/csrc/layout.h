@@ -193,11 +193,14 @@ struct ProbeParams {
   /* sliced mode */
   SliceGeom       geom;
   const Chunk    *chunks;
+  const uint32_t *small_tiles;     /* tiles handled by single waves, unstaged      */
+  uint32_t        nsmall;
+  uint32_t        pad3;
   const uint32_t *tile_list;       /* chunk c covers tiles tile_list[first .. first+n) */
   uint32_t        nchunks;
   uint32_t        debug;           /* ablation switches, 0 in production      */
   /* work distribution + statistics */
-  uint32_t           *tile_counter;
+  uint32_t           *tile_counter;  /* [0] chunks, [1] small tiles                  */
   unsigned long long *stats;       /* [variants, bloom+, hash==, matches]     */
 };
 

@@ -47,6 +47,10 @@ LAYOUTS = {
     "lds_tiny_mixed": {"variant": 1, "slice_words_log2": 3, "class_residues": 2,
                        "heavy_threshold": 2, "waves_per_block": 4},
     "lds_mixed_auto": {"variant": 1, "slice_words_log2": 6, "waves_per_block": 16},
+    # every slice handled by single waves, unstaged (the many-slices-few-queries regime)
+    "wave_phase_all": {"variant": 1, "slice_words_log2": 4, "class_residues": 2,
+                       "heavy_threshold": 2, "small_slice_tiles": 64},
+    "wave_phase_none": {"variant": 1, "slice_words_log2": 5, "small_slice_tiles": 0},
 }
 
 
