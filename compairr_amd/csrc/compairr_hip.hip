@@ -183,12 +183,16 @@ int validate_options(const cmpr_options *o, std::string &why)
   if (o->score < CMPR_SCORE_PRODUCT || o->score > CMPR_SCORE_JACCARD) {
     why = "unknown score"; return CMPR_EINVAL;
   }
+  if (o->existence && (o->score == CMPR_SCORE_MH || o->score == CMPR_SCORE_JACCARD)) {
+    why = "The Morisita-Horn / Jaccard index is only allowed when computing repertoire overlap";
+    return CMPR_EINVAL;
+  }
   if (o->differences > 0 &&
       (o->score == CMPR_SCORE_MH || o->score == CMPR_SCORE_JACCARD)) {
     why = "The Morisita-Horn / Jaccard index is not defined when d>0";
     return CMPR_EINVAL;
   }
-  for (int k = 0; k < 7; k++)
+  for (int k = 0; k < 6; k++)
     if (o->reserved[k]) { why = "reserved option fields must be zero"; return CMPR_EINVAL; }
   return CMPR_OK;
 }
@@ -917,7 +921,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     return fail(c, CMPR_EINVAL,
                 "query longer than the longest_query given to cmpr_set_reference");
   c->n1 = s->n;
-  c->R1 = s->n_repertoires;
+  c->R1 = c->opt.existence ? (uint32_t)s->n : s->n_repertoires;
 
   /* exact integer accumulation needs every cell < 2^64; a cell is at most
      (sum of counts of its row repertoire) x (sum of counts of its column one) */
@@ -1141,7 +1145,10 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     const uint64_t tile = slot / WAVE;
     const uint32_t lane = (uint32_t)(slot % WAVE);
     qlen[slot] = (uint16_t)L;
-    qrep[slot] = s->repertoire[i];
+    if (c->opt.existence)
+      qrep[slot] = (uint32_t)i;               /* -x: the row is the sequence itself */
+    if (!c->opt.existence)
+      qrep[slot] = s->repertoire[i];
     if (!c->opt.ignore_genes) { qv[slot] = s->v_gene[i]; qj[slot] = s->j_gene[i]; }
     if (!c->opt.ignore_counts) qcnt[slot] = s->count[i];
     uint32_t *dst = qres.data() + tiles[tile].res_base + lane;

@@ -37,7 +37,8 @@ class _Options(C.Structure):
                 ("ignore_genes", C.c_int32), ("ignore_counts", C.c_int32),
                 ("score", C.c_int32), ("alphabet_size", C.c_int32),
                 ("n_v_genes", C.c_uint32), ("n_j_genes", C.c_uint32),
-                ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("device", C.c_int32), ("existence", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class _SetView(C.Structure):
@@ -66,6 +67,7 @@ class Options:
     n_v_genes: int = 1
     n_j_genes: int = 1
     device: int = -1
+    existence: bool = False
 
 
 @dataclass
@@ -165,6 +167,7 @@ class HipOverlap:
         o.n_v_genes = opt.n_v_genes
         o.n_j_genes = opt.n_j_genes
         o.device = opt.device
+        o.existence = int(opt.existence)
         self.opt = opt
         self._ctx = C.c_void_p()
         rc = self._lib.cmpr_create(C.byref(o), C.byref(self._ctx))

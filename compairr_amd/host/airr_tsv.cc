@@ -80,7 +80,7 @@ void split_tabs(char *line, std::vector<char *> &fields)
 }
 
 /* db.cc:172-296 */
-void parse_header(char *line, const Options &o, Columns &c, FILE *log)
+void parse_header(char *line, const Options &o, Columns &c, FILE *log, bool need_id)
 {
   std::vector<char *> f;
   split_tabs(line, f);
@@ -99,11 +99,13 @@ void parse_header(char *line, const Options &o, Columns &c, FILE *log)
   }
   const int seqcol = o.cdr3 ? (o.nucleotides ? c.cdr3 : c.cdr3_aa)
                             : (o.nucleotides ? c.junction : c.junction_aa);
-  const bool missing = (!c.duplicate_count && !o.ignore_counts) ||
+  const bool missing = (!c.sequence_id && need_id) ||
+                       (!c.duplicate_count && !o.ignore_counts) ||
                        (!c.v_call && !o.ignore_genes) ||
                        (!c.j_call && !o.ignore_genes) || !seqcol;
   if (missing) {
     fprintf(log, "\nMissing essential column(s) in header of AIRR TSV input file:");
+    if (need_id && !c.sequence_id) fprintf(log, " sequence_id");
     if (!o.ignore_counts && !c.duplicate_count) fprintf(log, " duplicate_count");
     if (!o.ignore_genes) {
       if (!c.v_call) fprintf(log, " v_call");
@@ -141,6 +143,7 @@ struct RangeResult {
   std::vector<uint8_t>  residues;
   std::vector<uint32_t> lengths, v, j, rep;   /* range-local string numbers */
   std::vector<uint64_t> count;
+  std::vector<std::string> ids;              /* sequence_id, when required */
   LocalNames            reps, vs, js;
   uint64_t              ignored_unknown = 0, ignored_empty = 0;
   bool                  failed = false;
@@ -161,7 +164,7 @@ void fail_line(RangeResult &r, const char *fmt, ...)
 
 /* One data line (db.cc:298-706).  Returns false after recording an error. */
 bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
-                const char *default_rep, RangeResult &d, std::vector<char *> &f)
+                const char *default_rep, RangeResult &d, std::vector<char *> &f, bool need_id)
 {
   split_tabs(line, f);
   const char *repertoire_id = field(f, c.repertoire_id);
@@ -222,6 +225,14 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
   /* repertoire_id: default when the column or the field is absent (db.cc:505-520) */
   const uint32_t rep = d.reps.intern(repertoire_id ? repertoire_id : default_rep);
 
+  /* sequence_id (db.cc:523-542): required by -x for the first file */
+  const char *sequence_id = field(f, c.sequence_id);
+  if (need_id && !(sequence_id && *sequence_id)) {
+    fail_line(d, "\n\nError: missing or empty sequence_id value on line %lu\n",
+              (unsigned long)lineno);
+    return false;
+  }
+
   /* duplicate_count (db.cc:545-571) */
   uint64_t count = 1;
   if (duplicate_count && *duplicate_count) {
@@ -251,6 +262,8 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
     fail_line(d, "\n\nError: missing or empty j_call value on line %lu\n", (unsigned long)lineno);
     return false;
   }
+  if (need_id)
+    d.ids.push_back(sequence_id);
   d.lengths.push_back(len);
   d.rep.push_back(rep);
   d.count.push_back(count);
@@ -262,7 +275,7 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
 /* parses the lines of text[begin, end) (ends at a line end or at EOF) */
 void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
                  const Options &o, const Columns &c, const char *default_rep,
-                 RangeResult &out)
+                 RangeResult &out, bool need_id)
 {
   std::vector<char *> fields;
   uint64_t lineno = first_lineno;
@@ -276,7 +289,7 @@ void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
     line[n] = 0;
     if (n > 0 && line[n - 1] == '\r')
       line[--n] = 0;
-    if (!parse_line(line, lineno, o, c, default_rep, out, fields))
+    if (!parse_line(line, lineno, o, c, default_rep, out, fields, need_id))
       return;
     lineno++;
   }
@@ -312,7 +325,7 @@ bool read_whole_file(const char *filename, std::vector<char> &text)
 }  // namespace
 
 void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
-                   const char *default_rep, FILE *log, RepertoireSet &d)
+                   const char *default_rep, FILE *log, RepertoireSet &d, bool need_id)
 {
   std::vector<char> text;
   if (!read_whole_file(filename, text)) {
@@ -342,7 +355,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
       line[--n] = 0;
     if (line[0] == '#' || line[0] == '@')
       continue;
-    parse_header(line, o, cols, log);
+    parse_header(line, o, cols, log, need_id);
     have_header = true;
   }
 
@@ -387,7 +400,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     for (size_t r = 0; r < nranges; r++)
       pool.emplace_back([&, r]() {
         parse_range(text.data(), cut[r], cut[r + 1], first_line[r], o, cols, default_rep,
-                    part[r]);
+                    part[r], need_id);
       });
     for (auto &t : pool)
       t.join();
@@ -427,6 +440,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     for (size_t k = 0; k < mj.size(); k++)
       mj[k] = genes.j.intern(p.js.names[k].c_str());
     d.residues.insert(d.residues.end(), p.residues.begin(), p.residues.end());
+    d.sequence_id.insert(d.sequence_id.end(), p.ids.begin(), p.ids.end());
     for (size_t k = 0; k < p.lengths.size(); k++) {
       const uint32_t len = p.lengths[k];
       d.offsets.push_back(d.offsets.back() + len);

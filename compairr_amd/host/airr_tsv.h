@@ -37,6 +37,7 @@ struct RepertoireSet {
   std::vector<uint64_t> offsets;      /* n + 1                             */
   std::vector<uint32_t> v_gene, j_gene, repertoire;
   std::vector<uint64_t> count;
+  std::vector<std::string> sequence_id;   /* kept only when asked for (-x) */
   /* per set */
   Interner  repertoires;
   uint64_t  ignored_unknown = 0, ignored_empty = 0;
@@ -51,7 +52,7 @@ struct RepertoireSet {
    way the reference does: message on `log`, exit status 1. */
 void read_airr_tsv(const char *filename, const Options &opt, GeneTables &genes,
                    const char *default_repertoire_id, FILE *log,
-                   RepertoireSet &out);
+                   RepertoireSet &out, bool require_sequence_id = false);
 
 }  // namespace cmprhost
 #endif

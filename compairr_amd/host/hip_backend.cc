@@ -88,6 +88,7 @@ public:
     co.n_v_genes = (uint32_t)genes.v.names.size();
     co.n_j_genes = (uint32_t)genes.j.names.size();
     co.device = (int32_t)o.device;
+    co.existence = o.existence;
 
     cmpr_context *ctx = nullptr;
     if (api_.create(&co, &ctx)) {

@@ -47,7 +47,7 @@ void print_usage(FILE *f)
   fprintf(f, " -h, --help                  display this help and exit\n");
   fprintf(f, " -v, --version               display version information\n");
   fprintf(f, " -m, --matrix                compute overlap matrix between two sets\n");
-  fprintf(f, " -x, --existence             (not available in the MI355X build)\n");
+  fprintf(f, " -x, --existence             check existence of sequences in repertoires\n");
   fprintf(f, " -c, --cluster               (not available in the MI355X build)\n");
   fprintf(f, " -z, --deduplicate           (not available in the MI355X build)\n");
   fprintf(f, "\nGeneral options:\n");
@@ -71,9 +71,15 @@ void print_usage(FILE *f)
 
 void print_options(FILE *f, const Options &o, const char *backend_name)
 {
-  fprintf(f, "Command:           Overlap (-m)\n");
-  fprintf(f, "Repertoire set 1:  %s\n", o.input1);
-  fprintf(f, "Repertoire set 2:  %s\n", o.input2 ? o.input2 : "(same as set 1)");
+  if (o.existence) {
+    fprintf(f, "Command:           Existence (-x)\n");
+    fprintf(f, "Repertoire:        %s\n", o.input1);
+    fprintf(f, "Repertoire set:    %s\n", o.input2);
+  } else {
+    fprintf(f, "Command:           Overlap (-m)\n");
+    fprintf(f, "Repertoire set 1:  %s\n", o.input1);
+    fprintf(f, "Repertoire set 2:  %s\n", o.input2 ? o.input2 : "(same as set 1)");
+  }
   fprintf(f, "Nucleotides (n):   %s\n", o.nucleotides ? "Yes" : "No");
   fprintf(f, "Differences (d):   %ld\n", (long)o.differences);
   fprintf(f, "Indels (i):        %s\n", o.indels ? "Yes" : "No");
@@ -199,14 +205,20 @@ void parse_command_line(int argc, char **argv, Options &o)
   }
 
   /* commands outside the hot path this build replaces */
-  if (o.existence)
-    fatal("The -x / --existence command is not part of the MI355X build (only -m / --matrix is).");
   if (o.cluster)
     fatal("The -c / --cluster command is not part of the MI355X build (only -m / --matrix is).");
   if (o.deduplicate)
     fatal("The -z / --deduplicate command is not part of the MI355X build (only -m / --matrix is).");
 
-  if (optind + 2 == argc) {
+  if (o.existence) {
+    /* compairr.cc:589-600 */
+    if (optind + 2 == argc) {
+      o.input1 = argv[optind];
+      o.input2 = argv[optind + 1];
+    } else {
+      fatal("Incorrect number of arguments. Two input files must be specified.");
+    }
+  } else if (optind + 2 == argc) {
     o.input1 = argv[optind];
     o.input2 = argv[optind + 1];
   } else if (optind + 1 == argc) {
@@ -242,6 +254,13 @@ void parse_command_line(int argc, char **argv, Options &o)
       }
     if (o.score < 0)
       fatal("Argument to -s or --score must be MH, Jaccard, product, ratio, min, max or mean");
+  }
+  if (!o.matrix) {
+    /* compairr.cc:667-677 */
+    if (o.score == SCORE_MH)
+      fatal("The Morisita-Horn index is only allowed when computing repertoire overlap");
+    if (o.score == SCORE_JACCARD)
+      fatal("The Jaccard index is only allowed when computing repertoire overlap");
   }
   if (o.differences > 0) {
     if (o.score == SCORE_MH)

@@ -145,12 +145,16 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
 
   fprintf(log, "Immune receptor repertoire set 1\n\n");
   auto t0 = std::chrono::steady_clock::now();
-  read_airr_tsv(o.input1, o, genes, "1", log, set1);
+  read_airr_tsv(o.input1, o, genes, "1", log, set1, o.existence);
   auto t1 = std::chrono::steady_clock::now();
   fprintf(log, "Reading sequences: %.9lfs\n\n",
           std::chrono::duration<double>(t1 - t0).count());
   totals_of(set1, tot1);
   log_repertoires(log, set1, tot1);
+
+  if (o.existence && set1.repertoires.names.size() > 1)
+    fatal("Multiple repertoires are not allowed in the first file specified on the command "
+          "line with the -x or --existence command.");      /* overlap.cc:699-703 */
 
   fprintf(log, "Immune receptor repertoire set 2\n\n");
   const bool same = !(o.input2 && strcmp(o.input1, o.input2));
@@ -176,7 +180,9 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   fprintf(log, "Unique J genes:    %lu\n", (unsigned long)genes.j.names.size());
 
   /* ---- the per-query loop, on the backend (overlap.cc:840-938) ---- */
-  const size_t R1 = set1.repertoires.names.size(), R2 = set2.repertoires.names.size();
+  const size_t R2 = set2.repertoires.names.size();
+  /* -x: one matrix row per set-1 sequence, in input order (overlap.cc:889-899) */
+  const size_t R1 = o.existence ? (size_t)set1.size() : set1.repertoires.names.size();
   std::vector<double> cells(R1 * R2, 0.0);
   BackendReport rep;
   std::string error;
@@ -210,7 +216,29 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   /* ---- print (overlap.cc:944-1039): rows/columns in strcmp order of the
           ids, every value "\t%.10lg" ---- */
   t0 = std::chrono::steady_clock::now();
-  if (o.alternative) {
+  if (o.existence) {
+    /* overlap.cc:971-991, 1017-1037: rows are the sequences, by sequence_id */
+    if (o.alternative) {
+      fprintf(out, "#sequence_id_1\trepertoire_id_2\tmatches\n");
+      for (size_t i = 0; i < R1; i++)
+        for (size_t j = 0; j < R2; j++) {
+          const uint32_t t = tot2.order[j];
+          fprintf(out, "%s\t%s\t%.10lg\n", set1.sequence_id[i].c_str(),
+                  set2.repertoires.names[t].c_str(), cells[R2 * i + t]);
+        }
+    } else {
+      fprintf(out, "#");
+      for (size_t j = 0; j < R2; j++)
+        fprintf(out, "\t%s", set2.repertoires.names[tot2.order[j]].c_str());
+      fprintf(out, "\n");
+      for (size_t i = 0; i < R1; i++) {
+        fprintf(out, "%s", set1.sequence_id[i].c_str());
+        for (size_t j = 0; j < R2; j++)
+          fprintf(out, "\t%.10lg", cells[R2 * i + tot2.order[j]]);
+        fprintf(out, "\n");
+      }
+    }
+  } else if (o.alternative) {
     fprintf(out, "#repertoire_id_1\trepertoire_id_2\tmatches\n");
     for (size_t i = 0; i < R1; i++) {
       const uint32_t s = tot1.order[i];

@@ -66,7 +66,9 @@ typedef struct cmpr_options {
   uint32_t n_v_genes;       /* db_get_v_gene_count() (db.cc:1018)             */
   uint32_t n_j_genes;       /* db_get_j_gene_count() (db.cc:1023)             */
   int32_t  device;          /* HIP device ordinal; -1 = current device        */
-  int32_t  reserved[7];     /* must be zero                                   */
+  int32_t  existence;       /* opt_existence (-x): matrix rows are the set-1
+                               SEQUENCES, in input order (overlap.cc:226)       */
+  int32_t  reserved[6];     /* must be zero                                   */
 } cmpr_options;
 
 /*
@@ -144,8 +146,9 @@ int cmpr_set_queries(cmpr_context *ctx, const cmpr_set_view *set1);
 /*
  * The per-query loop (sim_thread / process_variants / find_variant_matches,
  * overlap.cc:376-538, 253-284, 168-251).  Writes the R1 x R2 matrix,
- * row = set-1 repertoire number, column = set-2 repertoire number
- * (overlap.cc:222), as exact integer sums:
+ * row = set-1 repertoire number (with options.existence: R1 = number of set-1
+ * sequences, row = sequence number), column = set-2 repertoire number
+ * (overlap.cc:222-226), as exact integer sums:
  *   product, MH : sum of count1 * count2
  *   min, Jaccard: sum of min;  max: sum of max;  -f: number of pairs
  *   mean        : sum of (count1 + count2), i.e. TWICE the reference's cell

@@ -415,7 +415,9 @@ static void chain_walk(job_t *J, uint64_t q, const variant_t *x, double *M,
           (A->v_gene[q] == B->v_gene[hit] && A->j_gene[q] == B->j_gene[hit])) {
         if (variant_is(seq_of(A, q), len_of(A, q), x,
                        seq_of(B, hit), len_of(B, hit))) {
-          M[(uint64_t)B->n_repertoires * A->repertoire[q] + B->repertoire[hit]] +=
+          /* overlap.cc:218-228: row = repertoire of the seed, or the seed with -x */
+          const uint64_t row = J->o->existence ? q : A->repertoire[q];
+          M[(uint64_t)B->n_repertoires * row + B->repertoire[hit]] +=
               pair_score(J->o, A->count[q], B->count[hit]);
           st->matches++;
         }
@@ -457,7 +459,8 @@ static void query_scan(job_t *J, uint64_t q, double *M, oracle_stats *st)
     for (unsigned p = 0; p < L && diffs <= J->o->differences; p++)
       diffs += s[p] != t[p];
     if (diffs <= J->o->differences) {
-      M[(uint64_t)B->n_repertoires * A->repertoire[q] + B->repertoire[hit]] +=
+      const uint64_t row = J->o->existence ? q : A->repertoire[q];
+      M[(uint64_t)B->n_repertoires * row + B->repertoire[hit]] +=
           pair_score(J->o, A->count[q], B->count[hit]);
       st->matches++;
     }
@@ -467,7 +470,8 @@ static void query_scan(job_t *J, uint64_t q, double *M, oracle_stats *st)
 static void *worker(void *arg)
 {
   job_t *J = (job_t *)arg;
-  const uint64_t cells = (uint64_t)J->s1->n_repertoires * J->s2->n_repertoires;
+  const uint64_t cells = (J->o->existence ? J->s1->n : (uint64_t)J->s1->n_repertoires) *
+                         J->s2->n_repertoires;
   const int hashed = J->o->differences <= MAX_HASHED_D;
   oracle_stats st;
   memset(&st, 0, sizeof st);
@@ -559,7 +563,7 @@ int oracle_overlap(const oracle_opts *o, const oracle_set *s1,
     return -1;
 
   const int same = (s1 == s2);
-  const uint64_t cells = (uint64_t)s1->n_repertoires * s2->n_repertoires;
+  const uint64_t cells = (o->existence ? s1->n : (uint64_t)s1->n_repertoires) * s2->n_repertoires;
   for (uint64_t k = 0; k < cells; k++)
     matrix[k] = 0;
 
@@ -675,7 +679,7 @@ static int one_removed(const uint8_t *s, unsigned L, const uint8_t *t)
 int oracle_bruteforce(const oracle_opts *o, const oracle_set *A,
                       const oracle_set *B, double *matrix)
 {
-  const uint64_t cells = (uint64_t)A->n_repertoires * B->n_repertoires;
+  const uint64_t cells = (o->existence ? A->n : (uint64_t)A->n_repertoires) * B->n_repertoires;
   for (uint64_t k = 0; k < cells; k++)
     matrix[k] = 0;
   for (uint64_t q = 0; q < A->n; q++) {
@@ -700,7 +704,7 @@ int oracle_bruteforce(const oracle_opts *o, const oracle_set *A,
           ok = one_removed(t, M, s);
       }
       if (ok)
-        matrix[(uint64_t)B->n_repertoires * A->repertoire[q] + B->repertoire[h]] +=
+        matrix[(uint64_t)B->n_repertoires * (o->existence ? q : A->repertoire[q]) + B->repertoire[h]] +=
             pair_score(o, A->count[q], B->count[h]);
     }
   }

@@ -56,6 +56,7 @@ typedef struct oracle_opts {
   int32_t  threads;        /* -t                                            */
   uint32_t n_v_genes;
   uint32_t n_j_genes;
+  int32_t  existence;      /* -x: rows are set-1 sequences (overlap.cc:226)  */
 } oracle_opts;
 
 typedef struct oracle_stats {
@@ -71,8 +72,9 @@ typedef struct oracle_stats {
 } oracle_stats;
 
 /*
- * matrix: caller-allocated double[set1->n_repertoires * set2->n_repertoires],
- * row = set-1 repertoire number, column = set-2 repertoire number; zeroed by
+ * matrix: caller-allocated double[rows * set2->n_repertoires], rows =
+ * set1->n_repertoires (or set1->n with -x); row = set-1 repertoire number (or
+ * sequence number with -x), column = set-2 repertoire number; zeroed by
  * the callee (overlap.cc:882-887).  set2 may alias set1 (one-file mode).
  * Returns 0, or -1 on an illegal option combination / allocation failure.
  */

@@ -27,7 +27,7 @@ class _Opts(C.Structure):
                 ("ignore_genes", C.c_int32), ("ignore_counts", C.c_int32),
                 ("score", C.c_int32), ("alphabet_size", C.c_int32),
                 ("threads", C.c_int32), ("n_v_genes", C.c_uint32),
-                ("n_j_genes", C.c_uint32)]
+                ("n_j_genes", C.c_uint32), ("existence", C.c_int32)]
 
 
 class _Stats(C.Structure):
@@ -90,6 +90,7 @@ def _opts(opt, threads, n_v, n_j) -> _Opts:
     o.threads = threads
     o.n_v_genes = n_v
     o.n_j_genes = n_j
+    o.existence = int(getattr(opt, "existence", False))
     return o
 
 
@@ -99,7 +100,8 @@ def overlap(set1, set2, opt, threads: int = 1):
     o = _opts(opt, threads, opt.n_v_genes, opt.n_j_genes)
     a = _set(set1)
     b = a if set2 is set1 else _set(set2)
-    m = np.zeros((set1.n_repertoires, set2.n_repertoires), dtype=np.float64)
+    rows = set1.n if getattr(opt, "existence", False) else set1.n_repertoires
+    m = np.zeros((rows, set2.n_repertoires), dtype=np.float64)
     st = _Stats()
     rc = lib().oracle_overlap(C.byref(o), C.byref(a), C.byref(b),
                               C.c_void_p(m.ctypes.data), C.byref(st))
@@ -112,7 +114,8 @@ def bruteforce(set1, set2, opt):
     o = _opts(opt, 1, opt.n_v_genes, opt.n_j_genes)
     a = _set(set1)
     b = a if set2 is set1 else _set(set2)
-    m = np.zeros((set1.n_repertoires, set2.n_repertoires), dtype=np.float64)
+    rows = set1.n if getattr(opt, "existence", False) else set1.n_repertoires
+    m = np.zeros((rows, set2.n_repertoires), dtype=np.float64)
     rc = lib().oracle_bruteforce(C.byref(o), C.byref(a), C.byref(b),
                                  C.c_void_p(m.ctypes.data))
     if rc:

@@ -46,8 +46,8 @@ def load_manifest():
 
 
 def run_cli(binary, case, timeout=120, log=None):
-    argv = [os.path.join(ROOT, binary), "-m"] + case["files"] + case["args"].split() + \
-           ["-l", log or os.devnull]
+    argv = [os.path.join(ROOT, binary), case.get("cmd", "-m")] + case["files"] + \
+           case["args"].split() + ["-l", log or os.devnull]
     return subprocess.run(argv, cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, timeout=timeout)
 

@@ -76,6 +76,9 @@ EDGE_FILES = {
                          "T\tg\t47\tV2\tJ1\taa\tAA", "S\th\t53\tV1\tJ2\tac\tAC"]),
     # empty duplicate_count is legal only with -f (db.cc:545-571)
     "nocount.tsv": rows(["X1\ta\t\tV1\tJ1\ttgt\tCASSL", "X2\tb\t\tV1\tJ1\ttgt\tCASSL", "X2\tc\t\tV1\tJ1\ttgt\tCASSV"]),
+    # no sequence_id column: fatal for the first file of -x (db.cc:229)
+    "noid.tsv": rows(["X1\t2\tV1\tJ1\tCASSL", "X1\t3\tV1\tJ1\tCASSV"],
+                     header="repertoire_id\tduplicate_count\tv_call\tj_call\tjunction_aa\n"),
     # no gene columns at all: legal with -g (db.cc:231-232)
     "nogenes.tsv": rows(["X1\ta\t2\tCASSL", "X2\tb\t3\tCASSV", "X2\tc\t5\tCASSL"],
                         header="repertoire_id\tsequence_id\tduplicate_count\tjunction_aa\n"),
@@ -103,14 +106,19 @@ def random_files():
         n = kw.pop("n")
         seed = kw.pop("seed")
         out[name] = (synth.tiny_set(n, seed, **kw), kw["alphabet_size"] == 4)
+    # single-repertoire query files for -x, sharing the pool of the rand_* sets
+    out["rand_x_aa.tsv"] = (synth.make_set(400, 51, pool_seed=777, prefix="Q", n_repertoires=1,
+                                           pool_size=200), False)
+    out["rand_x_nt.tsv"] = (synth.make_set(200, 52, pool_seed=777, prefix="Q", n_repertoires=1,
+                                           pool_size=80, nucleotides=True), True)
     return out
 
 
 def cases():
     c = []
 
-    def add(name, args, files, note=""):
-        c.append({"name": name, "args": args, "files": files, "note": note})
+    def add(name, args, files, note="", cmd="-m"):
+        c.append({"name": name, "args": args, "files": files, "note": note, "cmd": cmd})
 
     # (a) the reference's own test + README examples + the survey's KAT table
     add("ref_test_sh", "-d 1 -i", ["seta.tsv", "setb.tsv"], "test/test.sh:9, test/expected.tsv")
@@ -183,6 +191,26 @@ def cases():
         add("%s_mh_self" % fam, ("-s MH -a" + n).strip(), [b])
         add("%s_d1_t3" % fam, ("-d 1 -i -t 3" + n).strip(), [a, b])
     add("tiny_aa_d3", "-d 3", ["tiny_aa_a.tsv", "tiny_aa_b.tsv"], "d > 2: reference's brute-force path")
+
+    # (d) -x / --existence: rows are the sequences of the first file
+    add("x_readme_ex2", "-d 1 -f", ["setc.tsv", "setb.tsv"], "README.md:557-561", cmd="-x")
+    add("x_ref_a", "-d 1 -a", ["setc.tsv", "setb.tsv"], cmd="-x")
+    add("x_ref_min_i", "-d 1 -i -s min", ["setc.tsv", "setb.tsv"], cmd="-x")
+    add("x_ref_nt", "-d 2 -n -g", ["setc.tsv", "seta.tsv"], cmd="-x")
+    add("x_same_file", "-d 1", ["setc.tsv", "setc.tsv"], cmd="-x")
+    for fam, nt in (("aa", False), ("nt", True)):
+        q, r = "rand_x_%s.tsv" % fam, "rand_%s_b.tsv" % fam
+        n = " -n" if nt else ""
+        for d in ("", "-d 1", "-d 1 -i", "-d 2"):
+            tag = d.replace("-", "").replace(" ", "") or "d0"
+            add("x_%s_%s" % (fam, tag), (d + n).strip(), [q, r], cmd="-x")
+        add("x_%s_d1_g_f" % fam, ("-d 1 -g -f" + n).strip(), [q, r], cmd="-x")
+        add("x_%s_d1_a_max" % fam, ("-d 1 -a -s max" + n).strip(), [q, r], cmd="-x")
+        add("x_%s_d1_mean_t3" % fam, ("-d 1 -i -s mean -t 3" + n).strip(), [q, r], cmd="-x")
+    add("err_x_multi_rep", "-d 1", ["seta.tsv", "setb.tsv"], "exit 1", cmd="-x")
+    add("err_x_one_file", "-d 1", ["setc.tsv"], "exit 1", cmd="-x")
+    add("err_x_mh", "-s MH", ["setc.tsv", "setb.tsv"], "exit 1", cmd="-x")
+    add("err_x_no_sequence_id", "-d 1", ["noid.tsv", "crlf.tsv"], "exit 1", cmd="-x")
     return c
 
 
@@ -205,7 +233,7 @@ def main():
     manifest = []
     for case in cases():
         logf = os.path.join(HERE, "_log.tmp")
-        argv = [REF, "-m"] + case["files"] + case["args"].split() + ["-l", logf]
+        argv = [REF, case["cmd"]] + case["files"] + case["args"].split() + ["-l", logf]
         p = subprocess.run(argv, cwd=INPUTS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         entry = dict(case)
         entry["exit"] = p.returncode

@@ -47,6 +47,7 @@ public:
     oo.threads = (int32_t)o.threads;
     oo.n_v_genes = (uint32_t)genes.v.names.size();
     oo.n_j_genes = (uint32_t)genes.j.names.size();
+    oo.existence = o.existence;
     const oracle_set v1 = view_of(set1);
     const oracle_set v2 = view_of(set2);
     oracle_stats st;

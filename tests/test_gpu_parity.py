@@ -210,6 +210,21 @@ def test_long_sequences():
     assert st.matches >= n + 2 * (n // 2)
 
 
+@pytest.mark.parametrize("d,indels", [(0, False), (1, False), (1, True), (2, False)])
+def test_existence_rows_are_sequences(d, indels):
+    """-x: one matrix row per set-1 sequence, in input order (overlap.cc:226)."""
+    n = 3000 if d == 2 else 20000
+    q = synth.make_set(n, 31, prefix="Q", pool_size=4000, n_repertoires=1)
+    b = synth.make_set(30000, 32, prefix="B", pool_size=4000, n_repertoires=5)
+    o = Options(differences=d, indels=indels, existence=True, **FULL)
+    st = check(q, b, o)
+    assert st.matches > 0
+    t = synth.tiny_set(200, 7, letters=2, max_len=5, n_repertoires=1)
+    u = synth.tiny_set(300, 8, letters=2, max_len=5)
+    check(t, u, Options(differences=d, indels=indels, existence=True, n_v_genes=2, n_j_genes=2,
+                        score="min"))
+
+
 def test_duplicate_counts_match_the_reference_algorithm():
     """hash_insert's duplicate count (overlap.cc:76-115) on the GPU: set 2 from the
     resident index, set 1 from a temporary one."""

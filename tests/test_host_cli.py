@@ -37,7 +37,8 @@ def test_help_and_version():
     (["-m", "seta.tsv", "-d", "1", "-s", "jaccard"], b"Jaccard index is not defined"),
     (["-m", "seta.tsv", "-g", "-g"], b"specified more than once"),
     (["-m", "seta.tsv", "-k", "x"], b"--keep-columns only allowed with --pairs"),
-    (["-x", "seta.tsv", "setb.tsv"], b"not part of the MI355X build"),
+    (["-x", "seta.tsv"], b"Two input files must be specified"),
+    (["-x", "setc.tsv", "setb.tsv", "-s", "MH"], b"only allowed when computing repertoire overlap"),
     (["-c", "seta.tsv"], b"not part of the MI355X build"),
     (["-z", "seta.tsv"], b"not part of the MI355X build"),
     (["-m", "seta.tsv", "-p", "pairs.tsv"], b"not part of the MI355X build"),
