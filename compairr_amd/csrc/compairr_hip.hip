@@ -110,6 +110,7 @@ struct cmpr_context {
   DevBuf<uint32_t>  qres, qv, qj, qrep;
   DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
+  DevBuf<uint32_t>  qorig;
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;
@@ -119,6 +120,10 @@ struct cmpr_context {
   DevBuf<double>             matrix_f64;
   DevBuf<uint32_t>           tile_counter;
   uint32_t                   launches = 0;
+  /* pairs mode, set only while cmpr_overlap_pairs runs */
+  uint32_t           *pair_q = nullptr, *pair_h = nullptr;
+  unsigned long long *pair_count = nullptr;
+  uint64_t            pair_cap = 0;
 };
 
 namespace {
@@ -396,7 +401,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
-  c->qrep.release(); c->qcnt.release(); c->qlen.release();
+  c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
   c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1133,6 +1138,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   std::vector<uint32_t> qres((size_t)res_words, 0), qrep(slots, 0), qv, qj;
   std::vector<uint64_t> qcnt;
   std::vector<uint16_t> qlen(slots, 0);
+  std::vector<uint32_t> qorig(slots, 0);
   if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
   if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
   std::vector<uint64_t> fill((size_t)(S * per_slice), 0);
@@ -1145,6 +1151,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     const uint64_t tile = slot / WAVE;
     const uint32_t lane = (uint32_t)(slot % WAVE);
     qlen[slot] = (uint16_t)L;
+    qorig[slot] = (uint32_t)i;
     if (c->opt.existence)
       qrep[slot] = (uint32_t)i;               /* -x: the row is the sequence itself */
     if (!c->opt.existence)
@@ -1163,6 +1170,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
   if ((rc = dev_upload(c, c->qrep, qrep.data(), qrep.size()))) return rc;
   if ((rc = dev_upload(c, c->qlen, qlen.data(), qlen.size()))) return rc;
+  if ((rc = dev_upload(c, c->qorig, qorig.data(), qorig.size()))) return rc;
   if (!c->opt.ignore_genes) {
     if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
     if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
@@ -1224,6 +1232,11 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qrep = c->qrep.p;
     P.qcnt = c->qcnt.p;
     P.qlen = c->qlen.p;
+    P.qorig = c->qorig.p;
+    P.pair_q = c->pair_q;
+    P.pair_h = c->pair_h;
+    P.pair_count = c->pair_count;
+    P.pair_cap = c->pair_cap;
     P.ntiles = c->ntiles;
     P.first_tile = 0;
     P.matrix = d_out;
@@ -1361,6 +1374,46 @@ extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)
     for (size_t k = 0; k < cells; k++)
       out[k] = mean ? (double)tmp[k] / 2 : (double)tmp[k];
   }
+  return CMPR_OK;
+}
+
+extern "C" int cmpr_overlap_pairs(cmpr_context *c, uint64_t capacity, uint32_t *query_out,
+                                  uint32_t *hit_out, uint64_t *count_out)
+{
+  int rc = check_ready(c);
+  if (rc)
+    return rc;
+  if (!count_out || (capacity && (!query_out || !hit_out)))
+    return fail(c, CMPR_EINVAL, "cmpr_overlap_pairs: NULL output");
+  DevBuf<uint32_t> dq, dh;
+  DevBuf<unsigned long long> dn;
+  struct Cleanup {
+    cmpr_context *c; DevBuf<uint32_t> &a, &b; DevBuf<unsigned long long> &n;
+    ~Cleanup() { a.release(); b.release(); n.release();
+                 c->pair_q = c->pair_h = nullptr; c->pair_count = nullptr; c->pair_cap = 0; }
+  } cleanup{c, dq, dh, dn};
+  if ((rc = dev_alloc(c, dq, (size_t)capacity))) return rc;
+  if ((rc = dev_alloc(c, dh, (size_t)capacity))) return rc;
+  if ((rc = dev_alloc(c, dn, 1))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dn.p, 0, sizeof(unsigned long long), c->stream));
+  c->pair_q = dq.p;
+  c->pair_h = dh.p;
+  c->pair_count = dn.p;
+  c->pair_cap = capacity;
+  rc = enqueue_overlap(c, c->matrix.p, c->stream);
+  if (rc)
+    return rc;
+  unsigned long long n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, dn.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->events_valid = true;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t have = std::min<uint64_t>(n, capacity);
+  if (have) {
+    HIP_TRY(c, hipMemcpy(query_out, dq.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hit_out, dh.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  *count_out = n;
   return CMPR_OK;
 }
 

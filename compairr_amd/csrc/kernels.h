@@ -348,7 +348,14 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
       if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
         st.matches++;
         const uint32_t cell = P.R2 * q_rep + rec.rep;
-        if (P.score == 1 /* ratio */ && !P.ignore_counts) {
+        if (P.pair_count) {
+          /* pairs mode (overlap.cc:232-245) */
+          const unsigned long long k = atomicAdd(P.pair_count, 1ull);
+          if (k < P.pair_cap) {
+            P.pair_q[k] = P.qorig[qs];
+            P.pair_h[k] = hit;
+          }
+        } else if (P.score == 1 /* ratio */ && !P.ignore_counts) {
           unsafeAtomicAdd(P.matrix_f64 + cell, (double)q_cnt / (double)rec.cnt);
         } else {
           unsigned long long sc = 1;

@@ -180,6 +180,7 @@ struct ProbeParams {
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
+  const uint32_t *qorig;           /* per slot: index in the caller's set 1       */
   uint32_t        ntiles;
   uint32_t        first_tile;
   /* output */
@@ -190,6 +191,10 @@ struct ProbeParams {
   int32_t         ignore_counts;
   int32_t         lds_matrix;      /* 1: privatise the matrix in LDS          */
   int32_t         pad1;
+  /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
+  uint32_t           *pair_q, *pair_h;
+  unsigned long long *pair_count;   /* NULL: matrix mode                        */
+  uint64_t            pair_cap;
   /* sliced mode */
   SliceGeom       geom;
   const Chunk    *chunks;

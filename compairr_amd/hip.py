@@ -22,7 +22,7 @@ EXPORTS = [
     "cmpr_set_reference", "cmpr_set_queries", "cmpr_overlap_matrix",
     "cmpr_overlap_matrix_f64", "cmpr_overlap_matrix_device", "cmpr_get_stats",
     "cmpr_rows", "cmpr_cols", "cmpr_set_tunable", "cmpr_get_tunable",
-    "cmpr_count_duplicates",
+    "cmpr_count_duplicates", "cmpr_overlap_pairs",
 ]
 
 
@@ -124,6 +124,8 @@ def load_library() -> C.CDLL:
     lib.cmpr_overlap_matrix_f64.argtypes = [C.c_void_p, C.c_void_p]
     lib.cmpr_overlap_matrix_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cmpr_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    lib.cmpr_overlap_pairs.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_uint64)]
     lib.cmpr_count_duplicates.argtypes = [C.c_void_p, C.POINTER(_SetView), C.POINTER(C.c_uint64)]
     lib.cmpr_rows.argtypes = [C.c_void_p]
     lib.cmpr_rows.restype = C.c_uint32
@@ -234,6 +236,18 @@ class HipOverlap:
     def overlap_matrix_device(self, d_matrix: int, stream: Optional[int] = None) -> None:
         self._check(self._lib.cmpr_overlap_matrix_device(
             self._ctx, C.c_void_p(d_matrix), C.c_void_p(stream or 0)))
+
+    def overlap_pairs(self) -> np.ndarray:
+        """(query index, hit index) of every matching pair, sorted."""
+        n = C.c_uint64()
+        self._check(self._lib.cmpr_overlap_pairs(self._ctx, 0, None, None, C.byref(n)))
+        q = np.zeros(n.value, dtype=np.uint32)
+        h = np.zeros(n.value, dtype=np.uint32)
+        self._check(self._lib.cmpr_overlap_pairs(self._ctx, n.value, q.ctypes.data,
+                                                 h.ctypes.data, C.byref(n)))
+        assert n.value == len(q)
+        out = np.stack([q, h], axis=1)
+        return out[np.lexsort((out[:, 1], out[:, 0]))]
 
     def count_duplicates(self, s: Optional[RepertoireSet] = None) -> int:
         """Exact duplicates inside `s` (None: the resident reference set)."""

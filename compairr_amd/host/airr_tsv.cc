@@ -60,6 +60,8 @@ struct ResidueMaps {
 const ResidueMaps kMaps;
 
 struct Columns {
+  std::vector<int> keep;       /* -k columns, 0 = absent from the header */
+  bool store_ids = false;      /* keep sequence_id (empty when absent)   */
   int repertoire_id = 0, sequence_id = 0, duplicate_count = 0, v_call = 0,
       j_call = 0, junction = 0, junction_aa = 0, cdr3 = 0, cdr3_aa = 0;
 };
@@ -84,6 +86,7 @@ void parse_header(char *line, const Options &o, Columns &c, FILE *log, bool need
 {
   std::vector<char *> f;
   split_tabs(line, f);
+  c.keep.assign(o.keep_names.size(), 0);
   for (size_t k = 0; k < f.size(); k++) {
     const int i = (int)k + 1;
     const char *t = f[k];
@@ -96,6 +99,9 @@ void parse_header(char *line, const Options &o, Columns &c, FILE *log, bool need
     else if (!strcmp(t, "junction_aa")) c.junction_aa = i;
     else if (!strcmp(t, "cdr3")) c.cdr3 = i;
     else if (!strcmp(t, "cdr3_aa")) c.cdr3_aa = i;
+    for (size_t kk = 0; kk < o.keep_names.size(); kk++)
+      if (o.keep_names[kk] == t)
+        c.keep[kk] = i;
   }
   const int seqcol = o.cdr3 ? (o.nucleotides ? c.cdr3 : c.cdr3_aa)
                             : (o.nucleotides ? c.junction : c.junction_aa);
@@ -114,6 +120,17 @@ void parse_header(char *line, const Options &o, Columns &c, FILE *log, bool need
     if (!seqcol) fprintf(log, " %s", o.seq_header);
     fprintf(log, "\n");
     exit(1);
+  }
+  /* db.cc:283-295 */
+  bool any_missing = false;
+  for (int col : c.keep)
+    any_missing = any_missing || col < 1;
+  if (any_missing) {
+    fprintf(log, "\nWarning: missing column(s) to keep in header:");
+    for (size_t kk = 0; kk < c.keep.size(); kk++)
+      if (c.keep[kk] < 1)
+        fprintf(log, " %s", o.keep_names[kk].c_str());
+    fprintf(log, "\n");
   }
 }
 
@@ -143,7 +160,8 @@ struct RangeResult {
   std::vector<uint8_t>  residues;
   std::vector<uint32_t> lengths, v, j, rep;   /* range-local string numbers */
   std::vector<uint64_t> count;
-  std::vector<std::string> ids;              /* sequence_id, when required */
+  std::vector<std::string> ids;              /* sequence_id, when kept */
+  std::vector<std::string> keep;             /* -k columns, tab-joined */
   LocalNames            reps, vs, js;
   uint64_t              ignored_unknown = 0, ignored_empty = 0;
   bool                  failed = false;
@@ -262,8 +280,20 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
     fail_line(d, "\n\nError: missing or empty j_call value on line %lu\n", (unsigned long)lineno);
     return false;
   }
-  if (need_id)
-    d.ids.push_back(sequence_id);
+  if (need_id || c.store_ids)
+    d.ids.push_back(sequence_id ? sequence_id : "");
+  if (!c.keep.empty()) {
+    /* db.cc:671-701: the kept columns, tab separated, absent ones empty */
+    std::string k;
+    for (size_t kk = 0; kk < c.keep.size(); kk++) {
+      if (kk)
+        k.push_back('\t');
+      const char *val = field(f, c.keep[kk]);
+      if (val)
+        k += val;
+    }
+    d.keep.push_back(k);
+  }
   d.lengths.push_back(len);
   d.rep.push_back(rep);
   d.count.push_back(count);
@@ -325,7 +355,8 @@ bool read_whole_file(const char *filename, std::vector<char> &text)
 }  // namespace
 
 void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
-                   const char *default_rep, FILE *log, RepertoireSet &d, bool need_id)
+                   const char *default_rep, FILE *log, RepertoireSet &d, bool need_id,
+                   bool keep_id)
 {
   std::vector<char> text;
   if (!read_whole_file(filename, text)) {
@@ -356,6 +387,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     if (line[0] == '#' || line[0] == '@')
       continue;
     parse_header(line, o, cols, log, need_id);
+    cols.store_ids = keep_id;
     have_header = true;
   }
 
@@ -441,6 +473,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
       mj[k] = genes.j.intern(p.js.names[k].c_str());
     d.residues.insert(d.residues.end(), p.residues.begin(), p.residues.end());
     d.sequence_id.insert(d.sequence_id.end(), p.ids.begin(), p.ids.end());
+    d.keep.insert(d.keep.end(), p.keep.begin(), p.keep.end());
     for (size_t k = 0; k < p.lengths.size(); k++) {
       const uint32_t len = p.lengths[k];
       d.offsets.push_back(d.offsets.back() + len);

@@ -37,7 +37,8 @@ struct RepertoireSet {
   std::vector<uint64_t> offsets;      /* n + 1                             */
   std::vector<uint32_t> v_gene, j_gene, repertoire;
   std::vector<uint64_t> count;
-  std::vector<std::string> sequence_id;   /* kept only when asked for (-x) */
+  std::vector<std::string> sequence_id;   /* kept only when asked for (-x, -p) */
+  std::vector<std::string> keep;          /* -k columns, tab-joined (-p) */
   /* per set */
   Interner  repertoires;
   uint64_t  ignored_unknown = 0, ignored_empty = 0;
@@ -52,7 +53,8 @@ struct RepertoireSet {
    way the reference does: message on `log`, exit status 1. */
 void read_airr_tsv(const char *filename, const Options &opt, GeneTables &genes,
                    const char *default_repertoire_id, FILE *log,
-                   RepertoireSet &out, bool require_sequence_id = false);
+                   RepertoireSet &out, bool require_sequence_id = false,
+                   bool keep_sequence_id = false);
 
 }  // namespace cmprhost
 #endif

@@ -29,6 +29,7 @@ struct Api {
   int (*overlap_matrix_f64)(cmpr_context *, double *) = nullptr;
   int (*get_stats)(cmpr_context *, cmpr_stats *) = nullptr;
   int (*count_duplicates)(cmpr_context *, const cmpr_set_view *, uint64_t *) = nullptr;
+  int (*overlap_pairs)(cmpr_context *, uint64_t, uint32_t *, uint32_t *, uint64_t *) = nullptr;
 };
 
 template <typename F>
@@ -74,8 +75,9 @@ public:
 
   bool overlap(const Options &o, const GeneTables &genes, const RepertoireSet &set1,
                const RepertoireSet &set2, bool same, std::vector<double> &cells,
-               BackendReport &rep, std::string &error) override
+               BackendReport &rep, std::string &error, PairList *pairs) override
   {
+    pairs_ = pairs;
     same_ = same;
     cmpr_options co;
     memset(&co, 0, sizeof co);
@@ -148,11 +150,26 @@ private:
       rep.algorithmic_bytes = st.algorithmic_bytes;
     }
     rep.device_name = "HIP device";
+    if (pairs_) {
+      /* the matrix pass counted the pairs exactly; list them with a second pass */
+      uint64_t n = rep.matches, got = 0;
+      pairs_->seed.resize(n);
+      pairs_->hit.resize(n);
+      if (api_.overlap_pairs(ctx, n, pairs_->seed.data(), pairs_->hit.data(), &got)) {
+        error = api_.last_error(ctx);
+        return false;
+      }
+      if (got != n) {
+        error = "pair count changed between passes";
+        return false;
+      }
+    }
     return true;
   }
 
   Api api_;
   bool same_ = false;
+  PairList *pairs_ = nullptr;
 };
 
 }  // namespace
@@ -195,7 +212,8 @@ OverlapBackend *make_hip_backend(const char *argv0, std::string &error)
       !bind(api.handle, "cmpr_overlap_matrix", api.overlap_matrix, error) ||
       !bind(api.handle, "cmpr_overlap_matrix_f64", api.overlap_matrix_f64, error) ||
       !bind(api.handle, "cmpr_get_stats", api.get_stats, error) ||
-      !bind(api.handle, "cmpr_count_duplicates", api.count_duplicates, error)) {
+      !bind(api.handle, "cmpr_count_duplicates", api.count_duplicates, error) ||
+      !bind(api.handle, "cmpr_overlap_pairs", api.overlap_pairs, error)) {
     dlclose(api.handle);
     return nullptr;
   }

@@ -64,8 +64,12 @@ void print_usage(FILE *f)
   fprintf(f, "\nInput/output options:\n");
   fprintf(f, " -a, --alternative           output results in three-column format, not matrix\n");
   fprintf(f, "     --cdr3                  use the cdr3(_aa) column instead of junction(_aa)\n");
+  fprintf(f, "     --distance              include sequence distance in pairs file\n");
+  fprintf(f, " -k, --keep-columns STRING   comma-separated columns to copy to pairs file\n");
   fprintf(f, " -l, --log FILENAME          log to file (stderr*)\n");
   fprintf(f, " -o, --output FILENAME       output results to file (stdout*)\n");
+  fprintf(f, "     --no-matrix             do not keep or output any matrix\n");
+  fprintf(f, " -p, --pairs FILENAME        output matching pairs to file (none*)\n");
   fprintf(f, "\n                             * default value\n\n");
 }
 
@@ -89,9 +93,11 @@ void print_options(FILE *f, const Options &o, const char *backend_name)
   fprintf(f, "Ignore empty (e):  %s\n", o.ignore_empty ? "Yes" : "No");
   fprintf(f, "Use cdr3 column:   %s\n", o.cdr3 ? "Yes" : "No");
   fprintf(f, "Threads (t):       %ld\n", (long)o.threads);
-  fprintf(f, "Output file (o):   %s\n", o.output);
+  fprintf(f, "Output file (o):   %s\n", o.no_matrix ? "(none)" : o.output);
   fprintf(f, "Output format (a): %s\n", o.alternative ? "Column" : "Matrix");
   fprintf(f, "Score (s):         %s\n", score_description(o.score));
+  fprintf(f, "Pairs file (p):    %s\n", o.pairs ? o.pairs : "(none)");
+  fprintf(f, "Keep columns:      %s\n", o.keep_columns ? o.keep_columns : "");
   fprintf(f, "Log file (l):      %s\n", o.log ? o.log : "(stderr)");
   fprintf(f, "Backend:           %s\n", backend_name);
 }
@@ -228,12 +234,35 @@ void parse_command_line(int argc, char **argv, Options &o)
     fatal("Incorrect number of arguments. One or two input files must be specified.");
   }
 
-  if (o.keep_columns && !o.pairs)
-    fatal("Option --keep-columns only allowed with --pairs options.");
-  if (o.pairs || o.keep_columns || o.distance)
-    fatal("The -p / --pairs output (and -k, --distance) is not part of the MI355X build.");
-  if (o.no_matrix)
-    fatal("Option --no-matrix leaves nothing to compute without --pairs.");
+  if (o.keep_columns) {
+    /* compairr.cc:620-626, parse_keep_columns :114-173 */
+    if (!o.pairs)
+      fatal("Option --keep-columns only allowed with --pairs options.");
+    bool ok = true;
+    std::string cur;
+    for (const char *q = o.keep_columns;; q++) {
+      const char ch = *q;
+      if (ch == ',' || ch == 0) {
+        if (cur.empty()) {
+          ok = false;
+          break;
+        }
+        o.keep_names.push_back(cur);
+        cur.clear();
+        if (ch == 0)
+          break;
+      } else if ((ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') ||
+                 (ch >= '0' && ch <= '9') || ch == '_') {
+        cur.push_back(ch);
+      } else {
+        ok = false;
+        break;
+      }
+    }
+    if (!ok)
+      fatal("Illegal list of columns with --keep-columns option. It must be a comma-separated "
+            "list of column names. Allowed symbols: A-Z, a-z, _, and 0-9.");
+  }
 
   if (o.threads < 1 || o.threads > 256) {
     fprintf(stderr, "\nError: Illegal number of threads specified with "

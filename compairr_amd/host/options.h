@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 namespace cmprhost {
 
@@ -25,8 +26,8 @@ struct Options {
   bool cdr3 = false;             /* --cdr3 */
   bool cluster = false;          /* -c (not on this path) */
   bool deduplicate = false;      /* -z (not on this path) */
-  bool distance = false;         /* --distance (not on this path) */
-  bool existence = false;        /* -x (not on this path) */
+  bool distance = false;         /* --distance */
+  bool existence = false;        /* -x */
   bool help = false;             /* -h */
   bool ignore_counts = false;    /* -f */
   bool ignore_empty = false;     /* -e */
@@ -35,12 +36,13 @@ struct Options {
   bool indels = false;           /* -i */
   bool matrix = false;           /* -m */
   bool nucleotides = false;      /* -n */
-  bool no_matrix = false;        /* --no-matrix (not on this path) */
+  bool no_matrix = false;        /* --no-matrix */
   bool version = false;          /* -v */
-  const char *keep_columns = nullptr;  /* -k (not on this path) */
+  const char *keep_columns = nullptr;  /* -k */
+  std::vector<std::string> keep_names; /* parsed -k list */
   const char *log = nullptr;           /* -l */
   const char *output = "-";            /* -o */
-  const char *pairs = nullptr;         /* -p (not on this path) */
+  const char *pairs = nullptr;         /* -p */
   const char *score_string = nullptr;  /* -s */
   int64_t differences = 0;       /* -d */
   int64_t score = SCORE_PRODUCT;

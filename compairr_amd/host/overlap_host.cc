@@ -122,6 +122,12 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   FILE *out = open_output(o.output);
   if (!out)
     fatal("Unable to open output file for writing.");
+  FILE *pairsfile = nullptr;
+  if (o.pairs) {
+    pairsfile = open_output(o.pairs);
+    if (!pairsfile)
+      fatal("Unable to open pairs file for writing.");
+  }
 
   if (o.version || o.help) {
     print_header(log);
@@ -145,7 +151,7 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
 
   fprintf(log, "Immune receptor repertoire set 1\n\n");
   auto t0 = std::chrono::steady_clock::now();
-  read_airr_tsv(o.input1, o, genes, "1", log, set1, o.existence);
+  read_airr_tsv(o.input1, o, genes, "1", log, set1, o.existence, o.pairs != nullptr);
   auto t1 = std::chrono::steady_clock::now();
   fprintf(log, "Reading sequences: %.9lfs\n\n",
           std::chrono::duration<double>(t1 - t0).count());
@@ -160,7 +166,7 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   const bool same = !(o.input2 && strcmp(o.input1, o.input2));
   if (!same) {
     t0 = std::chrono::steady_clock::now();
-    read_airr_tsv(o.input2, o, genes, "2", log, set2_storage);
+    read_airr_tsv(o.input2, o, genes, "2", log, set2_storage, false, o.pairs != nullptr);
     t1 = std::chrono::steady_clock::now();
     fprintf(log, "Reading sequences: %.9lfs\n\n",
             std::chrono::duration<double>(t1 - t0).count());
@@ -186,7 +192,9 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   std::vector<double> cells(R1 * R2, 0.0);
   BackendReport rep;
   std::string error;
-  if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error)) {
+  PairList pairs;
+  if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error,
+                       o.pairs ? &pairs : nullptr)) {
     fprintf(stderr, "\nError: %s\n", error.c_str());
     return 1;
   }
@@ -213,10 +221,59 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
             (unsigned long)rep.hash_equal, (unsigned long)rep.matches);
   }
 
+  /* ---- pairs (overlap.cc:908-925 header, 455-507 lines; order unspecified,
+          README.md:163) ---- */
+  if (pairsfile) {
+    const char *letters = o.nucleotides ? "acgt" : "ACDEFGHIKLMNPQRSTVWY";   /* db.cc:73-75 */
+    fprintf(pairsfile, "#repertoire_id_1\tsequence_id_1\tduplicate_count_1\tv_call_1\tj_call_1\t%s_1",
+            o.seq_header);
+    for (const std::string &k : o.keep_names)
+      fprintf(pairsfile, "\t%s_1", k.c_str());
+    fprintf(pairsfile, "\trepertoire_id_2\tsequence_id_2\tduplicate_count_2\tv_call_2\tj_call_2\t%s_2",
+            o.seq_header);
+    for (const std::string &k : o.keep_names)
+      fprintf(pairsfile, "\t%s_2", k.c_str());
+    if (o.distance)
+      fprintf(pairsfile, "\tdistance");
+    fprintf(pairsfile, "\n");
+    auto put = [&](const RepertoireSet &s, uint32_t i) {
+      fprintf(pairsfile, "%s\t%s\t%lu\t%s\t%s\t", s.repertoires.names[s.repertoire[i]].c_str(),
+              i < s.sequence_id.size() ? s.sequence_id[i].c_str() : "",
+              (unsigned long)s.count[i], genes.v.names[s.v_gene[i]].c_str(),
+              genes.j.names[s.j_gene[i]].c_str());
+      for (uint64_t p = s.offsets[i]; p < s.offsets[i + 1]; p++)
+        fputc(letters[s.residues[p]], pairsfile);
+      if (!o.keep_names.empty())
+        fprintf(pairsfile, "\t%s", i < s.keep.size() ? s.keep[i].c_str() : "");
+    };
+    for (size_t k = 0; k < pairs.seed.size(); k++) {
+      const uint32_t a = pairs.seed[k], b = pairs.hit[k];
+      put(set1, a);
+      fputc('\t', pairsfile);
+      put(set2, b);
+      if (o.distance) {
+        /* Hamming distance for equal lengths, else one indel (overlap.cc:491-502) */
+        long dist = 1;
+        const uint64_t la = set1.offsets[a + 1] - set1.offsets[a];
+        const uint64_t lb = set2.offsets[b + 1] - set2.offsets[b];
+        if (la == lb) {
+          dist = 0;
+          for (uint64_t p = 0; p < la; p++)
+            dist += set1.residues[set1.offsets[a] + p] != set2.residues[set2.offsets[b] + p];
+        }
+        fprintf(pairsfile, "\t%ld", dist);
+      }
+      fputc('\n', pairsfile);
+    }
+    fclose(pairsfile);
+  }
+
   /* ---- print (overlap.cc:944-1039): rows/columns in strcmp order of the
           ids, every value "\t%.10lg" ---- */
   t0 = std::chrono::steady_clock::now();
-  if (o.existence) {
+  if (o.no_matrix) {
+    /* --no-matrix: nothing is printed (overlap.cc:944-946) */
+  } else if (o.existence) {
     /* overlap.cc:971-991, 1017-1037: rows are the sequences, by sequence_id */
     if (o.alternative) {
       fprintf(out, "#sequence_id_1\trepertoire_id_2\tmatches\n");

@@ -24,6 +24,11 @@ struct BackendReport {
   std::string device_name;
 };
 
+/* (seed, hit) pairs for -p/--pairs: indices into set 1 / set 2 */
+struct PairList {
+  std::vector<uint32_t> seed, hit;
+};
+
 /* The seam where the reference launches sim_thread (overlap.cc:926-936). */
 class OverlapBackend {
 public:
@@ -36,7 +41,8 @@ public:
   virtual bool overlap(const Options &opt, const GeneTables &genes,
                        const RepertoireSet &set1, const RepertoireSet &set2,
                        bool same, std::vector<double> &cells,
-                       BackendReport &report, std::string &error) = 0;
+                       BackendReport &report, std::string &error,
+                       PairList *pairs /* nullptr unless -p */) = 0;
 };
 
 /* Whole program: parse argv, run, print.  Returns the exit status. */

@@ -171,6 +171,20 @@ int cmpr_overlap_matrix_f64(cmpr_context *ctx, double *matrix_out);
 int cmpr_overlap_matrix_device(cmpr_context *ctx, void *d_matrix, void *stream);
 
 /*
+ * The matching (query, hit) pairs themselves -- what the reference appends to
+ * its pairs list in find_variant_matches (overlap.cc:232-245) and prints with
+ * -p/--pairs (overlap.cc:455-507).  Runs the same loop; up to `capacity` pairs are
+ * written (query_out[k] = index into the set given to cmpr_set_queries,
+ * hit_out[k] = index into the reference set; order unspecified, as in the
+ * reference, README.md:163), *count_out = number of pairs found.  When
+ * *count_out > capacity the arrays hold an arbitrary subset: call again with a
+ * larger capacity (cmpr_stats.matches of a previous cmpr_overlap_matrix() call is
+ * the exact number).  capacity == 0 with NULL arrays only counts.
+ */
+int cmpr_overlap_pairs(cmpr_context *ctx, uint64_t capacity, uint32_t *query_out,
+                       uint32_t *hit_out, uint64_t *count_out);
+
+/*
  * Exact duplicates inside one set: the number the reference reports as
  * "Warning: N duplicates detected in repertoire set K" -- sequences that repeat
  * an earlier one of the same repertoire with the same V, J (unless

@@ -398,6 +398,10 @@ typedef struct {
   uint64_t           cursor;       /* next unclaimed query              */
   oracle_stats       st;
   int                failed;
+  /* optional pair sink (overlap.cc:232-245) */
+  uint32_t          *pair_q, *pair_h;
+  uint64_t           pair_cap, pair_count;
+  int                want_pairs;
 } job_t;
 
 static void chain_walk(job_t *J, uint64_t q, const variant_t *x, double *M,
@@ -420,6 +424,15 @@ static void chain_walk(job_t *J, uint64_t q, const variant_t *x, double *M,
           M[(uint64_t)B->n_repertoires * row + B->repertoire[hit]] +=
               pair_score(J->o, A->count[q], B->count[hit]);
           st->matches++;
+          if (J->want_pairs) {
+            pthread_mutex_lock(&J->lock);
+            if (J->pair_count < J->pair_cap) {
+              J->pair_q[J->pair_count] = (uint32_t)q;
+              J->pair_h[J->pair_count] = (uint32_t)hit;
+            }
+            J->pair_count++;
+            pthread_mutex_unlock(&J->lock);
+          }
         }
       }
     }
@@ -459,6 +472,15 @@ static void query_scan(job_t *J, uint64_t q, double *M, oracle_stats *st)
     for (unsigned p = 0; p < L && diffs <= J->o->differences; p++)
       diffs += s[p] != t[p];
     if (diffs <= J->o->differences) {
+      if (J->want_pairs) {
+        pthread_mutex_lock(&J->lock);
+        if (J->pair_count < J->pair_cap) {
+          J->pair_q[J->pair_count] = (uint32_t)q;
+          J->pair_h[J->pair_count] = (uint32_t)hit;
+        }
+        J->pair_count++;
+        pthread_mutex_unlock(&J->lock);
+      }
       const uint64_t row = J->o->existence ? q : A->repertoire[q];
       M[(uint64_t)B->n_repertoires * row + B->repertoire[hit]] +=
           pair_score(J->o, A->count[q], B->count[hit]);
@@ -553,8 +575,33 @@ static uint64_t *hash_all(const zob_t *z, const oracle_set *s)
   return h;
 }
 
+static int run_overlap(const oracle_opts *o, const oracle_set *s1, const oracle_set *s2,
+                       double *matrix, oracle_stats *stats, uint64_t pair_cap,
+                       uint32_t *pair_q, uint32_t *pair_h, uint64_t *pair_count);
+
 int oracle_overlap(const oracle_opts *o, const oracle_set *s1,
                    const oracle_set *s2, double *matrix, oracle_stats *stats)
+{
+  return run_overlap(o, s1, s2, matrix, stats, 0, NULL, NULL, NULL);
+}
+
+int oracle_pairs(const oracle_opts *o, const oracle_set *s1, const oracle_set *s2,
+                 uint64_t capacity, uint32_t *seed_out, uint32_t *hit_out, uint64_t *count)
+{
+  const uint64_t cells = (o->existence ? s1->n : (uint64_t)s1->n_repertoires) * s2->n_repertoires;
+  double *m = (double *)malloc((cells ? cells : 1) * sizeof(double));
+  if (!m || !count)
+    return -1;
+  oracle_opts one = *o;
+  one.threads = 1;
+  int rc = run_overlap(&one, s1, s2, m, NULL, capacity, seed_out, hit_out, count);
+  free(m);
+  return rc;
+}
+
+static int run_overlap(const oracle_opts *o, const oracle_set *s1, const oracle_set *s2,
+                       double *matrix, oracle_stats *stats, uint64_t pair_cap,
+                       uint32_t *pair_q, uint32_t *pair_h, uint64_t *pair_count)
 {
   if (o->differences < 0 || (o->indels && o->differences != 1) ||
       (o->alphabet_size != 20 && o->alphabet_size != 4) ||
@@ -573,6 +620,10 @@ int oracle_overlap(const oracle_opts *o, const oracle_set *s1,
   J.s1 = s1;
   J.s2 = s2;
   J.matrix = matrix;
+  J.want_pairs = pair_count != NULL;
+  J.pair_cap = pair_cap;
+  J.pair_q = pair_q;
+  J.pair_h = pair_h;
   pthread_mutex_init(&J.lock, NULL);
 
   zob_t z;
@@ -645,6 +696,8 @@ int oracle_overlap(const oracle_opts *o, const oracle_set *s1,
   J.st.seconds_analysis = t2 - t1;
   if (stats)
     *stats = J.st;
+  if (pair_count)
+    *pair_count = J.pair_count;
 
 done:
   if (bloom) {

@@ -85,6 +85,15 @@ int oracle_overlap(const oracle_opts *opts,
                    oracle_stats      *stats);
 
 /*
+ * The (seed, hit) pairs the loop finds -- what the reference writes with
+ * -p/--pairs (overlap.cc:232-245, 455-507).  Single-threaded.  Up to `capacity`
+ * pairs are stored (seed = index into set1, hit = index into set2, in the order
+ * found); *count is the total number found.  Returns 0 or -1.
+ */
+int oracle_pairs(const oracle_opts *opts, const oracle_set *set1, const oracle_set *set2,
+                 uint64_t capacity, uint32_t *seed_out, uint32_t *hit_out, uint64_t *count);
+
+/*
  * Independent O(N*M) evaluation of the pair definition (SURVEY.md section 8a,
  * "Semantic summary"); shares no code with the hashing path above.  Small
  * inputs only.

@@ -123,6 +123,27 @@ def bruteforce(set1, set2, opt):
     return m
 
 
+def pairs(set1, set2, opt):
+    """Sorted array of (seed, hit) pairs the reference loop finds (-p/--pairs)."""
+    o = _opts(opt, 1, opt.n_v_genes, opt.n_j_genes)
+    a = _set(set1)
+    b = a if set2 is set1 else _set(set2)
+    count = C.c_uint64()
+    f = lib().oracle_pairs
+    f.restype = C.c_int
+    rc = f(C.byref(o), C.byref(a), C.byref(b), C.c_uint64(0), None, None, C.byref(count))
+    if rc:
+        raise RuntimeError("oracle_pairs failed")
+    q = np.zeros(count.value, dtype=np.uint32)
+    h = np.zeros(count.value, dtype=np.uint32)
+    rc = f(C.byref(o), C.byref(a), C.byref(b), C.c_uint64(count.value),
+           C.c_void_p(q.ctypes.data), C.c_void_p(h.ctypes.data), C.byref(count))
+    if rc:
+        raise RuntimeError("oracle_pairs failed")
+    out = np.stack([q, h], axis=1)
+    return out[np.lexsort((out[:, 1], out[:, 0]))]
+
+
 def integer_cells(m: np.ndarray, opt) -> np.ndarray:
     """Oracle cells (doubles) -> the exact integer sums the C ABI returns
     (mean is accumulated as a + b, i.e. twice the reference's cell)."""

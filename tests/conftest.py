@@ -45,9 +45,11 @@ def load_manifest():
         return json.load(fh)
 
 
-def run_cli(binary, case, timeout=120, log=None):
+def run_cli(binary, case, timeout=120, log=None, pairs=None):
     argv = [os.path.join(ROOT, binary), case.get("cmd", "-m")] + case["files"] + \
            case["args"].split() + ["-l", log or os.devnull]
+    if case.get("pairs"):
+        argv += ["-p", pairs or os.devnull]
     return subprocess.run(argv, cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, timeout=timeout)
 
@@ -55,6 +57,18 @@ def run_cli(binary, case, timeout=120, log=None):
 def warnings_of(logfile):
     with open(logfile, errors="replace") as fh:
         return [l.rstrip("\n") for l in fh if l.startswith("Warning:")]
+
+
+def sorted_pairs(path) -> bytes:
+    """Pairs file with its data lines sorted (their order is unspecified)."""
+    with open(path, "rb") as fh:
+        lines = fh.read().splitlines(keepends=True)
+    return b"".join(lines[:1] + sorted(lines[1:]))
+
+
+def expected_pairs_of(case) -> bytes:
+    with open(os.path.join(GOLDEN_EXPECTED, case["name"] + ".pairs.tsv"), "rb") as fh:
+        return fh.read()
 
 
 def expected_of(case) -> bytes:

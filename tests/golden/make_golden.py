@@ -117,8 +117,9 @@ def random_files():
 def cases():
     c = []
 
-    def add(name, args, files, note="", cmd="-m"):
-        c.append({"name": name, "args": args, "files": files, "note": note, "cmd": cmd})
+    def add(name, args, files, note="", cmd="-m", pairs=False):
+        c.append({"name": name, "args": args, "files": files, "note": note, "cmd": cmd,
+                  "pairs": pairs})
 
     # (a) the reference's own test + README examples + the survey's KAT table
     add("ref_test_sh", "-d 1 -i", ["seta.tsv", "setb.tsv"], "test/test.sh:9, test/expected.tsv")
@@ -207,6 +208,28 @@ def cases():
         add("x_%s_d1_g_f" % fam, ("-d 1 -g -f" + n).strip(), [q, r], cmd="-x")
         add("x_%s_d1_a_max" % fam, ("-d 1 -a -s max" + n).strip(), [q, r], cmd="-x")
         add("x_%s_d1_mean_t3" % fam, ("-d 1 -i -s mean -t 3" + n).strip(), [q, r], cmd="-x")
+    # (e) -p / --pairs (+ -k, --distance, --no-matrix): the pairs file, lines sorted
+    #     ("the order of the lines is unspecified", README.md:163)
+    add("p_readme_ex1", "-d 1", ["seta.tsv", "setb.tsv"], "README.md:440-444", pairs=True)
+    add("p_ref_indel_dist_keep", "-d 1 -i --distance -k sequence,productive,nosuchcolumn",
+        ["seta.tsv", "setb.tsv"], pairs=True)
+    add("p_ref_nt_nomatrix", "-d 1 -n -g --no-matrix", ["seta.tsv", "setb.tsv"], pairs=True)
+    add("p_x_readme_ex2", "-d 1 -f", ["setc.tsv", "setb.tsv"], "README.md:568-573", cmd="-x",
+        pairs=True)
+    add("p_self", "-d 1", ["setb.tsv"], pairs=True)
+    add("p_dups_d0", "", ["dups.tsv"], pairs=True)
+    add("p_noid_g", "-d 1 -g", ["nogenes.tsv", "crlf.tsv"], pairs=True)
+    add("p_noid_set1", "-d 1", ["noid.tsv", "crlf.tsv"], "no sequence_id column: empty ids",
+        pairs=True)
+    for fam, nt in (("rand_aa", False), ("rand_nt", True), ("tiny_aa", False), ("tiny_nt", True)):
+        a, b = "%s_a.tsv" % fam, "%s_b.tsv" % fam
+        n = " -n" if nt else ""
+        add("p_%s_d1i_dist" % fam, ("-d 1 -i --distance" + n).strip(), [a, b], pairs=True)
+        add("p_%s_d2_dist" % fam, ("-d 2 --distance" + n).strip(), [a, b], pairs=True)
+        add("p_%s_d0_self" % fam, n.strip(), [a], pairs=True)
+    add("p_x_aa_d1i", "-d 1 -i --distance", ["rand_x_aa.tsv", "rand_aa_b.tsv"], cmd="-x", pairs=True)
+    add("err_p_keep_without_pairs", "-d 1 -k sequence", ["seta.tsv", "setb.tsv"], "exit 1")
+    add("err_p_keep_bad_list", "-d 1 -k a,,b", ["seta.tsv", "setb.tsv"], "exit 1", pairs=True)
     add("err_x_multi_rep", "-d 1", ["seta.tsv", "setb.tsv"], "exit 1", cmd="-x")
     add("err_x_one_file", "-d 1", ["setc.tsv"], "exit 1", cmd="-x")
     add("err_x_mh", "-s MH", ["setc.tsv", "setb.tsv"], "exit 1", cmd="-x")
@@ -234,7 +257,16 @@ def main():
     for case in cases():
         logf = os.path.join(HERE, "_log.tmp")
         argv = [REF, case["cmd"]] + case["files"] + case["args"].split() + ["-l", logf]
+        pairsf = os.path.join(HERE, "_pairs.tmp")
+        if case["pairs"]:
+            argv += ["-p", pairsf]
         p = subprocess.run(argv, cwd=INPUTS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        if case["pairs"] and p.returncode == 0:
+            lines = open(pairsf, "rb").read().splitlines(keepends=True)
+            with open(os.path.join(EXPECTED, case["name"] + ".pairs.tsv"), "wb") as fh:
+                fh.writelines(lines[:1] + sorted(lines[1:]))
+        if os.path.exists(pairsf):
+            os.remove(pairsf)
         entry = dict(case)
         entry["exit"] = p.returncode
         # the duplicate warnings of the log are part of the contract

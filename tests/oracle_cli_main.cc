@@ -34,7 +34,7 @@ public:
   const char *name() const override { return "CPU oracle (test only)"; }
   bool overlap(const Options &o, const GeneTables &genes, const RepertoireSet &set1,
                const RepertoireSet &set2, bool same, std::vector<double> &cells,
-               BackendReport &rep, std::string &error) override
+               BackendReport &rep, std::string &error, PairList *pairs) override
   {
     oracle_opts oo;
     memset(&oo, 0, sizeof oo);
@@ -64,6 +64,16 @@ public:
     rep.matches = st.matches;
     rep.dup_set1 = st.dup_set1;
     rep.dup_set2 = st.dup_set2;
+    if (pairs) {
+      uint64_t n = 0;
+      pairs->seed.resize(st.matches);
+      pairs->hit.resize(st.matches);
+      if (oracle_pairs(&oo, &v1, same ? &v1 : &v2, st.matches, pairs->seed.data(),
+                       pairs->hit.data(), &n) || n != st.matches) {
+        error = "oracle_pairs failed";
+        return false;
+      }
+    }
     return true;
   }
 };

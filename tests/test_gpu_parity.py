@@ -10,7 +10,8 @@ import pytest
 import _oracle
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
-from conftest import expected_of, load_manifest, run_cli, warnings_of
+from conftest import (expected_of, expected_pairs_of, load_manifest, run_cli, sorted_pairs,
+                      warnings_of)
 
 pytestmark = pytest.mark.gpu
 
@@ -81,7 +82,8 @@ def check(a, b, opt, threads=4, layouts=None):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_cli_matches_reference_golden(case, tmp_path):
     log = str(tmp_path / "log.txt")
-    p = run_cli("bin/compairr", case, log=log)
+    pairs = str(tmp_path / "pairs.tsv")
+    p = run_cli("bin/compairr", case, log=log, pairs=pairs)
     d = [int(x) for x in [case["args"].split()[i + 1] for i, a in
                           enumerate(case["args"].split()) if a == "-d"][:1]]
     if case["exit"] == 0 and d and d[0] > 2:
@@ -93,6 +95,8 @@ def test_cli_matches_reference_golden(case, tmp_path):
         return
     assert p.returncode == 0, p.stderr.decode()
     assert warnings_of(log) == case["warnings"]      # duplicate counts, exact (log parity)
+    if case.get("pairs"):
+        assert sorted_pairs(pairs) == expected_pairs_of(case)
     if "ratio" in case["args"]:
         # order-dependent floating-point sum also inside the reference
         got = [l.split(b"\t") for l in p.stdout.splitlines()]
@@ -223,6 +227,32 @@ def test_existence_rows_are_sequences(d, indels):
     u = synth.tiny_set(300, 8, letters=2, max_len=5)
     check(t, u, Options(differences=d, indels=indels, existence=True, n_v_genes=2, n_j_genes=2,
                         score="min"))
+
+
+@pytest.mark.parametrize("d,indels", [(0, False), (1, False), (1, True), (2, False)])
+def test_pairs_list_equals_oracle(d, indels):
+    """cmpr_overlap_pairs: the (query, hit) pairs themselves (overlap.cc:232-245)."""
+    n = 2000 if d == 2 else 20000
+    a = synth.make_set(n, 41, prefix="A", pool_size=3000)
+    b = synth.make_set(n + 100, 42, prefix="B", pool_size=3000)
+    o = Options(differences=d, indels=indels, **FULL)
+    want = _oracle.pairs(a, b, o)
+    assert len(want) > 0
+    for tun in LAYOUTS.values():
+        with HipOverlap(o) as h:
+            for k, v in tun.items():
+                h.set_tunable(k, v)
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            got = h.overlap_pairs()
+            assert np.array_equal(got, want)
+            assert h.overlap_matrix().sum() > 0      # matrix mode still works afterwards
+    t = synth.tiny_set(300, 9, letters=2, max_len=5)
+    o = Options(differences=d, indels=indels, n_v_genes=2, n_j_genes=2)
+    with HipOverlap(o) as h:
+        h.set_reference(t, 0)
+        h.set_queries(t)
+        assert np.array_equal(h.overlap_pairs(), _oracle.pairs(t, t, o))
 
 
 def test_duplicate_counts_match_the_reference_algorithm():

@@ -41,7 +41,7 @@ def test_help_and_version():
     (["-x", "setc.tsv", "setb.tsv", "-s", "MH"], b"only allowed when computing repertoire overlap"),
     (["-c", "seta.tsv"], b"not part of the MI355X build"),
     (["-z", "seta.tsv"], b"not part of the MI355X build"),
-    (["-m", "seta.tsv", "-p", "pairs.tsv"], b"not part of the MI355X build"),
+    (["-m", "seta.tsv", "-p", "/dev/null", "-k", "a,,b"], b"Illegal list of columns"),
 ])
 def test_rejected_command_lines(args, msg):
     p = run(*args)

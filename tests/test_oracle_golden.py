@@ -9,7 +9,8 @@ import pytest
 
 import _oracle
 from compairr_amd import Options, synth
-from conftest import expected_of, load_manifest, run_cli, warnings_of
+from conftest import (expected_of, expected_pairs_of, load_manifest, run_cli, sorted_pairs,
+                      warnings_of)
 
 CASES = load_manifest()
 
@@ -17,13 +18,16 @@ CASES = load_manifest()
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_cli_matches_reference(case, tmp_path):
     log = str(tmp_path / "log.txt")
-    p = run_cli("tests/bin/compairr_oracle_cli", case, log=log)
+    pairs = str(tmp_path / "pairs.tsv")
+    p = run_cli("tests/bin/compairr_oracle_cli", case, log=log, pairs=pairs)
     if case["exit"] != 0:
         assert p.returncode == case["exit"], p.stderr.decode()
         return
     assert p.returncode == 0, p.stderr.decode()
     assert p.stdout == expected_of(case)
     assert warnings_of(log) == case["warnings"]
+    if case.get("pairs"):
+        assert sorted_pairs(pairs) == expected_pairs_of(case)
 
 
 def test_reference_own_golden_file():
