@@ -257,7 +257,8 @@ def main():
                                          "query_layout+upload": round(t_layout, 3)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "probe_kernel", "kernel_ms": k_avg_ms,
+                         "kernel": "probe_sliced_kernel" if layout.get("variant") == 1
+                         else "probe_kernel", "kernel_ms": k_avg_ms,
                          "algorithmic_bytes_per_launch": st.algorithmic_bytes,
                          "variants_per_launch": st.variants,
                          "bloom_positive_per_launch": st.bloom_positive,
