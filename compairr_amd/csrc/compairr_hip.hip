@@ -58,7 +58,7 @@ struct cmpr_context {
   int          device = 0;
   int          cus = 256;
   hipStream_t  stream = nullptr;
-  hipEvent_t   ev_start = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_stop = nullptr;
+  hipEvent_t   ev_start = nullptr, ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr, ev_stop = nullptr;
   bool         events_valid = false;
   std::string  err;
 
@@ -73,6 +73,8 @@ struct cmpr_context {
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
+  int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
   bool    waves_per_block_forced = false;
   int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
   int64_t slice_words_log2 = SLICE_WORDS_LOG2;
@@ -119,6 +121,9 @@ struct cmpr_context {
   DevBuf<unsigned long long> matrix, stats;
   DevBuf<double>             matrix_f64;
   DevBuf<uint32_t>           tile_counter;
+  DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
+  DevBuf<unsigned long long> pos_ctr;      /* [0] claimed, [1] first claim that did not fit */
+  uint64_t                   pos_cap = 0;
   uint32_t                   launches = 0;
   /* pairs mode, set only while cmpr_overlap_pairs runs */
   uint32_t           *pair_q = nullptr, *pair_h = nullptr;
@@ -370,6 +375,7 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipEventCreate(&c->ev_start));
   CREATE_TRY(hipEventCreate(&c->ev_k0));
   CREATE_TRY(hipEventCreate(&c->ev_k1));
+  CREATE_TRY(hipEventCreate(&c->ev_km));
   CREATE_TRY(hipEventCreate(&c->ev_stop));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
@@ -403,10 +409,11 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
-  c->tile_counter.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
+  c->tile_counter.release(); c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+  if (c->ev_km) (void)hipEventDestroy(c->ev_km);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -467,6 +474,16 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     c->chunk_tiles = value;
   } else if (n == "debug") {
     c->debug = value;
+  } else if (n == "deferred_resolve") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
+    c->deferred_resolve = value;
+  } else if (n == "pos_capacity") {
+    if (value < 0)
+      return fail(c, CMPR_EINVAL, "pos_capacity must be >= 0");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set pos_capacity before cmpr_set_queries");
+    c->pos_capacity = value;
   } else if (n == "small_slice_tiles") {
     if (value < 0 || value > 64)
       return fail(c, CMPR_EINVAL, "small_slice_tiles must be 0..64");
@@ -520,6 +537,8 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunks") *value = c->nchunks;
   else if (n == "small_tiles") *value = c->nsmall;
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
+  else if (n == "deferred_resolve") *value = c->deferred_resolve;
+  else if (n == "pos_capacity") *value = (int64_t)c->pos_cap;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
   else
     return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
@@ -1183,6 +1202,12 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
   if ((rc = dev_alloc(c, c->stats, STAT_COUNT))) return rc;
   if ((rc = dev_alloc(c, c->tile_counter, 2))) return rc;
+  /* positives buffer of the deferred resolve: a capacity, not a limit -- what
+     does not fit is resolved inline by the probe kernel */
+  c->pos_cap = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
+                                   : std::max<uint64_t>(1u << 20, 2 * c->n1);
+  if ((rc = dev_alloc(c, c->pos_buf, c->pos_cap + WAVE))) return rc;
+  if ((rc = dev_alloc(c, c->pos_ctr, 2))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
   return CMPR_OK;
@@ -1205,7 +1230,13 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, std::max<size_t>(cells, 1) * sizeof(double), st));
   HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * sizeof(unsigned long long), st));
   HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, 2 * sizeof(uint32_t), st));
+  const bool deferred = c->sliced && c->deferred_resolve;
+  if (deferred) {
+    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, sizeof(unsigned long long), st));
+    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p + 1, 0xff, sizeof(unsigned long long), st));
+  }
   c->launches = 0;
+  bool launched = false;
 
   HIP_TRY(c, hipEventRecord(c->ev_k0, st));
   if (c->ntiles > 0 && cells > 0) {
@@ -1255,6 +1286,12 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.nsmall = c->nsmall;
     P.nchunks = c->nchunks;
     P.debug = (uint32_t)c->debug;
+    if (deferred) {
+      P.pos_buf = c->pos_buf.p;
+      P.pos_count = c->pos_ctr.p;
+      P.pos_limit = c->pos_ctr.p + 1;
+      P.pos_cap = c->pos_cap;
+    }
 
     /* workgroups of 8 waves share one staged slice; when the chunks are short
        (many slices, few queries each) 4 waves keep more of them busy */
@@ -1287,7 +1324,21 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3((uint32_t)nw * WAVE), lds, st, P);
     HIP_TRY(c, hipGetLastError());
     c->launches = 1;
+    launched = true;
+    HIP_TRY(c, hipEventRecord(c->ev_km, st));
+    if (deferred && !(c->debug & DBG_SKIP_RESOLVE)) {
+      const size_t rlds = P.lds_matrix ? cells * sizeof(unsigned long long) : 0;
+      const uint32_t rgrid = (uint32_t)c->cus * 6;   /* 6 waves/SIMD fit its registers */
+      if (c->opt.ignore_genes)
+        hipLaunchKernelGGL(resolve_kernel<false>, dim3(rgrid), dim3(BLOCK_THREADS), rlds, st, P);
+      else
+        hipLaunchKernelGGL(resolve_kernel<true>, dim3(rgrid), dim3(BLOCK_THREADS), rlds, st, P);
+      HIP_TRY(c, hipGetLastError());
+      c->launches = 2;
+    }
   }
+  if (!launched)
+    HIP_TRY(c, hipEventRecord(c->ev_km, st));
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
   return CMPR_OK;
 }
@@ -1429,6 +1480,8 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipMemcpy(st, c->stats.p, sizeof st, hipMemcpyDeviceToHost));
   float k_ms = 0, t_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
+  float p_ms = 0;
+  HIP_TRY(c, hipEventElapsedTime(&p_ms, c->ev_k0, c->ev_km));
   HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_start, c->ev_stop));
   memset(out, 0, sizeof *out);
   out->queries = c->n1;
@@ -1438,6 +1491,7 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   out->matches = st[STAT_MATCHES];
   out->algorithmic_bytes = c->algorithmic_bytes;
   out->kernel_ms = k_ms;
+  out->probe_ms = p_ms;
   out->total_ms = t_ms;
   out->kernel_launches = c->launches;
   return CMPR_OK;

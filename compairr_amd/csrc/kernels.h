@@ -308,12 +308,10 @@ struct LaneStats {
    (find_variant_matches, overlap.cc:168-251), verify, score, accumulate.
    The chain is read four slots at a time (independent loads). */
 template <bool GENES>
-__device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
-                              unsigned long long *mat_lds, LaneStats &st)
+__device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, uint32_t ca,
+                            uint32_t cb, unsigned long long *mat_lds, LaneStats &st)
 {
-  const uint64_t key = table_key(q.hash[e]);
-  const uint32_t qs = q.slot[e];
-  const uint32_t ca = q.ca[e], cb = q.cb[e];
+  const uint64_t key = table_key(hash);
   /* everything of the query that a match needs is fetched now, next to the
      first table read, not after it: one memory round trip less per match */
   const TileDesc td = P.tiles[qs >> 6];
@@ -378,6 +376,60 @@ __device__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
     if (end)
       break;
     s = (s + 4) & P.slot_mask;
+  }
+}
+
+template <bool GENES>
+__device__ __forceinline__ void resolve_entry(const ProbeParams &P, const WaveQueue &q, int e,
+                                              unsigned long long *mat_lds, LaneStats &st)
+{
+  resolve_one<GENES>(P, q.hash[e], q.slot[e], q.ca[e], q.cb[e], mat_lds, st);
+}
+
+/* Second kernel of the deferred mode: one lane per queued Bloom positive, at
+   full occupancy (the walks are latency-bound; inside the probe kernel they
+   stall waves that should be probing). */
+template <bool GENES>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+resolve_kernel(const ProbeParams P)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long *mat_lds = (unsigned long long *)smem;
+  const uint32_t cells = P.R1 * P.R2;
+  if (P.lds_matrix) {
+    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
+      mat_lds[i] = 0;
+    __syncthreads();
+  }
+  unsigned long long n = *P.pos_count;
+  const unsigned long long lim = *P.pos_limit;
+  if (lim < n)
+    n = lim;                                  /* claims past the capacity were not written */
+  LaneStats st{0ull, 0u, 0u, 0u};
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK_THREADS + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * BLOCK_THREADS) {
+    const PosEntry e = P.pos_buf[i];
+    resolve_one<GENES>(P, e.hash, e.slot, e.ca, e.cb, P.lds_matrix ? mat_lds : nullptr, st);
+  }
+  {
+    const uint32_t lane = lane_id();
+    unsigned long long s[2] = {st.hash_eq, st.matches};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      unsigned long long x = s[k];
+      for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_down(x, off, WAVE);
+      if (lane == 0 && x)
+        atomicAdd(P.stats + (k == 0 ? STAT_HASH_EQ : STAT_MATCHES), x);
+    }
+  }
+  if (P.lds_matrix) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS) {
+      const unsigned long long x = mat_lds[i];
+      if (x)
+        atomicAdd(P.matrix + i, x);
+    }
   }
 }
 

@@ -52,6 +52,41 @@ struct SProber {
   LaneStats           st;
 };
 
+/* `n` queue entries starting at `first` leave the wave: in deferred mode they
+   are appended to the global positives buffer with ONE atomic claim (the walks
+   happen later, in resolve_kernel); if the buffer is full, or in inline mode,
+   lane k resolves entry first + k right here. */
+template <bool GENES>
+__device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
+{
+  const ProbeParams &P = W.P;
+  bool inline_resolve = P.pos_buf == nullptr;
+  if (!inline_resolve) {
+    unsigned long long base = 0;
+    if (W.lane == 0)
+      base = atomicAdd(P.pos_count, (unsigned long long)n);
+    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+           __builtin_amdgcn_readfirstlane((uint32_t)base);
+    if (base < P.pos_cap) {                   /* the buffer has 64 entries of slack */
+      if ((int)W.lane < n) {
+        PosEntry e;
+        e.hash = W.q.hash[first + W.lane];
+        e.slot = W.q.slot[first + W.lane];
+        e.ca = W.q.ca[first + W.lane];
+        e.cb = W.q.cb[first + W.lane];
+        e.pad = 0;
+        P.pos_buf[base + W.lane] = e;
+      }
+    } else {
+      if (W.lane == 0)
+        atomicMin(P.pos_limit, base);
+      inline_resolve = true;
+    }
+  }
+  if (inline_resolve && (int)W.lane < n)
+    resolve_entry<GENES>(P, W.q, first + (int)W.lane, W.mat_lds, W.st);
+}
+
 template <bool GENES>
 __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
                                        uint32_t ca, uint32_t cb)
@@ -71,7 +106,7 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       W.qn -= WAVE;
       if (!(W.P.debug & DBG_SKIP_RESOLVE))
-        resolve_entry<GENES>(W.P, W.q, W.qn + (int)W.lane, W.mat_lds, W.st);
+        flush_or_resolve<GENES>(W, W.qn, WAVE);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
@@ -739,8 +774,8 @@ probe_sliced_kernel(const ProbeParams P)
 
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if ((int)lane < W.qn)
-    resolve_entry<GENES>(P, W.q, (int)lane, W.mat_lds, W.st);
+  if (W.qn > 0)
+    flush_or_resolve<GENES>(W, 0, W.qn);
 
   {
     unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,

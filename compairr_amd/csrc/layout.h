@@ -141,6 +141,14 @@ struct Chunk {
                             sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
 };
 
+/* A Bloom-positive variant waiting for its hash-table walk */
+struct PosEntry {
+  uint64_t hash;
+  uint32_t slot;     /* query: tile * 64 + lane                         */
+  uint32_t ca, cb;   /* variant: kind | p1 << 3 | r1 << 24 ; p2 | r2 << 24 */
+  uint32_t pad;
+};
+
 /* One set-2 sequence as the verification step reads it: one 32-byte record
    (two 16-byte loads) instead of six scattered loads from the SoA arrays. */
 struct RefRec {
@@ -191,6 +199,12 @@ struct ProbeParams {
   int32_t         ignore_counts;
   int32_t         lds_matrix;      /* 1: privatise the matrix in LDS          */
   int32_t         pad1;
+  /* deferred resolve: Bloom positives are appended here by the probe kernel and
+     walked / verified / scored by resolve_kernel at full occupancy */
+  PosEntry           *pos_buf;      /* NULL: resolve inline in the probe kernel  */
+  unsigned long long *pos_count;    /* entries claimed (may exceed pos_cap)      */
+  unsigned long long *pos_limit;    /* first claim that did not fit (atomicMin)  */
+  uint64_t            pos_cap;
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
   unsigned long long *pair_count;   /* NULL: matrix mode                        */

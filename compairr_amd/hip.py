@@ -53,7 +53,8 @@ class _Stats(C.Structure):
                 ("bloom_positive", C.c_uint64), ("hash_equal", C.c_uint64),
                 ("matches", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("probe_ms", C.c_double)]
 
 
 @dataclass
@@ -81,6 +82,7 @@ class Stats:
     kernel_ms: float
     total_ms: float
     kernel_launches: int
+    probe_ms: float = 0.0
 
 
 def library_path() -> str:
@@ -262,7 +264,7 @@ class HipOverlap:
         self._check(self._lib.cmpr_get_stats(self._ctx, C.byref(st)))
         return Stats(st.queries, st.variants, st.bloom_positive, st.hash_equal,
                      st.matches, st.algorithmic_bytes, st.kernel_ms, st.total_ms,
-                     st.kernel_launches)
+                     st.kernel_launches, st.probe_ms)
 
 
 def overlap(set1: RepertoireSet, set2: RepertoireSet, opt: Options):

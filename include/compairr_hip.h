@@ -98,10 +98,11 @@ typedef struct cmpr_stats {
   uint64_t hash_equal;         /* hash slots equal to a variant hash          */
   uint64_t matches;            /* verified (query, hit) pairs                 */
   uint64_t algorithmic_bytes;  /* sum over queries of (L + 20) + 8 * V(L)     */
-  double   kernel_ms;          /* HIP-event time of the probe kernel(s)       */
+  double   kernel_ms;          /* HIP-event time of probe + resolve kernels   */
   double   total_ms;           /* first launch -> matrix ready on the stream  */
   uint32_t kernel_launches;
   uint32_t reserved;
+  double   probe_ms;           /* HIP-event time of the probe kernel alone    */
 } cmpr_stats;
 
 typedef struct cmpr_context cmpr_context;

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     # cmpr_options: 9 x 4 + 7 x 4; cmpr_set_view: 8 + 6 x 8 + 2 x 4; cmpr_stats
     assert ctypes.sizeof(hip._Options) == 64
     assert ctypes.sizeof(hip._SetView) == 64
-    assert ctypes.sizeof(hip._Stats) == 72
+    assert ctypes.sizeof(hip._Stats) == 80
 
 
 def test_invalid_options_rejected_before_any_device_work():

@@ -52,6 +52,10 @@ LAYOUTS = {
     "wave_phase_all": {"variant": 1, "slice_words_log2": 4, "class_residues": 2,
                        "heavy_threshold": 2, "small_slice_tiles": 64},
     "wave_phase_none": {"variant": 1, "slice_words_log2": 5, "small_slice_tiles": 0},
+    # Bloom positives resolved inside the probe kernel instead of by resolve_kernel
+    "resolve_inline": {"variant": 1, "deferred_resolve": 0},
+    # positives buffer of 64 entries: nearly everything takes the overflow path
+    "resolve_overflow": {"variant": 1, "slice_words_log2": 5, "pos_capacity": 64},
 }
 
 
