@@ -73,8 +73,11 @@ struct cmpr_context {
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t table_log2_delta = 0;   /* table slots = 2^delta x the 70 % rule       */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
+  int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
+  int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
   bool    waves_per_block_forced = false;
   int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
   int64_t slice_words_log2 = SLICE_WORDS_LOG2;
@@ -474,10 +477,26 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     c->chunk_tiles = value;
   } else if (n == "debug") {
     c->debug = value;
+  } else if (n == "table_log2_delta") {
+    if (value < 0 || value > 3)
+      return fail(c, CMPR_EINVAL, "table_log2_delta must be 0..3");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set table_log2_delta before cmpr_set_reference");
+    c->table_log2_delta = value;
   } else if (n == "deferred_resolve") {
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
     c->deferred_resolve = value;
+  } else if (n == "resolve_blocks_per_cu") {
+    if (value < 1 || value > 8)
+      return fail(c, CMPR_EINVAL, "resolve_blocks_per_cu must be 1..8");
+    c->resolve_blocks_per_cu = value;
+  } else if (n == "pos_segments") {
+    if (value < 1 || value > 256 || (value & (value - 1)))
+      return fail(c, CMPR_EINVAL, "pos_segments must be a power of two, 1..256");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set pos_segments before cmpr_set_queries");
+    c->pos_segments = value;
   } else if (n == "pos_capacity") {
     if (value < 0)
       return fail(c, CMPR_EINVAL, "pos_capacity must be >= 0");
@@ -538,7 +557,10 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "small_tiles") *value = c->nsmall;
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
-  else if (n == "pos_capacity") *value = (int64_t)c->pos_cap;
+  else if (n == "table_log2_delta") *value = c->table_log2_delta;
+  else if (n == "pos_capacity") *value = (int64_t)(c->pos_cap * c->pos_segments);
+  else if (n == "pos_segments") *value = c->pos_segments;
+  else if (n == "resolve_blocks_per_cu") *value = c->resolve_blocks_per_cu;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
   else
     return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
@@ -611,6 +633,9 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   while (FILL_PERCENT * c->slots < 100 * s->n)
     c->slots <<= 1;
   uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
+  /* results do not depend on the table size (every hit is verified), only the
+     length of the probe chains does: HBM is plentiful, round trips are not */
+  c->slots <<= c->table_log2_delta;
   /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
      whatever the total), so it takes 4 bytes per table slot: with the 2^20
      pattern space that leaves almost only true positives for the table walk. */
@@ -1204,10 +1229,14 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, c->tile_counter, 2))) return rc;
   /* positives buffer of the deferred resolve: a capacity, not a limit -- what
      does not fit is resolved inline by the probe kernel */
-  c->pos_cap = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
-                                   : std::max<uint64_t>(1u << 20, 2 * c->n1);
-  if ((rc = dev_alloc(c, c->pos_buf, c->pos_cap + WAVE))) return rc;
-  if ((rc = dev_alloc(c, c->pos_ctr, 2))) return rc;
+  {
+    const uint64_t total = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
+                                               : std::max<uint64_t>(1u << 20, 2 * c->n1);
+    const uint64_t S = (uint64_t)c->pos_segments;
+    c->pos_cap = (total + S - 1) / S;                     /* per segment */
+    if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
+    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE))) return rc;
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
   return CMPR_OK;
@@ -1232,8 +1261,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, 2 * sizeof(uint32_t), st));
   const bool deferred = c->sliced && c->deferred_resolve;
   if (deferred) {
-    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, sizeof(unsigned long long), st));
-    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p + 1, 0xff, sizeof(unsigned long long), st));
+    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, (size_t)c->pos_segments * POS_CTR_STRIDE *
+                                                   sizeof(unsigned long long), st));
   }
   c->launches = 0;
   bool launched = false;
@@ -1288,9 +1317,9 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.debug = (uint32_t)c->debug;
     if (deferred) {
       P.pos_buf = c->pos_buf.p;
-      P.pos_count = c->pos_ctr.p;
-      P.pos_limit = c->pos_ctr.p + 1;
+      P.pos_ctr = c->pos_ctr.p;
       P.pos_cap = c->pos_cap;
+      P.pos_segments = (uint32_t)c->pos_segments;
     }
 
     /* workgroups of 8 waves share one staged slice; when the chunks are short
@@ -1327,8 +1356,11 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     launched = true;
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
     if (deferred && !(c->debug & DBG_SKIP_RESOLVE)) {
-      const size_t rlds = P.lds_matrix ? cells * sizeof(unsigned long long) : 0;
-      const uint32_t rgrid = (uint32_t)c->cus * 6;   /* 6 waves/SIMD fit its registers */
+      const size_t rlds = (BLOCK_THREADS / WAVE) * sizeof(CandQueue) +
+                          (P.lds_matrix ? cells * sizeof(unsigned long long) : 0);
+      /* 5 waves/SIMD fit its registers; a multiple of the segment count */
+      uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
+      rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
       if (c->opt.ignore_genes)
         hipLaunchKernelGGL(resolve_kernel<false>, dim3(rgrid), dim3(BLOCK_THREADS), rlds, st, P);
       else

@@ -304,6 +304,38 @@ struct LaneStats {
   uint32_t bloom_pos, hash_eq, matches;
 };
 
+/* One verified (query, hit) pair: list it (pairs mode) or add its score to the
+   matrix cell (overlap.cc:218-245). */
+__device__ __forceinline__ void score_match(const ProbeParams &P, uint32_t qs, uint32_t hit,
+                                            uint32_t cell, unsigned long long f,
+                                            unsigned long long g, unsigned long long *mat_lds)
+{
+  if (P.pair_count) {
+    /* pairs mode (overlap.cc:232-245) */
+    const unsigned long long k = atomicAdd(P.pair_count, 1ull);
+    if (k < P.pair_cap) {
+      P.pair_q[k] = P.qorig[qs];
+      P.pair_h[k] = hit;
+    }
+  } else if (P.score == 1 /* ratio */ && !P.ignore_counts) {
+    unsafeAtomicAdd(P.matrix_f64 + cell, (double)f / (double)g);
+  } else {
+    unsigned long long sc = 1;
+    if (!P.ignore_counts) {
+      switch (P.score) {
+      case 2: case 6: sc = f < g ? f : g; break;       /* min, Jaccard */
+      case 3:         sc = f > g ? f : g; break;       /* max          */
+      case 4:         sc = f + g;         break;       /* 2 x mean     */
+      default:        sc = f * g;         break;       /* product, MH  */
+      }
+    }
+    if (mat_lds)
+      atomicAdd(mat_lds + cell, sc);
+    else
+      atomicAdd(P.matrix + cell, sc);
+  }
+}
+
 /* Lane e of the wave resolves queue entry `e`: walk the probe chain
    (find_variant_matches, overlap.cc:168-251), verify, score, accumulate.
    The chain is read four slots at a time (independent loads). */
@@ -345,32 +377,7 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
         ok = (q_v == rec.v) && (q_j == rec.j);
       if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
         st.matches++;
-        const uint32_t cell = P.R2 * q_rep + rec.rep;
-        if (P.pair_count) {
-          /* pairs mode (overlap.cc:232-245) */
-          const unsigned long long k = atomicAdd(P.pair_count, 1ull);
-          if (k < P.pair_cap) {
-            P.pair_q[k] = P.qorig[qs];
-            P.pair_h[k] = hit;
-          }
-        } else if (P.score == 1 /* ratio */ && !P.ignore_counts) {
-          unsafeAtomicAdd(P.matrix_f64 + cell, (double)q_cnt / (double)rec.cnt);
-        } else {
-          unsigned long long sc = 1;
-          if (!P.ignore_counts) {
-            const unsigned long long f = q_cnt, g = rec.cnt;
-            switch (P.score) {
-            case 2: case 6: sc = f < g ? f : g; break;       /* min, Jaccard */
-            case 3:         sc = f > g ? f : g; break;       /* max          */
-            case 4:         sc = f + g;         break;       /* 2 x mean     */
-            default:        sc = f * g;         break;       /* product, MH  */
-            }
-          }
-          if (mat_lds)
-            atomicAdd(mat_lds + cell, sc);
-          else
-            atomicAdd(P.matrix + cell, sc);
-        }
+        score_match(P, qs, hit, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
       }
     }
     if (end)
@@ -386,37 +393,125 @@ __device__ __forceinline__ void resolve_entry(const ProbeParams &P, const WaveQu
   resolve_one<GENES>(P, q.hash[e], q.slot[e], q.ca[e], q.cb[e], mat_lds, st);
 }
 
-/* Second kernel of the deferred mode: one lane per queued Bloom positive, at
-   full occupancy (the walks are latency-bound; inside the probe kernel they
-   stall waves that should be probing). */
+/* ---- deferred mode: resolve_kernel -------------------------------------- */
+
+/* (query, variant, set-2 sequence) triples whose table key equals the variant
+   hash, waiting for verification -- one queue per wave, in LDS */
+struct CandQueue {
+  uint32_t slot[QCAP], ca[QCAP], cb[QCAP], hit[QCAP];
+};
+
+/* Verification + scoring of one candidate per lane (all lanes busy, three
+   dependent memory round trips: record + query fields, residues, atomics). */
+template <bool GENES>
+__device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t ca,
+                                                 uint32_t cb, uint32_t hit,
+                                                 unsigned long long *mat_lds, LaneStats &st)
+{
+  const RefRec rec = P.rec2[hit];
+  const TileDesc td = P.tiles[qs >> 6];
+  const uint32_t ql = qs & 63u;
+  const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
+  const uint32_t q_rep = P.qrep[qs];
+  const uint32_t q_len = P.qlen[qs];
+  const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
+  bool ok = true;
+  if (GENES)
+    ok = (q_v == rec.v) && (q_j == rec.j);
+  if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
+    st.matches++;
+    score_match(P, qs, hit, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
+  }
+}
+
+/* Second kernel of the deferred mode.  Phase A, one lane per queued Bloom
+   positive: walk the probe chain comparing keys only (find_variant_matches,
+   overlap.cc:168-251) and queue every key match; phase B, whenever 64
+   candidates are queued: verify and score them, one per lane.  Keeping the
+   walk free of the verification's dependent loads is what matters: the kernel
+   is bound by memory round trips per wave, not by bytes. */
 template <bool GENES>
 __global__ void __launch_bounds__(BLOCK_THREADS)
 resolve_kernel(const ProbeParams P)
 {
   extern __shared__ __align__(16) unsigned char smem[];
-  unsigned long long *mat_lds = (unsigned long long *)smem;
+  CandQueue &cq = ((CandQueue *)smem)[threadIdx.x / WAVE];
+  unsigned long long *mat_lds =
+      (unsigned long long *)(smem + (BLOCK_THREADS / WAVE) * sizeof(CandQueue));
   const uint32_t cells = P.R1 * P.R2;
   if (P.lds_matrix) {
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
       mat_lds[i] = 0;
     __syncthreads();
+  } else {
+    mat_lds = nullptr;
   }
-  unsigned long long n = *P.pos_count;
-  const unsigned long long lim = *P.pos_limit;
+  /* workgroup b of the grid (a multiple of pos_segments) works on segment
+     b % pos_segments, together with the gridDim.x / pos_segments - 1 others */
+  const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
+  const uint32_t seg_block = blockIdx.x / P.pos_segments;
+  const uint32_t seg_blocks = gridDim.x / P.pos_segments;
+  const unsigned long long *ctr = P.pos_ctr + (size_t)seg * POS_CTR_STRIDE;
+  const PosEntry *pos = P.pos_buf + (size_t)seg * (P.pos_cap + WAVE);
+  unsigned long long n = ctr[0];
+  const unsigned long long lim = ~ctr[1];
   if (lim < n)
     n = lim;                                  /* claims past the capacity were not written */
+  const uint32_t lane = lane_id();
   LaneStats st{0ull, 0u, 0u, 0u};
-  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK_THREADS + threadIdx.x; i < n;
-       i += (unsigned long long)gridDim.x * BLOCK_THREADS) {
-    const PosEntry e = P.pos_buf[i];
-    resolve_one<GENES>(P, e.hash, e.slot, e.ca, e.cb, P.lds_matrix ? mat_lds : nullptr, st);
+  int qn = 0;
+  for (unsigned long long base = (unsigned long long)seg_block * BLOCK_THREADS +
+                                 (threadIdx.x & ~(WAVE - 1));
+       base < n; base += (unsigned long long)seg_blocks * BLOCK_THREADS) {
+    bool active = base + lane < n;
+    PosEntry e{};
+    if (active)
+      e = pos[base + lane];
+    const uint64_t key = table_key(e.hash);
+    uint64_t s = table_home(key, P.slot_mask);
+    while (__ballot(active)) {
+      Slot k[4];
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          k[i] = P.table[(s + i) & P.slot_mask];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (active && k[i].key == EMPTY_KEY)
+          active = false;
+        const bool m = active && k[i].key == key;
+        const uint64_t mm = __ballot(m);
+        if (mm) {
+          if (m) {
+            const int x = qn + (int)rank_below(mm);
+            cq.slot[x] = e.slot;
+            cq.ca[x] = e.ca;
+            cq.cb[x] = e.cb;
+            cq.hit[x] = k[i].val;
+            st.hash_eq++;
+          }
+          qn += __popcll(mm);
+          if (qn >= WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qn -= WAVE;
+            verify_candidate<GENES>(P, cq.slot[qn + lane], cq.ca[qn + lane], cq.cb[qn + lane],
+                                    cq.hit[qn + lane], mat_lds, st);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+        }
+      }
+      s = (s + 4) & P.slot_mask;
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if ((int)lane < qn)
+    verify_candidate<GENES>(P, cq.slot[lane], cq.ca[lane], cq.cb[lane], cq.hit[lane], mat_lds, st);
   {
-    const uint32_t lane = lane_id();
-    unsigned long long s[2] = {st.hash_eq, st.matches};
+    unsigned long long sum[2] = {st.hash_eq, st.matches};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      unsigned long long x = s[k];
+      unsigned long long x = sum[k];
       for (int off = 32; off > 0; off >>= 1)
         x += __shfl_down(x, off, WAVE);
       if (lane == 0 && x)

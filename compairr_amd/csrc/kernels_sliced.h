@@ -62,12 +62,14 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
   const ProbeParams &P = W.P;
   bool inline_resolve = P.pos_buf == nullptr;
   if (!inline_resolve) {
+    const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
+    unsigned long long *ctr = P.pos_ctr + (size_t)seg * POS_CTR_STRIDE;
     unsigned long long base = 0;
     if (W.lane == 0)
-      base = atomicAdd(P.pos_count, (unsigned long long)n);
+      base = atomicAdd(ctr, (unsigned long long)n);
     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
            __builtin_amdgcn_readfirstlane((uint32_t)base);
-    if (base < P.pos_cap) {                   /* the buffer has 64 entries of slack */
+    if (base < P.pos_cap) {                   /* the segment has 64 entries of slack */
       if ((int)W.lane < n) {
         PosEntry e;
         e.hash = W.q.hash[first + W.lane];
@@ -75,11 +77,11 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
         e.ca = W.q.ca[first + W.lane];
         e.cb = W.q.cb[first + W.lane];
         e.pad = 0;
-        P.pos_buf[base + W.lane] = e;
+        P.pos_buf[(size_t)seg * (P.pos_cap + WAVE) + base + W.lane] = e;
       }
     } else {
       if (W.lane == 0)
-        atomicMin(P.pos_limit, base);
+        atomicMax(ctr + 1, ~base);
       inline_resolve = true;
     }
   }

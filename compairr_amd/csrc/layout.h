@@ -141,6 +141,8 @@ struct Chunk {
                             sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
 };
 
+constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
+
 /* A Bloom-positive variant waiting for its hash-table walk */
 struct PosEntry {
   uint64_t hash;
@@ -202,9 +204,14 @@ struct ProbeParams {
   /* deferred resolve: Bloom positives are appended here by the probe kernel and
      walked / verified / scored by resolve_kernel at full occupancy */
   PosEntry           *pos_buf;      /* NULL: resolve inline in the probe kernel  */
-  unsigned long long *pos_count;    /* entries claimed (may exceed pos_cap)      */
-  unsigned long long *pos_limit;    /* first claim that did not fit (atomicMin)  */
-  uint64_t            pos_cap;
+  unsigned long long *pos_ctr;      /* per segment, POS_CTR_STRIDE apart: [0]
+                                       entries claimed (may exceed pos_cap), [1]
+                                       ~(first claim that did not fit), 0 = none */
+  uint64_t            pos_cap;      /* entries per segment (+ 64 of slack)       */
+  uint32_t            pos_segments; /* power of two; workgroup b appends to
+                                       segment b % pos_segments: claims are
+                                       same-address atomics, which serialise    */
+  uint32_t            pos_pad;
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
   unsigned long long *pair_count;   /* NULL: matrix mode                        */

@@ -56,6 +56,8 @@ LAYOUTS = {
     "resolve_inline": {"variant": 1, "deferred_resolve": 0},
     # positives buffer of 64 entries: nearly everything takes the overflow path
     "resolve_overflow": {"variant": 1, "slice_words_log2": 5, "pos_capacity": 64},
+    "resolve_one_segment": {"variant": 1, "slice_words_log2": 5, "pos_capacity": 256,
+                            "pos_segments": 1},
 }
 
 
