@@ -73,7 +73,7 @@ struct cmpr_context {
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
-  int64_t table_log2_delta = 0;   /* table slots = 2^delta x the 70 % rule       */
+  int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
   int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
@@ -104,7 +104,8 @@ struct cmpr_context {
   DevBuf<uint64_t>  off2, cnt2, bloom;
   DevBuf<uint32_t>  v2, j2, rep2;
   DevBuf<Slot>      table;
-  DevBuf<RefRec>    rec2;
+  DevBuf<unsigned char> rec2;      /* RefRec stream (header + residues) */
+  DevBuf<uint32_t>  voff2;          /* position of sequence i in it, REC_UNIT units */
   uint64_t          slots = 0, bloom_words = 0;
 
   /* set 1 tiles */
@@ -408,7 +409,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->zob.release();
   c->res2.release(); c->off2.release(); c->cnt2.release(); c->table.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
-  c->rec2.release();
+  c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
@@ -635,7 +636,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
   /* results do not depend on the table size (every hit is verified), only the
      length of the probe chains does: HBM is plentiful, round trips are not */
-  c->slots <<= c->table_log2_delta;
+  c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
   /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
      whatever the total), so it takes 4 bytes per table slot: with the 2^20
      pattern space that leaves almost only true positives for the table walk. */
@@ -789,6 +790,26 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
 
+  {
+    /* positions in the verification stream (layout.h RefRec) */
+    std::vector<uint32_t> voff((size_t)s->n + 1);
+    uint64_t units = 0;
+    for (uint64_t i = 0; i < s->n; i++) {
+      /* a record of at most 64 bytes never straddles a 64-byte boundary, and no
+         header does: one memory request fetches it */
+      const uint64_t u = rec_units((uint32_t)(s->offsets[i + 1] - s->offsets[i]));
+      const uint64_t room = 4 - (units & 3);
+      if (std::min<uint64_t>(u, 4) > room)
+        units += room;
+      voff[i] = (uint32_t)units;
+      units += u;
+    }
+    units += 8;                 /* verify_candidate reads 64 bytes whatever the length */
+    if (units >> 32)
+      return fail(c, CMPR_EUNSUPPORTED, "reference set too large for 32-bit record positions");
+    if ((rc = dev_upload(c, c->voff2, voff.data(), std::max<size_t>((size_t)s->n, 1)))) return rc;
+    if ((rc = dev_alloc(c, c->rec2, std::max<size_t>((size_t)units * REC_UNIT, REC_UNIT)))) return rc;
+  }
   if (s->n) {
     BuildParams B{};
     B.zob = c->zob.p;
@@ -796,6 +817,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.zpos = c->zpos;
     B.n_v = n_v;
     B.use_genes = c->opt.ignore_genes ? 0u : 1u;
+    B.voff = c->voff2.p;
     B.res = c->res2.p;
     B.off = c->off2.p;
     B.v = c->v2.p;
@@ -812,9 +834,10 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
                        c->stream, B);
     HIP_TRY(c, hipGetLastError());
   }
-  if ((rc = dev_alloc(c, c->rec2, (size_t)s->n))) return rc;
   if (s->n) {
     PackParams K{};
+    K.voff = c->voff2.p;
+    K.res = c->res2.p;
     K.off = c->off2.p;
     K.cnt = c->opt.ignore_counts ? nullptr : c->cnt2.p;
     K.v = c->opt.ignore_genes ? nullptr : c->v2.p;
@@ -867,6 +890,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     D.res = c->res2.p; D.off = c->off2.p; D.v = c->v2.p; D.j = c->j2.p; D.rep = c->rep2.p;
     D.n = c->n2;
     D.table = c->table.p; D.slot_mask = c->slots - 1;
+    D.rec = c->rec2.p;
   } else {
     std::string why;
     if ((rc = validate_view(c->opt, s, why)))
@@ -903,6 +927,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     uint64_t slots = 1;
     while (FILL_PERCENT * slots < 100 * s->n)
       slots <<= 1;
+    slots = std::max<uint64_t>(slots, 4);         /* chains start on 4-slot boundaries */
     if ((rc = dev_alloc(c, table, (size_t)slots))) return rc;
     HIP_TRY(c, hipMemsetAsync(table.p, 0xff, slots * sizeof(Slot), c->stream));
     DevBuf<uint64_t> scratch_bloom;               /* build_index_kernel wants a filter */
@@ -1179,7 +1204,10 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   }
 
   const size_t slots = (size_t)ntiles * WAVE;
-  std::vector<uint32_t> qres((size_t)res_words, 0), qrep(slots, 0), qv, qj;
+  if ((uint64_t)res_words >> 32)
+    return fail(c, CMPR_EUNSUPPORTED, "query set too large for 32-bit residue positions");
+  /* + 9 rows: verify_candidate reads nine dwords per query whatever its length */
+  std::vector<uint32_t> qres((size_t)res_words + 9 * WAVE, 0), qrep(slots, 0), qv, qj;
   std::vector<uint64_t> qcnt;
   std::vector<uint16_t> qlen(slots, 0);
   std::vector<uint32_t> qorig(slots, 0);

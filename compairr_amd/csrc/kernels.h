@@ -68,8 +68,10 @@ __host__ __device__ __forceinline__ uint64_t pattern_of(uint64_t h)
 
 __device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
 {
-  /* high half, independent of the Bloom address bits (hashtable.h:36-41) */
-  return (uint32_t)((key >> 32) & mask);
+  /* high half, independent of the Bloom address bits (hashtable.h:36-41); the
+     chain starts on a 4-slot boundary, so that the four slots a walk reads per
+     round are one aligned 64-byte piece of memory, not two */
+  return (uint32_t)((key >> 32) & mask & ~3ull);
 }
 
 /* ------------------------------------------------------------------ */
@@ -86,6 +88,7 @@ struct BuildParams {
   const uint64_t *off;
   const uint32_t *v;
   const uint32_t *j;
+  const uint32_t *voff;            /* table value of sequence i (NULL: i)   */
   uint64_t        n;
   Slot           *table;
   uint64_t        slot_mask;
@@ -126,7 +129,7 @@ build_index_kernel(const BuildParams B)
       break;
     slot = (slot + 1) & B.slot_mask;
   }
-  B.table[slot].val = (uint32_t)i;
+  B.table[slot].val = B.voff ? B.voff[i] : (uint32_t)i;
 
   uint64_t boff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & B.bloom_byte_mask;
   if (B.sliced) {
@@ -156,6 +159,7 @@ struct DupParams {
   uint64_t        n;
   const Slot     *table;
   uint64_t        slot_mask;
+  const unsigned char *rec;        /* non-NULL: table values are RefRec positions */
   unsigned long long *count;
 };
 
@@ -182,7 +186,8 @@ count_duplicates_kernel(const DupParams B)
       if (k == EMPTY_KEY)
         break;
       if (k == key) {
-        const uint64_t o = sl.val;
+        const uint64_t o = B.rec ? ((const RefRec *)(B.rec + (size_t)sl.val * REC_UNIT))->idx
+                                 : sl.val;
         if (o < i && B.rep[o] == B.rep[i] &&
             (!B.use_genes || (B.v[o] == B.v[i] && B.j[o] == B.j[i]))) {
           const uint64_t ob = B.off[o];
@@ -205,12 +210,13 @@ count_duplicates_kernel(const DupParams B)
     atomicAdd(B.count, (unsigned long long)__popcll(m));
 }
 
-/* SoA -> one 32-byte record per set-2 sequence (layout.h RefRec) */
+/* SoA -> header + residues per set-2 sequence (layout.h RefRec) */
 struct PackParams {
   const uint64_t *off, *cnt;
-  const uint32_t *v, *j, *rep;
+  const uint32_t *v, *j, *rep, *voff;
+  const uint8_t  *res;
   uint64_t        n;
-  RefRec         *out;
+  unsigned char  *out;
 };
 
 __global__ void __launch_bounds__(BLOCK_THREADS)
@@ -219,14 +225,21 @@ pack_records_kernel(const PackParams B)
   const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if (i >= B.n)
     return;
+  const uint64_t b = B.off[i];
   RefRec r;
-  r.off = B.off[i];
-  r.len = (uint32_t)(B.off[i + 1] - r.off);
+  r.idx = (uint32_t)i;
+  r.len = (uint32_t)(B.off[i + 1] - b);
   r.cnt = B.cnt ? B.cnt[i] : 1ull;
   r.v = B.v ? B.v[i] : 0u;
   r.j = B.j ? B.j[i] : 0u;
   r.rep = B.rep[i];
-  B.out[i] = r;
+  r.pad = 0;
+  unsigned char *o = B.out + (size_t)B.voff[i] * REC_UNIT;
+  *(RefRec *)o = r;
+  o += sizeof(RefRec);
+  const uint32_t padded = (r.len + REC_UNIT - 1) / REC_UNIT * REC_UNIT;
+  for (uint32_t p = 0; p < padded; p++)
+    o[p] = p < r.len ? B.res[b + p] : (unsigned char)0xff;
 }
 
 /* ------------------------------------------------------------------ */
@@ -263,12 +276,11 @@ __device__ __forceinline__ uint32_t query_residue(const ProbeParams &P,
    flight together (an early-exit loop costs one memory round trip per residue). */
 __device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
                                     uint32_t lane, uint32_t L, uint32_t ca, uint32_t cb,
-                                    const RefRec &rec)
+                                    const RefRec &rec, const unsigned char *t)
 {
   const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
   const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
   const uint32_t M = rec.len;
-  const uint8_t *t = P.res2 + rec.off;
   /* expected length of the hit */
   const uint32_t want = kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L);
   if (M != want)
@@ -369,13 +381,14 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
       }
       if (k[i].key != key)
         continue;
-      const uint32_t hit = k[i].val;
-      const RefRec rec = P.rec2[hit];
+      const unsigned char *rp = P.rec2 + (size_t)k[i].val * REC_UNIT;
+      const RefRec rec = *(const RefRec *)rp;
+      const uint32_t hit = rec.idx;
       st.hash_eq++;
       bool ok = true;
       if (GENES)
         ok = (q_v == rec.v) && (q_j == rec.j);
-      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
+      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, rp + sizeof(RefRec))) {
         st.matches++;
         score_match(P, qs, hit, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
       }
@@ -398,29 +411,103 @@ __device__ __forceinline__ void resolve_entry(const ProbeParams &P, const WaveQu
 /* (query, variant, set-2 sequence) triples whose table key equals the variant
    hash, waiting for verification -- one queue per wave, in LDS */
 struct CandQueue {
-  uint32_t slot[QCAP], ca[QCAP], cb[QCAP], hit[QCAP];
+  uint32_t slot[QCAP], qbase[QCAP], ca[QCAP], cb[QCAP], hit[QCAP];
 };
 
-/* Verification + scoring of one candidate per lane (all lanes busy, three
-   dependent memory round trips: record + query fields, residues, atomics). */
+/* n low bytes set (n <= 0: none, n >= 4: all) */
+__device__ __forceinline__ uint32_t low_bytes(int n)
+{
+  return n <= 0 ? 0u : (n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u));
+}
+
+/* check_variant (variants.cc:166-240) on packed words: positions [16c, 16c+16)
+   of the hit (`r`, four residues per dword) against what the variant of the
+   query must have there.  q[0..5] are the query's dwords 4c-1 .. 4c+4 (the
+   neighbours feed the one-residue shift of a deletion / insertion).  Returns
+   non-zero if any position below M differs. */
+__device__ __forceinline__ uint32_t block_mismatch(uint32_t c, const uint32_t q[6],
+                                                  const uint32_t r[4], uint32_t kind,
+                                                  uint32_t p1, uint32_t r1, uint32_t p2,
+                                                  uint32_t r2, uint32_t M)
+{
+  uint32_t bad = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pos0 = (int)(16 * c) + 4 * j;
+    const uint32_t prv = q[j], cur = q[j + 1], nxt = q[j + 2];
+    uint32_t e = cur;
+    if (kind == K_DEL || kind == K_INS) {
+      /* positions below p1 come straight from the query, the others from the
+         query shifted by one residue */
+      const uint32_t sh = kind == K_DEL ? (cur >> 8) | (nxt << 24) : (cur << 8) | (prv >> 24);
+      const uint32_t m = low_bytes((int)p1 - pos0);
+      e = (cur & m) | (sh & ~m);
+    }
+    if (kind == K_SUB || kind == K_INS || kind == K_SUB2) {
+      const uint32_t d = p1 - (uint32_t)pos0;
+      if (d < 4u)
+        e = (e & ~(0xffu << (8 * d))) | (r1 << (8 * d));
+    }
+    if (kind == K_SUB2) {
+      const uint32_t d = p2 - (uint32_t)pos0;
+      if (d < 4u)
+        e = (e & ~(0xffu << (8 * d))) | (r2 << (8 * d));
+    }
+    bad |= (e ^ r[j]) & low_bytes((int)M - pos0);
+  }
+  return bad;
+}
+
+/* Verification + scoring of one candidate per lane.  Everything a candidate
+   needs is requested at once -- the hit's record with its first 32 residues
+   (one 64-byte piece), the query's fields and its first 36 residues -- so a
+   CDR3 is verified after ONE memory round trip; sequences longer than 32 take
+   one more per 16 residues. */
 template <bool GENES>
-__device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t ca,
-                                                 uint32_t cb, uint32_t hit,
+__device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t qbase,
+                                                 uint32_t ca, uint32_t cb, uint32_t hit,
                                                  unsigned long long *mat_lds, LaneStats &st)
 {
-  const RefRec rec = P.rec2[hit];
-  const TileDesc td = P.tiles[qs >> 6];
-  const uint32_t ql = qs & 63u;
+  const uint4 *rp = (const uint4 *)(P.rec2 + (size_t)hit * REC_UNIT);
+  const uint4 h0 = rp[0], h1 = rp[1], t0 = rp[2], t1 = rp[3];
+  const uint32_t *qr = P.qres + qbase + (qs & 63u);
+  uint32_t q[10];
+  q[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++)
+    q[k + 1] = qr[(size_t)k * WAVE];
   const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
   const uint32_t q_rep = P.qrep[qs];
-  const uint32_t q_len = P.qlen[qs];
+  const uint32_t L = P.qlen[qs];
   const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
-  bool ok = true;
+
+  RefRec rec;
+  rec.cnt = ((unsigned long long)h0.y << 32) | h0.x;
+  rec.idx = h0.z; rec.len = h0.w; rec.v = h1.x; rec.j = h1.y; rec.rep = h1.z;
+  const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
+  const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
+  const uint32_t M = rec.len;
+  const uint32_t want = kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L);
+  bool ok = M == want;
   if (GENES)
-    ok = (q_v == rec.v) && (q_j == rec.j);
-  if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec)) {
+    ok = ok && (q_v == rec.v) && (q_j == rec.j);
+  const uint32_t r0[4] = {t0.x, t0.y, t0.z, t0.w}, r1w[4] = {t1.x, t1.y, t1.z, t1.w};
+  uint32_t bad = block_mismatch(0, q, r0, kind, p1, r1, p2, r2, M) |
+                 block_mismatch(1, q + 4, r1w, kind, p1, r1, p2, r2, M);
+  if (ok && M > 32) {
+    for (uint32_t c = 2; 16 * c < M; c++) {
+      const uint4 t = rp[2 + c];
+      uint32_t qq[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        qq[k] = qr[(size_t)(4 * c - 1 + k) * WAVE];
+      const uint32_t rr[4] = {t.x, t.y, t.z, t.w};
+      bad |= block_mismatch(c, qq, rr, kind, p1, r1, p2, r2, M);
+    }
+  }
+  if (ok && bad == 0) {
     st.matches++;
-    score_match(P, qs, hit, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
+    score_match(P, qs, rec.idx, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
   }
 }
 
@@ -486,6 +573,7 @@ resolve_kernel(const ProbeParams P)
           if (m) {
             const int x = qn + (int)rank_below(mm);
             cq.slot[x] = e.slot;
+            cq.qbase[x] = e.qbase;
             cq.ca[x] = e.ca;
             cq.cb[x] = e.cb;
             cq.hit[x] = k[i].val;
@@ -495,8 +583,8 @@ resolve_kernel(const ProbeParams P)
           if (qn >= WAVE) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qn -= WAVE;
-            verify_candidate<GENES>(P, cq.slot[qn + lane], cq.ca[qn + lane], cq.cb[qn + lane],
-                                    cq.hit[qn + lane], mat_lds, st);
+            verify_candidate<GENES>(P, cq.slot[qn + lane], cq.qbase[qn + lane], cq.ca[qn + lane],
+                                    cq.cb[qn + lane], cq.hit[qn + lane], mat_lds, st);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           }
         }
@@ -506,7 +594,8 @@ resolve_kernel(const ProbeParams P)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if ((int)lane < qn)
-    verify_candidate<GENES>(P, cq.slot[lane], cq.ca[lane], cq.cb[lane], cq.hit[lane], mat_lds, st);
+    verify_candidate<GENES>(P, cq.slot[lane], cq.qbase[lane], cq.ca[lane], cq.cb[lane],
+                            cq.hit[lane], mat_lds, st);
   {
     unsigned long long sum[2] = {st.hash_eq, st.matches};
 #pragma unroll

@@ -76,7 +76,7 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
         e.slot = W.q.slot[first + W.lane];
         e.ca = W.q.ca[first + W.lane];
         e.cb = W.q.cb[first + W.lane];
-        e.pad = 0;
+        e.qbase = (uint32_t)P.tiles[e.slot >> 6].res_base;
         P.pos_buf[(size_t)seg * (P.pos_cap + WAVE) + base + W.lane] = e;
       }
     } else {

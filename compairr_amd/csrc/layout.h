@@ -148,18 +148,28 @@ struct PosEntry {
   uint64_t hash;
   uint32_t slot;     /* query: tile * 64 + lane                         */
   uint32_t ca, cb;   /* variant: kind | p1 << 3 | r1 << 24 ; p2 | r2 << 24 */
-  uint32_t pad;
+  uint32_t qbase;    /* res_base of the query's tile (dword index in qres) */
 };
 
-/* One set-2 sequence as the verification step reads it: one 32-byte record
-   (two 16-byte loads) instead of six scattered loads from the SoA arrays. */
+/* One set-2 sequence as the verification step reads it: a 32-byte header
+   followed by its residues (one byte each, padded to 16): header + residues of
+   a CDR3 are 48-64 contiguous bytes, usually ONE memory line per verified hit
+   instead of one for the record and another for the residues.  The hash table
+   stores the record's position in this stream in 16-byte units. */
 struct RefRec {
-  uint64_t off;       /* first residue in res2                              */
   uint64_t cnt;       /* duplicate_count (1 with -f)                        */
+  uint32_t idx;       /* the sequence's number in set 2                     */
   uint32_t len;
   uint32_t v, j;      /* 0 with -g                                          */
   uint32_t rep;
+  uint32_t pad;
 };
+constexpr uint32_t REC_UNIT = 16;
+
+__host__ __device__ inline uint32_t rec_units(uint32_t len)
+{
+  return (uint32_t)(sizeof(RefRec) / REC_UNIT) + (len + REC_UNIT - 1) / REC_UNIT;
+}
 
 /* per-launch kernel arguments */
 struct ProbeParams {
@@ -181,7 +191,7 @@ struct ProbeParams {
   const uint32_t *j2;
   const uint32_t *rep2;
   const uint64_t *cnt2;
-  const RefRec   *rec2;
+  const unsigned char *rec2;        /* RefRec stream; table val * REC_UNIT = position */
   /* set 1 tiles */
   const TileDesc *tiles;
   const uint32_t *qres;
