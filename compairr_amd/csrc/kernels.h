@@ -51,19 +51,43 @@ __host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
   return h == EMPTY_KEY ? (h ^ 1ull) : h;
 }
 
+/* 1u << ((a >> 8) & 31) in ONE instruction: the shifter takes its amount from
+   byte 1 of the register (SDWA operand select) and ignores all but 5 bits */
+__device__ __forceinline__ uint32_t one_shl_byte1(uint32_t a)
+{
+  uint32_t d;
+  const uint32_t one = 1u;
+  /* not convergent: plain per-lane arithmetic (lets loops around it unroll) */
+  [[clang::noconvergent]] {
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 "
+        "src1_sel:DWORD"
+        : "=v"(d)
+        : "v"(a), "v"(one));
+  }
+  return d;
+}
+
 /* Bit pattern of a hash, computed, not looked up: two bits of the low dword of
-   the filter word picked by hash bits [0,5) and [5,10), two bits of the high
-   dword picked by hash bits [32,37) and [37,42).  (The reference reads one of
-   1024 precomputed 8-bit patterns, bloompat.h:45-48; at the >= 32 filter bits
-   per key this build uses, 4 bits from a 2^20 pattern space give a lower
-   false-positive rate than 8 bits from a 2^10 space, and cost two random LDS
-   reads less per probe.) */
-__host__ __device__ __forceinline__ uint64_t pattern_of(uint64_t h)
+   the filter word picked by hash bits [0,5) and [8,13), two bits of the high
+   dword picked by hash bits [32,37) and [40,45) -- four shifts whose amounts
+   are bytes of the hash as they lie in the registers (4 instructions).  (The
+   reference reads one of 1024 precomputed 8-bit patterns, bloompat.h:45-48; at
+   the >= 32 filter bits per key this build uses, 4 bits from a 2^20 pattern
+   space give a lower false-positive rate than 8 bits from a 2^10 space, and
+   cost two random LDS reads less per probe.) */
+__device__ __forceinline__ uint64_t pattern_of(uint64_t h)
 {
   const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
-  const uint32_t lo = (1u << (a & 31u)) | (1u << ((a >> 5) & 31u));
-  const uint32_t hi = (1u << (b & 31u)) | (1u << ((b >> 5) & 31u));
+  const uint32_t lo = (1u << (a & 31u)) | one_shl_byte1(a);
+  const uint32_t hi = (1u << (b & 31u)) | one_shl_byte1(b);
   return ((uint64_t)hi << 32) | lo;
+}
+
+/* Byte offset of a hash's filter word before masking to the filter (or slice)
+   size: hash bits from 13 up, clear of the low-dword pattern bits */
+__device__ __forceinline__ uint32_t bloom_off(uint64_t h)
+{
+  return (uint32_t)(h >> 10);
 }
 
 __device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
@@ -131,13 +155,13 @@ build_index_kernel(const BuildParams B)
   }
   B.table[slot].val = B.voff ? B.voff[i] : (uint32_t)i;
 
-  uint64_t boff = ((uint32_t)(h >> (PATTERN_BITS - 3))) & B.bloom_byte_mask;
+  uint64_t boff = bloom_off(h) & B.bloom_byte_mask;
   if (B.sliced) {
     const uint32_t slice = class_key_of(B.geom.ctab, B.geom, B.A, B.use_genes != 0,
                                         B.res + b, L, B.use_genes ? B.v[i] : 0u,
                                         B.use_genes ? B.j[i] : 0u, nullptr) & B.geom.smask;
     boff = ((uint64_t)slice << (B.geom.words_log2 + 3)) +
-           (((uint32_t)(h >> (PATTERN_BITS - 3))) & (((1u << B.geom.words_log2) - 1u) << 3));
+           (bloom_off(h) & (((1u << B.geom.words_log2) - 1u) << 3));
   }
   const uint64_t pat = pattern_of(h);
   atomicAnd((unsigned long long *)((char *)B.bloom + boff),
@@ -645,7 +669,7 @@ template <bool GENES>
 __device__ __forceinline__ void probe(Prober &W, uint64_t hv, bool live,
                                       uint32_t ca, uint32_t cb)
 {
-  const uint32_t boff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.P.bloom_byte_mask;
+  const uint32_t boff = bloom_off(hv) & W.P.bloom_byte_mask;
   const uint64_t word = *(const uint64_t *)((const char *)W.P.bloom + boff);
   const uint64_t pat = pattern_of(hv);
   const bool pos = live && ((word & pat) == 0);

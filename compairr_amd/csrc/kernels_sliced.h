@@ -114,13 +114,36 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
   }
 }
 
+/* (a & b) | c in one instruction */
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t d;
+  [[clang::noconvergent]] {
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  }
+  return d;
+}
+
+/* non-zero = absent.  Inverted polarity, bloompat.h:55-58: present iff
+   (word & pat) == 0; one and + one and-or */
+__device__ __forceinline__ uint32_t bloom_miss(uint64_t word, uint64_t pat)
+{
+  return and_or((uint32_t)(word >> 32), (uint32_t)(pat >> 32), (uint32_t)word & (uint32_t)pat);
+}
+
 __device__ __forceinline__ bool bloom_hit(uint64_t word, uint64_t pat)
 {
-  /* inverted polarity, bloompat.h:55-58: (word & pat) == 0, as one and + one
-     and-or + one 32-bit compare */
-  const uint32_t t = ((uint32_t)word & (uint32_t)pat) |
-                     ((uint32_t)(word >> 32) & (uint32_t)(pat >> 32));
-  return t == 0;
+  return bloom_miss(word, pat) == 0;
+}
+
+/* The dynamic LDS of the probe kernel starts at LDS address 0 (there is no
+   static __shared__ in front of it; checked at kernel entry), so LDS reads can
+   be addressed absolutely: no base add per read, constant offsets go into the
+   instruction. */
+typedef __attribute__((address_space(3))) const uint64_t lds_u64_t;
+__device__ __forceinline__ uint64_t lds_u64(uint32_t byte_addr, int index = 0)
+{
+  return ((lds_u64_t *)(uintptr_t)byte_addr)[index];
 }
 
 /* phase 1, class-preserving row: filter words from the LDS copy of the slice */
@@ -131,11 +154,49 @@ __device__ __forceinline__ uint32_t row_lds(const SProber &W, uint64_t h1, uint6
 #pragma unroll
   for (int v = 0; v < A; v++) {
     const uint64_t hv = h1 ^ readlane64(zrow, v);
-    const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
-    const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
+    const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
+    const uint64_t word = lds_u64(woff);
     mask |= bloom_hit(word, pattern_of(hv)) ? (1u << v) : 0u;
   }
   return mask;
+}
+
+/* phase 1, class-preserving row over the OTHER residues of a position: the lane
+   probes residue (r + k) mod A for k = 1 .. A-1, r being its own residue there
+   (never the original: one probe less per row, nothing to mask afterwards).
+   `zaddr` is the LDS address of the lane's own key zl[ZS * p + r]; key k is a
+   read at constant offset 8 k from it (20 consecutive keys over the lanes: no
+   bank conflict), which replaces the two cross-lane reads per probe of
+   row_lds.  Bit k - 1 of the result <-> residue (r + k) mod A. */
+template <int A>
+__device__ __forceinline__ uint32_t row_lds_others(const SProber &W, uint64_t h1, uint32_t zaddr)
+{
+  uint32_t mask = 0;
+#pragma unroll
+  for (int k = 1; k < A; k++) {
+    const uint64_t hv = h1 ^ lds_u64(zaddr, k);
+    const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
+    mask |= bloom_hit(lds_u64(woff), pattern_of(hv)) ? (1u << (k - 1)) : 0u;
+  }
+  return mask;
+}
+
+/* phase 2 of row_lds_others */
+template <bool GENES, int A>
+__device__ __forceinline__ void emit_row_others(SProber &W, uint32_t mask, uint64_t h1,
+                                                uint32_t zaddr, uint32_t r, uint32_t ca)
+{
+  if (W.P.debug & DBG_SKIP_EMIT)
+    mask = 0;
+  while (__ballot(mask != 0)) {
+    const bool pos = mask != 0;
+    const uint32_t k = pos ? (uint32_t)__ffs((int)mask) : 1u;
+    const uint64_t hv = h1 ^ lds_u64(zaddr + 8u * k);
+    uint32_t v = r + k;
+    v = v >= (uint32_t)A ? v - (uint32_t)A : v;
+    s_push<GENES>(W, pos, hv, ca | (v << 24), 0);
+    mask &= mask - 1u;
+  }
 }
 
 /* phase 1, class-changing row: slice of residue v = own slice ^ dk_lane ^ crow[v]
@@ -159,7 +220,7 @@ __device__ __forceinline__ uint32_t row_hbm(const SProber &W, uint64_t h1, uint6
       const uint64_t hv = h1 ^ readlane64(zrow, v);
       const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)crow, v);
       const uint32_t vslice = (W.tile_slice ^ dk_lane ^ (cv & crow_enable)) & W.smask;
-      const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+      const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
       const uint64_t off = ((uint64_t)vslice << W.slice_shift) + woff;
       word[k] = *(const uint64_t *)((const char *)W.P.bloom + off);
     }
@@ -196,7 +257,7 @@ __device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
 /* one probe, class-preserving: filter word from the staged slice */
 __device__ __forceinline__ bool probe_one_lds(const SProber &W, uint64_t hv)
 {
-  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
   const uint64_t word = *(const uint64_t *)((const char *)W.slice_lds + woff);
   return bloom_hit(word, pattern_of(hv));
 }
@@ -204,7 +265,7 @@ __device__ __forceinline__ bool probe_one_lds(const SProber &W, uint64_t hv)
 /* one probe of the tile's own slice: LDS copy when staged, else where it lies */
 __device__ __forceinline__ bool probe_one_own(const SProber &W, uint64_t hv, bool staged)
 {
-  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
   uint64_t word;
   if (staged)
     word = *(const uint64_t *)((const char *)W.slice_lds + woff);
@@ -218,7 +279,7 @@ __device__ __forceinline__ bool probe_one_own(const SProber &W, uint64_t hv, boo
 __device__ __forceinline__ const uint64_t *hbm_word(const SProber &W, uint64_t hv, uint32_t dk)
 {
   const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
-  const uint32_t woff = ((uint32_t)(hv >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+  const uint32_t woff = bloom_off(hv) & W.wmask_bytes;
   return (const uint64_t *)((const char *)W.P.bloom + ((uint64_t)vslice << W.slice_shift) + woff);
 }
 
@@ -271,7 +332,12 @@ probe_sliced_kernel(const ProbeParams P)
   uint64_t *slice_lds = (uint64_t *)smem;
   const uint32_t slice_words = 1u << P.geom.words_log2;
   uint64_t *zl = slice_lds + slice_words;
-  const uint32_t nz = (uint32_t)A * P.zpos;
+  /* amino acids: every row of keys is stored twice in a line, so that
+     "residue (r + k) mod A" is entry r + k (row_lds_others) */
+  constexpr uint32_t ZS = zrow_stride(A);
+  const uint32_t nz = ZS * P.zpos;
+  if ((uint32_t)(uintptr_t)smem != 0u)
+    __builtin_trap();                       /* lds_u64 addresses the LDS absolutely */
   unsigned long long *mat_all = (unsigned long long *)(zl + nz);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
@@ -281,7 +347,7 @@ probe_sliced_kernel(const ProbeParams P)
   TileRef *tref_lds = (TileRef *)(bcast + 4);           /* chunk_cap entries */
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
-    zl[i] = P.zob[i];
+    zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
   if (P.lds_matrix)
     for (uint32_t i = threadIdx.x; i < cells; i += NT)
       mat_all[i] = 0;
@@ -297,7 +363,8 @@ probe_sliced_kernel(const ProbeParams P)
   SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
             0u, 0, {0ull, 0u, 0u, 0u}};
-  const uint64_t *gene_keys = P.zob + nz;
+  const uint64_t *gene_keys = P.zob + (uint32_t)A * P.zpos;
+  const uint32_t zl_addr = slice_words * 8u;       /* LDS address of zl */
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
 
   /* Two kinds of work.  Block phase: chunks (several tiles that need the same
@@ -389,11 +456,11 @@ probe_sliced_kernel(const ProbeParams P)
       {
         for (uint32_t p = 0; p < L; p++) {
           const uint32_t r = rs.at(p);
-          h ^= p < Ll ? zl[A * p + r] : 0ull;
+          h ^= p < Ll ? zl[ZS * p + r] : 0ull;
           if (INDELS) {
-            hins ^= zl[A * (p + 1) + r];
+            hins ^= zl[ZS * (p + 1) + r];
             if (p > 0)
-              hdel ^= zl[A * (p - 1) + r];
+              hdel ^= zl[ZS * (p - 1) + r];
           }
         }
       }
@@ -492,8 +559,18 @@ probe_sliced_kernel(const ProbeParams P)
         } else
         for (uint32_t p = 0; p < L; p++) {
           const uint32_t r = rs.at(p);
-          const uint64_t h1 = h ^ zl[A * p + r];
-          const uint64_t zrow = zl[A * p + zlane];
+          if (staged && !is_class_pos(p)) {
+            const uint32_t zaddr = zl_addr + (ZS * p + r) * 8u;
+            const uint64_t h1 = h ^ lds_u64(zaddr);
+            uint32_t mask = 0;
+            if (!(P.debug & DBG_SKIP_LDS_ROWS))
+              mask = row_lds_others<A>(W, h1, zaddr);
+            mask &= p < Ll ? ~0u : 0u;                    /* not past the lane's own end */
+            emit_row_others<GENES, A>(W, mask, h1, zaddr, r, pack_a(K_SUB, p, 0));
+            continue;
+          }
+          const uint64_t h1 = h ^ zl[ZS * p + r];
+          const uint64_t zrow = zl[ZS * p + zlane];
           uint32_t mask = 0;
           if (!is_class_pos(p)) {
             if (!(P.debug & DBG_SKIP_LDS_ROWS))
@@ -504,7 +581,7 @@ probe_sliced_kernel(const ProbeParams P)
             mask = row_hbm<A>(W, h1, zrow, dk, crow);
           }
           mask &= (p < Ll ? ~0u : 0u) & ~(1u << r);      /* not past the lane's own end, not the original residue */
-          emit_row<GENES, true>(W, mask, h1, zl + A * p, pack_a(K_SUB, p, 0), 0);
+          emit_row<GENES, true>(W, mask, h1, zl + ZS * p, pack_a(K_SUB, p, 0), 0);
         }
       }
 
@@ -569,13 +646,13 @@ probe_sliced_kernel(const ProbeParams P)
               const uint32_t r = (w >> ((p & 3u) * 8)) & 0xffu;
               const bool fresh = (p == 0) || (r != gone);
               if (p > 0 && fresh)
-                hd ^= zl[A * (p - 1) + gone] ^ zl[A * (p - 1) + r];
+                hd ^= zl[ZS * (p - 1) + gone] ^ zl[ZS * (p - 1) + r];
               uint32_t dk = dl;
 #pragma unroll
               for (uint32_t i = 0; i < MCR; i++)
                 dk ^= md[i] < p ? lo[i] : hi[i];
               const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
-              const uint32_t woff = ((uint32_t)(hd >> (PATTERN_BITS - 3))) & W.wmask_bytes;
+              const uint32_t woff = bloom_off(hd) & W.wmask_bytes;
               uint64_t word;
               if (vslice == sibling)
                 word = *(const uint64_t *)((const char *)slice_lds + woff);
@@ -595,7 +672,7 @@ probe_sliced_kernel(const ProbeParams P)
               for (uint32_t p = p0; p < pe; p++) {
                 const uint32_t r = res_at(p);
                 if (p > 0 && r != g)
-                  hr ^= zl[A * (p - 1) + g] ^ zl[A * (p - 1) + r];
+                  hr ^= zl[ZS * (p - 1) + g] ^ zl[ZS * (p - 1) + r];
                 s_push<GENES>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
                 g = r;
               }
@@ -629,7 +706,7 @@ probe_sliced_kernel(const ProbeParams P)
             if (ip > 0) {
               const uint32_t p = ip - 1;
               r = rs.at(p);
-              hi_hash ^= zl[A * p + r] ^ zl[A * ip + r];
+              hi_hash ^= zl[ZS * p + r] ^ zl[ZS * ip + r];
             }
             uint32_t dk0 = dl, crow = 0;
             bool v_on_class_pos = false;
@@ -643,7 +720,7 @@ probe_sliced_kernel(const ProbeParams P)
                   dk0 ^= mi[i] < ip ? lo[i] : hi[i];
                 }
               }
-            const uint64_t zrow = zl[A * ip + zlane];
+            const uint64_t zrow = zl[ZS * ip + zlane];
             /* rows that put v on a class position spread over up to A slices */
             const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == sibling;
             uint32_t mask = 0;
@@ -658,7 +735,7 @@ probe_sliced_kernel(const ProbeParams P)
             mask &= vmask;
             if (ip > 0)
               mask &= ~(1u << r);                         /* v != s[ip - 1] */
-            emit_row<GENES, true>(W, mask, hi_hash, zl + A * ip, pack_a(K_INS, ip, 0), 0);
+            emit_row<GENES, true>(W, mask, hi_hash, zl + ZS * ip, pack_a(K_INS, ip, 0), 0);
           }
         }
       }
@@ -735,8 +812,8 @@ probe_sliced_kernel(const ProbeParams P)
         } else
         for (uint32_t p = 0; p + 1 < L; p++) {
           const uint32_t rp = res_at(p);
-          const uint64_t hp = h ^ zl[A * p + rp];
-          const uint64_t zrow_p = zl[A * p + zlane];
+          const uint64_t hp = h ^ zl[ZS * p + rp];
+          const uint64_t zrow_p = zl[ZS * p + zlane];
           uint32_t crow_p;
           const uint32_t dk_p = class_terms(p, rp, crow_p);
           const bool cp = is_class_pos(p);
@@ -751,8 +828,8 @@ probe_sliced_kernel(const ProbeParams P)
               if ((qq & 3u) == 0 || qq == p + 1)
                 w = qr[(qq >> 2) * WAVE];
               const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
-              const uint64_t hq = hpv ^ zl[A * qq + rq];
-              const uint64_t zrow_q = zl[A * qq + zlane];
+              const uint64_t hq = hpv ^ zl[ZS * qq + rq];
+              const uint64_t zrow_q = zl[ZS * qq + zlane];
               uint32_t mask;
               if (!cp && !is_class_pos(qq)) {
                 mask = staged ? row_lds<A>(W, hq, zrow_q) : row_hbm<A>(W, hq, zrow_q, 0u, 0u);
@@ -762,7 +839,7 @@ probe_sliced_kernel(const ProbeParams P)
                 mask = row_hbm<A>(W, hq, zrow_q, dk_pv ^ dk_q, crow_q);
               }
               mask &= pv & (qq < Ll ? ~0u : 0u) & ~(1u << rq);
-              emit_row<GENES, false>(W, mask, hq, zl + A * qq, ca, qq);
+              emit_row<GENES, false>(W, mask, hq, zl + ZS * qq, ca, qq);
             }
           }
         }

@@ -24,8 +24,9 @@ constexpr uint32_t EXTRA_POSITIONS   = 3;
    from ONE table of 1024 patterns, which floors its false-positive rate at
    (keys per word) / 1024; this build sets 4 bits per key computed directly from
    20 hash bits (kernels.h pattern_of): a 2^20 pattern space and no table. */
-constexpr uint32_t PATTERN_BITS      = 10;     /* hash bits [0,10) and [32,42): pattern;
-                                                  word address starts at bit 10      */
+constexpr uint32_t PATTERN_BITS      = 10;     /* per dword of the word: hash bits [0,5)
+                                                  and [8,13) / [32,37) and [40,45); the
+                                                  word address starts at bit 13      */
 constexpr uint32_t PATTERN_K         = 4;
 
 /* Open-addressing table: 64-bit key (the sequence hash) and 32-bit payload (the
@@ -142,6 +143,13 @@ struct Chunk {
 };
 
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
+
+/* entries per position of the sliced kernel's LDS copy of the Zobrist table:
+   amino-acid rows are stored twice in a line (kernels_sliced.h row_lds_others) */
+__host__ __device__ constexpr uint32_t zrow_stride(int A)
+{
+  return A == 4 ? 4u : 2u * (uint32_t)A;
+}
 
 /* A Bloom-positive variant waiting for its hash-table walk */
 struct PosEntry {
