@@ -182,9 +182,10 @@ __device__ __forceinline__ uint32_t row_lds_others(const SProber &W, uint64_t h1
 }
 
 /* phase 2 of row_lds_others */
-template <bool GENES, int A>
+template <bool GENES, int A, bool RES_IN_A = true>
 __device__ __forceinline__ void emit_row_others(SProber &W, uint32_t mask, uint64_t h1,
-                                                uint32_t zaddr, uint32_t r, uint32_t ca)
+                                                uint32_t zaddr, uint32_t r, uint32_t ca,
+                                                uint32_t cb = 0)
 {
   if (W.P.debug & DBG_SKIP_EMIT)
     mask = 0;
@@ -194,7 +195,8 @@ __device__ __forceinline__ void emit_row_others(SProber &W, uint32_t mask, uint6
     const uint64_t hv = h1 ^ lds_u64(zaddr + 8u * k);
     uint32_t v = r + k;
     v = v >= (uint32_t)A ? v - (uint32_t)A : v;
-    s_push<GENES>(W, pos, hv, ca | (v << 24), 0);
+    s_push<GENES>(W, pos, hv, RES_IN_A ? (ca | (v << 24)) : ca,
+                  RES_IN_A ? cb : (cb | (v << 24)));
     mask &= mask - 1u;
   }
 }
@@ -723,18 +725,27 @@ probe_sliced_kernel(const ProbeParams P)
             const uint64_t zrow = zl[ZS * ip + zlane];
             /* rows that put v on a class position spread over up to A slices */
             const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == sibling;
-            uint32_t mask = 0;
+            uint32_t mask = 0;          /* bit v: residue v */
+            uint32_t mask_o = 0;        /* bit k - 1: residue (r + k) mod A (row_lds_others) */
+            const uint32_t zaddr = zl_addr + (ZS * ip + (ip > 0 ? r : 0u)) * 8u;
             if (__ballot(in_lds)) {
-              const uint32_t ml = row_lds<A>(W, hi_hash, zrow);
-              mask = in_lds ? ml : 0u;
+              if (A != 4 && ip > 0) {          /* (nucleotide rows are not stored twice) */
+                const uint32_t ml = row_lds_others<A>(W, hi_hash, zaddr);
+                mask_o = in_lds ? ml : 0u;
+              } else {
+                const uint32_t ml = row_lds<A>(W, hi_hash, zrow);
+                mask = in_lds ? ml : 0u;
+              }
             }
             if (__ballot(!in_lds)) {
               if (!in_lds)
                 mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
             }
             mask &= vmask;
+            mask_o &= vmask;
             if (ip > 0)
               mask &= ~(1u << r);                         /* v != s[ip - 1] */
+            emit_row_others<GENES, A>(W, mask_o, hi_hash, zaddr, r, pack_a(K_INS, ip, 0));
             emit_row<GENES, true>(W, mask, hi_hash, zl + ZS * ip, pack_a(K_INS, ip, 0), 0);
           }
         }
@@ -831,8 +842,14 @@ probe_sliced_kernel(const ProbeParams P)
               const uint64_t hq = hpv ^ zl[ZS * qq + rq];
               const uint64_t zrow_q = zl[ZS * qq + zlane];
               uint32_t mask;
+              if (staged && !cp && !is_class_pos(qq)) {
+                const uint32_t zaddr = zl_addr + (ZS * qq + rq) * 8u;
+                mask = row_lds_others<A>(W, hq, zaddr) & pv & (qq < Ll ? ~0u : 0u);
+                emit_row_others<GENES, A, false>(W, mask, hq, zaddr, rq, ca, qq);
+                continue;
+              }
               if (!cp && !is_class_pos(qq)) {
-                mask = staged ? row_lds<A>(W, hq, zrow_q) : row_hbm<A>(W, hq, zrow_q, 0u, 0u);
+                mask = row_hbm<A>(W, hq, zrow_q, 0u, 0u);
               } else {
                 uint32_t crow_q;
                 const uint32_t dk_q = class_terms(qq, rq, crow_q);
