@@ -273,7 +273,11 @@ def main():
                          "algorithmic_bytes_per_launch": st.algorithmic_bytes,
                          "variants_per_launch": st.variants,
                          "bloom_positive_per_launch": st.bloom_positive,
-                         "pairs_per_launch": st.matches},
+                         "pairs_per_launch": st.matches,
+                         "note": "achieved = SURVEY 8d algorithmic bytes (8 B per variant, as the "
+                                 "reference reads its filter) / HIP-event time of the probe + "
+                                 "resolve kernels; it can exceed the HBM peak because the filter "
+                                 "words come from LDS; `traffic` is the measured HBM bytes"},
             "cpu_baseline": baseline,
             "parity_on_cpu_sample": parity,
         }

@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_round.sh <tag> <bench.py args...>
+# 1. rocprofv3 --kernel-trace --stats of the bench command (per-kernel durations);
+# 2. one rocprofv3 --pmc pass per counter group (FETCH_SIZE and WRITE_SIZE each alone,
+#    as MI355X_MICROARCH.md prescribes; PMC passes are never mixed with traces).
+# Everything lands in gpurun_out/<tag>/; tools/pmc_summary.py turns it into profiles/.
+tag=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o p --output-format csv -- \
+    python3 $R/bench.py --cpu-sample -1 "$@" > $O/stats_bench.json 2> $O/stats.err
+i=0
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
+            "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $ctrs -d $O/pmc_$i -o p --output-format csv -- \
+      python3 $R/bench.py --cpu-sample -1 --steps 3 --warmup 1 "$@" > $O/pmc_$i.log 2>&1
+done
+ls $O
