@@ -14,7 +14,8 @@ CXXFLAGS ?= -O2 -std=c++11 -Wall -Wextra -pedantic
 
 LIB      = compairr_amd/lib/libcompairr_hip.so
 CLI      = bin/compairr
-HOST_CORE = compairr_amd/host/airr_tsv.cc compairr_amd/host/options.cc compairr_amd/host/overlap_host.cc
+HOST_CORE = compairr_amd/host/airr_tsv.cc compairr_amd/host/options.cc compairr_amd/host/overlap_host.cc \
+            compairr_amd/host/cluster_host.cc
 HOST_SRC = $(HOST_CORE) compairr_amd/host/hip_backend.cc
 HOST_HDR = $(wildcard compairr_amd/host/*.h) include/compairr_hip.h
 KERN_SRC = compairr_amd/csrc/compairr_hip.hip

@@ -48,7 +48,7 @@ void print_usage(FILE *f)
   fprintf(f, " -v, --version               display version information\n");
   fprintf(f, " -m, --matrix                compute overlap matrix between two sets\n");
   fprintf(f, " -x, --existence             check existence of sequences in repertoires\n");
-  fprintf(f, " -c, --cluster               (not available in the MI355X build)\n");
+  fprintf(f, " -c, --cluster               cluster sequences in one repertoire\n");
   fprintf(f, " -z, --deduplicate           (not available in the MI355X build)\n");
   fprintf(f, "\nGeneral options:\n");
   fprintf(f, " -d, --differences INTEGER   number of differences accepted (0*, 1, 2)\n");
@@ -75,7 +75,10 @@ void print_usage(FILE *f)
 
 void print_options(FILE *f, const Options &o, const char *backend_name)
 {
-  if (o.existence) {
+  if (o.cluster) {
+    fprintf(f, "Command:           Cluster (-c)\n");
+    fprintf(f, "Repertoire:        %s\n", o.input1);
+  } else if (o.existence) {
     fprintf(f, "Command:           Existence (-x)\n");
     fprintf(f, "Repertoire:        %s\n", o.input1);
     fprintf(f, "Repertoire set:    %s\n", o.input2);
@@ -94,10 +97,12 @@ void print_options(FILE *f, const Options &o, const char *backend_name)
   fprintf(f, "Use cdr3 column:   %s\n", o.cdr3 ? "Yes" : "No");
   fprintf(f, "Threads (t):       %ld\n", (long)o.threads);
   fprintf(f, "Output file (o):   %s\n", o.no_matrix ? "(none)" : o.output);
-  fprintf(f, "Output format (a): %s\n", o.alternative ? "Column" : "Matrix");
-  fprintf(f, "Score (s):         %s\n", score_description(o.score));
-  fprintf(f, "Pairs file (p):    %s\n", o.pairs ? o.pairs : "(none)");
-  fprintf(f, "Keep columns:      %s\n", o.keep_columns ? o.keep_columns : "");
+  if (!o.cluster) {
+    fprintf(f, "Output format (a): %s\n", o.alternative ? "Column" : "Matrix");
+    fprintf(f, "Score (s):         %s\n", score_description(o.score));
+    fprintf(f, "Pairs file (p):    %s\n", o.pairs ? o.pairs : "(none)");
+    fprintf(f, "Keep columns:      %s\n", o.keep_columns ? o.keep_columns : "");
+  }
   fprintf(f, "Log file (l):      %s\n", o.log ? o.log : "(stderr)");
   fprintf(f, "Backend:           %s\n", backend_name);
 }
@@ -211,12 +216,16 @@ void parse_command_line(int argc, char **argv, Options &o)
   }
 
   /* commands outside the hot path this build replaces */
-  if (o.cluster)
-    fatal("The -c / --cluster command is not part of the MI355X build (only -m / --matrix is).");
   if (o.deduplicate)
     fatal("The -z / --deduplicate command is not part of the MI355X build (only -m / --matrix is).");
 
-  if (o.existence) {
+  if (o.cluster) {
+    /* compairr.cc:601-611 */
+    if (optind + 1 == argc)
+      o.input1 = argv[optind];
+    else
+      fatal("Incorrect number of arguments. One input file must be specified.");
+  } else if (o.existence) {
     /* compairr.cc:589-600 */
     if (optind + 2 == argc) {
       o.input1 = argv[optind];
@@ -273,6 +282,16 @@ void parse_command_line(int argc, char **argv, Options &o)
     fatal("Differences specified with -d or -differences cannot be negative.");
   if (o.indels && o.differences != 1)
     fatal("Indels are only allowed when d=1");
+
+  if (o.cluster) {
+    /* compairr.cc:642-650 */
+    if (o.pairs)
+      fatal("Option -p or --pairs is not allowed with -c or --cluster");
+    if (o.alternative)
+      fatal("Option -a or --alternative is not allowed with -c or --cluster");
+    if (o.score_string)
+      fatal("Option -s or --score is not allowed with -c or --cluster");
+  }
 
   if (o.score_string) {
     o.score = -1;

@@ -2,9 +2,10 @@
  * options.h -- command line of the MI355X build of `compairr`.
  *
  * Same option table, defaults and validation rules as the reference program
- * (/root/reference/src/compairr.cc:292-706) for the options on the --matrix
- * path; commands and options outside that path are recognised and rejected
- * with a clear message instead of being silently ignored.
+ * (/root/reference/src/compairr.cc:292-706) for the commands built on the
+ * per-query loop (--matrix, --existence, --cluster); --deduplicate is
+ * recognised and rejected with a clear message instead of being silently
+ * ignored.
  */
 #ifndef COMPAIRR_AMD_OPTIONS_H
 #define COMPAIRR_AMD_OPTIONS_H
@@ -24,7 +25,7 @@ enum Score {
 struct Options {
   bool alternative = false;      /* -a */
   bool cdr3 = false;             /* --cdr3 */
-  bool cluster = false;          /* -c (not on this path) */
+  bool cluster = false;          /* -c */
   bool deduplicate = false;      /* -z (not on this path) */
   bool distance = false;         /* --distance */
   bool existence = false;        /* -x */

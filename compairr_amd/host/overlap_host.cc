@@ -4,6 +4,8 @@
  */
 #include "overlap_host.h"
 
+#include "cluster_host.h"
+
 #include <math.h>
 #include <string.h>
 #include <time.h>
@@ -143,6 +145,19 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   log_time(log, "Start time:        ");
   print_options(log, o, backend.name());
   fprintf(log, "\n");
+
+  if (o.cluster) {
+    /* compairr.cc:776-777 */
+    const int rc = run_cluster(o, backend, log, out);
+    if (rc == 0) {
+      fprintf(log, "\n");
+      log_time(log, "End time:          ");
+    }
+    fclose(out);
+    if (log != stderr)
+      fclose(log);
+    return rc;
+  }
 
   /* ---- read (overlap.cc:611-825) ---- */
   GeneTables genes;

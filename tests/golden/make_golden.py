@@ -102,6 +102,11 @@ def random_files():
         "tiny_aa_b.tsv": dict(n=100, seed=32, alphabet_size=20, letters=2, prefix="B"),
         "tiny_nt_a.tsv": dict(n=150, seed=41, alphabet_size=4, letters=2, max_len=7, prefix="A"),
         "tiny_nt_b.tsv": dict(n=130, seed=42, alphabet_size=4, letters=3, max_len=7, prefix="B"),
+        # dense neighbourhoods for -c: clusters of many sizes, long breadth-first chains
+        "clus_aa.tsv": dict(n=1500, seed=61, alphabet_size=20, letters=3, min_len=3, max_len=8,
+                            prefix="C"),
+        "clus_nt.tsv": dict(n=1200, seed=62, alphabet_size=4, letters=4, min_len=4, max_len=9,
+                            n_v=3, prefix="C"),
     }.items():
         n = kw.pop("n")
         seed = kw.pop("seed")
@@ -228,6 +233,27 @@ def cases():
         add("p_%s_d2_dist" % fam, ("-d 2 --distance" + n).strip(), [a, b], pairs=True)
         add("p_%s_d0_self" % fam, n.strip(), [a], pairs=True)
     add("p_x_aa_d1i", "-d 1 -i --distance", ["rand_x_aa.tsv", "rand_aa_b.tsv"], cmd="-x", pairs=True)
+    # (f) -c / --cluster: single-linkage clusters of ONE file; the order of the lines is the
+    #     reference's breadth-first order (cluster.cc:200-223, 376-452)
+    add("c_ref_seta_d1", "-d 1", ["seta.tsv"], cmd="-c")
+    add("c_ref_setb_d1i", "-d 1 -i", ["setb.tsv"], cmd="-c")
+    add("c_ref_setb_d2_nt_g", "-d 2 -n -g", ["setb.tsv"], cmd="-c")
+    add("c_dups_d0", "", ["dups.tsv"], cmd="-c")
+    add("c_indel_a_d1i", "-d 1 -i", ["indel_a.tsv"], cmd="-c")
+    add("c_noid_g", "-d 1 -g", ["nogenes.tsv"], "no sequence_id / gene columns", cmd="-c")
+    add("c_cdr3", "-d 1 --cdr3", ["cdr3.tsv"], cmd="-c")
+    for fam, nt in (("rand_aa_a", False), ("rand_nt_a", True), ("tiny_aa_a", False),
+                    ("tiny_nt_b", True), ("clus_aa", False), ("clus_nt", True)):
+        n = " -n" if nt else ""
+        for d in ("", "-d 1", "-d 1 -i", "-d 2"):
+            tag = d.replace("-", "").replace(" ", "") or "d0"
+            add("c_%s_%s" % (fam, tag), (d + n).strip(), [fam + ".tsv"], cmd="-c")
+        add("c_%s_d1i_g_t3" % fam, ("-d 1 -i -g -t 3" + n).strip(), [fam + ".tsv"], cmd="-c")
+        add("c_%s_d2_g" % fam, ("-d 2 -g" + n).strip(), [fam + ".tsv"], cmd="-c")
+    add("err_c_two_files", "-d 1", ["seta.tsv", "setb.tsv"], "exit 1", cmd="-c")
+    add("err_c_pairs", "-d 1", ["seta.tsv"], "exit 1", cmd="-c", pairs=True)
+    add("err_c_alternative", "-d 1 -a", ["seta.tsv"], "exit 1", cmd="-c")
+    add("err_c_score", "-d 1 -s min", ["seta.tsv"], "exit 1", cmd="-c")
     add("err_p_keep_without_pairs", "-d 1 -k sequence", ["seta.tsv", "setb.tsv"], "exit 1")
     add("err_p_keep_bad_list", "-d 1 -k a,,b", ["seta.tsv", "setb.tsv"], "exit 1", pairs=True)
     add("err_x_multi_rep", "-d 1", ["seta.tsv", "setb.tsv"], "exit 1", cmd="-x")

@@ -39,7 +39,8 @@ def test_help_and_version():
     (["-m", "seta.tsv", "-k", "x"], b"--keep-columns only allowed with --pairs"),
     (["-x", "seta.tsv"], b"Two input files must be specified"),
     (["-x", "setc.tsv", "setb.tsv", "-s", "MH"], b"only allowed when computing repertoire overlap"),
-    (["-c", "seta.tsv"], b"not part of the MI355X build"),
+    (["-c", "seta.tsv", "setb.tsv"], b"One input file must be specified"),
+    (["-c", "seta.tsv", "-p", "/dev/null"], b"not allowed with -c or --cluster"),
     (["-z", "seta.tsv"], b"not part of the MI355X build"),
     (["-m", "seta.tsv", "-p", "/dev/null", "-k", "a,,b"], b"Illegal list of columns"),
 ])
