@@ -620,7 +620,7 @@ probe_sliced_kernel(const ProbeParams P)
                 u[x] = x < p ? s[x] : s[x + 1]; one per run of equal residues.
                 Blocks of up to 32 positions: phase 1 rolls the hash and gathers
                 the filter words, phase 2 replays the roll for the positives. */
-        if (L > 1 && do_del) {
+        if (L > 1 && do_del && !(P.debug & DBG_SKIP_DEL_ROWS)) {
           const uint32_t dlen = cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hv = heavy_of(base ^ dlen);          /* is the variant's class split? */
           const uint32_t dl = dlen ^ cbase;
@@ -653,7 +653,7 @@ probe_sliced_kernel(const ProbeParams P)
 #pragma unroll
               for (uint32_t i = 0; i < MCR; i++)
                 dk ^= md[i] < p ? lo[i] : hi[i];
-              const uint32_t vslice = (W.tile_slice ^ dk) & W.smask;
+              const uint32_t vslice = valid ? (W.tile_slice ^ dk) & W.smask : sibling;
               const uint32_t woff = bloom_off(hd) & W.wmask_bytes;
               uint64_t word;
               if (vslice == sibling)
@@ -684,7 +684,7 @@ probe_sliced_kernel(const ProbeParams P)
 
         /* ---- insertions (variants.cc:329-353): u = s with v put in front of
                 position ip, u[x] = x < ip ? s[x] : x == ip ? v : s[x - 1] ---- */
-        if (do_ins) {
+        if (do_ins && !(P.debug & DBG_SKIP_INS_ROWS)) {
           nvar += (uint64_t)A + (uint64_t)(A - 1) * L;
           const uint32_t dlen = cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hv = heavy_of(base ^ dlen);
@@ -724,11 +724,14 @@ probe_sliced_kernel(const ProbeParams P)
               }
             const uint64_t zrow = zl[ZS * ip + zlane];
             /* rows that put v on a class position spread over up to A slices */
-            const bool in_lds = !(v_on_class_pos && hv) && ((W.tile_slice ^ dk0) & W.smask) == sibling;
+            /* (idle lanes of a partial tile count as in LDS: they must not drag the
+               wave through the HBM row) */
+            const bool in_lds = !valid || (!(v_on_class_pos && hv) &&
+                                           ((W.tile_slice ^ dk0) & W.smask) == sibling);
             uint32_t mask = 0;          /* bit v: residue v */
             uint32_t mask_o = 0;        /* bit k - 1: residue (r + k) mod A (row_lds_others) */
             const uint32_t zaddr = zl_addr + (ZS * ip + (ip > 0 ? r : 0u)) * 8u;
-            if (__ballot(in_lds)) {
+            if (__ballot(in_lds) && !(P.debug & DBG_SKIP_LDS_ROWS)) {
               if (A != 4 && ip > 0) {          /* (nucleotide rows are not stored twice) */
                 const uint32_t ml = row_lds_others<A>(W, hi_hash, zaddr);
                 mask_o = in_lds ? ml : 0u;
@@ -737,7 +740,7 @@ probe_sliced_kernel(const ProbeParams P)
                 mask = in_lds ? ml : 0u;
               }
             }
-            if (__ballot(!in_lds)) {
+            if (__ballot(!in_lds) && !(P.debug & DBG_SKIP_HBM_ROWS)) {
               if (!in_lds)
                 mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
             }

@@ -250,7 +250,7 @@ struct ProbeParams {
 
 /* ProbeParams::debug bits: timing experiments only, results become wrong */
 enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
-                  DBG_SKIP_LDS_ROWS = 8 };
+                  DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32 };
 
 enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
        STAT_COUNT = 4 };
