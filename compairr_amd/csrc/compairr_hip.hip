@@ -1356,7 +1356,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     if (c->sliced && !c->waves_per_block_forced && c->nchunks > 0 &&
         (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
       nw = 4;
-    size_t lds = (size_t)(c->sliced ? zrow_stride((int)A) : A) * c->zpos * sizeof(uint64_t) +
+    size_t lds = (size_t)(c->sliced ? zrow_stride((int)A) + zdelta_entries((int)A) : A) * c->zpos *
+                     sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)nw * sizeof(WaveQueue);
     if (c->sliced)

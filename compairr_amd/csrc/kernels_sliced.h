@@ -329,6 +329,7 @@ probe_sliced_kernel(const ProbeParams P)
 {
   constexpr uint32_t NT = NW * WAVE;
   constexpr uint32_t MCR = max_class_res(A);   /* unrolled class-residue loops */
+  constexpr uint32_t NTB = 10;                 /* nucleotide positions per block (3 mask bits each) */
   extern __shared__ __align__(16) unsigned char smem[];
   /* the Bloom slice sits at LDS address 0: its reads need no base add */
   uint64_t *slice_lds = (uint64_t *)smem;
@@ -340,7 +341,13 @@ probe_sliced_kernel(const ProbeParams P)
   const uint32_t nz = ZS * P.zpos;
   if ((uint32_t)(uintptr_t)smem != 0u)
     __builtin_trap();                       /* lds_u64 addresses the LDS absolutely */
-  unsigned long long *mat_all = (unsigned long long *)(zl + nz);
+  /* nucleotides: per position and residue r the keys {Z[r], Z[r]^Z[r+1], Z[r]^Z[r+2],
+     Z[r]^Z[r+3]} (residues mod 4): the hash of "r replaced by (r + k) & 3" is the
+     current hash ^ entry k, a read at constant offset from the lane's own entry */
+  constexpr uint32_t ZE = zdelta_entries(A);
+  uint64_t *ze = zl + nz;
+  const uint32_t nze = ZE * P.zpos;
+  unsigned long long *mat_all = (unsigned long long *)(ze + nze);
   const uint32_t cells = P.R1 * P.R2;
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
   uint32_t *cr_lds = (uint32_t *)(queues + NW);
@@ -350,6 +357,11 @@ probe_sliced_kernel(const ProbeParams P)
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
+  for (uint32_t i = threadIdx.x; i < nze; i += NT) {
+    const uint32_t pos = i / 16u, r = (i / 4u) & 3u, k = i & 3u;
+    const uint64_t own = P.zob[pos * 4u + r];
+    ze[i] = k ? own ^ P.zob[pos * 4u + ((r + k) & 3u)] : own;
+  }
   if (P.lds_matrix)
     for (uint32_t i = threadIdx.x; i < cells; i += NT)
       mat_all[i] = 0;
@@ -367,6 +379,7 @@ probe_sliced_kernel(const ProbeParams P)
             0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *gene_keys = P.zob + (uint32_t)A * P.zpos;
   const uint32_t zl_addr = slice_words * 8u;       /* LDS address of zl */
+  const uint32_t ze_addr = zl_addr + nz * 8u;      /* ... and of ze */
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
 
   /* Two kinds of work.  Block phase: chunks (several tiles that need the same
@@ -472,12 +485,44 @@ probe_sliced_kernel(const ProbeParams P)
 #pragma unroll
       for (uint32_t i = 0; i < MCR; i++)
         m[i] = class_pos(L, i, P.geom.c0);
+      /* ... as a bit set over the positions (two scalar registers): the test sits
+         in the innermost loops, where eight compares per position made the
+         scalar unit the bottleneck of the nucleotide kernels */
+      uint64_t cpos_lo = 0, cpos_hi = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < MCR; i++)
+        if (i < K) {
+          if (m[i] < 64u)
+            cpos_lo |= 1ull << m[i];
+          else if (m[i] < 128u)
+            cpos_hi |= 1ull << (m[i] - 64u);
+        }
+      const bool cpos_far = L > 128u;          /* (positions >= 128: the compare loop) */
       auto is_class_pos = [&](uint32_t p) -> bool {
+        if (!cpos_far)
+          return ((p < 64u ? cpos_lo >> p : cpos_hi >> (p - 64u)) & 1ull) != 0;
         bool c = false;
 #pragma unroll
         for (uint32_t i = 0; i < MCR; i++)
           c = c || (i < K && m[i] == p);
         return c;
+      };
+      /* class-position flags of the NTB positions from p0 on (bit j: position p0 + j) */
+      auto class_bits = [&](uint32_t p0) -> uint32_t {
+        if (cpos_far) {
+          uint32_t b = 0;
+          for (uint32_t j = 0; j < NTB; j++)
+            b |= is_class_pos(p0 + j) ? (1u << j) : 0u;
+          return b;
+        }
+        uint64_t x;
+        if (p0 == 0)
+          x = cpos_lo;
+        else if (p0 < 64u)
+          x = (cpos_lo >> p0) | (cpos_hi << (64u - p0));
+        else
+          x = p0 < 128u ? cpos_hi >> (p0 - 64u) : 0ull;
+        return (uint32_t)x & ((1u << NTB) - 1u);
       };
       /* class-key terms of position p: of residue `r` (per lane) and, as a
          row, of every replacement residue (lane v holds the term of v) */
@@ -504,58 +549,61 @@ probe_sliced_kernel(const ProbeParams P)
         nvar += (uint64_t)(A - 1) * Ll;
         rs.start(qr, L);
         if constexpr (A == 4) {
-          /* Nucleotides: a row has only 3 variants, so 16 positions are probed
+          /* Nucleotides: a row has only 3 variants, so NTB positions are probed
              per block -- the three OTHER residues of each lane, (r + k) & 3, so
              that no probe is wasted on the original -- and their positives
-             share one 48-bit mask and one compaction loop. */
-          for (uint32_t p0 = 0; p0 < L; p0 += 16) {
-            uint64_t mask = 0;
-#pragma unroll 2
-            for (uint32_t jj = 0; jj < 16; jj++) {
+             share one 30-bit mask and one compaction loop. */
+          for (uint32_t p0 = 0; p0 < L; p0 += NTB) {
+            uint32_t mask = 0;
+            const uint32_t n = L - p0 < NTB ? L - p0 : NTB;
+            const uint32_t cbits = class_bits(p0);
+            for (uint32_t jj = 0; jj < n; jj++) {
               const uint32_t p = p0 + jj;
-              if (p < L) {
-                const uint32_t r = rs.at(p);
+              const uint32_t r = rs.at(p);
+              uint32_t b3 = 0;
+              if (staged && !((cbits >> jj) & 1u)) {
+                const uint32_t eaddr = ze_addr + (16u * p + 4u * r) * 8u;
+#pragma unroll
+                for (uint32_t k = 1; k <= 3; k++) {
+                  const uint64_t hv = h ^ lds_u64(eaddr, (int)k);
+                  const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
+                  b3 |= bloom_hit(word, pattern_of(hv)) ? (1u << (k - 1)) : 0u;
+                }
+              } else if (!((cbits >> jj) & 1u)) {
                 const uint64_t *zp = zl + 4 * p;
                 const uint64_t h1 = h ^ zp[r];
-                const bool act = p < Ll;
-                if (!is_class_pos(p)) {
 #pragma unroll
-                  for (uint32_t k = 1; k <= 3; k++) {
-                    const uint64_t hv = h1 ^ zp[(r + k) & 3u];
-                    mask |= (act && probe_one_own(W, hv, staged)) ? (1ull << (3 * jj + k - 1)) : 0ull;
-                  }
-                } else {
-                  uint32_t crow;
-                  const uint32_t dk_r = class_terms(p, r, crow);
-                  uint64_t word[3];
+                for (uint32_t k = 1; k <= 3; k++)
+                  b3 |= probe_one_own(W, h1 ^ zp[(r + k) & 3u], false) ? (1u << (k - 1)) : 0u;
+              } else {
+                const uint64_t *zp = zl + 4 * p;
+                const uint64_t h1 = h ^ zp[r];
+                uint32_t crow;
+                const uint32_t dk_r = class_terms(p, r, crow);
+                uint64_t word[3];
 #pragma unroll
-                  for (uint32_t k = 1; k <= 3; k++) {
-                    const uint32_t v = (r + k) & 3u;
-                    uint32_t dk_v;
-                    (void)crow;
-                    dk_v = class_terms(p, v, crow);
-                    word[k - 1] = *hbm_word(W, h1 ^ zp[v], dk_r ^ dk_v);
-                  }
-#pragma unroll
-                  for (uint32_t k = 1; k <= 3; k++) {
-                    const uint64_t hv = h1 ^ zp[(r + k) & 3u];
-                    mask |= (act && bloom_hit(word[k - 1], pattern_of(hv)))
-                                ? (1ull << (3 * jj + k - 1)) : 0ull;
-                  }
+                for (uint32_t k = 1; k <= 3; k++) {
+                  const uint32_t v = (r + k) & 3u;
+                  const uint32_t dk_v = class_terms(p, v, crow);
+                  word[k - 1] = *hbm_word(W, h1 ^ zp[v], dk_r ^ dk_v);
                 }
+#pragma unroll
+                for (uint32_t k = 1; k <= 3; k++)
+                  b3 |= bloom_hit(word[k - 1], pattern_of(h1 ^ zp[(r + k) & 3u])) ? (1u << (k - 1)) : 0u;
               }
+              mask |= (p < Ll ? b3 : 0u) << (3u * jj);
             }
             if (!valid || (P.debug & DBG_SKIP_EMIT))
               mask = 0;
             while (__ballot(mask != 0)) {
               const bool pos = mask != 0;
-              const uint32_t b = pos ? (uint32_t)__ffsll((long long)mask) - 1u : 0u;
+              const uint32_t b = pos ? (uint32_t)__ffs((int)mask) - 1u : 0u;
               const uint32_t p = p0 + b / 3u;
               const uint32_t r = res_at(p < L ? p : 0);
-              const uint32_t v = (r + b % 3u + 1u) & 3u;
-              const uint64_t hv = h ^ zl[4 * p + r] ^ zl[4 * p + v];
-              s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
-              mask &= mask - 1ull;
+              const uint32_t k = b % 3u + 1u;
+              const uint64_t hv = h ^ ze[16u * p + 4u * r + k];
+              s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, (r + k) & 3u), 0);
+              mask &= mask - 1u;
             }
           }
         } else
@@ -760,65 +808,76 @@ probe_sliced_kernel(const ProbeParams P)
         if constexpr (A == 4) {
           /* Nucleotides: both substitutions enumerate the three OTHER residues of
              the lane ((r + k) & 3), so none of the 9 (instead of 16) probes per
-             position pair is masked; the second position runs in blocks of 16
-             that share one 48-bit mask and one compaction loop. */
+             position pair is masked; the second position runs in blocks of NTB
+             that share one 30-bit mask and one compaction loop. */
           for (uint32_t p = 0; p + 1 < L; p++) {
             const uint32_t rp = res_at(p);
-            const uint64_t hp = h ^ zl[4 * p + rp];
             const bool cp = is_class_pos(p);
             uint32_t crow_unused;
             const uint32_t dk_rp = cp ? class_terms(p, rp, crow_unused) : 0u;
+            const bool fast = staged && !cp;       /* wave-uniform */
 #pragma unroll 1
             for (uint32_t kp = 1; kp <= 3; kp++) {
               const uint32_t vp = (rp + kp) & 3u;
-              const uint64_t hpv = hp ^ zl[4 * p + vp];
+              const uint64_t hpv = h ^ ze[16u * p + 4u * rp + kp];
               const uint32_t ca = pack_a(K_SUB2, p, vp);
               const uint32_t dk_pv = cp ? (dk_rp ^ class_terms(p, vp, crow_unused)) : 0u;
-              for (uint32_t q0 = p + 1; q0 < L; q0 += 16) {
-                uint64_t mask = 0;
+              for (uint32_t q0 = p + 1; q0 < L; q0 += NTB) {
+                uint32_t mask = 0;
                 uint32_t w = 0;
-#pragma unroll 2
-                for (uint32_t jj = 0; jj < 16; jj++) {
+                const uint32_t n = L - q0 < NTB ? L - q0 : NTB;
+                const uint32_t cbits = class_bits(q0);
+                for (uint32_t jj = 0; jj < n; jj++) {
                   const uint32_t qq = q0 + jj;
-                  if (qq < L) {
-                    if ((qq & 3u) == 0 || jj == 0)
-                      w = qr[(qq >> 2) * WAVE];
-                    const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
+                  if ((qq & 3u) == 0 || jj == 0)
+                    w = qr[(qq >> 2) * WAVE];
+                  const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
+                  const bool cq = ((cbits >> jj) & 1u) != 0;
+                  uint32_t b3 = 0;
+                  if (fast && !cq) {
+                    const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
+                    if (!(P.debug & DBG_SKIP_LDS_ROWS))
+#pragma unroll
+                    for (uint32_t k = 1; k <= 3; k++) {
+                      const uint64_t hv = hpv ^ lds_u64(eaddr, (int)k);
+                      const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
+                      b3 |= bloom_hit(word, pattern_of(hv)) ? (1u << (k - 1)) : 0u;
+                    }
+                  } else if (!cp && !cq) {
                     const uint64_t *zq = zl + 4 * qq;
                     const uint64_t hq = hpv ^ zq[rq];
-                    const bool act = qq < Ll;            /* implies p < Ll */
-                    if (!cp && !is_class_pos(qq)) {
 #pragma unroll
-                      for (uint32_t k = 1; k <= 3; k++)
-                        mask |= (act && probe_one_own(W, hq ^ zq[(rq + k) & 3u], staged))
-                                    ? (1ull << (3 * jj + k - 1)) : 0ull;
-                    } else {
-                      const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
-                      uint64_t word[3];
+                    for (uint32_t k = 1; k <= 3; k++)
+                      b3 |= probe_one_own(W, hq ^ zq[(rq + k) & 3u], false) ? (1u << (k - 1)) : 0u;
+                  } else if (!(P.debug & DBG_SKIP_HBM_ROWS)) {
+                    const uint64_t *zq = zl + 4 * qq;
+                    const uint64_t hq = hpv ^ zq[rq];
+                    const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
+                    uint64_t word[3];
 #pragma unroll
-                      for (uint32_t k = 1; k <= 3; k++) {
-                        const uint32_t x = (rq + k) & 3u;
-                        word[k - 1] = *hbm_word(W, hq ^ zq[x],
-                                                dk_pv ^ dk_rq ^ class_terms(qq, x, crow_unused));
-                      }
-#pragma unroll
-                      for (uint32_t k = 1; k <= 3; k++)
-                        mask |= (act && bloom_hit(word[k - 1], pattern_of(hq ^ zq[(rq + k) & 3u])))
-                                    ? (1ull << (3 * jj + k - 1)) : 0ull;
+                    for (uint32_t k = 1; k <= 3; k++) {
+                      const uint32_t x = (rq + k) & 3u;
+                      word[k - 1] = *hbm_word(W, hq ^ zq[x],
+                                              dk_pv ^ dk_rq ^ class_terms(qq, x, crow_unused));
                     }
+#pragma unroll
+                    for (uint32_t k = 1; k <= 3; k++)
+                      b3 |= bloom_hit(word[k - 1], pattern_of(hq ^ zq[(rq + k) & 3u]))
+                                ? (1u << (k - 1)) : 0u;
                   }
+                  mask |= (qq < Ll ? b3 : 0u) << (3u * jj);       /* qq < Ll implies p < Ll */
                 }
                 if (!valid || (P.debug & DBG_SKIP_EMIT))
                   mask = 0;
                 while (__ballot(mask != 0)) {
                   const bool pos = mask != 0;
-                  const uint32_t b = pos ? (uint32_t)__ffsll((long long)mask) - 1u : 0u;
+                  const uint32_t b = pos ? (uint32_t)__ffs((int)mask) - 1u : 0u;
                   const uint32_t qq = q0 + b / 3u;
                   const uint32_t rq = res_at(qq < L ? qq : 0);
-                  const uint32_t x = (rq + b % 3u + 1u) & 3u;
-                  const uint64_t hv = hpv ^ zl[4 * qq + rq] ^ zl[4 * qq + x];
-                  s_push<GENES>(W, pos, hv, ca, qq | (x << 24));
-                  mask &= mask - 1ull;
+                  const uint32_t k = b % 3u + 1u;
+                  const uint64_t hv = hpv ^ ze[16u * qq + 4u * rq + k];
+                  s_push<GENES>(W, pos, hv, ca, qq | (((rq + k) & 3u) << 24));
+                  mask &= mask - 1u;
                 }
               }
             }

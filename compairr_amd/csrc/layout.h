@@ -151,6 +151,13 @@ __host__ __device__ constexpr uint32_t zrow_stride(int A)
   return A == 4 ? 4u : 2u * (uint32_t)A;
 }
 
+/* entries per position of the nucleotide kernels' second LDS table (kernels_sliced.h):
+   4 residues x {own key, 3 replacement deltas} */
+__host__ __device__ constexpr uint32_t zdelta_entries(int A)
+{
+  return A == 4 ? 16u : 0u;
+}
+
 /* A Bloom-positive variant waiting for its hash-table walk */
 struct PosEntry {
   uint64_t hash;
