@@ -524,6 +524,7 @@ probe_sliced_kernel(const ProbeParams P)
           x = p0 < 128u ? cpos_hi >> (p0 - 64u) : 0ull;
         return (uint32_t)x & ((1u << NTB) - 1u);
       };
+      auto class_bits8 = [&](uint32_t p0) -> uint32_t { return class_bits(p0) & 0xffu; };
       /* class-key terms of position p: of residue `r` (per lane) and, as a
          row, of every replacement residue (lane v holds the term of v) */
       auto class_terms = [&](uint32_t p, uint32_t r, uint32_t &crow) -> uint32_t {
@@ -822,16 +823,19 @@ probe_sliced_kernel(const ProbeParams P)
               const uint64_t hpv = h ^ ze[16u * p + 4u * rp + kp];
               const uint32_t ca = pack_a(K_SUB2, p, vp);
               const uint32_t dk_pv = cp ? (dk_rp ^ class_terms(p, vp, crow_unused)) : 0u;
-              for (uint32_t q0 = p + 1; q0 < L; q0 += NTB) {
+              /* second position in blocks of 8 aligned positions = two residue dwords
+                 per lane, loaded together (one wait per 24 probes, not one per position) */
+              for (uint32_t q0 = (p + 1) & ~7u; q0 < L; q0 += 8) {
                 uint32_t mask = 0;
-                uint32_t w = 0;
-                const uint32_t n = L - q0 < NTB ? L - q0 : NTB;
-                const uint32_t cbits = class_bits(q0);
-                for (uint32_t jj = 0; jj < n; jj++) {
+                const uint32_t cbits = class_bits8(q0);
+                const uint32_t w0 = qr[(q0 >> 2) * WAVE];
+                const uint32_t w1 = q0 + 4 < L ? qr[((q0 >> 2) + 1) * WAVE] : 0u;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; jj++) {
                   const uint32_t qq = q0 + jj;
-                  if ((qq & 3u) == 0 || jj == 0)
-                    w = qr[(qq >> 2) * WAVE];
-                  const uint32_t rq = (w >> ((qq & 3u) * 8)) & 0xffu;
+                  if (qq <= p || qq >= L)
+                    continue;                              /* wave-uniform */
+                  const uint32_t rq = ((jj < 4 ? w0 : w1) >> ((jj & 3u) * 8)) & 0xffu;
                   const bool cq = ((cbits >> jj) & 1u) != 0;
                   uint32_t b3 = 0;
                   if (fast && !cq) {
