@@ -9,7 +9,9 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
+#include <thread>
 
 #include "compairr_hip.h"
 
@@ -77,8 +79,6 @@ public:
                const RepertoireSet &set2, bool same, std::vector<double> &cells,
                BackendReport &rep, std::string &error, PairList *pairs) override
   {
-    pairs_ = pairs;
-    same_ = same;
     cmpr_options co;
     memset(&co, 0, sizeof co);
     co.differences = (int32_t)std::min<int64_t>(o.differences, INT32_MAX);
@@ -92,50 +92,165 @@ public:
     co.device = (int32_t)o.device;
     co.existence = o.existence;
 
+    const cmpr_set_view v1 = view_of(set1), v2 = view_of(set2);
+    if (o.devices.size() <= 1) {
+      if (o.devices.size() == 1)
+        co.device = o.devices[0];
+      Shard sh;
+      sh.first = 0;
+      sh.view = v1;
+      sh.cells = &cells;
+      sh.pairs = pairs;
+      return run(co, sh, v1, v2, set1.longest, same, true, rep, error);
+    }
+
+    /* ---- several GPUs: the queries are cut into one contiguous
+            shard per listed device, every device builds the whole set-2 index,
+            one host thread drives each; the matrices are integer-valued sums
+            (exact in double below 2^53), so adding them gives the same cells as
+            one device.  -x rows belong to the queries: they are placed, not
+            added.  Pairs are concatenated. ---- */
+    const size_t G = o.devices.size();
+    const uint64_t n = set1.size();
+    const size_t R2 = set2.repertoires.names.size();
+    std::vector<Shard> shards(G);
+    std::vector<std::vector<double> > shard_cells(G);
+    std::vector<std::vector<uint64_t> > shard_offsets(G);
+    std::vector<PairList> shard_pairs(G);
+    std::vector<BackendReport> reports(G);
+    std::vector<std::string> errors(G);
+    std::vector<char> ok(G, 0);
+    /* balance by residues: variants per query grow with the length */
+    const uint64_t total_res = set1.residue_count();
+    uint64_t at = 0;
+    for (size_t g = 0; g < G; g++) {
+      uint64_t end = n;
+      if (g + 1 < G) {
+        const uint64_t want = total_res / G * (g + 1);
+        end = (uint64_t)(std::upper_bound(set1.offsets.begin(), set1.offsets.end(), want) -
+                         set1.offsets.begin());
+        end = std::min<uint64_t>(std::max<uint64_t>(end, at), n);
+      }
+      Shard &sh = shards[g];
+      sh.first = at;
+      shard_offsets[g].resize(end - at + 1);
+      for (uint64_t i = at; i <= end; i++)
+        shard_offsets[g][i - at] = set1.offsets[i] - set1.offsets[at];
+      sh.view = v1;
+      sh.view.n = end - at;
+      sh.view.residues = v1.residues + set1.offsets[at];
+      sh.view.offsets = shard_offsets[g].data();
+      sh.view.v_gene = v1.v_gene + at;
+      sh.view.j_gene = v1.j_gene + at;
+      sh.view.repertoire = v1.repertoire + at;
+      sh.view.count = v1.count + at;
+      shard_cells[g].assign(o.existence ? (size_t)(end - at) * R2 : cells.size(), 0.0);
+      sh.cells = &shard_cells[g];
+      sh.pairs = pairs ? &shard_pairs[g] : nullptr;
+      at = end;
+    }
+    std::vector<std::thread> threads;
+    for (size_t g = 0; g < G; g++)
+      threads.emplace_back([&, g]() {
+        cmpr_options cg = co;
+        cg.device = o.devices[g];
+        ok[g] = run(cg, shards[g], v1, v2, set1.longest, same, g == 0, reports[g], errors[g]);
+      });
+    for (std::thread &t : threads)
+      t.join();
+    for (size_t g = 0; g < G; g++)
+      if (!ok[g]) {
+        error = "device " + std::to_string(o.devices[g]) + ": " + errors[g];
+        return false;
+      }
+    rep = reports[0];
+    for (size_t g = 0; g < G; g++) {
+      if (o.existence)
+        std::copy(shard_cells[g].begin(), shard_cells[g].end(),
+                  cells.begin() + (size_t)shards[g].first * R2);
+      else
+        for (size_t k = 0; k < cells.size(); k++)
+          cells[k] += shard_cells[g][k];
+      if (g > 0) {
+        rep.seconds_index = std::max(rep.seconds_index, reports[g].seconds_index);
+        rep.seconds_queries = std::max(rep.seconds_queries, reports[g].seconds_queries);
+        rep.seconds_analysis = std::max(rep.seconds_analysis, reports[g].seconds_analysis);
+        rep.kernel_ms = std::max(rep.kernel_ms, reports[g].kernel_ms);
+        rep.variants += reports[g].variants;
+        rep.bloom_positive += reports[g].bloom_positive;
+        rep.hash_equal += reports[g].hash_equal;
+        rep.matches += reports[g].matches;
+        rep.algorithmic_bytes += reports[g].algorithmic_bytes;
+      }
+      if (pairs) {
+        for (size_t k = 0; k < shard_pairs[g].seed.size(); k++) {
+          pairs->seed.push_back(shard_pairs[g].seed[k] + (uint32_t)shards[g].first);
+          pairs->hit.push_back(shard_pairs[g].hit[k]);
+        }
+      }
+    }
+    rep.device_name = std::to_string(G) + " HIP devices";
+    return true;
+  }
+
+private:
+  /* the part of set 1 one device works on */
+  struct Shard {
+    uint64_t first = 0;                 /* number of its first query in set 1 */
+    cmpr_set_view view;
+    std::vector<double> *cells = nullptr;
+    PairList *pairs = nullptr;
+  };
+
+  bool run(const cmpr_options &co, const Shard &sh, const cmpr_set_view &v1_all,
+           const cmpr_set_view &v2, uint32_t longest_query, bool same, bool count_dups,
+           BackendReport &rep, std::string &error) const
+  {
     cmpr_context *ctx = nullptr;
     if (api_.create(&co, &ctx)) {
       error = api_.last_error(nullptr);
       return false;
     }
-    bool ok = run(ctx, set1, set2, cells, rep, error);
+    const bool ok = run_on(ctx, sh, v1_all, v2, longest_query, same, count_dups, rep, error);
     api_.destroy(ctx);
     return ok;
   }
 
-private:
-  bool run(cmpr_context *ctx, const RepertoireSet &set1, const RepertoireSet &set2,
-           std::vector<double> &cells, BackendReport &rep, std::string &error)
+  bool run_on(cmpr_context *ctx, const Shard &sh, const cmpr_set_view &v1_all,
+              const cmpr_set_view &v2, uint32_t longest_query, bool same, bool count_dups,
+              BackendReport &rep, std::string &error) const
   {
-    const cmpr_set_view v1 = view_of(set1), v2 = view_of(set2);
     auto t0 = std::chrono::steady_clock::now();
-    if (api_.set_reference(ctx, &v2, set1.longest)) {
+    if (api_.set_reference(ctx, &v2, longest_query)) {
       error = api_.last_error(ctx);
       return false;
     }
     /* duplicate warnings: set 2 from the resident index; set 1 only when it is a
        different file (check_duplicates, overlap.cc:846-851) */
-    uint64_t dups = 0;
-    if (api_.count_duplicates(ctx, nullptr, &dups)) {
-      error = api_.last_error(ctx);
-      return false;
-    }
-    rep.dup_set2 = dups;
-    if (!same_) {
-      if (api_.count_duplicates(ctx, &v1, &dups)) {
+    if (count_dups) {
+      uint64_t dups = 0;
+      if (api_.count_duplicates(ctx, nullptr, &dups)) {
         error = api_.last_error(ctx);
         return false;
       }
-      rep.dup_set1 = dups;
+      rep.dup_set2 = dups;
+      if (!same) {
+        if (api_.count_duplicates(ctx, &v1_all, &dups)) {
+          error = api_.last_error(ctx);
+          return false;
+        }
+        rep.dup_set1 = dups;
+      }
     }
     rep.seconds_index = since(t0);
     t0 = std::chrono::steady_clock::now();
-    if (api_.set_queries(ctx, &v1)) {
+    if (api_.set_queries(ctx, &sh.view)) {
       error = api_.last_error(ctx);
       return false;
     }
     rep.seconds_queries = since(t0);
     t0 = std::chrono::steady_clock::now();
-    if (api_.overlap_matrix_f64(ctx, cells.data())) {
+    if (api_.overlap_matrix_f64(ctx, sh.cells->data())) {
       error = api_.last_error(ctx);
       return false;
     }
@@ -150,12 +265,12 @@ private:
       rep.algorithmic_bytes = st.algorithmic_bytes;
     }
     rep.device_name = "HIP device";
-    if (pairs_) {
+    if (sh.pairs) {
       /* the matrix pass counted the pairs exactly; list them with a second pass */
       uint64_t n = rep.matches, got = 0;
-      pairs_->seed.resize(n);
-      pairs_->hit.resize(n);
-      if (api_.overlap_pairs(ctx, n, pairs_->seed.data(), pairs_->hit.data(), &got)) {
+      sh.pairs->seed.resize(n);
+      sh.pairs->hit.resize(n);
+      if (api_.overlap_pairs(ctx, n, sh.pairs->seed.data(), sh.pairs->hit.data(), &got)) {
         error = api_.last_error(ctx);
         return false;
       }
@@ -168,8 +283,6 @@ private:
   }
 
   Api api_;
-  bool same_ = false;
-  PairList *pairs_ = nullptr;
 };
 
 }  // namespace

@@ -61,6 +61,7 @@ void print_usage(FILE *f)
   fprintf(f, " -u, --ignore-unknown        ignore sequences with unknown symbols\n");
   fprintf(f, " -e, --ignore-empty          ignore empty sequences\n");
   fprintf(f, "     --device INTEGER        HIP device to run on (current device*)\n");
+  fprintf(f, "     --devices LIST          comma-separated HIP devices; queries are sharded over them\n");
   fprintf(f, "\nInput/output options:\n");
   fprintf(f, " -a, --alternative           output results in three-column format, not matrix\n");
   fprintf(f, "     --cdr3                  use the cdr3(_aa) column instead of junction(_aa)\n");
@@ -122,7 +123,7 @@ static int64_t numeric_argument(const char *str, const char *option)
 void parse_command_line(int argc, char **argv, Options &o)
 {
   static const char short_options[] = "acd:efghik:l:mno:p:s:t:uvxz";
-  enum { LONG_CDR3 = 1000, LONG_DISTANCE, LONG_NO_MATRIX, LONG_DEVICE };
+  enum { LONG_CDR3 = 1000, LONG_DISTANCE, LONG_NO_MATRIX, LONG_DEVICE, LONG_DEVICES };
   static const struct option long_options[] = {
       {"alternative", no_argument, nullptr, 'a'},
       {"cdr3", no_argument, nullptr, LONG_CDR3},
@@ -149,6 +150,7 @@ void parse_command_line(int argc, char **argv, Options &o)
       {"existence", no_argument, nullptr, 'x'},
       {"deduplicate", no_argument, nullptr, 'z'},
       {"device", required_argument, nullptr, LONG_DEVICE},
+      {"devices", required_argument, nullptr, LONG_DEVICES},
       {nullptr, 0, nullptr, 0}};
 
   bool seen[26] = {false};
@@ -195,6 +197,24 @@ void parse_command_line(int argc, char **argv, Options &o)
     case LONG_DISTANCE: o.distance = true; break;
     case LONG_NO_MATRIX: o.no_matrix = true; break;
     case LONG_DEVICE: o.device = numeric_argument(optarg, "--device"); break;
+    case LONG_DEVICES: {
+      /* comma-separated device ordinals; the same ordinal may be listed twice */
+      o.devices.clear();
+      std::string cur;
+      for (const char *q = optarg;; q++) {
+        if (*q == ',' || *q == 0) {
+          o.devices.push_back((int)numeric_argument(cur.c_str(), "--devices"));
+          if (cur.empty() || o.devices.back() < 0)
+            fatal("Argument to --devices must be a comma-separated list of device numbers");
+          cur.clear();
+          if (*q == 0)
+            break;
+        } else {
+          cur.push_back(*q);
+        }
+      }
+      break;
+    }
     default:
       print_header(stderr);
       print_usage(stderr);

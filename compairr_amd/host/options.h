@@ -49,6 +49,8 @@ struct Options {
   int64_t score = SCORE_PRODUCT;
   int64_t threads = 1;           /* -t (host threads; the loop runs on the GPU) */
   int64_t device = -1;           /* --device N: HIP device ordinal (addition) */
+  std::vector<int> devices;      /* --devices A,B,..: one shard of the queries per
+                                    listed device (addition) */
 
   const char *input1 = nullptr;
   const char *input2 = nullptr;

@@ -45,9 +45,9 @@ def load_manifest():
         return json.load(fh)
 
 
-def run_cli(binary, case, timeout=120, log=None, pairs=None):
+def run_cli(binary, case, timeout=120, log=None, pairs=None, extra=()):
     argv = [os.path.join(ROOT, binary), case.get("cmd", "-m")] + case["files"] + \
-           case["args"].split() + ["-l", log or os.devnull]
+           case["args"].split() + list(extra) + ["-l", log or os.devnull]
     if case.get("pairs"):
         argv += ["-p", pairs or os.devnull]
     return subprocess.run(argv, cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,

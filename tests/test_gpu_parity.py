@@ -116,6 +116,27 @@ def test_cli_matches_reference_golden(case, tmp_path):
     assert p.stdout == expected_of(case)
 
 
+# ---- several devices through the product binary: the query shards of
+#      --devices are independent contexts, here all on device 0 ----
+
+SHARDED = [c for c in CASES if c["exit"] == 0 and "ratio" not in c["args"] and "-d 3" not in c["args"]
+           and (c["name"].startswith(("rand_aa_d1", "tiny_nt_d2", "x_aa_d1", "x_nt_d2", "x_readme", "p_x_", "p_rand_nt", "p_tiny_aa",
+                                      "c_clus_aa_d1", "c_clus_nt_d2", "edge_dups", "ref_test_sh")))]
+
+
+@pytest.mark.parametrize("case", SHARDED, ids=[c["name"] for c in SHARDED])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+def test_cli_sharded_over_devices(case, devices, tmp_path):
+    log = str(tmp_path / "log.txt")
+    pairs = str(tmp_path / "pairs.tsv")
+    p = run_cli("bin/compairr", case, log=log, pairs=pairs, extra=["--devices", devices])
+    assert p.returncode == 0, p.stderr.decode()
+    assert warnings_of(log) == case["warnings"]
+    if case.get("pairs"):
+        assert sorted_pairs(pairs) == expected_pairs_of(case)
+    assert p.stdout == expected_of(case)
+
+
 # ---- HIP vs oracle on seeded inputs, option matrix ----
 
 @pytest.mark.parametrize("d,indels", [(0, False), (1, False), (1, True), (2, False)])
