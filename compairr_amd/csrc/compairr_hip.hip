@@ -1441,7 +1441,7 @@ extern "C" int cmpr_overlap_matrix(cmpr_context *c, uint64_t *out)
   int rc = check_ready(c);
   if (rc)
     return rc;
-  if (!out)
+  if (!out && (size_t)c->R1 * c->R2 > 0)
     return fail(c, CMPR_EINVAL, "matrix_out is NULL");
   if (is_f64_score(c->opt))
     return fail(c, CMPR_EINVAL, "ratio score needs cmpr_overlap_matrix_f64");
@@ -1463,7 +1463,7 @@ extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)
   int rc = check_ready(c);
   if (rc)
     return rc;
-  if (!out)
+  if (!out && (size_t)c->R1 * c->R2 > 0)
     return fail(c, CMPR_EINVAL, "matrix_out is NULL");
   rc = enqueue_overlap(c, c->matrix.p, c->stream);
   if (rc)

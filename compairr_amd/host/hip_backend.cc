@@ -149,13 +149,27 @@ public:
       sh.pairs = pairs ? &shard_pairs[g] : nullptr;
       at = end;
     }
-    std::vector<std::thread> threads;
+    /* empty shards (fewer queries than devices) have nothing to do; the first
+       shard that runs also counts the duplicates */
+    size_t first_busy = G;
     for (size_t g = 0; g < G; g++)
+      if (shards[g].view.n > 0 && first_busy == G)
+        first_busy = g;
+    if (first_busy == G)
+      first_busy = 0;                      /* empty set 1: shard 0 reports the index only */
+    std::vector<std::thread> threads;
+    for (size_t g = 0; g < G; g++) {
+      if (shards[g].view.n == 0 && g != first_busy) {
+        ok[g] = 1;
+        continue;
+      }
       threads.emplace_back([&, g]() {
         cmpr_options cg = co;
         cg.device = o.devices[g];
-        ok[g] = run(cg, shards[g], v1, v2, set1.longest, same, g == 0, reports[g], errors[g]);
+        ok[g] = run(cg, shards[g], v1, v2, set1.longest, same, g == first_busy, reports[g],
+                    errors[g]);
       });
+    }
     for (std::thread &t : threads)
       t.join();
     for (size_t g = 0; g < G; g++)
@@ -163,7 +177,7 @@ public:
         error = "device " + std::to_string(o.devices[g]) + ": " + errors[g];
         return false;
       }
-    rep = reports[0];
+    rep = reports[first_busy];
     for (size_t g = 0; g < G; g++) {
       if (o.existence)
         std::copy(shard_cells[g].begin(), shard_cells[g].end(),
@@ -171,7 +185,7 @@ public:
       else
         for (size_t k = 0; k < cells.size(); k++)
           cells[k] += shard_cells[g][k];
-      if (g > 0) {
+      if (g != first_busy) {
         rep.seconds_index = std::max(rep.seconds_index, reports[g].seconds_index);
         rep.seconds_queries = std::max(rep.seconds_queries, reports[g].seconds_queries);
         rep.seconds_analysis = std::max(rep.seconds_analysis, reports[g].seconds_analysis);
