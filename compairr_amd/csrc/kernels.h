@@ -51,43 +51,64 @@ __host__ __device__ __forceinline__ uint64_t table_key(uint64_t h)
   return h == EMPTY_KEY ? (h ^ 1ull) : h;
 }
 
-/* 1u << ((a >> 8) & 31) in ONE instruction: the shifter takes its amount from
-   byte 1 of the register (SDWA operand select) and ignores all but 5 bits */
-__device__ __forceinline__ uint32_t one_shl_byte1(uint32_t a)
+/* 1u << ((a >> 8 * BYTE) & 31) in ONE instruction: the shifter takes its amount
+   from a byte of the register (SDWA operand select) and ignores all but 5 bits */
+template <int BYTE>
+__device__ __forceinline__ uint32_t one_shl_byte(uint32_t a)
 {
   uint32_t d;
   const uint32_t one = 1u;
   /* not convergent: plain per-lane arithmetic (lets loops around it unroll) */
   [[clang::noconvergent]] {
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 "
-        "src1_sel:DWORD"
-        : "=v"(d)
-        : "v"(a), "v"(one));
+    if (BYTE == 1)
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 "
+          "src1_sel:DWORD" : "=v"(d) : "v"(a), "v"(one));
+    else if (BYTE == 2)
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 "
+          "src1_sel:DWORD" : "=v"(d) : "v"(a), "v"(one));
+    else
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 "
+          "src1_sel:DWORD" : "=v"(d) : "v"(a), "v"(one));
   }
   return d;
 }
 
-/* Bit pattern of a hash, computed, not looked up: two bits of the low dword of
-   the filter word picked by hash bits [0,5) and [8,13), two bits of the high
-   dword picked by hash bits [32,37) and [40,45) -- four shifts whose amounts
-   are bytes of the hash as they lie in the registers (4 instructions).  (The
+/* Bit pattern of a hash, computed, not looked up: the low 5 bits of the four
+   bytes of the hash's LOW dword pick two bits of the low dword of the filter
+   word (bytes 0, 1) and two of its high dword (bytes 2, 3) -- four shifts whose
+   amounts are bytes of the register as it lies (4 instructions).  (The
    reference reads one of 1024 precomputed 8-bit patterns, bloompat.h:45-48; at
    the >= 32 filter bits per key this build uses, 4 bits from a 2^20 pattern
    space give a lower false-positive rate than 8 bits from a 2^10 space, and
    cost two random LDS reads less per probe.) */
 __device__ __forceinline__ uint64_t pattern_of(uint64_t h)
 {
-  const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
-  const uint32_t lo = (1u << (a & 31u)) | one_shl_byte1(a);
-  const uint32_t hi = (1u << (b & 31u)) | one_shl_byte1(b);
+  const uint32_t a = (uint32_t)h;
+  const uint32_t lo = (1u << (a & 31u)) | one_shl_byte<1>(a);
+  const uint32_t hi = one_shl_byte<2>(a) | one_shl_byte<3>(a);
   return ((uint64_t)hi << 32) | lo;
 }
 
+/* the same pattern as the pieces the probe's test wants (kernels_sliced.h bloom_miss) */
+struct BloomPat {
+  uint32_t lo;        /* both bits of the word's low dword  */
+  uint32_t s2, s3;    /* the two bits of its high dword     */
+};
+__device__ __forceinline__ BloomPat pattern_fields(uint64_t h)
+{
+  const uint32_t a = (uint32_t)h;
+  BloomPat p;
+  p.lo = (1u << (a & 31u)) | one_shl_byte<1>(a);
+  p.s2 = one_shl_byte<2>(a);
+  p.s3 = one_shl_byte<3>(a);
+  return p;
+}
+
 /* Byte offset of a hash's filter word before masking to the filter (or slice)
-   size: hash bits from 13 up, clear of the low-dword pattern bits */
+   size: the HIGH dword as it lies (one AND per probe, no shift) */
 __device__ __forceinline__ uint32_t bloom_off(uint64_t h)
 {
-  return (uint32_t)(h >> 10);
+  return (uint32_t)(h >> 32);
 }
 
 __device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)

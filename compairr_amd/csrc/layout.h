@@ -25,8 +25,8 @@ constexpr uint32_t EXTRA_POSITIONS   = 3;
    (keys per word) / 1024; this build sets 4 bits per key computed directly from
    20 hash bits (kernels.h pattern_of): a 2^20 pattern space and no table. */
 constexpr uint32_t PATTERN_BITS      = 10;     /* per dword of the word: hash bits [0,5)
-                                                  and [8,13) / [32,37) and [40,45); the
-                                                  word address starts at bit 13      */
+                                                  and [8,13) / [16,21) and [24,29); the
+                                                  word address is taken from bit 35 up */
 constexpr uint32_t PATTERN_K         = 4;
 
 /* Open-addressing table: 64-bit key (the sequence hash) and 32-bit payload (the
