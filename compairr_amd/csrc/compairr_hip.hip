@@ -114,6 +114,8 @@ struct cmpr_context {
   uint32_t          R1 = 0, ntiles = 0;
   DevBuf<TileDesc>  tiles;
   DevBuf<uint32_t>  qres, qv, qj, qrep;
+  DevBuf<uint64_t>  qgh;            /* V-key ^ J-key per query: one load, not two dependent ones */
+  std::vector<uint64_t> gene_keys;  /* host copy of the V and J Zobrist keys */
   DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
   DevBuf<uint32_t>  qorig;
@@ -410,7 +412,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->res2.release(); c->off2.release(); c->cnt2.release(); c->table.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release();
-  c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release();
+  c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
   c->tile_counter.release(); c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
@@ -606,6 +608,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     rc = dev_upload(c, c->zob, z.data(), z.size());
     if (rc)
       return rc;
+    c->gene_keys.assign(z.begin() + (size_t)A * c->zpos, z.end());   /* for set_queries */
     HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
   }
 
@@ -1246,6 +1249,10 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   if (!c->opt.ignore_genes) {
     if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
     if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
+    std::vector<uint64_t> qgh(slots, 0);
+    for (size_t k = 0; k < slots; k++)
+      qgh[k] = c->gene_keys[qv[k]] ^ c->gene_keys[c->opt.n_v_genes + qj[k]];
+    if ((rc = dev_upload(c, c->qgh, qgh.data(), qgh.size()))) return rc;
   }
   if (!c->opt.ignore_counts)
     if ((rc = dev_upload(c, c->qcnt, qcnt.data(), qcnt.size()))) return rc;
@@ -1316,6 +1323,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.tiles = c->tiles.p;
     P.qres = c->qres.p;
     P.qv = c->qv.p;
+    P.qgh = c->qgh.p;
     P.qj = c->qj.p;
     P.qrep = c->qrep.p;
     P.qcnt = c->qcnt.p;

@@ -396,7 +396,6 @@ probe_sliced_kernel(const ProbeParams P)
   SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
             0u, 0, {0ull, 0u, 0u, 0u}};
-  const uint64_t *gene_keys = P.zob + (uint32_t)A * P.zpos;
   const uint32_t zl_addr = slice_words * 8u;       /* LDS address of zl */
   const uint32_t ze_addr = zl_addr + nz * 8u;      /* ... and of ze */
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
@@ -465,6 +464,8 @@ probe_sliced_kernel(const ProbeParams P)
         t = P.small_tiles[i];
         td = P.tiles[t];
       }
+      if (P.debug & DBG_SKIP_TILES)
+        continue;                          /* measures claiming + staging alone */
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
@@ -485,7 +486,7 @@ probe_sliced_kernel(const ProbeParams P)
       rs.start(qr, L);
       uint64_t h = 0;
       if (GENES)
-        h = gene_keys[P.qv[W.qslot]] ^ gene_keys[P.n_v + P.qj[W.qslot]];
+        h = P.qgh[W.qslot];
       uint64_t hdel = h, hins = h;
       {
         for (uint32_t p = 0; p < L; p++) {

@@ -212,6 +212,7 @@ struct ProbeParams {
   const uint32_t *qres;
   const uint32_t *qv;
   const uint32_t *qj;
+  const uint64_t *qgh;             /* per slot: V key ^ J key (NULL with -g)      */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
@@ -257,7 +258,8 @@ struct ProbeParams {
 
 /* ProbeParams::debug bits: timing experiments only, results become wrong */
 enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
-                  DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32 };
+                  DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32,
+                  DBG_SKIP_TILES = 64 };
 
 enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
        STAT_COUNT = 4 };
