@@ -128,9 +128,13 @@ struct cmpr_context {
   DevBuf<double>             matrix_f64;
   DevBuf<uint32_t>           tile_counter;
   DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
-  DevBuf<unsigned long long> pos_ctr;      /* [0] claimed, [1] first claim that did not fit */
+  DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
+  unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
+  uint32_t                  *d_tile_counter = nullptr; /* likewise */
   uint64_t                   pos_cap = 0;
   uint32_t                   launches = 0;
+  const void                *attr_fn = nullptr;   /* kernel whose LDS limit is raised */
+  size_t                     attr_lds = 0;
   /* pairs mode, set only while cmpr_overlap_pairs runs */
   uint32_t           *pair_q = nullptr, *pair_h = nullptr;
   unsigned long long *pair_count = nullptr;
@@ -1260,8 +1264,6 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   const size_t cells = (size_t)c->R1 * c->R2;
   if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
   if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
-  if ((rc = dev_alloc(c, c->stats, STAT_COUNT))) return rc;
-  if ((rc = dev_alloc(c, c->tile_counter, 2))) return rc;
   /* positives buffer of the deferred resolve: a capacity, not a limit -- what
      does not fit is resolved inline by the probe kernel */
   {
@@ -1270,7 +1272,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     const uint64_t S = (uint64_t)c->pos_segments;
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
     if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
-    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE))) return rc;
+    /* one block that is zeroed per launch with ONE memset: the segment counters,
+       then the statistics, then the two work cursors */
+    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE + STAT_COUNT + 1))) return rc;
+    c->d_stats = c->pos_ctr.p + S * POS_CTR_STRIDE;
+    c->d_tile_counter = (uint32_t *)(c->d_stats + STAT_COUNT);
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
@@ -1292,13 +1298,9 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   HIP_TRY(c, hipMemsetAsync(d_out, 0, std::max<size_t>(cells, 1) * sizeof(unsigned long long), st));
   if (is_f64_score(c->opt))
     HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, std::max<size_t>(cells, 1) * sizeof(double), st));
-  HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * sizeof(unsigned long long), st));
-  HIP_TRY(c, hipMemsetAsync(c->tile_counter.p, 0, 2 * sizeof(uint32_t), st));
   const bool deferred = c->sliced && c->deferred_resolve;
-  if (deferred) {
-    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, (size_t)c->pos_segments * POS_CTR_STRIDE *
-                                                   sizeof(unsigned long long), st));
-  }
+  HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, ((size_t)c->pos_segments * POS_CTR_STRIDE +
+                                              STAT_COUNT + 1) * sizeof(unsigned long long), st));
   c->launches = 0;
   bool launched = false;
 
@@ -1342,8 +1344,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.score = c->opt.score;
     P.ignore_counts = c->opt.ignore_counts;
     P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
-    P.tile_counter = c->tile_counter.p;
-    P.stats = c->stats.p;
+    P.tile_counter = c->d_tile_counter;
+    P.stats = c->d_stats;
     P.geom = c->geom;
     P.chunks = c->chunks.p;
     P.tile_list = c->tile_list.p;
@@ -1376,9 +1378,13 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
     ProbeFn fn = c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
-    if (lds > 48 * 1024)
+    if (lds > 48 * 1024 && (c->attr_fn != (const void *)fn || c->attr_lds < lds)) {
+      /* once per kernel and size, not once per launch */
       HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->attr_fn = (const void *)fn;
+      c->attr_lds = lds;
+    }
     /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
     uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
     per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
@@ -1546,7 +1552,7 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventSynchronize(c->ev_stop));
   unsigned long long st[STAT_COUNT];
-  HIP_TRY(c, hipMemcpy(st, c->stats.p, sizeof st, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
   float k_ms = 0, t_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
   float p_ms = 0;
