@@ -58,7 +58,13 @@ struct cmpr_context {
   int          device = 0;
   int          cus = 256;
   hipStream_t  stream = nullptr;
-  hipEvent_t   ev_start = nullptr, ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr, ev_stop = nullptr;
+  hipEvent_t   ev_start = nullptr, ev_stop = nullptr;
+  /* kernel-time events of the last TIME_RING calls (cmpr_get_kernel_times), so
+     that a caller can time many launches without synchronising after each */
+  static const uint32_t TIME_RING = 64;
+  hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
+  uint64_t     calls = 0;            /* overlap launches so far */
+  hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
   bool         events_valid = false;
   std::string  err;
 
@@ -383,9 +389,14 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreate(&c->ev_start));
-  CREATE_TRY(hipEventCreate(&c->ev_k0));
-  CREATE_TRY(hipEventCreate(&c->ev_k1));
-  CREATE_TRY(hipEventCreate(&c->ev_km));
+  for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
+    CREATE_TRY(hipEventCreate(&c->ring_k0[i]));
+    CREATE_TRY(hipEventCreate(&c->ring_km[i]));
+    CREATE_TRY(hipEventCreate(&c->ring_k1[i]));
+  }
+  c->ev_k0 = c->ring_k0[0];
+  c->ev_km = c->ring_km[0];
+  c->ev_k1 = c->ring_k1[0];
   CREATE_TRY(hipEventCreate(&c->ev_stop));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
@@ -421,9 +432,11 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->matrix.release(); c->stats.release(); c->matrix_f64.release();
   c->tile_counter.release(); c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-  if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
-  if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
-  if (c->ev_km) (void)hipEventDestroy(c->ev_km);
+  for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
+    if (c->ring_k0[i]) (void)hipEventDestroy(c->ring_k0[i]);
+    if (c->ring_km[i]) (void)hipEventDestroy(c->ring_km[i]);
+    if (c->ring_k1[i]) (void)hipEventDestroy(c->ring_k1[i]);
+  }
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1304,6 +1317,13 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   c->launches = 0;
   bool launched = false;
 
+  {
+    const uint32_t slot = (uint32_t)(c->calls % cmpr_context::TIME_RING);
+    c->ev_k0 = c->ring_k0[slot];
+    c->ev_km = c->ring_km[slot];
+    c->ev_k1 = c->ring_k1[slot];
+    c->calls++;
+  }
   HIP_TRY(c, hipEventRecord(c->ev_k0, st));
   if (c->ntiles > 0 && cells > 0) {
     const uint32_t A = (uint32_t)c->opt.alphabet_size;
@@ -1540,6 +1560,31 @@ extern "C" int cmpr_overlap_pairs(cmpr_context *c, uint64_t capacity, uint32_t *
     HIP_TRY(c, hipMemcpy(hit_out, dh.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   *count_out = n;
+  return CMPR_OK;
+}
+
+extern "C" int cmpr_get_kernel_times(cmpr_context *c, uint32_t max, double *kernel_ms,
+                                     double *probe_ms, uint32_t *count_out)
+{
+  if (!c || !count_out)
+    return CMPR_EINVAL;
+  *count_out = 0;
+  if (!c->events_valid)
+    return fail(c, CMPR_ESTATE, "no overlap call has been made");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventSynchronize(c->ev_k1));
+  uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max, c->calls), cmpr_context::TIME_RING);
+  for (uint64_t k = 0; k < n; k++) {
+    const uint32_t slot = (uint32_t)((c->calls - n + k) % cmpr_context::TIME_RING);
+    float a = 0, b = 0;
+    HIP_TRY(c, hipEventElapsedTime(&a, c->ring_k0[slot], c->ring_k1[slot]));
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ring_k0[slot], c->ring_km[slot]));
+    if (kernel_ms)
+      kernel_ms[k] = a;
+    if (probe_ms)
+      probe_ms[k] = b;
+  }
+  *count_out = (uint32_t)n;
   return CMPR_OK;
 }
 

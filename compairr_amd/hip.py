@@ -21,6 +21,7 @@ EXPORTS = [
     "cmpr_abi_version", "cmpr_create", "cmpr_destroy", "cmpr_last_error",
     "cmpr_set_reference", "cmpr_set_queries", "cmpr_overlap_matrix",
     "cmpr_overlap_matrix_f64", "cmpr_overlap_matrix_device", "cmpr_get_stats",
+    "cmpr_get_kernel_times",
     "cmpr_rows", "cmpr_cols", "cmpr_set_tunable", "cmpr_get_tunable",
     "cmpr_count_duplicates", "cmpr_overlap_pairs",
 ]
@@ -126,6 +127,8 @@ def load_library() -> C.CDLL:
     lib.cmpr_overlap_matrix_f64.argtypes = [C.c_void_p, C.c_void_p]
     lib.cmpr_overlap_matrix_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cmpr_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    lib.cmpr_get_kernel_times.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     lib.cmpr_overlap_pairs.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_uint64)]
     lib.cmpr_count_duplicates.argtypes = [C.c_void_p, C.POINTER(_SetView), C.POINTER(C.c_uint64)]
@@ -258,6 +261,15 @@ class HipOverlap:
         self._check(self._lib.cmpr_count_duplicates(
             self._ctx, C.byref(v) if v is not None else None, C.byref(out)))
         return out.value
+
+    def kernel_times(self, max_calls: int = 64):
+        """(kernel_ms[], probe_ms[]) of the last calls, oldest first (HIP events)."""
+        n = min(max_calls, 64)
+        k = (C.c_double * n)()
+        p = (C.c_double * n)()
+        got = C.c_uint32(0)
+        self._check(self._lib.cmpr_get_kernel_times(self._ctx, n, k, p, C.byref(got)))
+        return list(k[:got.value]), list(p[:got.value])
 
     def stats(self) -> Stats:
         st = _Stats()

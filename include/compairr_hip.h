@@ -200,6 +200,16 @@ int cmpr_count_duplicates(cmpr_context *ctx, const cmpr_set_view *set, uint64_t 
 /* Statistics of the last overlap call (synchronises the context's events). */
 int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);
 
+/*
+ * HIP-event kernel times of the last `max` (at most 64) cmpr_overlap_* calls,
+ * oldest first: kernel_ms[k] = probe + resolve kernels, probe_ms[k] = the probe
+ * kernel alone (either may be NULL).  Lets a caller queue many launches on a
+ * stream without synchronising after each (the reference has one timed region,
+ * "Analysing:", overlap.cc:906-938; this is its per-launch counterpart).
+ */
+int cmpr_get_kernel_times(cmpr_context *ctx, uint32_t max, double *kernel_ms,
+                          double *probe_ms, uint32_t *count_out);
+
 /* Sizes, for callers that allocate the matrix. */
 uint32_t cmpr_rows(const cmpr_context *ctx);      /* R1, after set_queries   */
 uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */

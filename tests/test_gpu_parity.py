@@ -369,3 +369,20 @@ def test_full_size_properties_1m():
     of = Options(differences=0, ignore_counts=True, **FULL)
     ms, _ = gpu_cells(a, a, of)
     assert np.trace(ms) >= n and np.array_equal(ms, ms.T)
+
+
+def test_kernel_times_ring():
+    """cmpr_get_kernel_times: one HIP-event pair per launch, the last 64 kept."""
+    a = synth.make_set(20000, 3, prefix="A", pool_size=3000)
+    b = synth.make_set(20000, 4, prefix="B", pool_size=3000)
+    with HipOverlap(Options(differences=1, **FULL)) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        first = h.overlap_matrix()
+        for _ in range(69):
+            assert np.array_equal(h.overlap_matrix(), first)
+        k, p = h.kernel_times(5)
+        assert len(k) == 5 and all(x > 0 for x in k) and all(0 < y <= x for x, y in zip(k, p))
+        k, p = h.kernel_times(1000)
+        assert len(k) == 64
+        assert abs(k[-1] - h.stats().kernel_ms) < 1e-9
