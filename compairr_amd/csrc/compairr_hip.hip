@@ -551,7 +551,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   if (!c || !name || !value)
     return CMPR_EINVAL;
   std::string n(name);
-  if (n == "variant") *value = c->variant;
+  if (n == "variant") *value = c->have_ref ? (c->sliced ? 1 : 0) : c->variant;
   else if (n == "blocks_per_cu") *value = c->blocks_per_cu;
   else if (n == "bloom_bits_log2_delta") {
     *value = 0;
@@ -660,7 +660,20 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
      whatever the total), so it takes 4 bytes per table slot: with the 2^20
      pattern space that leaves almost only true positives for the table walk. */
-  const int64_t delta = c->bloom_log2_delta == -100 ? (c->variant == 1 ? 2 : 0)
+  /* The staged layout keeps a slice, the Zobrist tables and the wave queues in
+     LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
+     no longer fits and the un-sliced filter is probed where it lies (variant 0). */
+  c->sliced = c->variant == 1;
+  if (c->sliced) {
+    const size_t need = ((size_t)8 << c->slice_words_log2) +
+                        (size_t)(zrow_stride((int)A) + zdelta_entries((int)A)) * c->zpos * sizeof(uint64_t) +
+                        4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
+                        MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
+                        64 * sizeof(TileRef);
+    if (need > 160 * 1024)
+      c->sliced = false;
+  }
+  const int64_t delta = c->bloom_log2_delta == -100 ? (c->sliced ? 2 : 0)
                                                     : c->bloom_log2_delta;
   if (delta > 0)
     bloom_bytes <<= delta;
@@ -671,7 +684,6 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   c->bloom_words = bloom_bytes / 8;
 
   /* ---- variant 1: cut the filter into class-keyed slices (layout.h) ---- */
-  c->sliced = c->variant == 1;
   if (c->sliced) {
     SliceGeom &g = c->geom;
     uint32_t wl = 0;
@@ -1386,14 +1398,22 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     if (c->sliced && !c->waves_per_block_forced && c->nchunks > 0 &&
         (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
       nw = 4;
-    size_t lds = (size_t)(c->sliced ? zrow_stride((int)A) + zdelta_entries((int)A) : A) * c->zpos *
+    auto lds_for = [&](int waves) -> size_t {
+      size_t b = (size_t)(c->sliced ? zrow_stride((int)A) + zdelta_entries((int)A) : A) * c->zpos *
                      sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
-                 (size_t)nw * sizeof(WaveQueue);
-    if (c->sliced)
-      lds += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
+                 (size_t)waves * sizeof(WaveQueue);
+      if (c->sliced)
+        b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
              MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
              (size_t)(c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block) * sizeof(TileRef);
+      return b;
+    };
+    size_t lds = lds_for(nw);
+    if (lds > 160 * 1024 && c->sliced && nw > 4) {
+      nw = 4;                              /* long sequences: fewer wave queues */
+      lds = lds_for(nw);
+    }
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");

@@ -386,3 +386,17 @@ def test_kernel_times_ring():
         k, p = h.kernel_times(1000)
         assert len(k) == 64
         assert abs(k[-1] - h.stats().kernel_ms) < 1e-9
+
+
+def test_very_long_sequences_fall_back_to_unsliced_kernel():
+    """Zobrist tables that do not fit the LDS next to a filter slice: variant 0 is
+    chosen automatically, results unchanged."""
+    a = synth.tiny_set(60, 1, alphabet_size=4, letters=4, min_len=900, max_len=1000,
+                       n_repertoires=2, prefix="A")
+    o = Options(differences=1, nucleotides=True, n_v_genes=2, n_j_genes=2, ignore_genes=True)
+    want, _ = _oracle.overlap(a, a, o, threads=2)
+    with HipOverlap(o) as h:
+        h.set_reference(a, a.longest)
+        h.set_queries(a)
+        assert h.get_tunable("variant") == 0
+        assert np.array_equal(h.overlap_matrix(), _oracle.integer_cells(want, o))
