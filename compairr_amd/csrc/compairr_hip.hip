@@ -130,9 +130,8 @@ struct cmpr_context {
   std::vector<double> tot1, tot2;
 
   /* per-launch scratch */
-  DevBuf<unsigned long long> matrix, stats;
+  DevBuf<unsigned long long> matrix;
   DevBuf<double>             matrix_f64;
-  DevBuf<uint32_t>           tile_counter;
   DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
   DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
@@ -429,8 +428,8 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
-  c->matrix.release(); c->stats.release(); c->matrix_f64.release();
-  c->tile_counter.release(); c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
+  c->matrix.release(); c->matrix_f64.release();
+  c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
     if (c->ring_k0[i]) (void)hipEventDestroy(c->ring_k0[i]);
