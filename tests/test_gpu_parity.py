@@ -371,6 +371,27 @@ def test_full_size_properties_1m():
     assert np.trace(ms) >= n and np.array_equal(ms, ms.T)
 
 
+@pytest.mark.parametrize("indels", [False, True])
+def test_full_size_properties_10m(indels):
+    """BASELINE configs 3 / 4 at their full size (10M x 10M CDR3aa, d = 1, with and
+    without indels): symmetry under swapping the sets, query-shard linearity, the
+    closed-form variant count, and with -f the matrix total = number of pairs."""
+    n = 10_000_000
+    a = synth.make_set(n, 1, prefix="A", pool_size=n // 4)
+    b = synth.make_set(n, 2, prefix="B", pool_size=n // 4)
+    o = Options(differences=1, indels=indels, **FULL)
+    mab, st = gpu_cells(a, b, o)
+    mba, st2 = gpu_cells(b, a, o)
+    assert np.array_equal(mab, mba.T)
+    assert st.matches == st2.matches > 0
+    if not indels:
+        assert st.variants == int((1 + 19 * a.lengths.astype(np.int64)).sum())
+    halves = [gpu_cells(a.subset(slice(k * n // 2, (k + 1) * n // 2)), b, o)[0] for k in range(2)]
+    assert np.array_equal(halves[0] + halves[1], mab)
+    mf, stf = gpu_cells(a, b, Options(differences=1, indels=indels, ignore_counts=True, **FULL))
+    assert int(mf.sum()) == stf.matches == st.matches
+
+
 def test_kernel_times_ring():
     """cmpr_get_kernel_times: one HIP-event pair per launch, the last 64 kept."""
     a = synth.make_set(20000, 3, prefix="A", pool_size=3000)
