@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace cmpr;
@@ -79,6 +80,7 @@ struct cmpr_context {
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
   int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
@@ -237,29 +239,60 @@ int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &wh
   return CMPR_OK;
 }
 
+/* Runs fn(t, begin, end) on `threads` host threads over [0, n) cut into equal
+   contiguous ranges (thread t gets range t): the per-sequence passes of the
+   layout code are independent or become so with per-thread histograms. */
+template <typename F>
+void parallel_ranges(uint64_t n, unsigned threads, F fn)
+{
+  if (threads <= 1 || n < 65536) {
+    fn(0u, (uint64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; t++)
+    pool.emplace_back([=]() { fn(t, n * t / threads, n * (t + 1) / threads); });
+  for (std::thread &th : pool)
+    th.join();
+}
+
 /* residue codes, gene and repertoire numbers in range; lengths >= 1 */
 int scan_view(const cmpr_options &o, const cmpr_set_view *s, uint32_t &longest,
-              std::vector<double> &rep_total, std::string &why)
+              std::vector<double> &rep_total, std::string &why, unsigned threads)
 {
   longest = 0;
   rep_total.assign(s->n_repertoires, 0.0);
-  for (uint64_t i = 0; i < s->n; i++) {
-    if (s->offsets[i + 1] < s->offsets[i]) { why = "offsets not monotone"; return CMPR_EINVAL; }
-    uint64_t L = s->offsets[i + 1] - s->offsets[i];
-    if (L > 0xffffu) { why = "sequence longer than 65535 residues"; return CMPR_EUNSUPPORTED; }
-    longest = std::max<uint32_t>(longest, (uint32_t)L);
-    if (s->repertoire[i] >= s->n_repertoires) { why = "repertoire number out of range"; return CMPR_EINVAL; }
-    if (!o.ignore_genes &&
-        (s->v_gene[i] >= o.n_v_genes || s->j_gene[i] >= o.n_j_genes)) {
-      why = "gene number out of range"; return CMPR_EINVAL;
-    }
-    if (!o.ignore_counts && s->count[i] < 1) { why = "duplicate_count must be >= 1"; return CMPR_EINVAL; }
-    rep_total[s->repertoire[i]] += o.ignore_counts ? 1.0 : (double)s->count[i];
-  }
-  const uint64_t total = s->n ? s->offsets[s->n] : 0;
+  if (s->n < 65536)
+    threads = 1;
+  threads = std::max(1u, threads);
+  std::vector<int> rcs(threads, CMPR_OK);
+  std::vector<const char *> whys(threads, "");
+  std::vector<uint32_t> longs(threads, 0);
+  std::vector<std::vector<double> > tots(threads, std::vector<double>(s->n_repertoires, 0.0));
   const uint8_t A = (uint8_t)o.alphabet_size;
-  for (uint64_t k = 0; k < total; k++)
-    if (s->residues[k] >= A) { why = "residue code out of range"; return CMPR_EINVAL; }
+  parallel_ranges(s->n, threads, [&](unsigned t, uint64_t b, uint64_t e) {
+    auto bad = [&](int rc, const char *w) { rcs[t] = rc; whys[t] = w; };
+    for (uint64_t i = b; i < e; i++) {
+      if (s->offsets[i + 1] < s->offsets[i]) return bad(CMPR_EINVAL, "offsets not monotone");
+      const uint64_t L = s->offsets[i + 1] - s->offsets[i];
+      if (L > 0xffffu) return bad(CMPR_EUNSUPPORTED, "sequence longer than 65535 residues");
+      longs[t] = std::max<uint32_t>(longs[t], (uint32_t)L);
+      if (s->repertoire[i] >= s->n_repertoires) return bad(CMPR_EINVAL, "repertoire number out of range");
+      if (!o.ignore_genes && (s->v_gene[i] >= o.n_v_genes || s->j_gene[i] >= o.n_j_genes))
+        return bad(CMPR_EINVAL, "gene number out of range");
+      if (!o.ignore_counts && s->count[i] < 1) return bad(CMPR_EINVAL, "duplicate_count must be >= 1");
+      tots[t][s->repertoire[i]] += o.ignore_counts ? 1.0 : (double)s->count[i];
+    }
+    /* the residues of this range of sequences (offsets are monotone here) */
+    for (uint64_t k = s->offsets[b]; k < s->offsets[e]; k++)
+      if (s->residues[k] >= A) return bad(CMPR_EINVAL, "residue code out of range");
+  });
+  for (unsigned t = 0; t < threads; t++) {
+    if (rcs[t] != CMPR_OK) { why = whys[t]; return rcs[t]; }
+    longest = std::max(longest, longs[t]);
+    for (uint32_t r = 0; r < s->n_repertoires; r++)
+      rep_total[r] += tots[t][r];
+  }
   return CMPR_OK;
 }
 
@@ -387,6 +420,7 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipGetDeviceProperties(&prop, c->device));
   c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->host_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   CREATE_TRY(hipEventCreate(&c->ev_start));
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
     CREATE_TRY(hipEventCreate(&c->ring_k0[i]));
@@ -496,6 +530,10 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     c->chunk_tiles = value;
   } else if (n == "debug") {
     c->debug = value;
+  } else if (n == "host_threads") {
+    if (value < 1 || value > 256)
+      return fail(c, CMPR_EINVAL, "host_threads must be 1..256");
+    c->host_threads = value;
   } else if (n == "table_log2_delta") {
     if (value < 0 || value > 3)
       return fail(c, CMPR_EINVAL, "table_log2_delta must be 0..3");
@@ -577,6 +615,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
+  else if (n == "host_threads") *value = c->host_threads;
   else if (n == "pos_capacity") *value = (int64_t)(c->pos_cap * c->pos_segments);
   else if (n == "pos_segments") *value = c->pos_segments;
   else if (n == "resolve_blocks_per_cu") *value = c->resolve_blocks_per_cu;
@@ -604,7 +643,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   c->have_q = false;
 
   uint32_t longest = 0;
-  rc = scan_view(c->opt, s, longest, c->tot2, why);
+  rc = scan_view(c->opt, s, longest, c->tot2, why, (unsigned)c->host_threads);
   if (rc)
     return fail(c, rc, why);
   c->longest2 = longest;
@@ -928,7 +967,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
       return fail(c, rc, why);
     uint32_t longest = 0;
     std::vector<double> tot;
-    if ((rc = scan_view(c->opt, s, longest, tot, why)))
+    if ((rc = scan_view(c->opt, s, longest, tot, why, (unsigned)c->host_threads)))
       return fail(c, rc, why);
     /* own Zobrist keys when no reference set is resident or it is too short */
     DevBuf<uint64_t> zob_own;
@@ -1019,7 +1058,7 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   c->have_q = false;
 
   uint32_t longest = 0;
-  rc = scan_view(c->opt, s, longest, c->tot1, why);
+  rc = scan_view(c->opt, s, longest, c->tot1, why, (unsigned)c->host_threads);
   if (rc)
     return fail(c, rc, why);
   if (longest + EXTRA_POSITIONS > c->zpos)
@@ -1046,26 +1085,48 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
   const uint64_t S = c->sliced ? 2 * ((uint64_t)c->geom.smask + 1) : 1;   /* (slice, heavy) */
   const uint64_t per_slice = (uint64_t)longest + 1;
-  std::vector<uint32_t> group_of((size_t)s->n);
-  std::vector<uint64_t> per_group((size_t)(S * per_slice), 0);
-  for (uint64_t i = 0; i < s->n; i++) {
-    const uint64_t b = s->offsets[i];
-    const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-    uint64_t sh = 0;
-    if (c->sliced) {
-      bool heavy = false;
-      const bool genes = !c->opt.ignore_genes;
-      const uint32_t slice = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b, L,
-                                          genes ? s->v_gene[i] : 0, genes ? s->j_gene[i] : 0,
-                                          &heavy) & c->geom.smask;
-      sh = 2 * (uint64_t)slice + (heavy ? 1 : 0);
-    }
-    const uint64_t g = sh * per_slice + (longest - L);
-    group_of[i] = (uint32_t)g;
-    per_group[g]++;
-  }
   if (S * per_slice >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
+  const uint64_t G = S * per_slice;
+  /* host threads: each takes one contiguous range of the queries in both passes
+     (class keys + histogram here, placement below), so that inside a group the
+     queries keep their input order, as in a serial counting sort */
+  unsigned T = (unsigned)std::max<int64_t>(1, c->host_threads);
+  T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1, (64ull << 20) / std::max<uint64_t>(G, 1)));
+  if (s->n < 65536)
+    T = 1;
+  std::vector<uint32_t> group_of((size_t)s->n);
+  std::vector<uint64_t> per_group((size_t)G, 0);
+  std::vector<std::vector<uint32_t> > hist(T, std::vector<uint32_t>((size_t)G, 0));
+  parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    std::vector<uint32_t> &mine = hist[t];
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint64_t b = s->offsets[i];
+      const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+      uint64_t sh = 0;
+      if (c->sliced) {
+        bool heavy = false;
+        const bool genes = !c->opt.ignore_genes;
+        const uint32_t slice = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b, L,
+                                            genes ? s->v_gene[i] : 0, genes ? s->j_gene[i] : 0,
+                                            &heavy) & c->geom.smask;
+        sh = 2 * (uint64_t)slice + (heavy ? 1 : 0);
+      }
+      const uint64_t g = sh * per_slice + (longest - L);
+      group_of[i] = (uint32_t)g;
+      mine[g]++;
+    }
+  });
+  /* per group: total, and for every thread the number of earlier threads' queries */
+  for (uint64_t g = 0; g < G; g++) {
+    uint64_t run = 0;
+    for (unsigned t = 0; t < T; t++) {
+      const uint32_t h = hist[t][g];
+      hist[t][g] = (uint32_t)run;
+      run += h;
+    }
+    per_group[g] = run;
+  }
   std::vector<uint64_t> tile_first((size_t)(S * per_slice), 0);
   const uint64_t chunk_tiles =
       c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : 8 * (uint64_t)c->waves_per_block;
@@ -1244,9 +1305,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   std::vector<uint32_t> qorig(slots, 0);
   if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
   if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
-  std::vector<uint64_t> fill((size_t)(S * per_slice), 0);
+  std::vector<uint64_t> alg_part(T, 0);
+  parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+  std::vector<uint32_t> &fill = hist[t];      /* queries of earlier threads + own so far */
   uint64_t alg = 0;
-  for (uint64_t i = 0; i < s->n; i++) {
+  for (uint64_t i = lo; i < hi; i++) {
     const uint64_t b = s->offsets[i];
     const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
     const uint64_t g = group_of[i];
@@ -1267,7 +1330,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
       dst[(size_t)(p >> 2) * WAVE] |= (uint32_t)src[p] << ((p & 3) * 8);
     alg += (uint64_t)L + 20 + 8 * variants_of(c->opt, src, L);
   }
-  c->algorithmic_bytes = alg;
+  alg_part[t] = alg;
+  });
+  c->algorithmic_bytes = 0;
+  for (unsigned t = 0; t < T; t++)
+    c->algorithmic_bytes += alg_part[t];
 
   if ((rc = dev_upload(c, c->tiles, tiles.data(), tiles.size()))) return rc;
   if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
@@ -1278,8 +1345,10 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
     if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
     std::vector<uint64_t> qgh(slots, 0);
-    for (size_t k = 0; k < slots; k++)
-      qgh[k] = c->gene_keys[qv[k]] ^ c->gene_keys[c->opt.n_v_genes + qj[k]];
+    parallel_ranges(slots, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+      for (uint64_t k = lo; k < hi; k++)
+        qgh[k] = c->gene_keys[qv[k]] ^ c->gene_keys[c->opt.n_v_genes + qj[k]];
+    });
     if ((rc = dev_upload(c, c->qgh, qgh.data(), qgh.size()))) return rc;
   }
   if (!c->opt.ignore_counts)
