@@ -805,14 +805,23 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     }
     if (S > 1 && s->n > 0) {
       /* population of every (length, V, J) class bucket */
+      const unsigned T = s->n < 65536 ? 1u : (unsigned)std::max<int64_t>(1, c->host_threads);
       std::vector<uint32_t> bucket((size_t)1 << HEAVY_BUCKETS_LOG2, 0);
       std::vector<uint32_t> base_of((size_t)s->n);
-      for (uint64_t i = 0; i < s->n; i++) {
-        const uint32_t L = (uint32_t)(s->offsets[i + 1] - s->offsets[i]);
-        const uint32_t b = class_base(c->ctab.data(), g, genes, L, genes ? s->v_gene[i] : 0,
-                                      genes ? s->j_gene[i] : 0);
-        base_of[i] = b;
-        bucket[b >> (32 - HEAVY_BUCKETS_LOG2)]++;
+      {
+        std::vector<std::vector<uint32_t> > part(T, std::vector<uint32_t>(bucket.size(), 0));
+        parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+          for (uint64_t i = lo; i < hi; i++) {
+            const uint32_t L = (uint32_t)(s->offsets[i + 1] - s->offsets[i]);
+            const uint32_t b = class_base(c->ctab.data(), g, genes, L, genes ? s->v_gene[i] : 0,
+                                          genes ? s->j_gene[i] : 0);
+            base_of[i] = b;
+            part[t][b >> (32 - HEAVY_BUCKETS_LOG2)]++;
+          }
+        });
+        for (unsigned t = 0; t < T; t++)
+          for (size_t b = 0; b < bucket.size(); b++)
+            bucket[b] += part[t][b];
       }
       /* heavy = would take more than half of a slice's budget on its own */
       const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold : slice_cap / 2;
@@ -832,14 +841,22 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
         std::vector<uint32_t> pop;
         for (uint32_t k = 1; k <= max_class_res(A); k++) {
           pop.assign((size_t)S, 0);
-          for (uint64_t i = 0; i < s->n; i++) {
-            const uint64_t b = s->offsets[i];
-            const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-            uint32_t ck = base_of[i];
-            if (L > 0 && class_is_heavy(c->ctab.data(), g, ck))
-              for (uint32_t r = 0; r < k; r++)
-                ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r, g.c0)]];
-            pop[ck & g.smask]++;
+          {
+            std::vector<std::vector<uint32_t> > part(T, std::vector<uint32_t>((size_t)S, 0));
+            parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+              for (uint64_t i = lo; i < hi; i++) {
+                const uint64_t b = s->offsets[i];
+                const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+                uint32_t ck = base_of[i];
+                if (L > 0 && class_is_heavy(c->ctab.data(), g, ck))
+                  for (uint32_t r = 0; r < k; r++)
+                    ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r, g.c0)]];
+                part[t][ck & g.smask]++;
+              }
+            });
+            for (unsigned t = 0; t < T; t++)
+              for (size_t x = 0; x < (size_t)S; x++)
+                pop[x] += part[t][x];
           }
           const double mx = *std::max_element(pop.begin(), pop.end());
           if (best_max < 0 || mx < best_max) {
