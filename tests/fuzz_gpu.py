@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: HIP path (through the C ABI) against the
+oracle over random inputs, options and layout tunables.  Not collected by pytest
+(run it by hand: `python tests/fuzz_gpu.py --seconds 300`); stops at the first
+mismatch and prints the configuration that produced it."""
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import _oracle  # noqa: E402
+from compairr_amd import HipOverlap, Options, synth  # noqa: E402
+
+
+def random_case(rng):
+    nt = bool(rng.integers(0, 2))
+    A = 4 if nt else 20
+    tiny = rng.random() < 0.5
+    n1 = int(rng.integers(1, 30000))
+    n2 = int(rng.integers(1, 30000))
+    if tiny:
+        letters = int(rng.integers(2, 5))
+        max_len = int(rng.integers(3, 12))
+        nrep = int(rng.integers(1, 5))
+        a = synth.tiny_set(min(n1, 3000), int(rng.integers(1 << 30)), alphabet_size=A, letters=letters,
+                           max_len=max_len, n_repertoires=nrep, prefix="A")
+        b = synth.tiny_set(min(n2, 3000), int(rng.integers(1 << 30)), alphabet_size=A, letters=letters,
+                           max_len=max_len, n_repertoires=nrep, prefix="B")
+        genes = dict(n_v_genes=2, n_j_genes=2)
+    else:
+        pool = int(rng.integers(50, 5000))
+        ps = int(rng.integers(1 << 30))
+        a = synth.make_set(n1, int(rng.integers(1 << 30)), pool_seed=ps, pool_size=pool, prefix="A",
+                           nucleotides=nt, n_repertoires=int(rng.integers(1, 40)))
+        b = synth.make_set(n2, int(rng.integers(1 << 30)), pool_seed=ps, pool_size=pool, prefix="B",
+                           nucleotides=nt, n_repertoires=int(rng.integers(1, 40)))
+        genes = dict(n_v_genes=synth.N_V, n_j_genes=synth.N_J)
+    d = int(rng.integers(0, 3))
+    indels = bool(d == 1 and rng.integers(0, 2))
+    if d == 2 and not tiny and not nt:
+        a = a.subset(slice(0, min(a.n, 4000)))          # oracle time
+    if d == 2 and nt and not tiny:
+        a = a.subset(slice(0, min(a.n, 1500)))
+    o = Options(differences=d, indels=indels, nucleotides=nt,
+                ignore_genes=bool(rng.integers(0, 2)), ignore_counts=bool(rng.integers(0, 2)),
+                score=["product", "min", "max", "mean"][int(rng.integers(0, 4))], **genes)
+    tun = {}
+    if rng.random() < 0.7:
+        tun["slice_words_log2"] = int(rng.integers(2, 13))
+    if rng.random() < 0.5:
+        tun["class_residues"] = int(rng.integers(0, 9 if nt else 4))
+    if rng.random() < 0.3:
+        tun["heavy_threshold"] = int(rng.integers(0, 50))
+    if rng.random() < 0.3:
+        tun["chunk_tiles"] = int(rng.integers(1, 65))
+    if rng.random() < 0.3:
+        tun["small_slice_tiles"] = int(rng.integers(0, 65))
+    if rng.random() < 0.3:
+        tun["waves_per_block"] = [4, 8, 16][int(rng.integers(0, 3))]
+    if rng.random() < 0.3:
+        tun["pos_capacity"] = int(rng.integers(1, 5000))
+    if rng.random() < 0.2:
+        tun["pos_segments"] = [1, 2, 64, 256][int(rng.integers(0, 4))]
+    if rng.random() < 0.2:
+        tun["deferred_resolve"] = 0
+    if rng.random() < 0.2:
+        tun["table_log2_delta"] = int(rng.integers(0, 3))
+    if rng.random() < 0.1:
+        tun["variant"] = 0
+    if rng.random() < 0.3:
+        tun["host_threads"] = int(rng.integers(1, 9))
+    same = rng.random() < 0.2
+    return a, (a if same else b), o, tun
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=12345)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < args.seconds:
+        a, b, o, tun = random_case(rng)
+        want, ost = _oracle.overlap(a, b, o, threads=8)
+        want = _oracle.integer_cells(want, o)
+        with HipOverlap(o) as h:
+            order = ["variant"] + [k for k in tun if k != "variant"]
+            for k in order:
+                if k in tun:
+                    h.set_tunable(k, tun[k])
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            got = h.overlap_matrix()
+            st = h.stats()
+            pairs = h.overlap_pairs() if n % 4 == 0 else None
+        ok = np.array_equal(got, want) and st.matches == ost.matches and st.variants == ost.variants
+        if ok and pairs is not None:
+            ok = len(pairs) == ost.matches
+        if not ok:
+            print("MISMATCH after %d cases: n1=%d n2=%d opt=%s tun=%s" % (n, a.n, b.n, o, tun))
+            sys.exit(1)
+        n += 1
+    print("%d random cases, all bit-exact (%.0f s)" % (n, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
