@@ -49,3 +49,19 @@ def test_rejected_command_lines(args, msg):
     assert p.returncode == 1
     assert msg in p.stderr
     assert p.stdout == b""
+
+
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_standard_input_as_a_set(threads):
+    """"-" = standard input (util.cc:156-170), here for set 1 and for set 2, through the
+    host program linked with the CPU oracle backend (no GPU needed)."""
+    exe = os.path.join(ROOT, "tests", "bin", "compairr_oracle_cli")
+    with open(os.path.join(ROOT, "tests", "golden", "expected", "ref_test_sh.tsv"), "rb") as fh:
+        want = fh.read()
+    for files, feed in ((["-", "setb.tsv"], "seta.tsv"), (["seta.tsv", "-"], "setb.tsv")):
+        with open(os.path.join(GOLDEN_INPUTS, feed), "rb") as fh:
+            p = subprocess.run([exe, "-m"] + files + ["-d", "1", "-i", "-t", threads, "-l", os.devnull],
+                               cwd=GOLDEN_INPUTS, stdin=fh, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == want
