@@ -18,16 +18,43 @@ HOST_CORE = compairr_amd/host/airr_tsv.cc compairr_amd/host/options.cc compairr_
             compairr_amd/host/cluster_host.cc
 HOST_SRC = $(HOST_CORE) compairr_amd/host/hip_backend.cc
 HOST_HDR = $(wildcard compairr_amd/host/*.h) include/compairr_hip.h
-KERN_SRC = compairr_amd/csrc/compairr_hip.hip
-KERN_HDR = compairr_amd/csrc/kernels.h compairr_amd/csrc/kernels_sliced.h compairr_amd/csrc/layout.h include/compairr_hip.h
+KERN_DIR = compairr_amd/csrc
+KERN_HDR = $(KERN_DIR)/kernels.h $(KERN_DIR)/kernels_sliced.h $(KERN_DIR)/kernels_rows.h \
+           $(KERN_DIR)/layout.h $(KERN_DIR)/select.h include/compairr_hip.h
+OBJ_DIR  = compairr_amd/lib/obj
+# the probe kernels are instantiated per (kernel variant, waves per workgroup) in
+# their own translation units, so that `make -j` compiles them side by side
+TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o \
+           $(OBJ_DIR)/probe_v1_nw4.o $(OBJ_DIR)/probe_v1_nw8.o $(OBJ_DIR)/probe_v1_nw16.o \
+           $(OBJ_DIR)/probe_v2_nw4.o $(OBJ_DIR)/probe_v2_nw8.o $(OBJ_DIR)/probe_v2_nw16.o
 
 all: lib cli oracle
 
-lib: $(LIB)
+lib:
+	$(MAKE) -j8 $(LIB)
 
-$(LIB): $(KERN_SRC) $(KERN_HDR)
-	@mkdir -p compairr_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KERN_SRC)
+$(OBJ_DIR)/main.o: $(KERN_DIR)/compairr_hip.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(OBJ_DIR)/probe_v0.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=0 -c -o $@ $<
+
+$(OBJ_DIR)/resolve.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=9 -c -o $@ $<
+
+$(OBJ_DIR)/probe_v1_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=1 -DTU_NW=$* -c -o $@ $<
+
+$(OBJ_DIR)/probe_v2_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -c -o $@ $<
+
+$(LIB): $(OBJ_DIR)/main.o $(TU_OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
 cli: $(CLI)
 

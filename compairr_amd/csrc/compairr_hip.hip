@@ -8,6 +8,8 @@
 #include "../../include/compairr_hip.h"
 #include "kernels.h"
 #include "kernels_sliced.h"
+#include "kernels_rows.h"
+#include "select.h"
 
 #include <algorithm>
 #include <cmath>
@@ -71,7 +73,8 @@ struct cmpr_context {
 
   /* tunables */
   int64_t blocks_per_cu = 8;
-  int64_t variant = 1;            /* 0: one global Bloom; 1: LDS-staged slices */
+  int64_t variant = -1;           /* 0: one global Bloom; 1: LDS-staged slices; 2: LDS-staged
+                                     row filter (kernels_rows.h); -1: by alphabet */
   int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
   int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
@@ -87,11 +90,14 @@ struct cmpr_context {
   int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
   int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
   bool    waves_per_block_forced = false;
-  int64_t debug = 0;              /* ablation switches (layout.h DBG_*)        */    /* sliced kernel: 4, 8 or 16                 */
-  int64_t slice_words_log2 = SLICE_WORDS_LOG2;
+  int64_t debug = 0;              /* ablation switches (layout.h DBG_*), -DCMPR_ABLATION builds only */
+  int64_t slice_words_log2 = -1;  /* -1: 12 (8-byte words, variant 1) / 11 (16-byte words, variant 2) */
+  uint32_t chunk_cap = 0;         /* tiles per chunk in effect since cmpr_set_queries */
 
   /* sliced Bloom layout (variant 1) */
-  bool                  sliced = false;
+  bool                  sliced = false;   /* variant 1 or 2 */
+  bool                  rows = false;     /* variant 2 */
+  uint32_t              npasses = 1;      /* variant 2: 1 + class-row passes */
   SliceGeom             geom{};
   std::vector<uint32_t> ctab;     /* host copy of the class tables             */
   DevBuf<uint32_t>      d_ctab;
@@ -126,7 +132,7 @@ struct cmpr_context {
   std::vector<uint64_t> gene_keys;  /* host copy of the V and J Zobrist keys */
   DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
-  DevBuf<uint32_t>  qorig;
+  DevBuf<uint32_t>  qorig, qck;
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;
@@ -319,48 +325,31 @@ uint64_t variants_of(const cmpr_options &o, const uint8_t *s, uint32_t L)
   return n;
 }
 
-using ProbeFn = void (*)(const ProbeParams);
-
-template <int NW>
-ProbeFn select_sliced_kernel_nw(const cmpr_options &o)
-{
-#define PICK(A_, D_, I_)                                                        \
-  (o.ignore_genes ? (ProbeFn)probe_sliced_kernel<A_, D_, I_, false, NW>         \
-                  : (ProbeFn)probe_sliced_kernel<A_, D_, I_, true, NW>)
-  if (o.alphabet_size == 20) {
-    if (o.differences == 0) return PICK(20, 0, false);
-    if (o.differences == 1) return o.indels ? PICK(20, 1, true) : PICK(20, 1, false);
-    return PICK(20, 2, false);
-  }
-  if (o.differences == 0) return PICK(4, 0, false);
-  if (o.differences == 1) return o.indels ? PICK(4, 1, true) : PICK(4, 1, false);
-  return PICK(4, 2, false);
-#undef PICK
-}
-
 ProbeFn select_sliced_kernel(const cmpr_options &o, int nw)
 {
+  const int A = o.alphabet_size, D = o.differences;
+  const bool i = o.indels != 0, g = !o.ignore_genes;
   switch (nw) {
-  case 4:  return select_sliced_kernel_nw<4>(o);
-  case 16: return select_sliced_kernel_nw<16>(o);
-  default: return select_sliced_kernel_nw<8>(o);
+  case 4:  return select_probe_v1_nw4(A, D, i, g);
+  case 16: return select_probe_v1_nw16(A, D, i, g);
+  default: return select_probe_v1_nw8(A, D, i, g);
+  }
+}
+
+ProbeFn select_rows_kernel(const cmpr_options &o, int nw)
+{
+  const int A = o.alphabet_size, D = o.differences;
+  const bool i = o.indels != 0, g = !o.ignore_genes;
+  switch (nw) {
+  case 4:  return select_probe_v2_nw4(A, D, i, g);
+  case 16: return select_probe_v2_nw16(A, D, i, g);
+  default: return select_probe_v2_nw8(A, D, i, g);
   }
 }
 
 ProbeFn select_kernel(const cmpr_options &o)
 {
-#define PICK(A_, D_, I_)                                                        \
-  (o.ignore_genes ? (ProbeFn)probe_kernel<A_, D_, I_, false>                    \
-                  : (ProbeFn)probe_kernel<A_, D_, I_, true>)
-  if (o.alphabet_size == 20) {
-    if (o.differences == 0) return PICK(20, 0, false);
-    if (o.differences == 1) return o.indels ? PICK(20, 1, true) : PICK(20, 1, false);
-    return PICK(20, 2, false);
-  }
-  if (o.differences == 0) return PICK(4, 0, false);
-  if (o.differences == 1) return o.indels ? PICK(4, 1, true) : PICK(4, 1, false);
-  return PICK(4, 2, false);
-#undef PICK
+  return select_probe_v0(o.alphabet_size, o.differences, o.indels != 0, !o.ignore_genes);
 }
 
 bool is_f64_score(const cmpr_options &o)
@@ -433,8 +422,11 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipEventCreate(&c->ev_stop));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
-  if (const char *e = getenv("COMPAIRR_HIP_VARIANT"))
-    c->variant = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("COMPAIRR_HIP_VARIANT")) {
+    int v = atoi(e);
+    if (v >= 0 && v <= 2)
+      c->variant = v;
+  }
   if (const char *e = getenv("COMPAIRR_HIP_SLICE_WORDS_LOG2")) {
     int v = atoi(e);
     if (v >= 1 && v <= 13)
@@ -461,7 +453,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
-  c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release();
+  c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -493,8 +485,8 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_EINVAL, "blocks_per_cu must be 1..16");
     c->blocks_per_cu = value;
   } else if (n == "variant") {
-    if (value < 0 || value > 1)
-      return fail(c, CMPR_EINVAL, "variant must be 0 or 1");
+    if (value < -1 || value > 2)
+      return fail(c, CMPR_EINVAL, "variant must be -1 (default), 0, 1 or 2");
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set variant before cmpr_set_reference");
     c->variant = value;
@@ -517,8 +509,8 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_ESTATE, "set heavy_threshold before cmpr_set_reference");
     c->heavy_threshold = value;
   } else if (n == "slice_words_log2") {
-    if (value < 1 || value > 13)
-      return fail(c, CMPR_EINVAL, "slice_words_log2 must be 1..13");
+    if (value < -1 || value == 0 || value > 13)
+      return fail(c, CMPR_EINVAL, "slice_words_log2 must be -1 (default) or 1..13");
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set slice_words_log2 before cmpr_set_reference");
     c->slice_words_log2 = value;
@@ -529,7 +521,11 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
       return fail(c, CMPR_ESTATE, "set chunk_tiles before cmpr_set_queries");
     c->chunk_tiles = value;
   } else if (n == "debug") {
+#ifdef CMPR_ABLATION
     c->debug = value;
+#else
+    return fail(c, CMPR_EINVAL, "the debug switches exist only in a -DCMPR_ABLATION build");
+#endif
   } else if (n == "host_threads") {
     if (value < 1 || value > 256)
       return fail(c, CMPR_EINVAL, "host_threads must be 1..256");
@@ -569,6 +565,8 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
   } else if (n == "waves_per_block") {
     if (value != 4 && value != 8 && value != 16)
       return fail(c, CMPR_EINVAL, "waves_per_block must be 4, 8 or 16");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set waves_per_block before cmpr_set_queries");
     c->waves_per_block = value;
     c->waves_per_block_forced = true;
   } else if (n == "bloom_bits_log2_delta") {
@@ -588,7 +586,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   if (!c || !name || !value)
     return CMPR_EINVAL;
   std::string n(name);
-  if (n == "variant") *value = c->have_ref ? (c->sliced ? 1 : 0) : c->variant;
+  if (n == "variant") *value = c->have_ref ? (c->rows ? 2 : c->sliced ? 1 : 0) : c->variant;
   else if (n == "blocks_per_cu") *value = c->blocks_per_cu;
   else if (n == "bloom_bits_log2_delta") {
     *value = 0;
@@ -597,6 +595,8 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   }
   else if (n == "class_residues") *value = c->sliced && c->have_ref ? (int64_t)c->geom.k : c->class_residues;
   else if (n == "slice_words_log2") *value = c->sliced && c->have_ref ? (int64_t)c->geom.words_log2 : c->slice_words_log2;
+  else if (n == "slice_bytes") *value = !c->sliced ? 0 : c->rows ? (int64_t)c->geom.rw_words * 16 : (int64_t)8 << c->geom.words_log2;
+  else if (n == "passes") *value = c->npasses;
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->waves_per_block;
   else if (n == "debug") *value = c->debug;
@@ -629,7 +629,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
 /* set 2: upload + index build on the device                            */
 /* ------------------------------------------------------------------ */
 
-extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
+static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
                                   uint32_t longest_query)
 {
   if (!c)
@@ -695,40 +695,83 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   /* results do not depend on the table size (every hit is verified), only the
      length of the probe chains does: HBM is plentiful, round trips are not */
   c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
-  /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
-     whatever the total), so it takes 4 bytes per table slot: with the 2^20
-     pattern space that leaves almost only true positives for the table walk. */
-  /* The staged layout keeps a slice, the Zobrist tables and the wave queues in
+  /* Kernel variant: the row filter (2) for amino acids -- one word read answers
+     the 19 substitutions of a position; nucleotides (3 per position, and L + 1
+     entries per sequence to pay for them) keep the per-variant filter (1). */
+  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 ? 2 : 1);
+  /* The staged layouts keep a slice, the Zobrist tables and the wave queues in
      LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
      no longer fits and the un-sliced filter is probed where it lies (variant 0). */
-  c->sliced = c->variant == 1;
+  c->sliced = variant >= 1;
+  c->rows = variant == 2;
+  int64_t swl = c->slice_words_log2;
+  if (swl < 0)
+    swl = c->rows ? 11 : SLICE_WORDS_LOG2;
+  if (c->rows)
+    swl = std::min<int64_t>(swl, 11);                 /* MAX_ROW_SLICE_WORDS */
   if (c->sliced) {
-    const size_t need = ((size_t)8 << c->slice_words_log2) +
-                        (size_t)(zrow_stride((int)A) + zdelta_entries((int)A)) * c->zpos * sizeof(uint64_t) +
+    const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
+    const size_t need = ((size_t)(c->rows ? 16 : 8) << swl) +
+                        zrow * c->zpos * sizeof(uint64_t) +
                         4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
                         MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
                         64 * sizeof(TileRef);
-    if (need > 160 * 1024)
+    if (need > 160 * 1024) {
       c->sliced = false;
+      c->rows = false;
+    }
   }
-  const int64_t delta = c->bloom_log2_delta == -100 ? (c->sliced ? 2 : 0)
-                                                    : c->bloom_log2_delta;
-  if (delta > 0)
-    bloom_bytes <<= delta;
-  else if (delta < 0)
-    bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 8);
-  if (bloom_bytes > (1ull << 32))
-    return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
-  c->bloom_words = bloom_bytes / 8;
+  const uint64_t entries = (s->n ? s->offsets[s->n] : 0) + s->n;   /* row filter: L + 1 per sequence */
+  if (c->rows) {
+    /* 4 bytes of filter per entry (4 entries per 16-byte word: every dword of a
+       word then has ~12 % of its bits set and a test of four of them passes by
+       chance ~3e-4 of the time), x 2^delta */
+    bloom_bytes = std::max<uint64_t>(entries * 4, 16);
+    const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
+    if (delta > 0)
+      bloom_bytes <<= delta;
+    else if (delta < 0)
+      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 16);
+    /* S slices (a power of two: sibling slices are XORs of slice numbers) of
+       rw_words <= 2^swl words each */
+    const uint64_t max_words = 1ull << swl;
+    uint64_t S = 1;
+    while (S * max_words * 16 < bloom_bytes)
+      S <<= 1;
+    uint64_t words = (bloom_bytes + S * 16 - 1) / (S * 16);
+    words = std::max<uint64_t>(1, std::min<uint64_t>(words, max_words));
+    if (S > (1ull << 31))
+      return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
+    c->geom.rw_words = (uint32_t)words;
+    c->geom.words_log2 = 0;
+    c->bloom_words = S * words * 2;                  /* 8-byte units */
+    c->geom.smask = (uint32_t)(S - 1);
+  } else {
+    /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
+       whatever the total), so it takes 4 bytes per table slot: with the 2^20
+       pattern space that leaves almost only true positives for the table walk. */
+    const int64_t delta = c->bloom_log2_delta == -100 ? (c->sliced ? 2 : 0)
+                                                      : c->bloom_log2_delta;
+    if (delta > 0)
+      bloom_bytes <<= delta;
+    else if (delta < 0)
+      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 8);
+    if (bloom_bytes > (1ull << 32))
+      return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
+    c->bloom_words = bloom_bytes / 8;
+    c->geom.rw_words = 0;
+  }
 
-  /* ---- variant 1: cut the filter into class-keyed slices (layout.h) ---- */
+  /* ---- variants 1, 2: cut the filter into class-keyed slices (layout.h) ---- */
   if (c->sliced) {
     SliceGeom &g = c->geom;
-    uint32_t wl = 0;
-    while ((1ull << (wl + 1)) <= c->bloom_words && wl + 1 <= (uint32_t)c->slice_words_log2)
-      wl++;
-    g.words_log2 = wl;
-    g.smask = (uint32_t)(c->bloom_words >> wl) - 1;
+    if (!c->rows) {
+      uint32_t wl = 0;
+      while ((1ull << (wl + 1)) <= c->bloom_words && wl + 1 <= (uint32_t)swl)
+        wl++;
+      g.words_log2 = wl;
+      g.smask = (uint32_t)(c->bloom_words >> wl) - 1;
+    }
     g.ncl = c->zpos + 1;
     g.off_cv = g.ncl;
     g.off_cj = g.off_cv + n_v;
@@ -742,8 +785,11 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     const uint64_t S = (uint64_t)g.smask + 1;
     const double slice_bits = (double)(64ull << g.words_log2);
     /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
-       bits per key, false-positive rate <= 6e-3 there and far less elsewhere */
-    const double slice_cap = slice_bits / 12.0;
+       bits per key, false-positive rate <= 6e-3 there and far less elsewhere.
+       Row filter: sequences per slice at 6 entries per word (1.5 x the average). */
+    const double slice_cap = c->rows
+        ? (double)g.rw_words * 6.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
+        : slice_bits / 12.0;
     g.k = 0;
     /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
        (<= 5th-percentile length of set 2) and be informative (a conserved
@@ -875,7 +921,8 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
+  /* inverted polarity (bloompat.cc:54-57) for variants 0, 1; the row filter sets bits */
+  HIP_TRY(c, hipMemsetAsync(c->bloom.p, c->rows ? 0 : 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
 
   {
     /* positions in the verification stream (layout.h RefRec) */
@@ -912,7 +959,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     B.n = s->n;
     B.table = c->table.p;
     B.slot_mask = c->slots - 1;
-    B.bloom = c->bloom.p;
+    B.bloom = c->rows ? nullptr : c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.sliced = c->sliced ? 1u : 0u;
     B.geom = c->geom;
@@ -920,6 +967,11 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
                        c->stream, B);
     HIP_TRY(c, hipGetLastError());
+    if (c->rows) {
+      B.bloom = c->bloom.p;
+      hipLaunchKernelGGL(build_rows_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
+      HIP_TRY(c, hipGetLastError());
+    }
   }
   if (s->n) {
     PackParams K{};
@@ -941,7 +993,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
   return CMPR_OK;
 }
 
-extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
+static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
 {
   if (!c || !out)
     return CMPR_EINVAL;
@@ -1017,15 +1069,12 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
     slots = std::max<uint64_t>(slots, 4);         /* chains start on 4-slot boundaries */
     if ((rc = dev_alloc(c, table, (size_t)slots))) return rc;
     HIP_TRY(c, hipMemsetAsync(table.p, 0xff, slots * sizeof(Slot), c->stream));
-    DevBuf<uint64_t> scratch_bloom;               /* build_index_kernel wants a filter */
-    struct Sb { DevBuf<uint64_t> &z; ~Sb() { z.release(); } } sbclean{scratch_bloom};
-    if ((rc = dev_alloc(c, scratch_bloom, 1))) return rc;
     if (s->n) {
       BuildParams B{};
       B.zob = zob; B.A = A; B.zpos = zpos; B.n_v = n_v; B.use_genes = D.use_genes;
       B.res = res.p; B.off = off.p; B.v = v.p; B.j = j.p; B.n = s->n;
       B.table = table.p; B.slot_mask = slots - 1;
-      B.bloom = scratch_bloom.p; B.bloom_byte_mask = 0; B.sliced = 0;
+      B.bloom = nullptr; B.bloom_byte_mask = 0; B.sliced = 0;   /* table only */
       const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
       hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
       HIP_TRY(c, hipGetLastError());
@@ -1061,7 +1110,7 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
 /* set 1: sort by length, cut into 64-query tiles, upload               */
 /* ------------------------------------------------------------------ */
 
-extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
+static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
 {
   if (!c)
     return CMPR_EINVAL;
@@ -1098,13 +1147,22 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
 
   /* Counting sort into groups of equal (slice, length): slices ascending,
      inside a slice longest first.  Variant 0 has one slice.  Every group is
-     cut into 64-query tiles. */
+     cut into 64-query tiles.  Variant 2 lays the heavy queries out once more per
+     class position i (pass 3 + i, kernels_rows.h), grouped by the slice the
+     substitution row of that position is filed under. */
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
   const uint64_t S = c->sliced ? 2 * ((uint64_t)c->geom.smask + 1) : 1;   /* (slice, heavy) */
   const uint64_t per_slice = (uint64_t)longest + 1;
   if (S * per_slice >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
   const uint64_t G = S * per_slice;
+  const bool genes = !c->opt.ignore_genes;
+  std::vector<uint32_t> pass_ids(1, 0u);
+  if (c->rows && c->geom.k > 0 && c->opt.differences >= 1)
+    for (uint32_t i = 0; i < c->geom.k; i++)
+      pass_ids.push_back(3 + i);
+  c->npasses = (uint32_t)pass_ids.size();
+  const size_t NP = pass_ids.size();
   /* host threads: each takes one contiguous range of the queries in both passes
      (class keys + histogram here, placement below), so that inside a group the
      queries keep their input order, as in a serial counting sort */
@@ -1112,41 +1170,25 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1, (64ull << 20) / std::max<uint64_t>(G, 1)));
   if (s->n < 65536)
     T = 1;
-  std::vector<uint32_t> group_of((size_t)s->n);
-  std::vector<uint64_t> per_group((size_t)G, 0);
-  std::vector<std::vector<uint32_t> > hist(T, std::vector<uint32_t>((size_t)G, 0));
-  parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-    std::vector<uint32_t> &mine = hist[t];
-    for (uint64_t i = lo; i < hi; i++) {
-      const uint64_t b = s->offsets[i];
-      const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-      uint64_t sh = 0;
-      if (c->sliced) {
+  const uint32_t NO_GROUP = 0xffffffffu;
+  /* class key of every query */
+  std::vector<uint32_t> ckey(c->sliced ? (size_t)s->n : 0);
+  std::vector<uint8_t> is_heavy(c->sliced ? (size_t)s->n : 0);
+  if (c->sliced)
+    parallel_ranges(s->n, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+      for (uint64_t i = lo; i < hi; i++) {
+        const uint64_t b = s->offsets[i];
         bool heavy = false;
-        const bool genes = !c->opt.ignore_genes;
-        const uint32_t slice = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b, L,
-                                            genes ? s->v_gene[i] : 0, genes ? s->j_gene[i] : 0,
-                                            &heavy) & c->geom.smask;
-        sh = 2 * (uint64_t)slice + (heavy ? 1 : 0);
+        ckey[i] = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b,
+                               (uint32_t)(s->offsets[i + 1] - b), genes ? s->v_gene[i] : 0,
+                               genes ? s->j_gene[i] : 0, &heavy);
+        is_heavy[i] = heavy ? 1 : 0;
       }
-      const uint64_t g = sh * per_slice + (longest - L);
-      group_of[i] = (uint32_t)g;
-      mine[g]++;
-    }
-  });
-  /* per group: total, and for every thread the number of earlier threads' queries */
-  for (uint64_t g = 0; g < G; g++) {
-    uint64_t run = 0;
-    for (unsigned t = 0; t < T; t++) {
-      const uint32_t h = hist[t][g];
-      hist[t][g] = (uint32_t)run;
-      run += h;
-    }
-    per_group[g] = run;
-  }
-  std::vector<uint64_t> tile_first((size_t)(S * per_slice), 0);
+    });
+
   const uint64_t chunk_tiles =
       c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : 8 * (uint64_t)c->waves_per_block;
+  c->chunk_cap = (uint32_t)chunk_tiles;
   uint64_t ntiles = 0, res_words = 0;
   std::vector<TileDesc> tiles;
   std::vector<Chunk> chunks;
@@ -1167,112 +1209,165 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
      length), keep one tile group per length. */
   const bool mixed_ok = c->sliced && !c->opt.indels;
   const uint64_t min_mixed = mixed_ok ? (uint64_t)c->geom.c0 + c->geom.k : ~0ull;
-  std::vector<uint64_t> slot_base((size_t)(S * per_slice), 0);
-  for (uint64_t sh = 0; sh < S; sh++) {
-    const uint64_t slice = c->sliced ? sh / 2 : 0;
-    const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
-    const uint64_t slice_first = ntiles;
-    /* mixed-length tiles */
-    {
-      uint64_t n_long = 0;
-      for (uint64_t gl = 0; gl < per_slice; gl++) {
-        const uint64_t L = longest - gl;
-        if (L < min_mixed)
-          break;
-        const uint64_t g = sh * per_slice + gl;
-        slot_base[g] = ntiles * WAVE + n_long;
-        tile_first[g] = ntiles + n_long / WAVE;
-        n_long += per_group[g];
-      }
-      uint64_t gl = 0, seen = 0;        /* group that holds element k * 64 */
-      for (uint64_t k = 0; k * WAVE < n_long; k++) {
-        while (seen + per_group[sh * per_slice + gl] <= k * WAVE) {
-          seen += per_group[sh * per_slice + gl];
-          gl++;
-        }
-        const uint64_t L = longest - gl;              /* longest query of the tile */
-        TileDesc td;
-        td.len = (uint32_t)L;
-        td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, n_long - k * WAVE);
-        td.res_base = res_words;
-        td.slice = (uint32_t)slice;
-        td.k = tile_k;
-        res_words += ((L + 3) / 4) * WAVE;
-        tiles.push_back(td);
-      }
-      ntiles += (n_long + WAVE - 1) / WAVE;
-    }
-    /* one tile group per length */
-    for (uint64_t gl = 0; gl < per_slice; gl++) {
-      const uint64_t g = sh * per_slice + gl;
-      const uint64_t L = longest - gl;
-      if (L >= min_mixed)
-        continue;
-      tile_first[g] = ntiles;
-      slot_base[g] = ntiles * WAVE;
-      const uint64_t cnt = per_group[g];
-      const uint64_t nt = (cnt + WAVE - 1) / WAVE;
-      const uint64_t words = (L + 3) / 4;
-      for (uint64_t k = 0; k < nt; k++) {
-        TileDesc td;
-        td.len = (uint32_t)L;
-        td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
-        td.res_base = res_words;
-        td.slice = (uint32_t)slice;
-        td.k = tile_k;
-        res_words += words * WAVE;
-        tiles.push_back(td);
-      }
-      ntiles += nt;
-    }
-    if (c->sliced) {
-      /* main pass: the tiles of this slice, any length.  A slice with very few
-         query tiles is not worth a workgroup + a staged copy: its tiles go to the
-         list that single waves work through, probing the slice in HBM / L2. */
-      if (!c->opt.indels && ntiles - slice_first <= (uint64_t)c->small_slice_tiles) {
-        for (uint64_t t = slice_first; t < ntiles; t++)
-          small_tiles.push_back((uint32_t)t);
-      } else
-      for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
-        Chunk ck;
-        ck.slice = (uint32_t)slice;
-        ck.first_tile = (uint32_t)tile_list.size();
-        ck.ntiles = (uint32_t)std::min<uint64_t>(chunk_tiles, ntiles - t0);
-        ck.pass = 0;
-        uint64_t work = 0;
-        for (uint32_t t = 0; t < ck.ntiles; t++) {
-          work += (uint64_t)(tiles[t0 + t].len + 1) * tiles[t0 + t].nvalid;
-          tile_list.push_back((uint32_t)(t0 + t));
-        }
-        chunks.push_back(ck);
-        chunk_work.push_back(work);
-      }
-      /* indel passes: file every tile under the sibling slice its insertion /
-         deletion variants fall into (own ^ CL[L] ^ CL[L+-1]) */
-      if (c->opt.indels)
-        for (uint64_t gl = 0; gl < per_slice; gl++) {
-          const uint64_t g = sh * per_slice + gl;
-          const uint64_t L = longest - gl;
-          const uint64_t nt = (per_group[g] + WAVE - 1) / WAVE;
-          for (uint32_t pass = 1; pass <= 2; pass++) {
-            if (pass == 2 && L < 2)
+
+  struct PassLayout {
+    std::vector<uint32_t> group_of;
+    std::vector<std::vector<uint32_t> > hist;      /* per thread: queries of earlier threads */
+    std::vector<uint64_t> slot_base;
+  };
+  std::vector<PassLayout> PL(NP);
+  for (size_t pi = 0; pi < NP; pi++) {
+    const uint32_t pass = pass_ids[pi];
+    PassLayout &pl = PL[pi];
+    pl.group_of.assign((size_t)s->n, NO_GROUP);
+    pl.hist.assign(T, std::vector<uint32_t>((size_t)G, 0));
+    parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+      std::vector<uint32_t> &mine = pl.hist[t];
+      for (uint64_t i = lo; i < hi; i++) {
+        const uint64_t b = s->offsets[i];
+        const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
+        uint64_t sh = 0;
+        if (c->sliced) {
+          uint32_t key = ckey[i];
+          if (pass >= 3) {
+            /* the row of class position i = pass - 3: the key without the terms of
+               that position */
+            if (!is_heavy[i] || L == 0)
               continue;
-            const uint32_t dlen = c->ctab[L] ^ c->ctab[pass == 1 ? L + 1 : L - 1];
-            std::vector<uint32_t> &dst =
-                sibling[pass - 1][((uint32_t)slice ^ dlen) & c->geom.smask];
-            for (uint64_t t = 0; t < nt; t++)
-              dst.push_back((uint32_t)(tile_first[g] + t));
+            const uint32_t pos = class_pos(L, pass - 3, c->geom.c0);
+            for (uint32_t k = 0; k < c->geom.k; k++)
+              if (class_pos(L, k, c->geom.c0) == pos)
+                key ^= c->ctab[c->geom.off_cr + k * A + s->residues[b + pos]];
           }
+          sh = 2 * (uint64_t)(key & c->geom.smask) + (is_heavy[i] ? 1 : 0);
         }
+        const uint64_t g = sh * per_slice + (longest - L);
+        pl.group_of[i] = (uint32_t)g;
+        mine[g]++;
+      }
+    });
+    /* per group: total, and for every thread the number of earlier threads' queries */
+    std::vector<uint64_t> per_group((size_t)G, 0);
+    for (uint64_t g = 0; g < G; g++) {
+      uint64_t run = 0;
+      for (unsigned t = 0; t < T; t++) {
+        const uint32_t h = pl.hist[t][g];
+        pl.hist[t][g] = (uint32_t)run;
+        run += h;
+      }
+      per_group[g] = run;
+    }
+    std::vector<uint64_t> tile_first((size_t)G, 0);
+    pl.slot_base.assign((size_t)G, 0);
+    std::vector<uint64_t> &slot_base = pl.slot_base;
+    for (uint64_t sh = 0; sh < S; sh++) {
+      const uint64_t slice = c->sliced ? sh / 2 : 0;
+      const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
+      const uint64_t slice_first = ntiles;
+      /* mixed-length tiles */
+      {
+        uint64_t n_long = 0;
+        for (uint64_t gl = 0; gl < per_slice; gl++) {
+          const uint64_t L = longest - gl;
+          if (L < min_mixed)
+            break;
+          const uint64_t g = sh * per_slice + gl;
+          slot_base[g] = ntiles * WAVE + n_long;
+          tile_first[g] = ntiles + n_long / WAVE;
+          n_long += per_group[g];
+        }
+        uint64_t gl = 0, seen = 0;        /* group that holds element k * 64 */
+        for (uint64_t k = 0; k * WAVE < n_long; k++) {
+          while (seen + per_group[sh * per_slice + gl] <= k * WAVE) {
+            seen += per_group[sh * per_slice + gl];
+            gl++;
+          }
+          const uint64_t L = longest - gl;              /* longest query of the tile */
+          TileDesc td;
+          td.len = (uint32_t)L;
+          td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, n_long - k * WAVE);
+          td.res_base = (uint32_t)res_words;
+          td.pass = pass;
+          td.slice = (uint32_t)slice;
+          td.k = tile_k;
+          res_words += ((L + 3) / 4) * WAVE;
+          tiles.push_back(td);
+        }
+        ntiles += (n_long + WAVE - 1) / WAVE;
+      }
+      /* one tile group per length */
+      for (uint64_t gl = 0; gl < per_slice; gl++) {
+        const uint64_t g = sh * per_slice + gl;
+        const uint64_t L = longest - gl;
+        if (L >= min_mixed)
+          continue;
+        tile_first[g] = ntiles;
+        slot_base[g] = ntiles * WAVE;
+        const uint64_t cnt = per_group[g];
+        const uint64_t nt = (cnt + WAVE - 1) / WAVE;
+        const uint64_t words = (L + 3) / 4;
+        for (uint64_t k = 0; k < nt; k++) {
+          TileDesc td;
+          td.len = (uint32_t)L;
+          td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
+          td.res_base = (uint32_t)res_words;
+          td.pass = pass;
+          td.slice = (uint32_t)slice;
+          td.k = tile_k;
+          res_words += words * WAVE;
+          tiles.push_back(td);
+        }
+        ntiles += nt;
+      }
+      if (c->sliced) {
+        /* the tiles of this slice, any length.  A slice with very few query tiles
+           is not worth a workgroup + a staged copy: its tiles go to the list that
+           single waves work through, probing the slice in HBM / L2. */
+        if (!c->opt.indels && ntiles - slice_first <= (uint64_t)c->small_slice_tiles) {
+          for (uint64_t t = slice_first; t < ntiles; t++)
+            small_tiles.push_back((uint32_t)t);
+        } else
+        for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
+          Chunk ck;
+          ck.slice = (uint32_t)slice;
+          ck.first_tile = (uint32_t)tile_list.size();
+          ck.ntiles = (uint32_t)std::min<uint64_t>(chunk_tiles, ntiles - t0);
+          ck.pass = pass;
+          uint64_t work = 0;
+          for (uint32_t t = 0; t < ck.ntiles; t++) {
+            work += (uint64_t)(pass == 0 ? tiles[t0 + t].len + 1 : 2) * tiles[t0 + t].nvalid;
+            tile_list.push_back((uint32_t)(t0 + t));
+          }
+          chunks.push_back(ck);
+          chunk_work.push_back(work);
+        }
+        /* indel passes: file every tile of the main pass under the sibling slice its
+           insertion / deletion variants fall into (own ^ CL[L] ^ CL[L+-1]) */
+        if (c->opt.indels && pass == 0)
+          for (uint64_t gl = 0; gl < per_slice; gl++) {
+            const uint64_t g = sh * per_slice + gl;
+            const uint64_t L = longest - gl;
+            const uint64_t nt = (per_group[g] + WAVE - 1) / WAVE;
+            for (uint32_t ip = 1; ip <= 2; ip++) {
+              if (ip == 2 && L < 2)
+                continue;
+              const uint32_t dlen = c->ctab[L] ^ c->ctab[ip == 1 ? L + 1 : L - 1];
+              std::vector<uint32_t> &dst =
+                  sibling[ip - 1][((uint32_t)slice ^ dlen) & c->geom.smask];
+              for (uint64_t t = 0; t < nt; t++)
+                dst.push_back((uint32_t)(tile_first[g] + t));
+            }
+          }
+      }
     }
   }
   if (c->sliced && c->opt.indels)
     for (uint32_t pass = 1; pass <= 2; pass++)
-      for (size_t T = 0; T < sibling[pass - 1].size(); T++) {
-        const std::vector<uint32_t> &src = sibling[pass - 1][T];
+      for (size_t sl = 0; sl < sibling[pass - 1].size(); sl++) {
+        const std::vector<uint32_t> &src = sibling[pass - 1][sl];
         for (size_t t0 = 0; t0 < src.size(); t0 += chunk_tiles) {
           Chunk ck;
-          ck.slice = (uint32_t)T;
+          ck.slice = (uint32_t)sl;
           ck.first_tile = (uint32_t)tile_list.size();
           ck.ntiles = (uint32_t)std::min<size_t>(chunk_tiles, src.size() - t0);
           ck.pass = pass;
@@ -1313,28 +1408,34 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
   }
 
   const size_t slots = (size_t)ntiles * WAVE;
-  if ((uint64_t)res_words >> 32)
+  if ((uint64_t)res_words + 9 * WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "query set too large for 32-bit residue positions");
   /* + 9 rows: verify_candidate reads nine dwords per query whatever its length */
   std::vector<uint32_t> qres((size_t)res_words + 9 * WAVE, 0), qrep(slots, 0), qv, qj;
   std::vector<uint64_t> qcnt;
   std::vector<uint16_t> qlen(slots, 0);
-  std::vector<uint32_t> qorig(slots, 0);
+  std::vector<uint32_t> qorig(slots, 0), qck(c->rows ? slots : 1, 0);
   if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
   if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
   std::vector<uint64_t> alg_part(T, 0);
+  for (size_t pi = 0; pi < NP; pi++) {
+  PassLayout &pl = PL[pi];
   parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-  std::vector<uint32_t> &fill = hist[t];      /* queries of earlier threads + own so far */
+  std::vector<uint32_t> &fill = pl.hist[t];      /* queries of earlier threads + own so far */
   uint64_t alg = 0;
   for (uint64_t i = lo; i < hi; i++) {
+    const uint64_t g = pl.group_of[i];
+    if (g == NO_GROUP)
+      continue;
     const uint64_t b = s->offsets[i];
     const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-    const uint64_t g = group_of[i];
-    const size_t slot = (size_t)(slot_base[g] + fill[g]++);
+    const size_t slot = (size_t)(pl.slot_base[g] + fill[g]++);
     const uint64_t tile = slot / WAVE;
     const uint32_t lane = (uint32_t)(slot % WAVE);
     qlen[slot] = (uint16_t)L;
     qorig[slot] = (uint32_t)i;
+    if (c->rows)
+      qck[slot] = ckey[i];
     if (c->opt.existence)
       qrep[slot] = (uint32_t)i;               /* -x: the row is the sequence itself */
     if (!c->opt.existence)
@@ -1345,19 +1446,23 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
     const uint8_t *src = s->residues + b;
     for (uint32_t p = 0; p < L; p++)
       dst[(size_t)(p >> 2) * WAVE] |= (uint32_t)src[p] << ((p & 3) * 8);
-    alg += (uint64_t)L + 20 + 8 * variants_of(c->opt, src, L);
+    if (pi == 0)
+      alg += (uint64_t)L + 20 + 8 * variants_of(c->opt, src, L);
   }
-  alg_part[t] = alg;
+  alg_part[t] += alg;
   });
+  }
   c->algorithmic_bytes = 0;
   for (unsigned t = 0; t < T; t++)
     c->algorithmic_bytes += alg_part[t];
+  PL.clear();
 
   if ((rc = dev_upload(c, c->tiles, tiles.data(), tiles.size()))) return rc;
   if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
   if ((rc = dev_upload(c, c->qrep, qrep.data(), qrep.size()))) return rc;
   if ((rc = dev_upload(c, c->qlen, qlen.data(), qlen.size()))) return rc;
   if ((rc = dev_upload(c, c->qorig, qorig.data(), qorig.size()))) return rc;
+  if ((rc = dev_upload(c, c->qck, qck.data(), qck.size()))) return rc;
   if (!c->opt.ignore_genes) {
     if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
     if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
@@ -1373,7 +1478,11 @@ extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
 
   const size_t cells = (size_t)c->R1 * c->R2;
   if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
-  if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
+  if (is_f64_score(c->opt)) {
+    if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
+  } else {
+    c->matrix_f64.release();
+  }
   /* positives buffer of the deferred resolve: a capacity, not a limit -- what
      does not fit is resolved inline by the probe kernel */
   {
@@ -1405,9 +1514,10 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 {
   const size_t cells = (size_t)c->R1 * c->R2;
   HIP_TRY(c, hipEventRecord(c->ev_start, st));
-  HIP_TRY(c, hipMemsetAsync(d_out, 0, std::max<size_t>(cells, 1) * sizeof(unsigned long long), st));
-  if (is_f64_score(c->opt))
-    HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, std::max<size_t>(cells, 1) * sizeof(double), st));
+  if (cells)
+    HIP_TRY(c, hipMemsetAsync(d_out, 0, cells * sizeof(unsigned long long), st));
+  if (cells && is_f64_score(c->opt))
+    HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, cells * sizeof(double), st));
   const bool deferred = c->sliced && c->deferred_resolve;
   HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, ((size_t)c->pos_segments * POS_CTR_STRIDE +
                                               STAT_COUNT + 1) * sizeof(unsigned long long), st));
@@ -1448,6 +1558,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qcnt = c->qcnt.p;
     P.qlen = c->qlen.p;
     P.qorig = c->qorig.p;
+    P.qck = c->qck.p;
     P.pair_q = c->pair_q;
     P.pair_h = c->pair_h;
     P.pair_count = c->pair_count;
@@ -1484,14 +1595,20 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
         (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
       nw = 4;
     auto lds_for = [&](int waves) -> size_t {
-      size_t b = (size_t)(c->sliced ? zrow_stride((int)A) + zdelta_entries((int)A) : A) * c->zpos *
-                     sizeof(uint64_t) +
+      const size_t zrow = c->rows ? (c->opt.differences == 2 ? 2 * (size_t)A : (size_t)A)
+                                  : c->sliced ? (size_t)(zrow_stride((int)A) + zdelta_entries((int)A))
+                                              : (size_t)A;
+      size_t b = zrow * c->zpos * sizeof(uint64_t) +
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)waves * sizeof(WaveQueue);
-      if (c->sliced)
+      if (c->rows)
+        b += (size_t)c->geom.rw_words * 16 + MAX_CLASS_RES * A * sizeof(uint32_t) +
+             (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) + 16 +
+             (size_t)c->chunk_cap * sizeof(TileRef);
+      else if (c->sliced)
         b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
              MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
-             (size_t)(c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block) * sizeof(TileRef);
+             (size_t)c->chunk_cap * sizeof(TileRef);
       return b;
     };
     size_t lds = lds_for(nw);
@@ -1502,7 +1619,17 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    ProbeFn fn = c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
+    /* a chunk's tile descriptors are staged one per thread (kernels_rows.h) */
+    if (c->rows && c->chunk_cap > (uint32_t)nw * WAVE)
+      nw = c->chunk_cap > 8 * WAVE ? 16 : 8;
+    if (c->rows && c->chunk_cap > (uint32_t)nw * WAVE)
+      return fail(c, CMPR_EINVAL, "chunk_tiles exceeds the threads of a workgroup (variant 2)");
+    lds = lds_for(nw);
+    if (lds > 160 * 1024)
+      return fail(c, CMPR_EUNSUPPORTED,
+                  "sequences too long: Zobrist table does not fit the 160 KiB LDS");
+    ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw)
+                         : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
     if (lds > 48 * 1024 && (c->attr_fn != (const void *)fn || c->attr_lds < lds)) {
       /* once per kernel and size, not once per launch */
       HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
@@ -1529,10 +1656,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       /* 5 waves/SIMD fit its registers; a multiple of the segment count */
       uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
       rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
-      if (c->opt.ignore_genes)
-        hipLaunchKernelGGL(resolve_kernel<false>, dim3(rgrid), dim3(BLOCK_THREADS), rlds, st, P);
-      else
-        hipLaunchKernelGGL(resolve_kernel<true>, dim3(rgrid), dim3(BLOCK_THREADS), rlds, st, P);
+      hipLaunchKernelGGL(select_resolve(!c->opt.ignore_genes), dim3(rgrid), dim3(BLOCK_THREADS),
+                         rlds, st, P);
       HIP_TRY(c, hipGetLastError());
       c->launches = 2;
     }
@@ -1597,7 +1722,7 @@ extern "C" int cmpr_overlap_matrix(cmpr_context *c, uint64_t *out)
   return CMPR_OK;
 }
 
-extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)
+static int cmpr_overlap_matrix_f64_impl(cmpr_context *c, double *out)
 {
   int rc = check_ready(c);
   if (rc)
@@ -1714,10 +1839,52 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   out->bloom_positive = st[STAT_BLOOM_POS];
   out->hash_equal = st[STAT_HASH_EQ];
   out->matches = st[STAT_MATCHES];
+  out->filter_reads = st[STAT_READS];
   out->algorithmic_bytes = c->algorithmic_bytes;
   out->kernel_ms = k_ms;
   out->probe_ms = p_ms;
   out->total_ms = t_ms;
   out->kernel_launches = c->launches;
   return CMPR_OK;
+}
+
+extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
+                                  uint32_t longest_query)
+{
+  /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
+  try {
+    return cmpr_set_reference_impl(c, s, longest_query);
+  } catch (const std::bad_alloc &) {
+    return fail(c, CMPR_ENOMEM, "out of host memory");
+  }
+}
+
+extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
+{
+  /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
+  try {
+    return cmpr_count_duplicates_impl(c, s, out);
+  } catch (const std::bad_alloc &) {
+    return fail(c, CMPR_ENOMEM, "out of host memory");
+  }
+}
+
+extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
+{
+  /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
+  try {
+    return cmpr_set_queries_impl(c, s);
+  } catch (const std::bad_alloc &) {
+    return fail(c, CMPR_ENOMEM, "out of host memory");
+  }
+}
+
+extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)
+{
+  /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
+  try {
+    return cmpr_overlap_matrix_f64_impl(c, out);
+  } catch (const std::bad_alloc &) {
+    return fail(c, CMPR_ENOMEM, "out of host memory");
+  }
 }

@@ -137,7 +137,7 @@ struct BuildParams {
   uint64_t        n;
   Slot           *table;
   uint64_t        slot_mask;
-  uint64_t       *bloom;
+  uint64_t       *bloom;           /* NULL: build the table only            */
   uint32_t        bloom_byte_mask;
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
   uint32_t        pad[2];
@@ -148,7 +148,7 @@ struct BuildParams {
    first free slot of the probe chain with a 64-bit CAS (hash_insert,
    overlap.cc:63-128: every entry is inserted, duplicates included), clear the
    pattern bits in the Bloom word (bloom_set, bloompat.h:50-53). */
-__global__ void __launch_bounds__(BLOCK_THREADS)
+static __global__ void __launch_bounds__(BLOCK_THREADS)
 build_index_kernel(const BuildParams B)
 {
   const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
@@ -176,6 +176,8 @@ build_index_kernel(const BuildParams B)
   }
   B.table[slot].val = B.voff ? B.voff[i] : (uint32_t)i;
 
+  if (!B.bloom)
+    return;                            /* table only: duplicate counting, row filter */
   uint64_t boff = bloom_off(h) & B.bloom_byte_mask;
   if (B.sliced) {
     const uint32_t slice = class_key_of(B.geom.ctab, B.geom, B.A, B.use_genes != 0,
@@ -208,7 +210,7 @@ struct DupParams {
   unsigned long long *count;
 };
 
-__global__ void __launch_bounds__(BLOCK_THREADS)
+static __global__ void __launch_bounds__(BLOCK_THREADS)
 count_duplicates_kernel(const DupParams B)
 {
   const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
@@ -264,7 +266,7 @@ struct PackParams {
   unsigned char  *out;
 };
 
-__global__ void __launch_bounds__(BLOCK_THREADS)
+static __global__ void __launch_bounds__(BLOCK_THREADS)
 pack_records_kernel(const PackParams B)
 {
   const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
@@ -364,7 +366,7 @@ struct LaneStats {
 /* One verified (query, hit) pair: list it (pairs mode) or add its score to the
    matrix cell (overlap.cc:218-245). */
 __device__ __forceinline__ void score_match(const ProbeParams &P, uint32_t qs, uint32_t hit,
-                                            uint32_t cell, unsigned long long f,
+                                            uint64_t cell, unsigned long long f,
                                             unsigned long long g, unsigned long long *mat_lds)
 {
   if (P.pair_count) {
@@ -435,7 +437,7 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
         ok = (q_v == rec.v) && (q_j == rec.j);
       if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, rp + sizeof(RefRec))) {
         st.matches++;
-        score_match(P, qs, hit, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
+        score_match(P, qs, hit, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
       }
     }
     if (end)
@@ -552,7 +554,7 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
   }
   if (ok && bad == 0) {
     st.matches++;
-    score_match(P, qs, rec.idx, P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
+    score_match(P, qs, rec.idx, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
   }
 }
 
@@ -570,7 +572,7 @@ resolve_kernel(const ProbeParams P)
   CandQueue &cq = ((CandQueue *)smem)[threadIdx.x / WAVE];
   unsigned long long *mat_lds =
       (unsigned long long *)(smem + (BLOCK_THREADS / WAVE) * sizeof(CandQueue));
-  const uint32_t cells = P.R1 * P.R2;
+  const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
   if (P.lds_matrix) {
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
       mat_lds[i] = 0;
@@ -731,7 +733,7 @@ probe_kernel(const ProbeParams P)
   uint64_t *zl = (uint64_t *)smem;
   const uint32_t nz = (uint32_t)A * P.zpos;
   unsigned long long *mat_all = (unsigned long long *)(zl + nz);
-  const uint32_t cells = P.R1 * P.R2;
+  const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
 
   for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)

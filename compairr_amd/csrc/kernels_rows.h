@@ -1,0 +1,801 @@
+/*
+ * kernels_rows.h -- probe kernel, variant 2: the ROW filter.
+ *
+ * Same path as kernels.h / kernels_sliced.h (variant enumeration -> Zobrist
+ * hash -> Bloom test -> hash-table walk -> exact verify -> matrix accumulate;
+ * reference: overlap.cc:253-284, variants.cc:260-428, bloompat.h:40-58,
+ * overlap.cc:168-251), but the Bloom test of the A-1 substitution variants of
+ * one position (a "row", variants.cc:280-293) costs ONE filter-word read
+ * instead of A-1:
+ *
+ *   Every set-2 sequence t is entered into the filter once per position p, under
+ *   the hash of t WITH POSITION p BLANKED,  W = H(t) ^ Z[p][t[p]],  together with
+ *   the residue it has there (code t[p] < A), and once more under H(t) itself
+ *   with code A ("the sequence as it is").  An entry (W, code) sets four bits of
+ *   the 128-bit filter word addressed by the high half of W: bit
+ *   (a_k + code) mod 32 of dword k, a_0..a_3 being the low five bits of the four
+ *   bytes of W's low half.
+ *
+ *   A query q reads, for position p, the word of W = H(q) ^ Z[p][q[p]] -- the same
+ *   W as every t that differs from q at most at p -- rotates dword k right by a_k
+ *   and ANDs the four: bit v of the result is the Bloom answer for "q with v at
+ *   p" (4 bits per entry, block = one word, bloompat.h:22-58 geometry).  All A
+ *   answers of the row come out of one 16-byte LDS read and ~12 instructions.
+ *
+ * The same entries serve the other variant kinds: an insertion variant of q
+ * (v put in front of position ip) blanked at ip IS q with a gap at ip, so the
+ * row of all A insertions at ip is one read under the rolling gap hash
+ * (variants.cc:329-353); a deletion variant is a whole sequence, looked up by its
+ * code-A entry (variants.cc:301-325); a double substitution (p, q) is read as
+ * row p of "q already substituted at q" (variants.cc:370-399): A-1 reads instead
+ * of (A-1)^2 probes.  Bloom positives are queued with their full variant hash
+ * exactly as in the other kernels, so everything behind the filter
+ * (resolve_kernel: table walk, check_variant, score) is unchanged.
+ *
+ * Slices: as in variant 1 the filter is cut into class-keyed slices that a
+ * workgroup stages in LDS (layout.h), with one refinement the blanking makes
+ * possible: the entry of (t, p) is filed under t's class key WITHOUT the term of
+ * position p when p is a class position.  All A variants of a class-position
+ * row therefore live in ONE slice (the "sibling" of the query's own), and the
+ * host schedules those rows as separate passes whose tiles are grouped by that
+ * sibling: no substitution probe of d = 1 goes to HBM.
+ */
+#ifndef COMPAIRR_AMD_KERNELS_ROWS_H
+#define COMPAIRR_AMD_KERNELS_ROWS_H
+
+#include "kernels_sliced.h"
+#include <type_traits>
+
+namespace cmpr {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_u128_t;
+typedef __attribute__((address_space(3))) u32x4 lds_u128_w_t;
+
+__device__ __forceinline__ u32x4 lds_u128(uint32_t byte_addr)
+{
+  return *(lds_u128_t *)(uintptr_t)byte_addr;
+}
+
+/* bit c of the result <-> "an entry with code c may be present under this W":
+   each dword rotated right by its five hash bits, the four ANDed */
+__device__ __forceinline__ uint32_t row_bits(u32x4 w, uint32_t wl)
+{
+  const uint32_t x0 = __builtin_amdgcn_alignbit(w.x, w.x, wl);
+  const uint32_t x1 = __builtin_amdgcn_alignbit(w.y, w.y, wl >> 8);
+  const uint32_t x2 = __builtin_amdgcn_alignbit(w.z, w.z, wl >> 16);
+  const uint32_t x3 = __builtin_amdgcn_alignbit(w.w, w.w, wl >> 24);
+  return x0 & x1 & x2 & x3;
+}
+
+/* the four bits of entry (W, code), as the two 64-bit halves of the word */
+__host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint64_t &lo, uint64_t &hi)
+{
+  const uint32_t wl = (uint32_t)Wk;
+  lo = (1ull << ((wl + code) & 31u)) | (1ull << (32u + (((wl >> 8) + code) & 31u)));
+  hi = (1ull << (((wl >> 16) + code) & 31u)) | (1ull << (32u + (((wl >> 24) + code) & 31u)));
+}
+
+/* word of W inside a slice of `nwords` 16-byte words (any count, not only
+   powers of two: the filter is sized to the entry count) */
+__host__ __device__ inline uint32_t row_word(uint64_t Wk, uint32_t nwords)
+{
+  return (uint32_t)(((uint64_t)(uint32_t)(Wk >> 32) * nwords) >> 32);
+}
+
+/* ------------------------------------------------------------------ */
+/* filter build                                                         */
+/* ------------------------------------------------------------------ */
+
+/* One thread per set-2 sequence: L + 1 entries (bloom_set, bloompat.h:50-53,
+   once per blanked position and once for the sequence as it is). */
+static __global__ void __launch_bounds__(BLOCK_THREADS)
+build_rows_kernel(const BuildParams B)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if (i >= B.n)
+    return;
+  const uint64_t b = B.off[i];
+  const uint32_t L = (uint32_t)(B.off[i + 1] - b);
+  const uint8_t *s = B.res + b;
+  uint64_t h = 0;
+  if (B.use_genes) {
+    const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+    h = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+  }
+  for (uint32_t p = 0; p < L; p++)
+    h ^= B.zob[B.A * p + s[p]];
+  const SliceGeom &g = B.geom;
+  bool heavy = false;
+  const uint32_t ck = class_key_of(g.ctab, g, B.A, B.use_genes != 0, s, L,
+                                   B.use_genes ? B.v[i] : 0u, B.use_genes ? B.j[i] : 0u, &heavy);
+  const uint32_t nwords = g.rw_words;
+  unsigned long long *words = (unsigned long long *)B.bloom;
+  auto enter = [&](uint64_t Wk, uint32_t code, uint32_t key) {
+    const uint64_t w = (uint64_t)(key & g.smask) * nwords + row_word(Wk, nwords);
+    uint64_t lo, hi;
+    row_entry_bits(Wk, code, lo, hi);
+    atomicOr(words + 2 * w, (unsigned long long)lo);
+    atomicOr(words + 2 * w + 1, (unsigned long long)hi);
+  };
+  enter(h, B.A, ck);
+  for (uint32_t p = 0; p < L; p++) {
+    uint32_t key = ck;
+    if (heavy)
+      for (uint32_t k = 0; k < g.k; k++)
+        if (class_pos(L, k, g.c0) == p)
+          key ^= g.ctab[g.off_cr + k * B.A + s[p]];
+    enter(h ^ B.zob[B.A * p + s[p]], s[p], key);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* probe kernel                                                         */
+/* ------------------------------------------------------------------ */
+
+/* rows per 64-bit mask register / rows per block / bits of a packed residue */
+template <int A> struct RowCfg {
+  static constexpr int RPW = A == 20 ? 3 : 16;
+  static constexpr int RB = A == 20 ? 6 : 8;
+  static constexpr uint32_t RBITS = A == 20 ? 5u : 2u;
+};
+
+/*
+ * Chunk::pass of this kernel:
+ *   0      the sequence itself + every substitution row that is not a class
+ *          position of a split ("heavy") tile (+ the double substitutions)
+ *   1, 2   insertion rows / deletion variants, the tiles grouped by the slice
+ *          most of those variants fall into (as in variant 1)
+ *   3 + i  the substitution row of class position i of the heavy queries, the
+ *          tiles grouped by that row's slice
+ * TileDesc::slice is the slice the tile's rows of this pass are filed under;
+ * for a staged chunk it is the slice in LDS.
+ *
+ * LDS: [slice, rw_words x 16 B][ZS x zpos Zobrist keys][R1 x R2 matrix (optional)]
+ *      [NW WaveQueues][CR tables][heavy bitmap (-i)][chunk broadcast][tile refs]
+ */
+template <int A, int D, bool INDELS, bool GENES, int NW>
+__global__ void __launch_bounds__(NW * WAVE, 4)
+probe_rows_kernel(const ProbeParams P)
+{
+  constexpr uint32_t NT = NW * WAVE;
+  constexpr uint32_t MCR = max_class_res(A);
+  constexpr uint32_t ZS = D == 2 ? 2u * A : (uint32_t)A;   /* d = 2: rows stored twice (rotated reads) */
+  constexpr int RPW = RowCfg<A>::RPW;
+  constexpr int RB = RowCfg<A>::RB;
+  constexpr uint32_t RBITS = RowCfg<A>::RBITS;
+  constexpr uint32_t RMASK = (1u << RBITS) - 1u;
+  constexpr uint32_t AMASK = (1u << A) - 1u;
+  constexpr uint32_t PF = (MAX_ROW_SLICE_WORDS + NT - 1) / NT;   /* staged words per thread */
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  if ((uint32_t)(uintptr_t)smem != 0u)
+    __builtin_trap();                       /* the slice is read at absolute LDS addresses */
+  const uint32_t nwords = P.geom.rw_words;
+  const uint32_t slice_bytes = nwords * 16u;
+  const unsigned char *filter = (const unsigned char *)P.bloom;
+  uint64_t *zl = (uint64_t *)(smem + slice_bytes);
+  const uint32_t nz = ZS * P.zpos;
+  unsigned long long *mat_all = (unsigned long long *)(zl + nz);
+  const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
+  WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
+  uint32_t *cr_lds = (uint32_t *)(queues + NW);
+  uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;
+  uint32_t *bcast = hv_lds + (INDELS ? HEAVY_WORDS : 0u);
+  TileRef *tref_lds = (TileRef *)(bcast + 4);
+
+  for (uint32_t i = threadIdx.x; i < nz; i += NT)
+    zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
+  if (P.lds_matrix)
+    for (uint32_t i = threadIdx.x; i < cells; i += NT)
+      mat_all[i] = 0;
+  for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += NT)
+    cr_lds[i] = P.geom.ctab[P.geom.off_cr + i];
+  if (INDELS)
+    for (uint32_t i = threadIdx.x; i < HEAVY_WORDS; i += NT)
+      hv_lds[i] = P.geom.ctab[P.geom.off_hv + i];
+
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x / WAVE;
+  const uint32_t KH = P.geom.k;
+  const uint32_t smask = P.geom.smask;
+  SProber W{P, (const uint64_t *)smem, queues[wave], P.lds_matrix ? mat_all : nullptr,
+            lane, 0u, 0u, 0u, smask, 0u, 0, {0ull, 0u, 0u, 0u}};
+  const uint32_t zl_addr = slice_bytes;           /* LDS address of zl */
+  unsigned long long reads = 0;                   /* filter words read by this lane */
+
+  /* next chunk, prefetched into registers while the current one is worked on */
+  Chunk ck_next;
+  ck_next.slice = ck_next.first_tile = ck_next.ntiles = ck_next.pass = 0;
+  u32x4 pf[PF];
+  uint32_t pft_t = 0;                             /* this thread's tile of the next chunk */
+  u32x4 pft_a = {0, 0, 0, 0};                     /* its descriptor: len, nvalid, res_base, pass */
+  uint32_t pft_slice = 0, pft_k = 0;
+  auto load_chunk = [&](uint32_t item) {
+    ck_next = P.chunks[item];
+    const u32x4 *src = (const u32x4 *)(filter + (size_t)ck_next.slice * slice_bytes);
+#pragma unroll
+    for (uint32_t k = 0; k < PF; k++) {
+      const uint32_t idx = threadIdx.x + k * NT;
+      if (idx < nwords)
+        pf[k] = src[idx];
+    }
+    if (threadIdx.x < ck_next.ntiles) {
+      pft_t = P.tile_list[ck_next.first_tile + threadIdx.x];
+      const TileDesc *tp = P.tiles + pft_t;
+      pft_a = *(const u32x4 *)tp;
+      pft_slice = tp->slice;
+      pft_k = tp->k;
+    }
+  };
+
+  if (threadIdx.x == 0)
+    bcast[0] = atomicAdd(P.tile_counter, 1u);
+  __syncthreads();                                /* also: the tables above are in place */
+  bool have_next = bcast[0] < P.nchunks;
+  if (have_next)
+    load_chunk(bcast[0]);
+
+  bool block_phase = true;
+  for (;;) {
+    Chunk ck;
+    ck.slice = ck.first_tile = ck.ntiles = ck.pass = 0;
+    if (block_phase) {
+      if (!have_next) {
+        block_phase = false;                      /* the same for every thread of the block */
+      } else {
+        __syncthreads();                          /* everyone is done with the old slice */
+        ck = ck_next;
+#pragma unroll
+        for (uint32_t k = 0; k < PF; k++) {
+          const uint32_t idx = threadIdx.x + k * NT;
+          if (idx < nwords)
+            *(lds_u128_w_t *)(uintptr_t)(idx * 16u) = pf[k];
+        }
+        if (threadIdx.x < ck.ntiles) {
+          TileRef *tr = tref_lds + threadIdx.x;
+          tr->td.len = pft_a.x;
+          tr->td.nvalid = pft_a.y;
+          tr->td.res_base = pft_a.z;
+          tr->td.pass = pft_a.w;
+          tr->td.slice = pft_slice;
+          tr->td.k = pft_k;
+          tr->t = pft_t;
+        }
+        if (threadIdx.x == 0) {
+          bcast[0] = atomicAdd(P.tile_counter, 1u);
+          bcast[1] = 0;                           /* tiles of the chunk handed out so far */
+        }
+        __syncthreads();
+        have_next = bcast[0] < P.nchunks;
+        if (have_next)
+          load_chunk(bcast[0]);
+      }
+    }
+    const bool staged = block_phase;
+    const uint32_t pass = ck.pass;
+
+    bool all_done = false;
+    for (;;) {
+      uint32_t t;
+      TileDesc td;
+      if (block_phase) {
+        uint32_t tk = 0;
+        if (lane == 0)
+          tk = atomicAdd(&bcast[1], 1u);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= ck.ntiles)
+          break;
+        t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
+        td = tref_lds[tk].td;
+      } else {
+        uint32_t i = 0;
+        if (lane == 0)
+          i = atomicAdd(P.tile_counter + 1, 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= P.nsmall) {
+          all_done = true;
+          break;
+        }
+        t = P.small_tiles[i];
+        td = P.tiles[t];
+      }
+      const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
+      const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
+      const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);       /* 0: light tile */
+      const uint32_t tslice = __builtin_amdgcn_readfirstlane(td.slice);
+      /* the indel passes reuse the tiles of pass 0 and are named by their chunk */
+      const uint32_t tpass = (staged && pass) ? pass : __builtin_amdgcn_readfirstlane(td.pass);
+      const uint32_t *qr = P.qres + td.res_base + lane;
+      const bool valid = lane < nvalid;
+      const uint32_t vmask = valid ? ~0u : 0u;
+      W.qslot = t * WAVE + lane;
+      const uint32_t Ll = valid ? (uint32_t)P.qlen[W.qslot] : 0u;
+      const uint32_t qck = P.qck[W.qslot];         /* the query's class key */
+      const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
+
+      auto woff_of = [&](uint64_t Wk) -> uint32_t {
+        return __umulhi((uint32_t)(Wk >> 32), nwords) << 4;
+      };
+      /* the tile's slice: the staged copy, or where it lies */
+      auto fetch_own = [&](uint64_t Wk) -> u32x4 {
+        const uint32_t wo = woff_of(Wk);
+        reads += valid ? 1u : 0u;
+        if (staged)
+          return lds_u128(wo);
+        return *(const u32x4 *)(own_glob + wo);
+      };
+      /* a slice of the lane's own */
+      auto fetch_at = [&](uint64_t Wk, uint32_t slice, bool in_lds) -> u32x4 {
+        const uint32_t wo = woff_of(Wk);
+        reads += valid ? 1u : 0u;
+        u32x4 w;
+        if (in_lds)
+          w = lds_u128(wo);
+        else
+          w = *(const u32x4 *)(filter + (size_t)slice * slice_bytes + wo);
+        return w;
+      };
+      auto res_at = [&](uint32_t p) -> uint32_t {
+        return (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
+      };
+
+      /* ---- query hash (zobrist.cc:74-88) and, with -i, the two shifted
+              hashes of the rolling indel enumeration (:90-104, :122-136) ---- */
+      ResStream rs;
+      uint64_t h = 0;
+      if (GENES)
+        h = P.qgh[W.qslot];
+      uint64_t hdel = h, hins = h;
+      {
+        /* a residue dword (4 positions) at a time, the next one requested first */
+        const uint32_t nd = (L + 3u) >> 2;
+        uint32_t dn = nd ? qr[0] : 0u;
+        for (uint32_t wq = 0; wq < nd; wq++) {
+          const uint32_t d = dn;
+          if (wq + 1 < nd)
+            dn = qr[(wq + 1) * WAVE];
+#pragma unroll
+          for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t p = 4u * wq + b;
+            const uint32_t r = (d >> (8u * b)) & 0xffu;
+            const uint64_t kz = lds_u64(zl_addr + (ZS * p + r) * 8u);
+            h ^= p < Ll ? kz : 0ull;
+            if (INDELS) {
+              /* (-i tiles hold one length: Ll == L for every valid lane) */
+              hins ^= p < L ? lds_u64(zl_addr + (ZS * (p + 1) + r) * 8u) : 0ull;
+              if (p > 0)
+                hdel ^= p < L ? lds_u64(zl_addr + (ZS * (p - 1) + r) * 8u) : 0ull;
+            }
+          }
+        }
+      }
+
+      /* class positions of this length (wave-uniform), as a bit set */
+      uint32_t m[MCR];
+#pragma unroll
+      for (uint32_t i = 0; i < MCR; i++)
+        m[i] = class_pos(L, i, P.geom.c0);
+      uint64_t cpos_lo = 0, cpos_hi = 0;
+      bool cpos_far = false;
+#pragma unroll
+      for (uint32_t i = 0; i < MCR; i++)
+        if (i < K) {
+          if (m[i] < 64u)
+            cpos_lo |= 1ull << m[i];
+          else if (m[i] < 128u)
+            cpos_hi |= 1ull << (m[i] - 64u);
+          else
+            cpos_far = true;
+        }
+      auto is_class_pos = [&](uint32_t p) -> bool {
+        if (p < 64u)
+          return ((cpos_lo >> p) & 1ull) != 0;
+        if (p < 128u)
+          return ((cpos_hi >> (p - 64u)) & 1ull) != 0;
+        bool c = false;
+        if (cpos_far) {
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++)
+            c = c || (i < K && m[i] == p);
+        }
+        return c;
+      };
+      /* class-key terms of residue r at position p (zero when p is no class position) */
+      auto class_term = [&](uint32_t p, uint32_t r) -> uint32_t {
+        uint32_t dk = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < MCR; i++)
+          if (i < K && m[i] == p)
+            dk ^= cr_lds[i * A + r];
+        return dk;
+      };
+
+      uint64_t nvar = 0;
+
+      /* queue the positives of a block of substitution rows: bit A * j + v of
+         (m0, m1) <-> residue v at row j of the block; rpack holds the lanes' own
+         residues of those rows */
+      auto emit_sub_rows = [&](uint64_t m0, uint64_t m1, uint32_t p0, uint32_t rpack) {
+        while (__ballot((m0 | m1) != 0)) {
+          const bool pos = (m0 | m1) != 0;
+          const bool first = m0 != 0;
+          const uint64_t mm = first ? m0 : m1;
+          const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
+          uint32_t j = idx / (uint32_t)A;
+          const uint32_t v = idx - j * (uint32_t)A;
+          j += (pos && !first) ? (uint32_t)RPW : 0u;
+          const uint32_t p = p0 + j;
+          const uint32_t r = (rpack >> (RBITS * j)) & RMASK;
+          const uint32_t za = zl_addr + ZS * p * 8u;
+          const uint64_t hv = h ^ lds_u64(za + r * 8u) ^ lds_u64(za + v * 8u);
+          s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+          if (first)
+            m0 &= m0 - 1ull;
+          else
+            m1 &= m1 - 1ull;
+        }
+      };
+
+      if (tpass == 0) {
+        /* ---- the unchanged sequence (variants.cc:260-268) ---- */
+        {
+          const u32x4 w = fetch_own(h);
+          const bool hit = ((row_bits(w, (uint32_t)h) >> A) & 1u) != 0;
+          s_push<GENES>(W, valid && hit, h, pack_a(K_SAME, 0, 0), 0);
+          nvar += 1;
+        }
+
+        if (D >= 1) {
+          /* ---- single substitutions (variants.cc:280-293), a row per position, RB
+                  rows per block.  A block is branch-free, so that its 2 RB LDS
+                  reads (own key, filter word) are in flight together: rows past
+                  the end of the tile and the class positions of a heavy tile
+                  (left to their own pass) are computed and masked. ---- */
+          const uint32_t nd = (L + 3u) >> 2;
+          /* the residues of positions p0 .. p0 + RB - 1 lie in two dwords (RB = 6:
+             p0 % 4 is 0 or 2; RB = 8: aligned); requested one block ahead */
+          uint32_t dn0 = 0, dn1 = 0;
+          auto request = [&](uint32_t p0) {
+            const uint32_t w0 = p0 >> 2;
+            dn0 = qr[w0 * WAVE];
+            dn1 = qr[(w0 + 1u < nd ? w0 + 1u : w0) * WAVE];
+          };
+          if (L)
+            request(0);
+          auto sub_rows = [&](auto staged_c) {
+          constexpr bool STAGED = decltype(staged_c)::value;
+          for (uint32_t p0 = 0; p0 < L; p0 += RB) {
+            const uint64_t rr = (((uint64_t)dn1 << 32) | dn0) >> ((p0 & 3u) * 8u);
+            if (p0 + RB < L)
+              request(p0 + RB);
+            /* class positions among the rows of the block (wave-uniform bits) */
+            uint32_t cbits = 0;
+            if (K) {
+              if (p0 + RB <= 64u)
+                cbits = (uint32_t)(cpos_lo >> p0);
+              else
+                for (uint32_t j = 0; j < (uint32_t)RB; j++)
+                  cbits |= is_class_pos(p0 + j) ? (1u << j) : 0u;
+            }
+            uint64_t m0 = 0, m1 = 0;
+            uint32_t rpack = 0;
+            uint64_t Wk[RB];
+            uint32_t rj[RB];
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+              rj[j] = (uint32_t)(rr >> (8 * j)) & 31u;
+              rpack |= (rj[j] & RMASK) << (RBITS * j);
+              Wk[j] = h ^ lds_u64(zl_addr + (ZS * (p0 + (uint32_t)j) + rj[j]) * 8u);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+              const uint32_t p = p0 + (uint32_t)j;
+              const uint32_t wo = woff_of(Wk[j]);
+              const u32x4 w = STAGED ? lds_u128(wo) : *(const u32x4 *)(own_glob + wo);
+              reads += valid ? 1u : 0u;
+              uint32_t x = row_bits(w, (uint32_t)Wk[j]) & AMASK & ~(1u << rj[j]);
+              const bool live = (p < Ll) & !((cbits >> j) & 1u);
+              x = live ? x : 0u;
+              nvar += live ? (uint64_t)(A - 1) : 0ull;
+              if (j < RPW)
+                m0 |= (uint64_t)x << (A * j);
+              else
+                m1 |= (uint64_t)x << (A * (j - RPW));
+            }
+            emit_sub_rows(m0, m1, p0, rpack);
+          }
+          };
+          if (staged)
+            sub_rows(std::true_type{});
+          else
+            sub_rows(std::false_type{});
+        }
+
+        if (D >= 2) {
+          /* ---- double substitutions (variants.cc:370-399).  For the pair of
+                  positions (b, e) -- b blanked, e substituted by w -- one word read
+                  per w answers every replacement at b.  When exactly one of the two
+                  is a class position it takes the role of b (its term then drops
+                  out of the slice key); rows that change the class go to the
+                  filter where it lies. ---- */
+          for (uint32_t pa = 0; pa + 1 < L; pa++) {
+            const bool ca_cls = is_class_pos(pa);
+            for (uint32_t pb = pa + 1; pb < L; pb++) {
+              const bool cb_cls = is_class_pos(pb);
+              const bool swap = cb_cls && !ca_cls;               /* wave-uniform */
+              const uint32_t b = swap ? pb : pa, e = swap ? pa : pb;
+              const bool b_cls = swap ? cb_cls : ca_cls, e_cls = swap ? ca_cls : cb_cls;
+              const uint32_t rb = res_at(b), re = res_at(e);
+              const uint32_t ea = zl_addr + (ZS * e + re) * 8u;
+              const uint64_t hb = h ^ lds_u64(zl_addr + (ZS * b + rb) * 8u) ^ lds_u64(ea);
+              const bool own = !b_cls && !e_cls;
+              const uint32_t key_b = b_cls ? qck ^ class_term(b, rb) : qck;
+              const uint32_t te_own = e_cls ? class_term(e, re) : 0u;
+              const bool live = pb < Ll;                          /* pb < Ll implies pa < Ll */
+              nvar += live ? (uint64_t)(A - 1) * (A - 1) : 0ull;
+              for (uint32_t k0 = 1; k0 < (uint32_t)A; k0 += RB) {
+                uint64_t m0 = 0, m1 = 0;
+#pragma unroll
+                for (int j = 0; j < RB; j++) {
+                  const uint32_t k = k0 + (uint32_t)j;
+                  if (k < (uint32_t)A) {
+                    const uint64_t Wk = hb ^ lds_u64(ea + 8u * k);     /* e <- (re + k) mod A */
+                    u32x4 w;
+                    if (own) {
+                      w = fetch_own(Wk);
+                    } else {
+                      uint32_t wres = re + k;
+                      wres = wres >= (uint32_t)A ? wres - (uint32_t)A : wres;
+                      const uint32_t key = key_b ^ (e_cls ? te_own ^ class_term(e, wres) : 0u);
+                      const uint32_t sl = key & smask;
+                      w = fetch_at(Wk, sl, staged && sl == tslice);
+                    }
+                    uint32_t x = row_bits(w, (uint32_t)Wk) & AMASK & ~(1u << rb);
+                    x = live ? x : 0u;
+                    if (j < RPW)
+                      m0 |= (uint64_t)x << (A * j);
+                    else
+                      m1 |= (uint64_t)x << (A * (j - RPW));
+                  }
+                }
+                while (__ballot((m0 | m1) != 0)) {
+                  const bool pos = (m0 | m1) != 0;
+                  const bool first = m0 != 0;
+                  const uint64_t mm = first ? m0 : m1;
+                  const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
+                  uint32_t j = idx / (uint32_t)A;
+                  const uint32_t v = idx - j * (uint32_t)A;
+                  j += (pos && !first) ? (uint32_t)RPW : 0u;
+                  const uint32_t k = k0 + j;
+                  uint32_t wres = re + k;
+                  wres = wres >= (uint32_t)A ? wres - (uint32_t)A : wres;
+                  const uint64_t hv = hb ^ lds_u64(ea + 8u * k) ^ lds_u64(zl_addr + (ZS * b + v) * 8u);
+                  /* (position, residue) pairs in increasing position order */
+                  const uint32_t p1 = swap ? e : b, r1 = swap ? wres : v;
+                  const uint32_t p2 = swap ? b : e, r2 = swap ? v : wres;
+                  s_push<GENES>(W, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24));
+                  if (first)
+                    m0 &= m0 - 1ull;
+                  else
+                    m1 &= m1 - 1ull;
+                }
+              }
+            }
+          }
+        }
+      } else if (tpass >= 3) {
+        /* ---- the substitution row of class position i = pass - 3 (heavy tiles
+                only); the tile is grouped by that row's slice.  A position that
+                carries several class residues is handled by the first of them. ---- */
+        const uint32_t ci = tpass - 3u;
+        bool dup = ci >= K;
+        uint32_t p = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < MCR; i++)
+          if (i == ci)
+            p = m[i];
+#pragma unroll
+        for (uint32_t i = 0; i < MCR; i++)
+          if (i < ci && i < K && m[i] == p)
+            dup = true;
+        if (!dup && D >= 1 && p < L) {
+          const uint32_t r = res_at(p);
+          const uint64_t Wk = h ^ lds_u64(zl_addr + (ZS * p + r) * 8u);
+          const u32x4 w = fetch_own(Wk);
+          uint32_t x = row_bits(w, (uint32_t)Wk) & AMASK & ~(1u << r);
+          x = p < Ll ? x : 0u;
+          nvar += p < Ll ? (uint64_t)(A - 1) : 0ull;
+          emit_sub_rows((uint64_t)x, 0ull, p, r & RMASK);
+        }
+      }
+
+      if (INDELS && (tpass == 1 || tpass == 2)) {
+        /* Indel variants change the length, hence the class.  t = the variant:
+             base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
+           and its rows are filed under base(t) ^ (class residues of t other than
+           the blanked position).  Most of them fall into the slice staged for
+           this pass; a lane whose row lands elsewhere reads the filter where it
+           lies. */
+        const uint32_t cl_L = P.geom.ctab[L];
+        uint32_t cbase = 0;                      /* XOR_i CR[i][q[m_i]], heavy tiles */
+#pragma unroll
+        for (uint32_t i = 0; i < MCR; i++)
+          if (i < K && L > 0)
+            cbase ^= cr_lds[i * A + res_at(m[i])];
+        const uint32_t base_q = qck ^ cbase;
+        auto heavy_of = [&](uint32_t bs) -> uint32_t {
+          const uint32_t b = bs >> (32 - HEAVY_BUCKETS_LOG2);
+          return (KH > 0 && ((hv_lds[b >> 5] >> (b & 31u)) & 1u)) ? ~0u : 0u;
+        };
+
+        /* ---- deletions (variants.cc:301-325): t = q without position p, one
+                per run of equal residues; t is looked up as a whole sequence
+                (code A).  Blocks of up to 32 positions. ---- */
+        if (tpass == 2 && L > 1) {
+          const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L - 1];
+          const uint32_t hvy = heavy_of(base_t);
+          uint32_t md[MCR], lo[MCR], hi[MCR];
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++) {
+            md[i] = class_pos(L - 1, i, P.geom.c0);
+            lo[i] = hi[i] = 0;
+            if (i < KH) {
+              lo[i] = cr_lds[i * A + res_at(md[i])] & hvy;        /* t[md] = q[md],     md < p  */
+              hi[i] = cr_lds[i * A + res_at(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
+            }
+          }
+          uint64_t hd = hdel;
+          uint32_t gone = 0;
+          for (uint32_t p0 = 0; p0 < L; p0 += 32) {
+            const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
+            const uint64_t hd0 = hd;
+            const uint32_t gone0 = gone;
+            uint32_t mask = 0, wd = 0;
+#pragma unroll 4
+            for (uint32_t p = p0; p < pe; p++) {
+              if ((p & 3u) == 0 || p == p0)
+                wd = qr[(p >> 2) * WAVE];
+              const uint32_t r = (wd >> ((p & 3u) * 8)) & 0xffu;
+              const bool fresh = (p == 0) || (r != gone);
+              if (p > 0 && fresh)
+                hd ^= zl[ZS * (p - 1) + gone] ^ zl[ZS * (p - 1) + r];
+              uint32_t key = base_t;
+#pragma unroll
+              for (uint32_t i = 0; i < MCR; i++)
+                key ^= md[i] < p ? lo[i] : hi[i];
+              const uint32_t sl = key & smask;
+              const u32x4 w = fetch_at(hd, sl, !valid || sl == ck.slice);
+              const bool hit = ((row_bits(w, (uint32_t)hd) >> A) & 1u) != 0;
+              nvar += fresh ? 1u : 0u;
+              mask |= (fresh && hit) ? (1u << (p - p0)) : 0u;
+              gone = r;
+            }
+            mask &= vmask;
+            if (__ballot(mask != 0)) {
+              uint64_t hr = hd0;
+              uint32_t g = gone0;
+#pragma unroll 1
+              for (uint32_t p = p0; p < pe; p++) {
+                const uint32_t r = res_at(p);
+                if (p > 0 && r != g)
+                  hr ^= zl[ZS * (p - 1) + g] ^ zl[ZS * (p - 1) + r];
+                s_push<GENES>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
+                g = r;
+              }
+            }
+          }
+        }
+
+        /* ---- insertions (variants.cc:329-353): t = q with v in front of
+                position ip; blanked at ip it is q with a gap there, whose rolling
+                hash addresses the row of all A residues. ---- */
+        if (tpass == 1) {
+          const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L + 1];
+          const uint32_t hvy = heavy_of(base_t);
+          uint32_t mi[MCR], lo[MCR], hi[MCR];
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++) {
+            mi[i] = class_pos(L + 1, i, P.geom.c0);
+            lo[i] = hi[i] = 0;
+            if (i < KH) {
+              if (mi[i] < L)
+                lo[i] = cr_lds[i * A + res_at(mi[i])] & hvy;      /* t[mi] = q[mi],     mi < ip */
+              if (mi[i] >= 1)
+                hi[i] = cr_lds[i * A + res_at(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
+            }
+          }
+          uint64_t hg = hins;                     /* hash of q with a gap at ip */
+          uint32_t r = 0;
+          rs.start(qr, L);
+          for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
+            uint64_t m0 = 0, m1 = 0;
+            uint64_t hrow[RB];
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+              const uint32_t ip = ip0 + (uint32_t)j;
+              hrow[j] = 0;
+              if (ip <= L) {                                  /* wave-uniform */
+                if (ip > 0) {
+                  const uint32_t p = ip - 1;
+                  r = rs.at(p);
+                  hg ^= zl[ZS * p + r] ^ zl[ZS * ip + r];
+                }
+                hrow[j] = hg;
+                uint32_t key = base_t;
+#pragma unroll
+                for (uint32_t i = 0; i < MCR; i++)
+                  if (i < KH && mi[i] != ip)
+                    key ^= mi[i] < ip ? lo[i] : hi[i];
+                const uint32_t sl = key & smask;
+                const u32x4 w = fetch_at(hg, sl, !valid || sl == ck.slice);
+                uint32_t x = row_bits(w, (uint32_t)hg) & AMASK & vmask;
+                if (ip > 0)
+                  x &= ~(1u << r);                              /* v != q[ip - 1] */
+                nvar += ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A;
+                if (j < RPW)
+                  m0 |= (uint64_t)x << (A * j);
+                else
+                  m1 |= (uint64_t)x << (A * (j - RPW));
+              }
+            }
+            while (__ballot((m0 | m1) != 0)) {
+              const bool pos = (m0 | m1) != 0;
+              const bool first = m0 != 0;
+              const uint64_t mm = first ? m0 : m1;
+              const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
+              uint32_t j = idx / (uint32_t)A;
+              const uint32_t v = idx - j * (uint32_t)A;
+              j += (pos && !first) ? (uint32_t)RPW : 0u;
+              uint64_t hw = hrow[0];
+#pragma unroll
+              for (int jj = 1; jj < RB; jj++)
+                hw = j == (uint32_t)jj ? hrow[jj] : hw;
+              const uint32_t ip = ip0 + j;
+              const uint64_t hv = hw ^ lds_u64(zl_addr + (ZS * ip + v) * 8u);
+              s_push<GENES>(W, pos, hv, pack_a(K_INS, ip, v), 0);
+              if (first)
+                m0 &= m0 - 1ull;
+              else
+                m1 &= m1 - 1ull;
+            }
+          }
+        }
+      }
+
+      W.st.variants += valid ? nvar : 0ull;
+    }
+    if (all_done)
+      break;
+  }
+
+  /* leftovers: fewer than 64 entries */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (W.qn > 0)
+    flush_or_resolve<GENES>(W, 0, W.qn);
+
+  {
+    unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,
+                                        W.st.hash_eq, W.st.matches, reads};
+#pragma unroll
+    for (int k = 0; k < STAT_COUNT; k++) {
+      unsigned long long x = s[k];
+      for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_down(x, off, WAVE);
+      if (lane == 0 && x)
+        atomicAdd(P.stats + k, x);
+    }
+  }
+
+  if (P.lds_matrix) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cells; i += NT) {
+      const unsigned long long x = mat_all[i];
+      if (x)
+        atomicAdd(P.matrix + i, x);
+    }
+  }
+}
+
+}  // namespace cmpr
+#endif

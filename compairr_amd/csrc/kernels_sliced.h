@@ -56,6 +56,64 @@ struct SProber {
    are appended to the global positives buffer with ONE atomic claim (the walks
    happen later, in resolve_kernel); if the buffer is full, or in inline mode,
    lane k resolves entry first + k right here. */
+/* The rare path (positives buffer full, or deferred_resolve = 0): the same walk,
+   verification and scoring as resolve_one (kernels.h), one slot and one residue
+   at a time with nothing unrolled -- inlined at every push site, the fast form
+   cost the probe loops ~40 registers. */
+template <bool GENES>
+__device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n)
+{
+  const ProbeParams &P = W.P;
+  if ((int)W.lane >= n)
+    return;
+  const int e = first + (int)W.lane;
+  const uint64_t key = table_key(W.q.hash[e]);
+  const uint32_t qs = W.q.slot[e], ca = W.q.ca[e], cb = W.q.cb[e];
+  uint64_t s = table_home(key, P.slot_mask);
+#pragma unroll 1
+  for (;;) {
+    const uint64_t k = P.table[s].key;
+    if (k == EMPTY_KEY)
+      break;
+    if (k == key) {
+      const unsigned char *rp = P.rec2 + (size_t)P.table[s].val * REC_UNIT;
+      const RefRec *rec = (const RefRec *)rp;
+      W.st.hash_eq++;
+      bool ok = true;
+      if (GENES)
+        ok = P.qv[qs] == rec->v && P.qj[qs] == rec->j;
+      if (ok) {
+        const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
+        const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
+        const uint32_t L = P.qlen[qs], M = rec->len;
+        ok = M == (kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L));
+        const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
+#pragma unroll 1
+        for (uint32_t x = 0; ok && x < M; x++) {
+          /* check_variant (variants.cc:166-240): residue the variant has at x */
+          uint32_t want;
+          if ((kind == K_SUB || kind == K_INS || kind == K_SUB2) && x == p1)
+            want = r1;
+          else if (kind == K_SUB2 && x == p2)
+            want = r2;
+          else {
+            const uint32_t qp = kind == K_DEL ? (x < p1 ? x : x + 1)
+                                              : (kind == K_INS ? (x < p1 ? x : x - 1) : x);
+            want = (qr[(size_t)(qp >> 2) * WAVE] >> ((qp & 3u) * 8)) & 0xffu;
+          }
+          ok = want == (uint32_t)rp[sizeof(RefRec) + x];
+        }
+        if (ok) {
+          W.st.matches++;
+          score_match(P, qs, rec->idx, (uint64_t)P.R2 * P.qrep[qs] + rec->rep,
+                      P.ignore_counts ? 1ull : P.qcnt[qs], rec->cnt, W.mat_lds);
+        }
+      }
+    }
+    s = (s + 1) & P.slot_mask;
+  }
+}
+
 template <bool GENES>
 __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
 {
@@ -85,8 +143,10 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
       inline_resolve = true;
     }
   }
-  if (inline_resolve && (int)W.lane < n)
-    resolve_entry<GENES>(P, W.q, first + (int)W.lane, W.mat_lds, W.st);
+#ifndef EXPERIMENT_NO_INLINE_RESOLVE
+  if (inline_resolve)
+    resolve_inline_slow<GENES>(W, first, n);
+#endif
 }
 
 template <bool GENES>
@@ -107,7 +167,7 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
     if (W.qn >= WAVE) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       W.qn -= WAVE;
-      if (!(W.P.debug & DBG_SKIP_RESOLVE))
+      if (!CMPR_DBG(W.P, DBG_SKIP_RESOLVE))
         flush_or_resolve<GENES>(W, W.qn, WAVE);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -206,7 +266,7 @@ __device__ __forceinline__ void emit_row_others(SProber &W, uint32_t mask, uint6
                                                 uint32_t zaddr, uint32_t r, uint32_t ca,
                                                 uint32_t cb = 0)
 {
-  if (W.P.debug & DBG_SKIP_EMIT)
+  if (CMPR_DBG(W.P, DBG_SKIP_EMIT))
     mask = 0;
   while (__ballot(mask != 0)) {
     const bool pos = mask != 0;
@@ -263,7 +323,7 @@ template <bool GENES, bool RES_IN_A>
 __device__ __forceinline__ void emit_row(SProber &W, uint32_t mask, uint64_t h1,
                                          const uint64_t *zl_row, uint32_t ca, uint32_t cb)
 {
-  if (W.P.debug & DBG_SKIP_EMIT)
+  if (CMPR_DBG(W.P, DBG_SKIP_EMIT))
     mask = 0;
   while (__ballot(mask != 0)) {
     const bool pos = mask != 0;
@@ -367,7 +427,7 @@ probe_sliced_kernel(const ProbeParams P)
   uint64_t *ze = zl + nz;
   const uint32_t nze = ZE * P.zpos;
   unsigned long long *mat_all = (unsigned long long *)(ze + nze);
-  const uint32_t cells = P.R1 * P.R2;
+  const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
   uint32_t *cr_lds = (uint32_t *)(queues + NW);
   uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;     /* heavy-class bitmap */
@@ -464,7 +524,7 @@ probe_sliced_kernel(const ProbeParams P)
         t = P.small_tiles[i];
         td = P.tiles[t];
       }
-      if (P.debug & DBG_SKIP_TILES)
+      if (CMPR_DBG(P, DBG_SKIP_TILES))
         continue;                          /* measures claiming + staging alone */
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
@@ -614,7 +674,7 @@ probe_sliced_kernel(const ProbeParams P)
               }
               mask |= (p < Ll ? b3 : 0u) << (3u * jj);
             }
-            if (!valid || (P.debug & DBG_SKIP_EMIT))
+            if (!valid || CMPR_DBG(P, DBG_SKIP_EMIT))
               mask = 0;
             while (__ballot(mask != 0)) {
               const bool pos = mask != 0;
@@ -634,7 +694,7 @@ probe_sliced_kernel(const ProbeParams P)
             const uint32_t zaddr = zl_addr + (ZS * p + r) * 8u;
             const uint64_t h1 = h ^ lds_u64(zaddr);
             uint32_t mask = 0;
-            if (!(P.debug & DBG_SKIP_LDS_ROWS))
+            if (!CMPR_DBG(P, DBG_SKIP_LDS_ROWS))
               mask = row_lds_others<A>(W, h1, zaddr);
             mask &= p < Ll ? ~0u : 0u;                    /* not past the lane's own end */
             emit_row_others<GENES, A>(W, mask, h1, zaddr, r, pack_a(K_SUB, p, 0));
@@ -644,9 +704,9 @@ probe_sliced_kernel(const ProbeParams P)
           const uint64_t zrow = zl[ZS * p + zlane];
           uint32_t mask = 0;
           if (!is_class_pos(p)) {
-            if (!(P.debug & DBG_SKIP_LDS_ROWS))
+            if (!CMPR_DBG(P, DBG_SKIP_LDS_ROWS))
               mask = staged ? row_lds<A>(W, h1, zrow) : row_hbm<A>(W, h1, zrow, 0u, 0u);
-          } else if (!(P.debug & DBG_SKIP_HBM_ROWS)) {
+          } else if (!CMPR_DBG(P, DBG_SKIP_HBM_ROWS)) {
             uint32_t crow;
             const uint32_t dk = class_terms(p, r, crow);
             mask = row_hbm<A>(W, h1, zrow, dk, crow);
@@ -689,7 +749,7 @@ probe_sliced_kernel(const ProbeParams P)
                 u[x] = x < p ? s[x] : s[x + 1]; one per run of equal residues.
                 Blocks of up to 32 positions: phase 1 rolls the hash and gathers
                 the filter words, phase 2 replays the roll for the positives. */
-        if (L > 1 && do_del && !(P.debug & DBG_SKIP_DEL_ROWS)) {
+        if (L > 1 && do_del && !CMPR_DBG(P, DBG_SKIP_DEL_ROWS)) {
           const uint32_t dlen = cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hv = heavy_of(base ^ dlen);          /* is the variant's class split? */
           const uint32_t dl = dlen ^ cbase;
@@ -753,7 +813,7 @@ probe_sliced_kernel(const ProbeParams P)
 
         /* ---- insertions (variants.cc:329-353): u = s with v put in front of
                 position ip, u[x] = x < ip ? s[x] : x == ip ? v : s[x - 1] ---- */
-        if (do_ins && !(P.debug & DBG_SKIP_INS_ROWS)) {
+        if (do_ins && !CMPR_DBG(P, DBG_SKIP_INS_ROWS)) {
           nvar += (uint64_t)A + (uint64_t)(A - 1) * L;
           const uint32_t dlen = cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hv = heavy_of(base ^ dlen);
@@ -800,7 +860,7 @@ probe_sliced_kernel(const ProbeParams P)
             uint32_t mask = 0;          /* bit v: residue v */
             uint32_t mask_o = 0;        /* bit k - 1: residue (r + k) mod A (row_lds_others) */
             const uint32_t zaddr = zl_addr + (ZS * ip + (ip > 0 ? r : 0u)) * 8u;
-            if (__ballot(in_lds) && !(P.debug & DBG_SKIP_LDS_ROWS)) {
+            if (__ballot(in_lds) && !CMPR_DBG(P, DBG_SKIP_LDS_ROWS)) {
               if (A != 4 && ip > 0) {          /* (nucleotide rows are not stored twice) */
                 const uint32_t ml = row_lds_others<A>(W, hi_hash, zaddr);
                 mask_o = in_lds ? ml : 0u;
@@ -809,7 +869,7 @@ probe_sliced_kernel(const ProbeParams P)
                 mask = in_lds ? ml : 0u;
               }
             }
-            if (__ballot(!in_lds) && !(P.debug & DBG_SKIP_HBM_ROWS)) {
+            if (__ballot(!in_lds) && !CMPR_DBG(P, DBG_SKIP_HBM_ROWS)) {
               if (!in_lds)
                 mask = row_hbm<A>(W, hi_hash, zrow, dk0, crow, hv);
             }
@@ -860,7 +920,7 @@ probe_sliced_kernel(const ProbeParams P)
                   uint32_t b3 = 0;
                   if (fast && !cq) {
                     const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
-                    if (!(P.debug & DBG_SKIP_LDS_ROWS))
+                    if (!CMPR_DBG(P, DBG_SKIP_LDS_ROWS))
 #pragma unroll
                     for (uint32_t k = 1; k <= 3; k++) {
                       const uint64_t hv = hpv ^ lds_u64(eaddr, (int)k);
@@ -873,7 +933,7 @@ probe_sliced_kernel(const ProbeParams P)
 #pragma unroll
                     for (uint32_t k = 1; k <= 3; k++)
                       b3 |= probe_one_own(W, hq ^ zq[(rq + k) & 3u], false) ? (1u << (k - 1)) : 0u;
-                  } else if (!(P.debug & DBG_SKIP_HBM_ROWS)) {
+                  } else if (!CMPR_DBG(P, DBG_SKIP_HBM_ROWS)) {
                     const uint64_t *zq = zl + 4 * qq;
                     const uint64_t hq = hpv ^ zq[rq];
                     const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
@@ -891,7 +951,7 @@ probe_sliced_kernel(const ProbeParams P)
                   }
                   mask |= (qq < Ll ? b3 : 0u) << (3u * jj);       /* qq < Ll implies p < Ll */
                 }
-                if (!valid || (P.debug & DBG_SKIP_EMIT))
+                if (!valid || CMPR_DBG(P, DBG_SKIP_EMIT))
                   mask = 0;
                 while (__ballot(mask != 0)) {
                   const bool pos = mask != 0;

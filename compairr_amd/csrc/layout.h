@@ -53,8 +53,11 @@ enum : uint32_t { K_SAME = 0, K_SUB = 1, K_DEL = 2, K_INS = 3, K_SUB2 = 4 };
 struct TileDesc {
   uint32_t len;       /* residues of the longest query of the tile          */
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
-  uint64_t res_base;  /* dword offset of the tile's residues in qres         */
-  uint32_t slice;     /* Bloom slice of every query of the tile (sliced mode) */
+  uint32_t res_base;  /* dword offset of the tile's residues in qres         */
+  uint32_t pass;      /* variant 2: 0, or 3 + i for a tile of class-row pass i
+                         (kernels_rows.h); the indel passes 1, 2 reuse the
+                         tiles of pass 0 and are named by their Chunk         */
+  uint32_t slice;     /* filter slice the tile's probes go to (sliced modes)  */
   uint32_t k;         /* class residues of the tile's queries: 0 (light) or K  */
 };
 
@@ -79,6 +82,7 @@ constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 3 for aa (20^3
                                                  K <= 8 for nt (4^8 splits)            */
 __host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 3u; }
 constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
+constexpr uint32_t MAX_ROW_SLICE_WORDS = 2048; /* variant 2: 32 KiB of 16-byte words per slice */
 constexpr uint32_t HEAVY_BUCKETS_LOG2 = 16;
 constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
 
@@ -92,7 +96,8 @@ struct SliceGeom {
   const uint32_t *ctab;
   uint32_t off_cv, off_cj, off_cr, off_hv;
   uint32_t c0;             /* first class position                          */
-  uint32_t pad;
+  uint32_t rw_words;       /* variant 2 (kernels_rows.h): 16-byte words per
+                              slice, any count <= MAX_ROW_SLICE_WORDS          */
 };
 
 __host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i, uint32_t c0)
@@ -217,6 +222,7 @@ struct ProbeParams {
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
   const uint32_t *qorig;           /* per slot: index in the caller's set 1       */
+  const uint32_t *qck;             /* per slot: class key (variant 2)             */
   uint32_t        ntiles;
   uint32_t        first_tile;
   /* output */
@@ -256,13 +262,23 @@ struct ProbeParams {
   unsigned long long *stats;       /* [variants, bloom+, hash==, matches]     */
 };
 
-/* ProbeParams::debug bits: timing experiments only, results become wrong */
+/* ProbeParams::debug bits: timing experiments only, results become wrong.  They
+   exist only in a library built with -DCMPR_ABLATION (make ablation); in the
+   shipped build CMPR_DBG() is the constant false and the "debug" tunable is
+   rejected. */
 enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
                   DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32,
                   DBG_SKIP_TILES = 64 };
+#ifdef CMPR_ABLATION
+#define CMPR_DBG(P, bit) (((P).debug & (bit)) != 0)
+#else
+#define CMPR_DBG(P, bit) false
+#endif
 
+/* STAT_VARIANTS counts the variant tests the kernel executed (one per variant
+   hash held against the filter); STAT_READS the filter words read for them */
 enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
-       STAT_COUNT = 4 };
+       STAT_READS = 4, STAT_COUNT = 5 };
 
 }  // namespace cmpr
 #endif

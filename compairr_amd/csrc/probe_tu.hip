@@ -1,0 +1,52 @@
+/*
+ * probe_tu.hip -- one translation unit per (kernel variant, workgroup size):
+ * compiled with -DTU_VARIANT=0|1|2|9 and -DTU_NW=4|8|16 (variants 1, 2).
+ * TU_VARIANT 9 = resolve_kernel.
+ */
+#include "select.h"
+#if TU_VARIANT == 2
+#include "kernels_rows.h"
+#elif TU_VARIANT == 1
+#include "kernels_sliced.h"
+#else
+#include "kernels.h"
+#endif
+
+namespace cmpr {
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+#if TU_VARIANT == 0
+#define KERNEL(A_, D_, I_, G_) probe_kernel<A_, D_, I_, G_>
+#define SELECT_NAME select_probe_v0
+#elif TU_VARIANT == 1
+#define KERNEL(A_, D_, I_, G_) probe_sliced_kernel<A_, D_, I_, G_, TU_NW>
+#define SELECT_NAME CAT(select_probe_v1_nw, TU_NW)
+#elif TU_VARIANT == 2
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW>
+#define SELECT_NAME CAT(select_probe_v2_nw, TU_NW)
+#endif
+
+#if TU_VARIANT == 9
+ProbeFn select_resolve(bool genes)
+{
+  return genes ? (ProbeFn)resolve_kernel<true> : (ProbeFn)resolve_kernel<false>;
+}
+#else
+ProbeFn SELECT_NAME(int A, int D, bool indels, bool genes)
+{
+#define PICK(A_, D_, I_) (genes ? (ProbeFn)KERNEL(A_, D_, I_, true) : (ProbeFn)KERNEL(A_, D_, I_, false))
+  if (A == 20) {
+    if (D == 0) return PICK(20, 0, false);
+    if (D == 1) return indels ? PICK(20, 1, true) : PICK(20, 1, false);
+    return PICK(20, 2, false);
+  }
+  if (D == 0) return PICK(4, 0, false);
+  if (D == 1) return indels ? PICK(4, 1, true) : PICK(4, 1, false);
+  return PICK(4, 2, false);
+#undef PICK
+}
+#endif
+
+}  // namespace cmpr

@@ -55,7 +55,7 @@ class _Stats(C.Structure):
                 ("matches", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double),
                 ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
-                ("probe_ms", C.c_double)]
+                ("probe_ms", C.c_double), ("filter_reads", C.c_uint64)]
 
 
 @dataclass
@@ -84,6 +84,7 @@ class Stats:
     total_ms: float
     kernel_launches: int
     probe_ms: float = 0.0
+    filter_reads: int = 0
 
 
 def library_path() -> str:
@@ -138,7 +139,7 @@ def load_library() -> C.CDLL:
     lib.cmpr_cols.restype = C.c_uint32
     lib.cmpr_set_tunable.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cmpr_get_tunable.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
-    if lib.cmpr_abi_version() != 1:
+    if lib.cmpr_abi_version() != 2:
         raise RuntimeError("libcompairr_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -276,7 +277,7 @@ class HipOverlap:
         self._check(self._lib.cmpr_get_stats(self._ctx, C.byref(st)))
         return Stats(st.queries, st.variants, st.bloom_positive, st.hash_equal,
                      st.matches, st.algorithmic_bytes, st.kernel_ms, st.total_ms,
-                     st.kernel_launches, st.probe_ms)
+                     st.kernel_launches, st.probe_ms, st.filter_reads)
 
 
 def overlap(set1: RepertoireSet, set2: RepertoireSet, opt: Options):

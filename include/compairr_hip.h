@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CMPR_ABI_VERSION 1
+#define CMPR_ABI_VERSION 2
 
 enum {
   CMPR_OK          = 0,
@@ -93,7 +93,8 @@ typedef struct cmpr_set_view {
 /* Work and timing of the last cmpr_overlap_* call. */
 typedef struct cmpr_stats {
   uint64_t queries;            /* set-1 sequences processed                   */
-  uint64_t variants;           /* variant hashes probed against the Bloom     */
+  uint64_t variants;           /* variant hashes held against the Bloom filter
+                                  (executed tests, counted by the kernel)      */
   uint64_t bloom_positive;     /* probes that passed the Bloom filter         */
   uint64_t hash_equal;         /* hash slots equal to a variant hash          */
   uint64_t matches;            /* verified (query, hit) pairs                 */
@@ -103,6 +104,9 @@ typedef struct cmpr_stats {
   uint32_t kernel_launches;
   uint32_t reserved;
   double   probe_ms;           /* HIP-event time of the probe kernel alone    */
+  uint64_t filter_reads;       /* filter words read for those tests: one per
+                                  variant (kernel variants 0, 1), one per ROW of
+                                  up to alphabet_size variants (variant 2)      */
 } cmpr_stats;
 
 typedef struct cmpr_context cmpr_context;
@@ -215,17 +219,23 @@ uint32_t cmpr_rows(const cmpr_context *ctx);      /* R1, after set_queries   */
 uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
 
 /* Tuning knobs (unknown names -> CMPR_EINVAL).  Results never depend on them.
-     "variant"               0: one Bloom filter probed in HBM; 1 (default):
-                             class-keyed 32 KiB slices staged in LDS
+     "variant"               0: one Bloom filter probed in HBM; 1: class-keyed
+                             32 KiB slices staged in LDS, one filter word per
+                             variant (default for nucleotides); 2: the same
+                             slices over the row filter, one filter word per
+                             position (default for amino acids); -1: default
      "blocks_per_cu"         resident workgroups per CU the grid is sized for
      "bloom_bits_log2_delta" filter bytes = hash-table slots << delta
                              (default 0 for variant 0, +2 for variant 1)
      "class_residues"        -1 (default: from the data) or 0..3
-     "slice_words_log2"      log2 of 64-bit words per slice (default 12)
+     "slice_words_log2"      log2 of the (largest) slice in filter words: 64-bit
+                             words, default 12 (variant 1); 128-bit words,
+                             default and at most 11 (variant 2)
      "chunk_tiles"           tiles per workgroup work item (default 8 x waves)
-     "waves_per_block"       4, 8 (default) or 16 waves per workgroup (variant 1)
+     "waves_per_block"       4, 8 (default) or 16 waves per workgroup (variants 1, 2)
    "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
-   must be set before cmpr_set_reference(). */
+   must be set before cmpr_set_reference(); "chunk_tiles" and "waves_per_block"
+   before cmpr_set_queries(). */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 
 /* Current value of a tunable (for the data-dependent ones, the value in effect

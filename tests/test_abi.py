@@ -27,14 +27,14 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.cmpr_abi_version() == 1
+    assert lib.cmpr_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
     # cmpr_options: 9 x 4 + 7 x 4; cmpr_set_view: 8 + 6 x 8 + 2 x 4; cmpr_stats
     assert ctypes.sizeof(hip._Options) == 64
     assert ctypes.sizeof(hip._SetView) == 64
-    assert ctypes.sizeof(hip._Stats) == 80
+    assert ctypes.sizeof(hip._Stats) == 88
 
 
 def test_invalid_options_rejected_before_any_device_work():

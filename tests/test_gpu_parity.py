@@ -58,6 +58,24 @@ LAYOUTS = {
     "resolve_overflow": {"variant": 1, "slice_words_log2": 5, "pos_capacity": 64},
     "resolve_one_segment": {"variant": 1, "slice_words_log2": 5, "pos_capacity": 256,
                             "pos_segments": 1},
+    # ---- variant 2: the row filter (one filter word per position) ----
+    "rows": {"variant": 2},
+    # 64-byte slices, every class split by 3 / 1 class residues: class-row passes
+    "rows_tiny_k3": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
+                     "heavy_threshold": 0},
+    "rows_tiny_k1": {"variant": 2, "slice_words_log2": 3, "class_residues": 1, "chunk_tiles": 3,
+                     "heavy_threshold": 0},
+    "rows_tiny_k0": {"variant": 2, "slice_words_log2": 4, "class_residues": 0},
+    "rows_tiny_mixed": {"variant": 2, "slice_words_log2": 2, "class_residues": 2,
+                        "heavy_threshold": 2, "waves_per_block": 4},
+    "rows_mixed_auto": {"variant": 2, "slice_words_log2": 5, "waves_per_block": 16},
+    "rows_wave_all": {"variant": 2, "slice_words_log2": 3, "class_residues": 2,
+                      "heavy_threshold": 2, "small_slice_tiles": 64},
+    "rows_wave_none": {"variant": 2, "slice_words_log2": 4, "small_slice_tiles": 0},
+    "rows_inline": {"variant": 2, "deferred_resolve": 0},
+    "rows_overflow": {"variant": 2, "slice_words_log2": 4, "pos_capacity": 64},
+    # a filter 8 x denser than the default: mostly false positives behind it
+    "rows_dense": {"variant": 2, "bloom_bits_log2_delta": -3, "slice_words_log2": 6},
 }
 
 
@@ -67,6 +85,10 @@ NT_LAYOUTS["lds_tiny_k8"] = {"variant": 1, "slice_words_log2": 3, "class_residue
                              "heavy_threshold": 0, "chunk_tiles": 5}
 NT_LAYOUTS["lds_tiny_k5_mixed"] = {"variant": 1, "slice_words_log2": 4, "class_residues": 5,
                                    "heavy_threshold": 3}
+NT_LAYOUTS["rows_tiny_k8"] = {"variant": 2, "slice_words_log2": 2, "class_residues": 8,
+                              "heavy_threshold": 0, "chunk_tiles": 5}
+NT_LAYOUTS["rows_tiny_k5_mixed"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 5,
+                                    "heavy_threshold": 3}
 
 
 def check(a, b, opt, threads=4, layouts=None):

@@ -1,0 +1,191 @@
+/*
+ * calib.hip -- calibration of the units the probe kernels are priced against
+ * (gfx950): cycles per wave64 integer VALU instruction at 1 / 2 / 4 waves per
+ * SIMD, latency of a dependent ds_read_b64 chain, and throughput of
+ * conflict-free vs random-address ds_read_b64 / ds_read_b128.
+ *
+ *   hipcc -O3 --offload-arch=gfx950 -o tools/calib tools/calib.hip && tools/calib
+ *
+ * Prints one JSON object (committed as profiles/rNN/calibration.json).
+ */
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+/* 8 independent chains of v_xor / v_and_or: 64 VALU instructions per iteration */
+__global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *cyc, int iters)
+{
+  uint32_t a[8];
+  for (int k = 0; k < 8; k++)
+    a[k] = threadIdx.x * 2654435761u + k;
+  const uint32_t m = out[0], c = out[1];
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        a[k] ^= m;
+        asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a[k]) : "v"(a[k]), "v"(m), "v"(c));
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  uint32_t x = 0;
+  for (int k = 0; k < 8; k++)
+    x ^= a[k];
+  out[2 + blockIdx.x * 256 + threadIdx.x] = x;
+  if ((threadIdx.x & 63) == 0)
+    cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
+/* one wave: idx = lds[idx], a dependent chain of ds_read_b64 */
+__global__ void __launch_bounds__(64) lds_chain_kernel(uint32_t *out, uint64_t *cyc, int iters)
+{
+  __shared__ uint64_t tab[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64)
+    tab[i] = (uint64_t)((i * 1237 + 71) & 4095);
+  __syncthreads();
+  uint64_t idx = threadIdx.x;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++)
+    idx = tab[idx & 4095];
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)idx;
+  if (threadIdx.x == 0)
+    cyc[blockIdx.x] = t1 - t0;
+}
+
+/* every wave: 8 reads in flight per lane, addresses conflict-free (MODE 0) or
+   pseudo-random (MODE 1); WIDTH 8 or 16 bytes; 32 KiB table */
+template <int WIDTH, int MODE>
+__global__ void __launch_bounds__(256) lds_tput_kernel(uint32_t *out, uint64_t *cyc, int iters)
+{
+  __shared__ __align__(16) unsigned char tab[32768];
+  for (int i = threadIdx.x; i < 32768 / 4; i += 256)
+    ((uint32_t *)tab)[i] = i * 2654435761u;
+  __syncthreads();
+  uint32_t s = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+  uint32_t acc = 0;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+    uint32_t addr[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (MODE == 0) {
+        addr[k] = ((lane * WIDTH) + (uint32_t)(i * 8 + k) * 1024u) & 32767u;
+      } else {
+        s = s * 1664525u + 1013904223u;
+        addr[k] = (s >> 12) & (32768u - WIDTH);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (WIDTH == 8) {
+        const uint64_t v = *(const uint64_t *)(tab + addr[k]);
+        acc ^= (uint32_t)v ^ (uint32_t)(v >> 32);
+      } else {
+        const uint4 v = *(const uint4 *)(tab + addr[k]);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+  if ((threadIdx.x & 63) == 0)
+    cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
+static double mean(const std::vector<uint64_t> &v, size_t n)
+{
+  double s = 0;
+  for (size_t i = 0; i < n; i++)
+    s += (double)v[i];
+  return s / (double)n;
+}
+
+int main()
+{
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  uint32_t *d_out;
+  uint64_t *d_cyc;
+  const size_t max_blocks = (size_t)cus * 8;
+  CHECK(hipMalloc(&d_out, (max_blocks * 256 + 16) * sizeof(uint32_t)));
+  CHECK(hipMalloc(&d_cyc, max_blocks * 4 * sizeof(uint64_t)));
+  CHECK(hipMemset(d_out, 0x5a, (max_blocks * 256 + 16) * sizeof(uint32_t)));
+  std::vector<uint64_t> cyc(max_blocks * 4);
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d", prop.gcnArchName, cus,
+         prop.clockRate / 1000);
+
+  /* two clocks per figure: the wall time of the launch x the nominal shader clock,
+     and the s_memtime ticks a wave counted around its loop (shader cycles) */
+  auto timed = [&](auto launch) -> double {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    launch();                                  /* warm-up */
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+  };
+  const double ghz = prop.clockRate / 1e6;
+
+  /* VALU: W blocks of 4 waves per CU = W waves per SIMD */
+  printf(", \"valu\": [");
+  for (int W = 1; W <= 4; W *= 2) {
+    const int iters = 20000;
+    const int grid = cus * W;
+    const double ms = timed([&] { hipLaunchKernelGGL(valu_kernel, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, iters); });
+    CHECK(hipMemcpy(cyc.data(), d_cyc, (size_t)grid * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const double instr = (double)iters * 64.0;           /* per wave */
+    printf("%s{\"waves_per_simd\": %d, \"ms\": %.4f, \"memtime_ticks_per_wave\": %.0f, "
+           "\"cycles_per_instr_per_simd_at_nominal_clock\": %.3f}",
+           W == 1 ? "" : ", ", W, ms, mean(cyc, (size_t)grid * 4),
+           ms * 1e-3 * ghz * 1e9 / (instr * W));
+  }
+  printf("]");
+
+  /* dependent LDS chain */
+  {
+    const int iters = 200000;
+    const double ms = timed([&] { hipLaunchKernelGGL(lds_chain_kernel, dim3(1), dim3(64), 0, 0, d_out, d_cyc, iters); });
+    CHECK(hipMemcpy(cyc.data(), d_cyc, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    printf(", \"lds_dependent_read_b64\": {\"ms\": %.4f, \"cycles_per_read_at_nominal_clock\": %.1f, "
+           "\"memtime_ticks_per_read\": %.1f}",
+           ms, ms * 1e-3 * ghz * 1e9 / iters, (double)cyc[0] / iters);
+  }
+
+  /* LDS throughput, 4 blocks of 4 waves per CU */
+  printf(", \"lds_throughput\": [");
+  const int iters = 4000;
+  const int grid = cus * 4;
+  const char *names[4] = {"b64_conflict_free", "b64_random", "b128_conflict_free", "b128_random"};
+  for (int k = 0; k < 4; k++) {
+    double ms = 0;
+    if (k == 0) ms = timed([&] { hipLaunchKernelGGL((lds_tput_kernel<8, 0>), dim3(grid), dim3(256), 0, 0, d_out, d_cyc, iters); });
+    if (k == 1) ms = timed([&] { hipLaunchKernelGGL((lds_tput_kernel<8, 1>), dim3(grid), dim3(256), 0, 0, d_out, d_cyc, iters); });
+    if (k == 2) ms = timed([&] { hipLaunchKernelGGL((lds_tput_kernel<16, 0>), dim3(grid), dim3(256), 0, 0, d_out, d_cyc, iters); });
+    if (k == 3) ms = timed([&] { hipLaunchKernelGGL((lds_tput_kernel<16, 1>), dim3(grid), dim3(256), 0, 0, d_out, d_cyc, iters); });
+    const double reads_per_cu = (double)iters * 8.0 * 16.0;      /* wave-instructions per CU */
+    CHECK(hipMemcpy(cyc.data(), d_cyc, (size_t)grid * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    printf("%s{\"access\": \"%s\", \"ms\": %.4f, \"cycles_per_wave_read_per_cu_at_nominal_clock\": %.2f, "
+           "\"memtime_ticks_per_wave_read_per_cu\": %.2f}",
+           k ? ", " : "", names[k], ms, ms * 1e-3 * ghz * 1e9 / reads_per_cu,
+           mean(cyc, (size_t)grid * 4) / reads_per_cu);
+  }
+  printf("]}\n");
+  return 0;
+}
