@@ -20,7 +20,7 @@ HOST_SRC = $(HOST_CORE) compairr_amd/host/hip_backend.cc
 HOST_HDR = $(wildcard compairr_amd/host/*.h) include/compairr_hip.h
 KERN_DIR = compairr_amd/csrc
 KERN_HDR = $(KERN_DIR)/kernels.h $(KERN_DIR)/kernels_sliced.h $(KERN_DIR)/kernels_rows.h \
-           $(KERN_DIR)/layout.h $(KERN_DIR)/select.h include/compairr_hip.h
+           $(KERN_DIR)/layout.h $(KERN_DIR)/select.h $(KERN_DIR)/context.h include/compairr_hip.h
 OBJ_DIR  = compairr_amd/lib/obj
 # the probe kernels are instantiated per (kernel variant, waves per workgroup) in
 # their own translation units, so that `make -j` compiles them side by side
@@ -34,6 +34,10 @@ lib:
 	$(MAKE) -j8 $(LIB)
 
 $(OBJ_DIR)/main.o: $(KERN_DIR)/compairr_hip.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(OBJ_DIR)/query_layout.o: $(KERN_DIR)/query_layout.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
@@ -53,7 +57,7 @@ $(OBJ_DIR)/probe_v2_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -c -o $@ $<
 
-$(LIB): $(OBJ_DIR)/main.o $(TU_OBJS)
+$(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
 cli: $(CLI)

@@ -5,8 +5,7 @@
  * No CPU fallback lives here: every entry point either runs on the HIP device
  * or fails with an error code.
  */
-#include "../../include/compairr_hip.h"
-#include "kernels.h"
+#include "context.h"
 #include "kernels_sliced.h"
 #include "kernels_rows.h"
 #include "select.h"
@@ -23,177 +22,28 @@
 
 using namespace cmpr;
 
-namespace {
-
-thread_local std::string g_create_error;
-
-/* deterministic table contents; the result does not depend on them
-   (check_variant makes matches hash-independent, variants.cc:166-240) */
-struct SplitMix64 {
-  uint64_t s;
-  explicit SplitMix64(uint64_t seed) : s(seed) {}
-  uint64_t next()
-  {
-    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-  }
-};
-
-template <typename T>
-struct DevBuf {
-  T     *p = nullptr;
-  size_t n = 0;
-  void release()
-  {
-    if (p)
-      (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-};
-
-}  // namespace
-
-struct cmpr_context {
-  cmpr_options opt{};
-  int          device = 0;
-  int          cus = 256;
-  hipStream_t  stream = nullptr;
-  hipEvent_t   ev_start = nullptr, ev_stop = nullptr;
-  /* kernel-time events of the last TIME_RING calls (cmpr_get_kernel_times), so
-     that a caller can time many launches without synchronising after each */
-  static const uint32_t TIME_RING = 64;
-  hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
-  uint64_t     calls = 0;            /* overlap launches so far */
-  hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
-  bool         events_valid = false;
-  std::string  err;
-
-  /* tunables */
-  int64_t blocks_per_cu = 8;
-  int64_t variant = -1;           /* 0: one global Bloom; 1: LDS-staged slices; 2: LDS-staged
-                                     row filter (kernels_rows.h); -1: by alphabet */
-  int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
-  int64_t class_residues = -1;    /* -1: choose from the data                  */
-  int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
-  int64_t heavy_threshold = -1;   /* class population above which it is split;
-                                     -1: from the slice size, 0: every class   */
-  int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
-  int64_t waves_per_block = 8;
-  int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
-  int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
-  int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
-  int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
-  int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
-  int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
-  int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
-  bool    waves_per_block_forced = false;
-  int64_t debug = 0;              /* ablation switches (layout.h DBG_*), -DCMPR_ABLATION builds only */
-  int64_t slice_words_log2 = -1;  /* -1: 12 (8-byte words, variant 1) / 11 (16-byte words, variant 2) */
-  uint32_t chunk_cap = 0;         /* tiles per chunk in effect since cmpr_set_queries */
-
-  /* sliced Bloom layout (variant 1) */
-  bool                  sliced = false;   /* variant 1 or 2 */
-  bool                  rows = false;     /* variant 2 */
-  uint32_t              npasses = 1;      /* variant 2: 1 + class-row passes */
-  SliceGeom             geom{};
-  std::vector<uint32_t> ctab;     /* host copy of the class tables             */
-  DevBuf<uint32_t>      d_ctab;
-  DevBuf<Chunk>         chunks;
-  DevBuf<uint32_t>      tile_list, small_tiles;
-  uint32_t              nsmall = 0;
-  uint32_t              nchunks = 0;
-
-  /* Zobrist + patterns */
-  uint32_t          zpos = 0;
-  DevBuf<uint64_t>  zob;
-
-  /* set 2 + index */
-  bool              have_ref = false;
-  uint64_t          n2 = 0;
-  uint32_t          R2 = 0, longest2 = 0;
-  DevBuf<uint8_t>   res2;
-  DevBuf<uint64_t>  off2, cnt2, bloom;
-  DevBuf<uint32_t>  v2, j2, rep2;
-  DevBuf<Slot>      table;
-  DevBuf<unsigned char> rec2;      /* RefRec stream (header + residues) */
-  DevBuf<uint32_t>  voff2;          /* position of sequence i in it, REC_UNIT units */
-  uint64_t          slots = 0, bloom_words = 0;
-
-  /* set 1 tiles */
-  bool              have_q = false;
-  uint64_t          n1 = 0;
-  uint32_t          R1 = 0, ntiles = 0;
-  DevBuf<TileDesc>  tiles;
-  DevBuf<uint32_t>  qres, qv, qj, qrep;
-  DevBuf<uint64_t>  qgh;            /* V-key ^ J-key per query: one load, not two dependent ones */
-  std::vector<uint64_t> gene_keys;  /* host copy of the V and J Zobrist keys */
-  DevBuf<uint64_t>  qcnt;
-  DevBuf<uint16_t>  qlen;
-  DevBuf<uint32_t>  qorig, qck;
-  uint64_t          algorithmic_bytes = 0;
-  double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
-  std::vector<double> tot1, tot2;
-
-  /* per-launch scratch */
-  DevBuf<unsigned long long> matrix;
-  DevBuf<double>             matrix_f64;
-  DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
-  DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
-  unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
-  uint32_t                  *d_tile_counter = nullptr; /* likewise */
-  uint64_t                   pos_cap = 0;
-  uint32_t                   launches = 0;
-  const void                *attr_fn = nullptr;   /* kernel whose LDS limit is raised */
-  size_t                     attr_lds = 0;
-  /* pairs mode, set only while cmpr_overlap_pairs runs */
-  uint32_t           *pair_q = nullptr, *pair_h = nullptr;
-  unsigned long long *pair_count = nullptr;
-  uint64_t            pair_cap = 0;
-};
-
-namespace {
-
-int fail(cmpr_context *c, int code, const std::string &msg)
+std::string &cmpr_create_error()
 {
-  if (c)
-    c->err = msg;
-  else
-    g_create_error = msg;
-  return code;
+  static thread_local std::string e;
+  return e;
 }
 
-#define HIP_TRY(c, call)                                                        \
-  do {                                                                          \
-    hipError_t e_ = (call);                                                     \
-    if (e_ != hipSuccess)                                                       \
-      return fail((c), e_ == hipErrorOutOfMemory ? CMPR_ENOMEM : CMPR_EDEVICE,  \
-                  std::string(#call) + ": " + hipGetErrorString(e_));           \
-  } while (0)
-
-template <typename T>
-int dev_alloc(cmpr_context *c, DevBuf<T> &b, size_t n)
+int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
 {
-  b.release();
-  if (n == 0)
-    n = 1;
-  HIP_TRY(c, hipMalloc((void **)&b.p, n * sizeof(T)));
-  b.n = n;
+  if (!s) { why = "set view is NULL"; return CMPR_EINVAL; }
+  if (s->n_repertoires == 0 && s->n > 0) { why = "n_repertoires is 0"; return CMPR_EINVAL; }
+  if (s->n >= 0xffffffc0ull) { why = "more than 2^32-64 sequences in one set"; return CMPR_EUNSUPPORTED; }
+  if (s->n == 0)
+    return CMPR_OK;
+  if (!s->offsets || !s->repertoire) { why = "offsets/repertoire is NULL"; return CMPR_EINVAL; }
+  if (!s->residues && s->offsets[s->n] > 0) { why = "residues is NULL"; return CMPR_EINVAL; }
+  if (!o.ignore_genes && (!s->v_gene || !s->j_gene)) { why = "v_gene/j_gene is NULL without ignore_genes"; return CMPR_EINVAL; }
+  if (!o.ignore_counts && !s->count) { why = "count is NULL without ignore_counts"; return CMPR_EINVAL; }
+  if (s->offsets[0] != 0) { why = "offsets[0] must be 0"; return CMPR_EINVAL; }
   return CMPR_OK;
 }
 
-template <typename T>
-int dev_upload(cmpr_context *c, DevBuf<T> &b, const T *src, size_t n)
-{
-  int rc = dev_alloc(c, b, n);
-  if (rc)
-    return rc;
-  if (n)
-    HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
-  return CMPR_OK;
-}
+namespace {
 
 int validate_options(const cmpr_options *o, std::string &why)
 {
@@ -230,20 +80,6 @@ int validate_options(const cmpr_options *o, std::string &why)
   return CMPR_OK;
 }
 
-int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
-{
-  if (!s) { why = "set view is NULL"; return CMPR_EINVAL; }
-  if (s->n_repertoires == 0 && s->n > 0) { why = "n_repertoires is 0"; return CMPR_EINVAL; }
-  if (s->n >= 0xffffffc0ull) { why = "more than 2^32-64 sequences in one set"; return CMPR_EUNSUPPORTED; }
-  if (s->n == 0)
-    return CMPR_OK;
-  if (!s->offsets || !s->repertoire) { why = "offsets/repertoire is NULL"; return CMPR_EINVAL; }
-  if (!s->residues && s->offsets[s->n] > 0) { why = "residues is NULL"; return CMPR_EINVAL; }
-  if (!o.ignore_genes && (!s->v_gene || !s->j_gene)) { why = "v_gene/j_gene is NULL without ignore_genes"; return CMPR_EINVAL; }
-  if (!o.ignore_counts && !s->count) { why = "count is NULL without ignore_counts"; return CMPR_EINVAL; }
-  if (s->offsets[0] != 0) { why = "offsets[0] must be 0"; return CMPR_EINVAL; }
-  return CMPR_OK;
-}
 
 /* Runs fn(t, begin, end) on `threads` host threads over [0, n) cut into equal
    contiguous ranges (thread t gets range t): the per-sequence passes of the
@@ -352,10 +188,6 @@ ProbeFn select_kernel(const cmpr_options &o)
   return select_probe_v0(o.alphabet_size, o.differences, o.indels != 0, !o.ignore_genes);
 }
 
-bool is_f64_score(const cmpr_options &o)
-{
-  return o.score == CMPR_SCORE_RATIO && !o.ignore_counts;
-}
 
 }  // namespace
 
@@ -454,6 +286,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->cres.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -469,7 +302,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
 
 extern "C" const char *cmpr_last_error(const cmpr_context *c)
 {
-  return c ? c->err.c_str() : g_create_error.c_str();
+  return c ? c->err.c_str() : cmpr_create_error().c_str();
 }
 
 extern "C" uint32_t cmpr_rows(const cmpr_context *c) { return c ? c->R1 : 0; }
@@ -663,7 +496,6 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
     rc = dev_upload(c, c->zob, z.data(), z.size());
     if (rc)
       return rc;
-    c->gene_keys.assign(z.begin() + (size_t)A * c->zpos, z.end());   /* for set_queries */
     HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
   }
 
@@ -1123,358 +955,10 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_q = false;
 
-  uint32_t longest = 0;
-  rc = scan_view(c->opt, s, longest, c->tot1, why, (unsigned)c->host_threads);
-  if (rc)
-    return fail(c, rc, why);
-  if (longest + EXTRA_POSITIONS > c->zpos)
-    return fail(c, CMPR_EINVAL,
-                "query longer than the longest_query given to cmpr_set_reference");
-  c->n1 = s->n;
-  c->R1 = c->opt.existence ? (uint32_t)s->n : s->n_repertoires;
-
-  /* exact integer accumulation needs every cell < 2^64; a cell is at most
-     (sum of counts of its row repertoire) x (sum of counts of its column one) */
-  {
-    double m1 = 0, m2 = 0;
-    for (double x : c->tot1) m1 = std::max(m1, x);
-    for (double x : c->tot2) m2 = std::max(m2, x);
-    c->max_cell_bound = m1 * m2;
-    if (!is_f64_score(c->opt) && c->max_cell_bound >= 18446744073709551616.0 / 2)
-      return fail(c, CMPR_EUNSUPPORTED,
-                  "duplicate counts too large for exact 64-bit accumulation");
-  }
-
-  /* Counting sort into groups of equal (slice, length): slices ascending,
-     inside a slice longest first.  Variant 0 has one slice.  Every group is
-     cut into 64-query tiles.  Variant 2 lays the heavy queries out once more per
-     class position i (pass 3 + i, kernels_rows.h), grouped by the slice the
-     substitution row of that position is filed under. */
-  const uint32_t A = (uint32_t)c->opt.alphabet_size;
-  const uint64_t S = c->sliced ? 2 * ((uint64_t)c->geom.smask + 1) : 1;   /* (slice, heavy) */
-  const uint64_t per_slice = (uint64_t)longest + 1;
-  if (S * per_slice >= 0xffffffffull)
-    return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
-  const uint64_t G = S * per_slice;
-  const bool genes = !c->opt.ignore_genes;
-  std::vector<uint32_t> pass_ids(1, 0u);
-  if (c->rows && c->geom.k > 0 && c->opt.differences >= 1)
-    for (uint32_t i = 0; i < c->geom.k; i++)
-      pass_ids.push_back(3 + i);
-  c->npasses = (uint32_t)pass_ids.size();
-  const size_t NP = pass_ids.size();
-  /* host threads: each takes one contiguous range of the queries in both passes
-     (class keys + histogram here, placement below), so that inside a group the
-     queries keep their input order, as in a serial counting sort */
-  unsigned T = (unsigned)std::max<int64_t>(1, c->host_threads);
-  T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1, (64ull << 20) / std::max<uint64_t>(G, 1)));
-  if (s->n < 65536)
-    T = 1;
-  const uint32_t NO_GROUP = 0xffffffffu;
-  /* class key of every query */
-  std::vector<uint32_t> ckey(c->sliced ? (size_t)s->n : 0);
-  std::vector<uint8_t> is_heavy(c->sliced ? (size_t)s->n : 0);
-  if (c->sliced)
-    parallel_ranges(s->n, T, [&](unsigned, uint64_t lo, uint64_t hi) {
-      for (uint64_t i = lo; i < hi; i++) {
-        const uint64_t b = s->offsets[i];
-        bool heavy = false;
-        ckey[i] = class_key_of(c->ctab.data(), c->geom, A, genes, s->residues + b,
-                               (uint32_t)(s->offsets[i + 1] - b), genes ? s->v_gene[i] : 0,
-                               genes ? s->j_gene[i] : 0, &heavy);
-        is_heavy[i] = heavy ? 1 : 0;
-      }
-    });
-
-  const uint64_t chunk_tiles =
-      c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : 8 * (uint64_t)c->waves_per_block;
-  c->chunk_cap = (uint32_t)chunk_tiles;
-  uint64_t ntiles = 0, res_words = 0;
-  std::vector<TileDesc> tiles;
-  std::vector<Chunk> chunks;
-  std::vector<uint64_t> chunk_work;
-  std::vector<uint32_t> tile_list;              /* chunk -> tile ids */
-  std::vector<uint32_t> small_tiles;            /* wave-phase tiles */
-  std::vector<std::vector<uint32_t>> sibling[2];
-  if (c->sliced && c->opt.indels)
-    for (int k = 0; k < 2; k++)
-      sibling[k].resize((size_t)c->geom.smask + 1);
-  /* Without -i, queries long enough to contain all class positions unwrapped
-     (len >= c0 + K) may share a tile with queries of other lengths: inside a
-     (slice, heavy) group they are laid out longest first and cut every 64,
-     whatever their lengths; the kernel masks each lane by its own length.
-     This keeps the padding small when there are many slices and lengths
-     (100M references x 49 nucleotide lengths = 1.6M groups).  Shorter queries,
-     and all queries with -i (the indel passes stage one sibling slice per
-     length), keep one tile group per length. */
-  const bool mixed_ok = c->sliced && !c->opt.indels;
-  const uint64_t min_mixed = mixed_ok ? (uint64_t)c->geom.c0 + c->geom.k : ~0ull;
-
-  struct PassLayout {
-    std::vector<uint32_t> group_of;
-    std::vector<std::vector<uint32_t> > hist;      /* per thread: queries of earlier threads */
-    std::vector<uint64_t> slot_base;
-  };
-  std::vector<PassLayout> PL(NP);
-  for (size_t pi = 0; pi < NP; pi++) {
-    const uint32_t pass = pass_ids[pi];
-    PassLayout &pl = PL[pi];
-    pl.group_of.assign((size_t)s->n, NO_GROUP);
-    pl.hist.assign(T, std::vector<uint32_t>((size_t)G, 0));
-    parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-      std::vector<uint32_t> &mine = pl.hist[t];
-      for (uint64_t i = lo; i < hi; i++) {
-        const uint64_t b = s->offsets[i];
-        const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-        uint64_t sh = 0;
-        if (c->sliced) {
-          uint32_t key = ckey[i];
-          if (pass >= 3) {
-            /* the row of class position i = pass - 3: the key without the terms of
-               that position */
-            if (!is_heavy[i] || L == 0)
-              continue;
-            const uint32_t pos = class_pos(L, pass - 3, c->geom.c0);
-            for (uint32_t k = 0; k < c->geom.k; k++)
-              if (class_pos(L, k, c->geom.c0) == pos)
-                key ^= c->ctab[c->geom.off_cr + k * A + s->residues[b + pos]];
-          }
-          sh = 2 * (uint64_t)(key & c->geom.smask) + (is_heavy[i] ? 1 : 0);
-        }
-        const uint64_t g = sh * per_slice + (longest - L);
-        pl.group_of[i] = (uint32_t)g;
-        mine[g]++;
-      }
-    });
-    /* per group: total, and for every thread the number of earlier threads' queries */
-    std::vector<uint64_t> per_group((size_t)G, 0);
-    for (uint64_t g = 0; g < G; g++) {
-      uint64_t run = 0;
-      for (unsigned t = 0; t < T; t++) {
-        const uint32_t h = pl.hist[t][g];
-        pl.hist[t][g] = (uint32_t)run;
-        run += h;
-      }
-      per_group[g] = run;
-    }
-    std::vector<uint64_t> tile_first((size_t)G, 0);
-    pl.slot_base.assign((size_t)G, 0);
-    std::vector<uint64_t> &slot_base = pl.slot_base;
-    for (uint64_t sh = 0; sh < S; sh++) {
-      const uint64_t slice = c->sliced ? sh / 2 : 0;
-      const uint32_t tile_k = (c->sliced && (sh & 1)) ? c->geom.k : 0;
-      const uint64_t slice_first = ntiles;
-      /* mixed-length tiles */
-      {
-        uint64_t n_long = 0;
-        for (uint64_t gl = 0; gl < per_slice; gl++) {
-          const uint64_t L = longest - gl;
-          if (L < min_mixed)
-            break;
-          const uint64_t g = sh * per_slice + gl;
-          slot_base[g] = ntiles * WAVE + n_long;
-          tile_first[g] = ntiles + n_long / WAVE;
-          n_long += per_group[g];
-        }
-        uint64_t gl = 0, seen = 0;        /* group that holds element k * 64 */
-        for (uint64_t k = 0; k * WAVE < n_long; k++) {
-          while (seen + per_group[sh * per_slice + gl] <= k * WAVE) {
-            seen += per_group[sh * per_slice + gl];
-            gl++;
-          }
-          const uint64_t L = longest - gl;              /* longest query of the tile */
-          TileDesc td;
-          td.len = (uint32_t)L;
-          td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, n_long - k * WAVE);
-          td.res_base = (uint32_t)res_words;
-          td.pass = pass;
-          td.slice = (uint32_t)slice;
-          td.k = tile_k;
-          res_words += ((L + 3) / 4) * WAVE;
-          tiles.push_back(td);
-        }
-        ntiles += (n_long + WAVE - 1) / WAVE;
-      }
-      /* one tile group per length */
-      for (uint64_t gl = 0; gl < per_slice; gl++) {
-        const uint64_t g = sh * per_slice + gl;
-        const uint64_t L = longest - gl;
-        if (L >= min_mixed)
-          continue;
-        tile_first[g] = ntiles;
-        slot_base[g] = ntiles * WAVE;
-        const uint64_t cnt = per_group[g];
-        const uint64_t nt = (cnt + WAVE - 1) / WAVE;
-        const uint64_t words = (L + 3) / 4;
-        for (uint64_t k = 0; k < nt; k++) {
-          TileDesc td;
-          td.len = (uint32_t)L;
-          td.nvalid = (uint32_t)std::min<uint64_t>(WAVE, cnt - k * WAVE);
-          td.res_base = (uint32_t)res_words;
-          td.pass = pass;
-          td.slice = (uint32_t)slice;
-          td.k = tile_k;
-          res_words += words * WAVE;
-          tiles.push_back(td);
-        }
-        ntiles += nt;
-      }
-      if (c->sliced) {
-        /* the tiles of this slice, any length.  A slice with very few query tiles
-           is not worth a workgroup + a staged copy: its tiles go to the list that
-           single waves work through, probing the slice in HBM / L2. */
-        if (!c->opt.indels && ntiles - slice_first <= (uint64_t)c->small_slice_tiles) {
-          for (uint64_t t = slice_first; t < ntiles; t++)
-            small_tiles.push_back((uint32_t)t);
-        } else
-        for (uint64_t t0 = slice_first; t0 < ntiles; t0 += chunk_tiles) {
-          Chunk ck;
-          ck.slice = (uint32_t)slice;
-          ck.first_tile = (uint32_t)tile_list.size();
-          ck.ntiles = (uint32_t)std::min<uint64_t>(chunk_tiles, ntiles - t0);
-          ck.pass = pass;
-          uint64_t work = 0;
-          for (uint32_t t = 0; t < ck.ntiles; t++) {
-            work += (uint64_t)(pass == 0 ? tiles[t0 + t].len + 1 : 2) * tiles[t0 + t].nvalid;
-            tile_list.push_back((uint32_t)(t0 + t));
-          }
-          chunks.push_back(ck);
-          chunk_work.push_back(work);
-        }
-        /* indel passes: file every tile of the main pass under the sibling slice its
-           insertion / deletion variants fall into (own ^ CL[L] ^ CL[L+-1]) */
-        if (c->opt.indels && pass == 0)
-          for (uint64_t gl = 0; gl < per_slice; gl++) {
-            const uint64_t g = sh * per_slice + gl;
-            const uint64_t L = longest - gl;
-            const uint64_t nt = (per_group[g] + WAVE - 1) / WAVE;
-            for (uint32_t ip = 1; ip <= 2; ip++) {
-              if (ip == 2 && L < 2)
-                continue;
-              const uint32_t dlen = c->ctab[L] ^ c->ctab[ip == 1 ? L + 1 : L - 1];
-              std::vector<uint32_t> &dst =
-                  sibling[ip - 1][((uint32_t)slice ^ dlen) & c->geom.smask];
-              for (uint64_t t = 0; t < nt; t++)
-                dst.push_back((uint32_t)(tile_first[g] + t));
-            }
-          }
-      }
-    }
-  }
-  if (c->sliced && c->opt.indels)
-    for (uint32_t pass = 1; pass <= 2; pass++)
-      for (size_t sl = 0; sl < sibling[pass - 1].size(); sl++) {
-        const std::vector<uint32_t> &src = sibling[pass - 1][sl];
-        for (size_t t0 = 0; t0 < src.size(); t0 += chunk_tiles) {
-          Chunk ck;
-          ck.slice = (uint32_t)sl;
-          ck.first_tile = (uint32_t)tile_list.size();
-          ck.ntiles = (uint32_t)std::min<size_t>(chunk_tiles, src.size() - t0);
-          ck.pass = pass;
-          uint64_t work = 0;
-          for (uint32_t t = 0; t < ck.ntiles; t++) {
-            const TileDesc &td = tiles[src[t0 + t]];
-            work += (uint64_t)(pass == 1 ? td.len + 2 : 2) * td.nvalid;
-            tile_list.push_back(src[t0 + t]);
-          }
-          chunks.push_back(ck);
-          chunk_work.push_back(work);
-        }
-      }
-  if (ntiles * WAVE >= 0xffffffffull)
-    return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
-  c->ntiles = (uint32_t)ntiles;
-  if (c->sliced) {
-    /* heaviest chunks first: the tail of the launch is made of light ones */
-    std::vector<uint32_t> order(chunks.size());
-    for (uint32_t i = 0; i < order.size(); i++)
-      order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      return chunk_work[x] > chunk_work[y];
-    });
-    std::vector<Chunk> sorted(chunks.size());
-    for (size_t i = 0; i < order.size(); i++)
-      sorted[i] = chunks[order[i]];
-    c->nchunks = (uint32_t)sorted.size();
-    if ((rc = dev_upload(c, c->chunks, sorted.data(), sorted.size()))) return rc;
-    if ((rc = dev_upload(c, c->tile_list, tile_list.data(), tile_list.size()))) return rc;
-    /* longest first, like the chunks */
-    std::stable_sort(small_tiles.begin(), small_tiles.end(), [&](uint32_t x, uint32_t y) {
-      return tiles[x].len > tiles[y].len;
-    });
-    c->nsmall = (uint32_t)small_tiles.size();
-    if ((rc = dev_upload(c, c->small_tiles, small_tiles.data(), small_tiles.size()))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
-
-  const size_t slots = (size_t)ntiles * WAVE;
-  if ((uint64_t)res_words + 9 * WAVE >= 0xffffffffull)
-    return fail(c, CMPR_EUNSUPPORTED, "query set too large for 32-bit residue positions");
-  /* + 9 rows: verify_candidate reads nine dwords per query whatever its length */
-  std::vector<uint32_t> qres((size_t)res_words + 9 * WAVE, 0), qrep(slots, 0), qv, qj;
-  std::vector<uint64_t> qcnt;
-  std::vector<uint16_t> qlen(slots, 0);
-  std::vector<uint32_t> qorig(slots, 0), qck(c->rows ? slots : 1, 0);
-  if (!c->opt.ignore_genes) { qv.assign(slots, 0); qj.assign(slots, 0); }
-  if (!c->opt.ignore_counts) qcnt.assign(slots, 0);
-  std::vector<uint64_t> alg_part(T, 0);
-  for (size_t pi = 0; pi < NP; pi++) {
-  PassLayout &pl = PL[pi];
-  parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-  std::vector<uint32_t> &fill = pl.hist[t];      /* queries of earlier threads + own so far */
-  uint64_t alg = 0;
-  for (uint64_t i = lo; i < hi; i++) {
-    const uint64_t g = pl.group_of[i];
-    if (g == NO_GROUP)
-      continue;
-    const uint64_t b = s->offsets[i];
-    const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-    const size_t slot = (size_t)(pl.slot_base[g] + fill[g]++);
-    const uint64_t tile = slot / WAVE;
-    const uint32_t lane = (uint32_t)(slot % WAVE);
-    qlen[slot] = (uint16_t)L;
-    qorig[slot] = (uint32_t)i;
-    if (c->rows)
-      qck[slot] = ckey[i];
-    if (c->opt.existence)
-      qrep[slot] = (uint32_t)i;               /* -x: the row is the sequence itself */
-    if (!c->opt.existence)
-      qrep[slot] = s->repertoire[i];
-    if (!c->opt.ignore_genes) { qv[slot] = s->v_gene[i]; qj[slot] = s->j_gene[i]; }
-    if (!c->opt.ignore_counts) qcnt[slot] = s->count[i];
-    uint32_t *dst = qres.data() + tiles[tile].res_base + lane;
-    const uint8_t *src = s->residues + b;
-    for (uint32_t p = 0; p < L; p++)
-      dst[(size_t)(p >> 2) * WAVE] |= (uint32_t)src[p] << ((p & 3) * 8);
-    if (pi == 0)
-      alg += (uint64_t)L + 20 + 8 * variants_of(c->opt, src, L);
-  }
-  alg_part[t] += alg;
-  });
-  }
-  c->algorithmic_bytes = 0;
-  for (unsigned t = 0; t < T; t++)
-    c->algorithmic_bytes += alg_part[t];
-  PL.clear();
-
-  if ((rc = dev_upload(c, c->tiles, tiles.data(), tiles.size()))) return rc;
-  if ((rc = dev_upload(c, c->qres, qres.data(), qres.size()))) return rc;
-  if ((rc = dev_upload(c, c->qrep, qrep.data(), qrep.size()))) return rc;
-  if ((rc = dev_upload(c, c->qlen, qlen.data(), qlen.size()))) return rc;
-  if ((rc = dev_upload(c, c->qorig, qorig.data(), qorig.size()))) return rc;
-  if ((rc = dev_upload(c, c->qck, qck.data(), qck.size()))) return rc;
-  if (!c->opt.ignore_genes) {
-    if ((rc = dev_upload(c, c->qv, qv.data(), qv.size()))) return rc;
-    if ((rc = dev_upload(c, c->qj, qj.data(), qj.size()))) return rc;
-    std::vector<uint64_t> qgh(slots, 0);
-    parallel_ranges(slots, T, [&](unsigned, uint64_t lo, uint64_t hi) {
-      for (uint64_t k = lo; k < hi; k++)
-        qgh[k] = c->gene_keys[qv[k]] ^ c->gene_keys[c->opt.n_v_genes + qj[k]];
-    });
-    if ((rc = dev_upload(c, c->qgh, qgh.data(), qgh.size()))) return rc;
-  }
-  if (!c->opt.ignore_counts)
-    if ((rc = dev_upload(c, c->qcnt, qcnt.data(), qcnt.size()))) return rc;
+  /* upload, validation, grouping by slice, tiles, chunks: all on the device
+     (query_layout.hip) */
+  if ((rc = cmpr_layout_queries(c, s)))
+    return rc;
 
   const size_t cells = (size_t)c->R1 * c->R2;
   if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
@@ -1559,6 +1043,11 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qlen = c->qlen.p;
     P.qorig = c->qorig.p;
     P.qck = c->qck.p;
+    P.qhins = c->qhins.p;
+    P.qhdel = c->qhdel.p;
+    P.cw = c->cw.p;
+    P.cmain = c->cmain.p;
+    P.cres = c->cres.p;
     P.pair_q = c->pair_q;
     P.pair_h = c->pair_h;
     P.pair_count = c->pair_count;

@@ -1,0 +1,211 @@
+/*
+ * context.h -- private to libcompairr_hip.so: the context behind the C ABI and
+ * the helpers its translation units share (compairr_hip.hip: the entry points;
+ * query_layout.hip: the device-side layout of set 1; ref_index.hip: the index
+ * of set 2).
+ */
+#ifndef COMPAIRR_AMD_CONTEXT_H
+#define COMPAIRR_AMD_CONTEXT_H
+
+#include "../../include/compairr_hip.h"
+#include "kernels.h"
+
+#include <string>
+#include <vector>
+
+/* deterministic table contents; the result does not depend on them
+   (check_variant makes matches hash-independent, variants.cc:166-240) */
+struct SplitMix64 {
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next()
+  {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  }
+};
+
+template <typename T>
+struct DevBuf {
+  T     *p = nullptr;
+  size_t n = 0;
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+using cmpr::Chunk;
+using cmpr::PosEntry;
+using cmpr::SliceGeom;
+using cmpr::Slot;
+using cmpr::TileDesc;
+
+struct cmpr_context {
+  cmpr_options opt{};
+  int          device = 0;
+  int          cus = 256;
+  hipStream_t  stream = nullptr;
+  hipEvent_t   ev_start = nullptr, ev_stop = nullptr;
+  /* kernel-time events of the last TIME_RING calls (cmpr_get_kernel_times), so
+     that a caller can time many launches without synchronising after each */
+  static const uint32_t TIME_RING = 64;
+  hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
+  uint64_t     calls = 0;            /* overlap launches so far */
+  hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
+  bool         events_valid = false;
+  std::string  err;
+
+  /* tunables */
+  int64_t blocks_per_cu = 8;
+  int64_t variant = -1;           /* 0: one global Bloom; 1: LDS-staged slices; 2: LDS-staged
+                                     row filter (kernels_rows.h); -1: by alphabet */
+  int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
+  int64_t class_residues = -1;    /* -1: choose from the data                  */
+  int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
+  int64_t heavy_threshold = -1;   /* class population above which it is split;
+                                     -1: from the slice size, 0: every class   */
+  int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
+  int64_t waves_per_block = 8;
+  int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
+  int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
+  int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
+  int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
+  int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
+  int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
+  bool    waves_per_block_forced = false;
+  int64_t debug = 0;              /* ablation switches (layout.h DBG_*), -DCMPR_ABLATION builds only */
+  int64_t slice_words_log2 = -1;  /* -1: 12 (8-byte words, variant 1) / 11 (16-byte words, variant 2) */
+  uint32_t chunk_cap = 0;         /* tiles per chunk in effect since cmpr_set_queries */
+
+  /* sliced Bloom layout (variant 1) */
+  bool                  sliced = false;   /* variant 1 or 2 */
+  bool                  rows = false;     /* variant 2 */
+  uint32_t              npasses = 1;      /* variant 2: 1 + class-row passes */
+  SliceGeom             geom{};
+  std::vector<uint32_t> ctab;     /* host copy of the class tables             */
+  DevBuf<uint32_t>      d_ctab;
+  DevBuf<Chunk>         chunks;
+  DevBuf<uint32_t>      tile_list, small_tiles;
+  uint32_t              nsmall = 0;
+  uint32_t              nchunks = 0;
+
+  /* Zobrist + patterns */
+  uint32_t          zpos = 0;
+  DevBuf<uint64_t>  zob;
+
+  /* set 2 + index */
+  bool              have_ref = false;
+  uint64_t          n2 = 0;
+  uint32_t          R2 = 0, longest2 = 0;
+  DevBuf<uint8_t>   res2;
+  DevBuf<uint64_t>  off2, cnt2, bloom;
+  DevBuf<uint32_t>  v2, j2, rep2;
+  DevBuf<Slot>      table;
+  DevBuf<unsigned char> rec2;      /* RefRec stream (header + residues) */
+  DevBuf<uint32_t>  voff2;          /* position of sequence i in it, REC_UNIT units */
+  uint64_t          slots = 0, bloom_words = 0;
+
+  /* set 1 tiles */
+  bool              have_q = false;
+  uint64_t          n1 = 0;
+  uint32_t          R1 = 0, ntiles = 0;
+  DevBuf<TileDesc>  tiles;
+  uint32_t          nmain_tiles = 0;     /* tiles of pass 0: slot = tile * 64 + lane */
+  DevBuf<uint32_t>  qres, qv, qj, qrep;
+  DevBuf<uint64_t>  qgh;            /* per slot: V key ^ J key (variants 0, 1: one load, not
+                                       two dependent ones) / the query's Zobrist hash
+                                       (variant 2; db_hash, db.cc:903-916) */
+  DevBuf<uint64_t>  qhins, qhdel;   /* variant 2 with -i: the two shifted hashes
+                                       (zobrist.cc:90-104, 122-136) */
+  DevBuf<uint64_t>  qcnt;
+  DevBuf<uint16_t>  qlen;
+  DevBuf<uint32_t>  qorig, qck;
+  /* variant 2, class-row passes: per class slot the row's blanked hash, the
+     query's slot in pass 0 and its residue at the class position */
+  DevBuf<uint64_t>  cw;
+  DevBuf<uint32_t>  cmain;
+  DevBuf<uint8_t>   cres;
+  uint64_t          algorithmic_bytes = 0;
+  double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
+  std::vector<double> tot1, tot2;
+
+  /* per-launch scratch */
+  DevBuf<unsigned long long> matrix;
+  DevBuf<double>             matrix_f64;
+  DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
+  DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
+  unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
+  uint32_t                  *d_tile_counter = nullptr; /* likewise */
+  uint64_t                   pos_cap = 0;
+  uint32_t                   launches = 0;
+  const void                *attr_fn = nullptr;   /* kernel whose LDS limit is raised */
+  size_t                     attr_lds = 0;
+  /* pairs mode, set only while cmpr_overlap_pairs runs */
+  uint32_t           *pair_q = nullptr, *pair_h = nullptr;
+  unsigned long long *pair_count = nullptr;
+  uint64_t            pair_cap = 0;
+};
+
+
+/* message of a failed cmpr_create() (no context yet), per thread */
+std::string &cmpr_create_error();
+
+inline int fail(cmpr_context *c, int code, const std::string &msg)
+{
+  if (c)
+    c->err = msg;
+  else
+    cmpr_create_error() = msg;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                        \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess)                                                       \
+      return fail((c), e_ == hipErrorOutOfMemory ? CMPR_ENOMEM : CMPR_EDEVICE,  \
+                  std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+template <typename T>
+int dev_alloc(cmpr_context *c, DevBuf<T> &b, size_t n)
+{
+  b.release();
+  if (n == 0)
+    n = 1;
+  HIP_TRY(c, hipMalloc((void **)&b.p, n * sizeof(T)));
+  b.n = n;
+  return CMPR_OK;
+}
+
+template <typename T>
+int dev_upload(cmpr_context *c, DevBuf<T> &b, const T *src, size_t n)
+{
+  int rc = dev_alloc(c, b, n);
+  if (rc)
+    return rc;
+  if (n)
+    HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return CMPR_OK;
+}
+
+inline bool is_f64_score(const cmpr_options &o)
+{
+  return o.score == CMPR_SCORE_RATIO && !o.ignore_counts;
+}
+
+/* pointer / size sanity of a set view (no pass over the data) */
+int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why);
+
+/* query_layout.hip: upload set 1, validate it and lay it out for the kernels,
+   all on the device (cmpr_set_queries) */
+int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s);
+
+#endif

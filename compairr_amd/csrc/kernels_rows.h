@@ -229,8 +229,14 @@ probe_rows_kernel(const ProbeParams P)
     }
   };
 
-  if (threadIdx.x == 0)
+  /* Chunks are claimed two ahead by thread 0: the id of the next one is handed to
+     the workgroup through LDS at the barrier, the atomic for the one after it is
+     in flight while the current chunk's tiles are worked on. */
+  uint32_t claimed = 0;
+  if (threadIdx.x == 0) {
     bcast[0] = atomicAdd(P.tile_counter, 1u);
+    claimed = atomicAdd(P.tile_counter, 1u);
+  }
   __syncthreads();                                /* also: the tables above are in place */
   bool have_next = bcast[0] < P.nchunks;
   if (have_next)
@@ -263,13 +269,15 @@ probe_rows_kernel(const ProbeParams P)
           tr->t = pft_t;
         }
         if (threadIdx.x == 0) {
-          bcast[0] = atomicAdd(P.tile_counter, 1u);
+          bcast[0] = claimed;
           bcast[1] = 0;                           /* tiles of the chunk handed out so far */
         }
         __syncthreads();
         have_next = bcast[0] < P.nchunks;
         if (have_next)
           load_chunk(bcast[0]);
+        if (threadIdx.x == 0)
+          claimed = atomicAdd(P.tile_counter, 1u);
       }
     }
     const bool staged = block_phase;
@@ -310,8 +318,20 @@ probe_rows_kernel(const ProbeParams P)
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
       W.qslot = t * WAVE + lane;
-      const uint32_t Ll = valid ? (uint32_t)P.qlen[W.qslot] : 0u;
-      const uint32_t qck = P.qck[W.qslot];         /* the query's class key */
+      const bool class_tile = tpass >= 3;
+      /* a class-row tile carries, per lane, the row's blanked hash, the query's slot
+         in pass 0 and its residue at the class position (query_layout.hip) */
+      const uint32_t cs = td.res_base + lane;
+      uint64_t cW = 0;
+      uint32_t cr = 0;
+      if (class_tile) {
+        if (valid) {
+          cW = P.cw[cs];
+          W.qslot = P.cmain[cs];
+          cr = P.cres[cs];
+        }
+      }
+      const uint32_t Ll = (valid && !class_tile) ? (uint32_t)P.qlen[W.qslot] : 0u;
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 
       auto woff_of = [&](uint64_t Wk) -> uint32_t {
@@ -340,36 +360,11 @@ probe_rows_kernel(const ProbeParams P)
         return (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
       };
 
-      /* ---- query hash (zobrist.cc:74-88) and, with -i, the two shifted
-              hashes of the rolling indel enumeration (:90-104, :122-136) ---- */
-      ResStream rs;
-      uint64_t h = 0;
-      if (GENES)
-        h = P.qgh[W.qslot];
-      uint64_t hdel = h, hins = h;
-      {
-        /* a residue dword (4 positions) at a time, the next one requested first */
-        const uint32_t nd = (L + 3u) >> 2;
-        uint32_t dn = nd ? qr[0] : 0u;
-        for (uint32_t wq = 0; wq < nd; wq++) {
-          const uint32_t d = dn;
-          if (wq + 1 < nd)
-            dn = qr[(wq + 1) * WAVE];
-#pragma unroll
-          for (uint32_t b = 0; b < 4; b++) {
-            const uint32_t p = 4u * wq + b;
-            const uint32_t r = (d >> (8u * b)) & 0xffu;
-            const uint64_t kz = lds_u64(zl_addr + (ZS * p + r) * 8u);
-            h ^= p < Ll ? kz : 0ull;
-            if (INDELS) {
-              /* (-i tiles hold one length: Ll == L for every valid lane) */
-              hins ^= p < L ? lds_u64(zl_addr + (ZS * (p + 1) + r) * 8u) : 0ull;
-              if (p > 0)
-                hdel ^= p < L ? lds_u64(zl_addr + (ZS * (p - 1) + r) * 8u) : 0ull;
-            }
-          }
-        }
-      }
+      /* ---- the query's hash (db_hash, db.cc:903-916 / zobrist.cc:74-88) was
+              computed when the set was laid out, like the reference's
+              seqinfo hash; with -i also the two shifted hashes of the rolling
+              indel enumeration (zobrist.cc:90-104, 122-136) ---- */
+      const uint64_t h = (valid && !class_tile) ? P.qgh[W.qslot] : 0ull;
 
       /* class positions of this length (wave-uniform), as a bit set */
       uint32_t m[MCR];
@@ -519,6 +514,7 @@ probe_rows_kernel(const ProbeParams P)
                   is a class position it takes the role of b (its term then drops
                   out of the slice key); rows that change the class go to the
                   filter where it lies. ---- */
+          const uint32_t qck = K ? P.qck[W.qslot] : 0u;      /* the query's class key */
           for (uint32_t pa = 0; pa + 1 < L; pa++) {
             const bool ca_cls = is_class_pos(pa);
             for (uint32_t pb = pa + 1; pb < L; pb++) {
@@ -585,7 +581,7 @@ probe_rows_kernel(const ProbeParams P)
           }
         }
       } else if (tpass >= 3) {
-        /* ---- the substitution row of class position i = pass - 3 (heavy tiles
+        /* ---- the substitution row of class position i = pass - 3 (heavy queries
                 only); the tile is grouped by that row's slice.  A position that
                 carries several class residues is handled by the first of them. ---- */
         const uint32_t ci = tpass - 3u;
@@ -599,14 +595,18 @@ probe_rows_kernel(const ProbeParams P)
         for (uint32_t i = 0; i < MCR; i++)
           if (i < ci && i < K && m[i] == p)
             dup = true;
-        if (!dup && D >= 1 && p < L) {
-          const uint32_t r = res_at(p);
-          const uint64_t Wk = h ^ lds_u64(zl_addr + (ZS * p + r) * 8u);
-          const u32x4 w = fetch_own(Wk);
-          uint32_t x = row_bits(w, (uint32_t)Wk) & AMASK & ~(1u << r);
-          x = p < Ll ? x : 0u;
-          nvar += p < Ll ? (uint64_t)(A - 1) : 0ull;
-          emit_sub_rows((uint64_t)x, 0ull, p, r & RMASK);
+        if (!dup && D >= 1 && L > 0) {
+          const u32x4 w = fetch_own(cW);
+          uint32_t x = row_bits(w, (uint32_t)cW) & AMASK & ~(1u << cr) & vmask;
+          nvar += (uint64_t)(A - 1);
+          const uint32_t za = zl_addr + ZS * p * 8u;
+          while (__ballot(x != 0)) {
+            const bool pos = x != 0;
+            const uint32_t v = pos ? (uint32_t)__ffs((int)x) - 1u : 0u;
+            const uint64_t hv = cW ^ lds_u64(za + v * 8u);
+            s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+            x &= x - 1u;
+          }
         }
       }
 
@@ -618,6 +618,7 @@ probe_rows_kernel(const ProbeParams P)
            this pass; a lane whose row lands elsewhere reads the filter where it
            lies. */
         const uint32_t cl_L = P.geom.ctab[L];
+        const uint32_t qck = P.qck[W.qslot];     /* the query's class key */
         uint32_t cbase = 0;                      /* XOR_i CR[i][q[m_i]], heavy tiles */
 #pragma unroll
         for (uint32_t i = 0; i < MCR; i++)
@@ -645,7 +646,7 @@ probe_rows_kernel(const ProbeParams P)
               hi[i] = cr_lds[i * A + res_at(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
             }
           }
-          uint64_t hd = hdel;
+          uint64_t hd = P.qhdel[W.qslot];
           uint32_t gone = 0;
           for (uint32_t p0 = 0; p0 < L; p0 += 32) {
             const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
@@ -705,8 +706,9 @@ probe_rows_kernel(const ProbeParams P)
                 hi[i] = cr_lds[i * A + res_at(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
             }
           }
-          uint64_t hg = hins;                     /* hash of q with a gap at ip */
+          uint64_t hg = P.qhins[W.qslot];         /* hash of q with a gap at ip */
           uint32_t r = 0;
+          ResStream rs;
           rs.start(qr, L);
           for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
             uint64_t m0 = 0, m1 = 0;

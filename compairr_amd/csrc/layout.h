@@ -217,7 +217,13 @@ struct ProbeParams {
   const uint32_t *qres;
   const uint32_t *qv;
   const uint32_t *qj;
-  const uint64_t *qgh;             /* per slot: V key ^ J key (NULL with -g)      */
+  const uint64_t *qgh;             /* per slot: V key ^ J key (NULL with -g); variant 2:
+                                      the query's Zobrist hash                   */
+  const uint64_t *qhins, *qhdel;   /* variant 2 with -i: the shifted hashes that seed
+                                      the rolling indel enumeration              */
+  const uint64_t *cw;              /* variant 2, class-row tiles, per class slot: the  */
+  const uint32_t *cmain;           /* row's blanked hash, the query's slot in pass 0,  */
+  const uint8_t  *cres;            /* its residue at the class position               */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
