@@ -26,7 +26,8 @@ OBJ_DIR  = compairr_amd/lib/obj
 # their own translation units, so that `make -j` compiles them side by side
 TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o \
            $(OBJ_DIR)/probe_v1_nw4.o $(OBJ_DIR)/probe_v1_nw8.o $(OBJ_DIR)/probe_v1_nw16.o \
-           $(OBJ_DIR)/probe_v2_nw4.o $(OBJ_DIR)/probe_v2_nw8.o $(OBJ_DIR)/probe_v2_nw16.o
+           $(OBJ_DIR)/probe_v2_nw4.o $(OBJ_DIR)/probe_v2_nw8.o $(OBJ_DIR)/probe_v2_nw16.o \
+           $(OBJ_DIR)/probe_v2i_nw4.o $(OBJ_DIR)/probe_v2i_nw8.o $(OBJ_DIR)/probe_v2i_nw16.o
 
 all: lib cli oracle
 
@@ -55,7 +56,11 @@ $(OBJ_DIR)/probe_v1_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 
 $(OBJ_DIR)/probe_v2_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
-	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -c -o $@ $<
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=0 -c -o $@ $<
+
+$(OBJ_DIR)/probe_v2i_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=1 -c -o $@ $<
 
 $(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^

@@ -28,6 +28,10 @@ std::string &cmpr_create_error()
   return e;
 }
 
+/* u64s behind the segment counters of the positives buffer: statistics, cursors,
+   overflow flag, and the statistics + cursors of the redo pass */
+static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
+
 int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
 {
   if (!s) { why = "set view is NULL"; return CMPR_EINVAL; }
@@ -172,10 +176,16 @@ ProbeFn select_sliced_kernel(const cmpr_options &o, int nw)
   }
 }
 
-ProbeFn select_rows_kernel(const cmpr_options &o, int nw)
+ProbeFn select_rows_kernel(const cmpr_options &o, int nw, bool inline_resolve)
 {
   const int A = o.alphabet_size, D = o.differences;
   const bool i = o.indels != 0, g = !o.ignore_genes;
+  if (inline_resolve)
+    switch (nw) {
+    case 4:  return select_probe_v2_inline_nw4(A, D, i, g);
+    case 16: return select_probe_v2_inline_nw16(A, D, i, g);
+    default: return select_probe_v2_inline_nw8(A, D, i, g);
+    }
   switch (nw) {
   case 4:  return select_probe_v2_nw4(A, D, i, g);
   case 16: return select_probe_v2_nw16(A, D, i, g);
@@ -288,7 +298,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
   c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->cres.release();
   c->matrix.release(); c->matrix_f64.release();
-  c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_list.release(); c->small_tiles.release();
+  c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
     if (c->ring_k0[i]) (void)hipEventDestroy(c->ring_k0[i]);
@@ -395,6 +405,12 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (c->have_q)
       return fail(c, CMPR_ESTATE, "set small_slice_tiles before cmpr_set_queries");
     c->small_slice_tiles = value;
+  } else if (n == "class_rows_unstaged") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "class_rows_unstaged must be 0 or 1");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set class_rows_unstaged before cmpr_set_queries");
+    c->class_rows_unstaged = value;
   } else if (n == "waves_per_block") {
     if (value != 4 && value != 8 && value != 16)
       return fail(c, CMPR_EINVAL, "waves_per_block must be 4, 8 or 16");
@@ -428,7 +444,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   }
   else if (n == "class_residues") *value = c->sliced && c->have_ref ? (int64_t)c->geom.k : c->class_residues;
   else if (n == "slice_words_log2") *value = c->sliced && c->have_ref ? (int64_t)c->geom.words_log2 : c->slice_words_log2;
-  else if (n == "slice_bytes") *value = !c->sliced ? 0 : c->rows ? (int64_t)c->geom.rw_words * 16 : (int64_t)8 << c->geom.words_log2;
+  else if (n == "slice_bytes") *value = !c->sliced ? 0 : c->rows ? (int64_t)c->geom.rw_words * ROW_WORD_BYTES : (int64_t)8 << c->geom.words_log2;
   else if (n == "passes") *value = c->npasses;
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->waves_per_block;
@@ -446,6 +462,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunks") *value = c->nchunks;
   else if (n == "small_tiles") *value = c->nsmall;
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
+  else if (n == "class_rows_unstaged") *value = c->class_rows_unstaged;
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
   else if (n == "host_threads") *value = c->host_threads;
@@ -538,45 +555,53 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
   c->rows = variant == 2;
   int64_t swl = c->slice_words_log2;
   if (swl < 0)
-    swl = c->rows ? 11 : SLICE_WORDS_LOG2;
-  if (c->rows)
-    swl = std::min<int64_t>(swl, 11);                 /* MAX_ROW_SLICE_WORDS */
+    swl = SLICE_WORDS_LOG2;
+  /* variant 2: the largest slice in 32-byte words -- 40 KiB by default (two
+     workgroups of slice + tables + queues per CU), a power of two on request */
+  uint64_t row_max_words = c->slice_words_log2 < 0
+      ? MAX_ROW_SLICE_WORDS : std::min<uint64_t>(1ull << c->slice_words_log2, 1024);
   if (c->sliced) {
     const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
-    const size_t need = ((size_t)(c->rows ? 16 : 8) << swl) +
-                        zrow * c->zpos * sizeof(uint64_t) +
-                        4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
-                        MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
-                        64 * sizeof(TileRef);
-    if (need > 160 * 1024) {
+    /* everything but the slice */
+    const size_t fixed = zrow * c->zpos * sizeof(uint64_t) +
+                         4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
+                         MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
+                         64 * sizeof(TileRef);
+    if (c->rows && c->slice_words_log2 < 0) {
+      /* long sequences: a smaller slice next to the bigger Zobrist table */
+      const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
+      row_max_words = std::min<uint64_t>(row_max_words, room / ROW_WORD_BYTES);
+    }
+    const size_t need = fixed + (c->rows ? (size_t)row_max_words * ROW_WORD_BYTES : ((size_t)8 << swl));
+    if (need > 160 * 1024 || (c->rows && row_max_words < 32)) {
       c->sliced = false;
       c->rows = false;
     }
   }
   const uint64_t entries = (s->n ? s->offsets[s->n] : 0) + s->n;   /* row filter: L + 1 per sequence */
   if (c->rows) {
-    /* 4 bytes of filter per entry (4 entries per 16-byte word: every dword of a
-       word then has ~12 % of its bits set and a test of four of them passes by
-       chance ~3e-4 of the time), x 2^delta */
-    bloom_bytes = std::max<uint64_t>(entries * 4, 16);
+    /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a
+       word then has ~40 % of its bits set and a test of eight of them passes by
+       chance ~6e-4 of the time -- the optimum of a Bloom filter at 16 bits per
+       entry), x 2^delta */
+    bloom_bytes = std::max<uint64_t>(entries * 2, ROW_WORD_BYTES);
     const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
     if (delta > 0)
       bloom_bytes <<= delta;
     else if (delta < 0)
-      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 16);
+      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), ROW_WORD_BYTES);
     /* S slices (a power of two: sibling slices are XORs of slice numbers) of
-       rw_words <= 2^swl words each */
-    const uint64_t max_words = 1ull << swl;
+       rw_words <= row_max_words words each */
     uint64_t S = 1;
-    while (S * max_words * 16 < bloom_bytes)
+    while (S * row_max_words * ROW_WORD_BYTES < bloom_bytes)
       S <<= 1;
-    uint64_t words = (bloom_bytes + S * 16 - 1) / (S * 16);
-    words = std::max<uint64_t>(1, std::min<uint64_t>(words, max_words));
+    uint64_t words = (bloom_bytes + S * ROW_WORD_BYTES - 1) / (S * ROW_WORD_BYTES);
+    words = std::max<uint64_t>(1, std::min<uint64_t>(words, row_max_words));
     if (S > (1ull << 31))
       return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
     c->geom.rw_words = (uint32_t)words;
     c->geom.words_log2 = 0;
-    c->bloom_words = S * words * 2;                  /* 8-byte units */
+    c->bloom_words = S * words * (ROW_WORD_BYTES / 8);       /* 8-byte units */
     c->geom.smask = (uint32_t)(S - 1);
   } else {
     /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
@@ -618,9 +643,9 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
     const double slice_bits = (double)(64ull << g.words_log2);
     /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
        bits per key, false-positive rate <= 6e-3 there and far less elsewhere.
-       Row filter: sequences per slice at 6 entries per word (1.5 x the average). */
+       Row filter: sequences per slice at 24 entries per word (1.5 x the average). */
     const double slice_cap = c->rows
-        ? (double)g.rw_words * 6.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
+        ? (double)g.rw_words * 24.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
         : slice_bits / 12.0;
     g.k = 0;
     /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
@@ -976,10 +1001,14 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
     if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
     /* one block that is zeroed per launch with ONE memset: the segment counters,
-       then the statistics, then the two work cursors */
-    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE + STAT_COUNT + 1))) return rc;
+       then the statistics, the two work cursors, the overflow flag, and the
+       statistics + cursors of a redo pass (kernels_rows.h) */
+    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE + CTR_TAIL))) return rc;
     c->d_stats = c->pos_ctr.p + S * POS_CTR_STRIDE;
     c->d_tile_counter = (uint32_t *)(c->d_stats + STAT_COUNT);
+    c->d_overflow = c->d_stats + STAT_COUNT + 1;
+    c->d_stats2 = c->d_overflow + 1;
+    c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
@@ -1004,7 +1033,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, cells * sizeof(double), st));
   const bool deferred = c->sliced && c->deferred_resolve;
   HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, ((size_t)c->pos_segments * POS_CTR_STRIDE +
-                                              STAT_COUNT + 1) * sizeof(unsigned long long), st));
+                                              CTR_TAIL) * sizeof(unsigned long long), st));
   c->launches = 0;
   bool launched = false;
 
@@ -1065,7 +1094,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.stats = c->d_stats;
     P.geom = c->geom;
     P.chunks = c->chunks.p;
-    P.tile_list = c->tile_list.p;
+    P.tile_refs = c->tile_refs.p;
     P.small_tiles = c->small_tiles.p;
     P.nsmall = c->nsmall;
     P.nchunks = c->nchunks;
@@ -1091,7 +1120,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)waves * sizeof(WaveQueue);
       if (c->rows)
-        b += (size_t)c->geom.rw_words * 16 + MAX_CLASS_RES * A * sizeof(uint32_t) +
+        b += (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
              (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) + 16 +
              (size_t)c->chunk_cap * sizeof(TileRef);
       else if (c->sliced)
@@ -1117,8 +1146,12 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw)
+    /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
+       that resolves inline is deferred_resolve = 0 and the redo pass below */
+    ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !deferred)
                          : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
+    if (c->rows && deferred)
+      P.overflow = c->d_overflow;
     if (lds > 48 * 1024 && (c->attr_fn != (const void *)fn || c->attr_lds < lds)) {
       /* once per kernel and size, not once per launch */
       HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
@@ -1128,6 +1161,14 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     }
     /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
     uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
+    if (c->rows) {
+      /* variant 2 deals its chunks out statically over the workgroups of the grid:
+         exactly as many as are resident at once (registers count too) */
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, nw * WAVE, lds) ==
+              hipSuccess && occ > 0)
+        per_cu = std::min<uint64_t>(per_cu, (uint64_t)occ);
+    }
     per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
     uint64_t grid = (uint64_t)c->cus * per_cu;
     grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks + ((uint64_t)c->nsmall + nw - 1) / nw
@@ -1149,6 +1190,27 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
                          rlds, st, P);
       HIP_TRY(c, hipGetLastError());
       c->launches = 2;
+      if (c->rows) {
+        /* Redo pass: if the positives of the fast launch did not fit their buffer
+           (flag set: resolve_kernel then did nothing), the same step with every
+           positive resolved inline; otherwise its workgroups return at once.
+           Capacity is therefore never a limit, and nothing here waits for the host. */
+        ProbeFn fn2 = select_rows_kernel(c->opt, nw, true);
+        if (lds > 48 * 1024 && (c->attr_fn2 != (const void *)fn2 || c->attr_lds2 < lds)) {
+          HIP_TRY(c, hipFuncSetAttribute((const void *)fn2,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          c->attr_fn2 = (const void *)fn2;
+          c->attr_lds2 = lds;
+        }
+        ProbeParams P2 = P;
+        P2.pos_buf = nullptr;
+        P2.redo = 1;
+        P2.stats = c->d_stats2;
+        P2.tile_counter = c->d_tile_counter2;
+        hipLaunchKernelGGL(fn2, dim3((uint32_t)grid), dim3((uint32_t)nw * WAVE), lds, st, P2);
+        HIP_TRY(c, hipGetLastError());
+        c->launches = 3;
+      }
     }
   }
   if (!launched)
@@ -1315,8 +1377,11 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
     return fail(c, CMPR_ESTATE, "no overlap call has been made");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventSynchronize(c->ev_stop));
-  unsigned long long st[STAT_COUNT];
+  unsigned long long st[STAT_COUNT], ovf = 0;
   HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(&ovf, c->d_overflow, sizeof ovf, hipMemcpyDeviceToHost));
+  if (ovf)       /* the positives buffer overflowed: the redo pass did the step */
+    HIP_TRY(c, hipMemcpy(st, c->d_stats2, sizeof st, hipMemcpyDeviceToHost));
   float k_ms = 0, t_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
   float p_ms = 0;

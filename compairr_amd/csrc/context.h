@@ -73,6 +73,7 @@ struct cmpr_context {
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t class_rows_unstaged = 0; /* variant 2: class-row tiles read the filter where it lies */
   int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
   int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
@@ -92,7 +93,8 @@ struct cmpr_context {
   std::vector<uint32_t> ctab;     /* host copy of the class tables             */
   DevBuf<uint32_t>      d_ctab;
   DevBuf<Chunk>         chunks;
-  DevBuf<uint32_t>      tile_list, small_tiles;
+  DevBuf<cmpr::TileRef> tile_refs;    /* what the chunks list */
+  DevBuf<uint32_t>      small_tiles;
   uint32_t              nsmall = 0;
   uint32_t              nchunks = 0;
 
@@ -143,6 +145,10 @@ struct cmpr_context {
   DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
+  unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */
+  uint32_t                  *d_tile_counter2 = nullptr;
+  const void                *attr_fn2 = nullptr;
+  size_t                     attr_lds2 = 0;
   uint64_t                   pos_cap = 0;
   uint32_t                   launches = 0;
   const void                *attr_fn = nullptr;   /* kernel whose LDS limit is raised */

@@ -582,6 +582,10 @@ resolve_kernel(const ProbeParams P)
   }
   /* workgroup b of the grid (a multiple of pos_segments) works on segment
      b % pos_segments, together with the gridDim.x / pos_segments - 1 others */
+  /* a probe launch whose positives did not all fit is redone with inline resolve
+     (kernels_rows.h): what did fit is not to be counted twice */
+  if (P.overflow && *(volatile unsigned long long *)P.overflow != 0ull)
+    return;
   const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
   const uint32_t seg_block = blockIdx.x / P.pos_segments;
   const uint32_t seg_blocks = gridDim.x / P.pos_segments;

@@ -18,9 +18,10 @@
  *
  *   A query q reads, for position p, the word of W = H(q) ^ Z[p][q[p]] -- the same
  *   W as every t that differs from q at most at p -- rotates dword k right by a_k
- *   and ANDs the four: bit v of the result is the Bloom answer for "q with v at
- *   p" (4 bits per entry, block = one word, bloompat.h:22-58 geometry).  All A
- *   answers of the row come out of one 16-byte LDS read and ~12 instructions.
+ *   and ANDs the eight: bit v of the result is the Bloom answer for "q with v at
+ *   p" (8 bits per entry, block = one word, bloompat.h:22-58 geometry; at 16
+ *   filter bits per entry a false-positive rate of ~6e-4).  All A answers of the
+ *   row come out of one 32-byte LDS read and ~20 instructions.
  *
  * The same entries serve the other variant kinds: an insertion variant of q
  * (v put in front of position ip) blanked at ip IS q with a gap at ip, so the
@@ -57,26 +58,41 @@ __device__ __forceinline__ u32x4 lds_u128(uint32_t byte_addr)
   return *(lds_u128_t *)(uintptr_t)byte_addr;
 }
 
+/* one filter word: 8 dwords */
+struct RowWord {
+  u32x4 a, b;
+};
+
+/* the eight rotation amounts of an entry / a test: the low five bits of the four
+   bytes of W's low half and four 5-bit fields of the low 20 bits of its high
+   half (the word address is taken from the top of the high half) */
 /* bit c of the result <-> "an entry with code c may be present under this W":
-   each dword rotated right by its five hash bits, the four ANDed */
-__device__ __forceinline__ uint32_t row_bits(u32x4 w, uint32_t wl)
+   each dword rotated right by its five hash bits, the eight ANDed */
+__device__ __forceinline__ uint32_t row_bits(const RowWord &w, uint64_t Wk)
 {
-  const uint32_t x0 = __builtin_amdgcn_alignbit(w.x, w.x, wl);
-  const uint32_t x1 = __builtin_amdgcn_alignbit(w.y, w.y, wl >> 8);
-  const uint32_t x2 = __builtin_amdgcn_alignbit(w.z, w.z, wl >> 16);
-  const uint32_t x3 = __builtin_amdgcn_alignbit(w.w, w.w, wl >> 24);
-  return x0 & x1 & x2 & x3;
+  const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
+  const uint32_t x0 = __builtin_amdgcn_alignbit(w.a.x, w.a.x, wl);
+  const uint32_t x1 = __builtin_amdgcn_alignbit(w.a.y, w.a.y, wl >> 8);
+  const uint32_t x2 = __builtin_amdgcn_alignbit(w.a.z, w.a.z, wl >> 16);
+  const uint32_t x3 = __builtin_amdgcn_alignbit(w.a.w, w.a.w, wl >> 24);
+  const uint32_t x4 = __builtin_amdgcn_alignbit(w.b.x, w.b.x, wh);
+  const uint32_t x5 = __builtin_amdgcn_alignbit(w.b.y, w.b.y, wh >> 5);
+  const uint32_t x6 = __builtin_amdgcn_alignbit(w.b.z, w.b.z, wh >> 10);
+  const uint32_t x7 = __builtin_amdgcn_alignbit(w.b.w, w.b.w, wh >> 15);
+  return (x0 & x1 & x2 & x3) & (x4 & x5 & x6 & x7);
 }
 
-/* the four bits of entry (W, code), as the two 64-bit halves of the word */
-__host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint64_t &lo, uint64_t &hi)
+/* the eight bits of entry (W, code), as the four 64-bit quarters of the word */
+__host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint64_t q[4])
 {
-  const uint32_t wl = (uint32_t)Wk;
-  lo = (1ull << ((wl + code) & 31u)) | (1ull << (32u + (((wl >> 8) + code) & 31u)));
-  hi = (1ull << (((wl >> 16) + code) & 31u)) | (1ull << (32u + (((wl >> 24) + code) & 31u)));
+  const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
+  q[0] = (1ull << ((wl + code) & 31u)) | (1ull << (32u + (((wl >> 8) + code) & 31u)));
+  q[1] = (1ull << (((wl >> 16) + code) & 31u)) | (1ull << (32u + (((wl >> 24) + code) & 31u)));
+  q[2] = (1ull << ((wh + code) & 31u)) | (1ull << (32u + (((wh >> 5) + code) & 31u)));
+  q[3] = (1ull << (((wh >> 10) + code) & 31u)) | (1ull << (32u + (((wh >> 15) + code) & 31u)));
 }
 
-/* word of W inside a slice of `nwords` 16-byte words (any count, not only
+/* word of W inside a slice of `nwords` 32-byte words (any count, not only
    powers of two: the filter is sized to the entry count) */
 __host__ __device__ inline uint32_t row_word(uint64_t Wk, uint32_t nwords)
 {
@@ -113,10 +129,11 @@ build_rows_kernel(const BuildParams B)
   unsigned long long *words = (unsigned long long *)B.bloom;
   auto enter = [&](uint64_t Wk, uint32_t code, uint32_t key) {
     const uint64_t w = (uint64_t)(key & g.smask) * nwords + row_word(Wk, nwords);
-    uint64_t lo, hi;
-    row_entry_bits(Wk, code, lo, hi);
-    atomicOr(words + 2 * w, (unsigned long long)lo);
-    atomicOr(words + 2 * w + 1, (unsigned long long)hi);
+    uint64_t q[4];
+    row_entry_bits(Wk, code, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
   };
   enter(h, B.A, ck);
   for (uint32_t p = 0; p < L; p++) {
@@ -136,7 +153,8 @@ build_rows_kernel(const BuildParams B)
 /* rows per 64-bit mask register / rows per block / bits of a packed residue */
 template <int A> struct RowCfg {
   static constexpr int RPW = A == 20 ? 3 : 16;
-  static constexpr int RB = A == 20 ? 6 : 8;
+  static constexpr int RB = A == 20 ? 3 : 4;       /* one mask register; 3 x (2 + 8) registers
+                                                      of keys and filter words in flight */
   static constexpr uint32_t RBITS = A == 20 ? 5u : 2u;
 };
 
@@ -154,10 +172,16 @@ template <int A> struct RowCfg {
  * LDS: [slice, rw_words x 16 B][ZS x zpos Zobrist keys][R1 x R2 matrix (optional)]
  *      [NW WaveQueues][CR tables][heavy bitmap (-i)][chunk broadcast][tile refs]
  */
-template <int A, int D, bool INDELS, bool GENES, int NW>
+template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE>
 __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_rows_kernel(const ProbeParams P)
 {
+  /* INLINE = false: the fast form, Bloom positives go to the positives buffer for
+     resolve_kernel.  INLINE = true: positives are walked and verified here -- the
+     deferred_resolve = 0 mode, and the redo pass after a launch whose positives
+     did not fit the buffer (it does nothing unless that launch was flagged). */
+  if (INLINE && P.redo && *(volatile unsigned long long *)P.overflow == 0ull)
+    return;
   constexpr uint32_t NT = NW * WAVE;
   constexpr uint32_t MCR = max_class_res(A);
   constexpr uint32_t ZS = D == 2 ? 2u * A : (uint32_t)A;   /* d = 2: rows stored twice (rotated reads) */
@@ -166,13 +190,14 @@ probe_rows_kernel(const ProbeParams P)
   constexpr uint32_t RBITS = RowCfg<A>::RBITS;
   constexpr uint32_t RMASK = (1u << RBITS) - 1u;
   constexpr uint32_t AMASK = (1u << A) - 1u;
-  constexpr uint32_t PF = (MAX_ROW_SLICE_WORDS + NT - 1) / NT;   /* staged words per thread */
+  constexpr uint32_t PF = (MAX_ROW_SLICE_WORDS * 2 + NT - 1) / NT;   /* staged 16-byte pieces per thread */
 
   extern __shared__ __align__(16) unsigned char smem[];
   if ((uint32_t)(uintptr_t)smem != 0u)
     __builtin_trap();                       /* the slice is read at absolute LDS addresses */
   const uint32_t nwords = P.geom.rw_words;
-  const uint32_t slice_bytes = nwords * 16u;
+  const uint32_t slice_bytes = nwords * ROW_WORD_BYTES;
+  const uint32_t npieces = nwords * 2u;     /* 16-byte pieces of a slice */
   const unsigned char *filter = (const unsigned char *)P.bloom;
   uint64_t *zl = (uint64_t *)(smem + slice_bytes);
   const uint32_t nz = ZS * P.zpos;
@@ -204,43 +229,85 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t zl_addr = slice_bytes;           /* LDS address of zl */
   unsigned long long reads = 0;                   /* filter words read by this lane */
 
-  /* next chunk, prefetched into registers while the current one is worked on */
-  Chunk ck_next;
+  /* Chunks are dealt out statically: workgroup b takes chunks b, b + G, b + 2G, ...
+     of the list (sorted heaviest first, so the sums even out).  Knowing its
+     chunks in advance, a workgroup has the descriptor of the chunk after the next
+     and the slice + tile descriptors of the next chunk in flight while it works
+     on the current one; nothing on the way to a chunk waits for an atomic. */
+  const uint32_t G = gridDim.x;
+  uint32_t ci = blockIdx.x;                       /* index of the NEXT chunk */
+  Chunk ck_next, ck_next2;
   ck_next.slice = ck_next.first_tile = ck_next.ntiles = ck_next.pass = 0;
+  ck_next2 = ck_next;
   u32x4 pf[PF];
   uint32_t pft_t = 0;                             /* this thread's tile of the next chunk */
   u32x4 pft_a = {0, 0, 0, 0};                     /* its descriptor: len, nvalid, res_base, pass */
   uint32_t pft_slice = 0, pft_k = 0;
-  auto load_chunk = [&](uint32_t item) {
-    ck_next = P.chunks[item];
+  auto load_chunk = [&]() {                       /* slice + tile descriptors of ck_next */
     const u32x4 *src = (const u32x4 *)(filter + (size_t)ck_next.slice * slice_bytes);
 #pragma unroll
     for (uint32_t k = 0; k < PF; k++) {
       const uint32_t idx = threadIdx.x + k * NT;
-      if (idx < nwords)
+      if (idx < npieces)
         pf[k] = src[idx];
     }
     if (threadIdx.x < ck_next.ntiles) {
-      pft_t = P.tile_list[ck_next.first_tile + threadIdx.x];
-      const TileDesc *tp = P.tiles + pft_t;
+      const TileRef *tp = P.tile_refs + ck_next.first_tile + threadIdx.x;
       pft_a = *(const u32x4 *)tp;
-      pft_slice = tp->slice;
-      pft_k = tp->k;
+      pft_slice = tp->td.slice;
+      pft_k = tp->td.k;
+      pft_t = tp->t;
     }
   };
-
-  /* Chunks are claimed two ahead by thread 0: the id of the next one is handed to
-     the workgroup through LDS at the barrier, the atomic for the one after it is
-     in flight while the current chunk's tiles are worked on. */
-  uint32_t claimed = 0;
-  if (threadIdx.x == 0) {
-    bcast[0] = atomicAdd(P.tile_counter, 1u);
-    claimed = atomicAdd(P.tile_counter, 1u);
+  bool have_next = ci < P.nchunks;
+  if (have_next) {
+    ck_next = P.chunks[ci];
+    load_chunk();
   }
-  __syncthreads();                                /* also: the tables above are in place */
-  bool have_next = bcast[0] < P.nchunks;
-  if (have_next)
-    load_chunk(bcast[0]);
+  if (ci + G < P.nchunks)
+    ck_next2 = P.chunks[ci + G];
+  __syncthreads();                                /* the tables above are in place */
+
+  /* what a tile needs per lane before its first row: pass 0 -- the query's hash, its
+     length and the residues of the first block; passes 1, 2 -- the shifted hash
+     instead; class-row tiles -- the row's blanked hash, the query's slot in pass 0
+     and its residue there */
+  struct TileData {
+    uint64_t a;
+    uint32_t b, c, d;
+  };
+  auto load_tile_data = [&](uint32_t len, uint32_t nvalid, uint32_t res_base, uint32_t t,
+                            uint32_t tpass) -> TileData {
+    TileData x;
+    x.a = 0;
+    x.b = x.c = x.d = 0;
+    const bool valid = lane < nvalid;
+    if (tpass >= 3) {
+      const uint32_t cs = res_base + lane;
+      if (valid) {
+        x.a = P.cw[cs];
+        x.b = P.cmain[cs];
+        x.c = P.cres[cs];
+      }
+    } else {
+      const uint32_t slot = t * WAVE + lane;
+      if (valid) {
+        x.a = tpass == 1 ? P.qhins[slot] : tpass == 2 ? P.qhdel[slot] : P.qgh[slot];
+        x.b = P.qlen[slot];
+      }
+      const uint32_t nd = (len + 3u) >> 2;
+      if (nd) {
+        x.c = P.qres[res_base + lane];
+        x.d = P.qres[res_base + (nd > 1u ? WAVE : 0u) + lane];
+      }
+    }
+    return x;
+  };
+  const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+  TileData nxt;
+  nxt.a = 0;
+  nxt.b = nxt.c = nxt.d = 0;
+  bool pre_ok = false;                      /* nxt holds my first tile of the next chunk */
 
   bool block_phase = true;
   for (;;) {
@@ -255,7 +322,7 @@ probe_rows_kernel(const ProbeParams P)
 #pragma unroll
         for (uint32_t k = 0; k < PF; k++) {
           const uint32_t idx = threadIdx.x + k * NT;
-          if (idx < nwords)
+          if (idx < npieces)
             *(lds_u128_w_t *)(uintptr_t)(idx * 16u) = pf[k];
         }
         if (threadIdx.x < ck.ntiles) {
@@ -268,34 +335,45 @@ probe_rows_kernel(const ProbeParams P)
           tr->td.k = pft_k;
           tr->t = pft_t;
         }
-        if (threadIdx.x == 0) {
-          bcast[0] = claimed;
-          bcast[1] = 0;                           /* tiles of the chunk handed out so far */
-        }
         __syncthreads();
-        have_next = bcast[0] < P.nchunks;
+        ci += G;
+        have_next = ci < P.nchunks;
+        ck_next = ck_next2;
         if (have_next)
-          load_chunk(bcast[0]);
-        if (threadIdx.x == 0)
-          claimed = atomicAdd(P.tile_counter, 1u);
+          load_chunk();
+        if (ci + G < P.nchunks)
+          ck_next2 = P.chunks[ci + G];
       }
     }
     const bool staged = block_phase;
     const uint32_t pass = ck.pass;
+
+    /* The tiles of a chunk are dealt to the waves round-robin (wave w: tiles w,
+       w + NW, ...), so a wave knows its next tile while it works on the current one
+       and has that tile's per-lane data in flight -- also across the chunk
+       boundary: the reference of its first tile of the next chunk is a scalar
+       load issued as soon as that chunk's descriptor is known. */
+    const bool nref_ok = block_phase && have_next && wave_u < ck_next.ntiles;
+    TileRef nref;
+    nref.t = 0;
+    nref.pad = 0;
+    nref.td = TileDesc{0, 0, 0, 0, 0, 0};
+    if (nref_ok)
+      nref = P.tile_refs[ck_next.first_tile + wave_u];
+    uint32_t k = wave_u;                    /* my tile of the chunk being worked on */
+    TileData cur = nxt;                     /* fetched while the previous chunk was worked on */
+    bool cur_ok = pre_ok;
+    pre_ok = false;
 
     bool all_done = false;
     for (;;) {
       uint32_t t;
       TileDesc td;
       if (block_phase) {
-        uint32_t tk = 0;
-        if (lane == 0)
-          tk = atomicAdd(&bcast[1], 1u);
-        tk = __builtin_amdgcn_readfirstlane(tk);
-        if (tk >= ck.ntiles)
+        if (k >= ck.ntiles)
           break;
-        t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
-        td = tref_lds[tk].td;
+        t = __builtin_amdgcn_readfirstlane(tref_lds[k].t);
+        td = tref_lds[k].td;
       } else {
         uint32_t i = 0;
         if (lane == 0)
@@ -307,53 +385,80 @@ probe_rows_kernel(const ProbeParams P)
         }
         t = P.small_tiles[i];
         td = P.tiles[t];
+        cur_ok = false;
       }
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);       /* 0: light tile */
       const uint32_t tslice = __builtin_amdgcn_readfirstlane(td.slice);
+      const uint32_t tres = __builtin_amdgcn_readfirstlane(td.res_base);
       /* the indel passes reuse the tiles of pass 0 and are named by their chunk */
       const uint32_t tpass = (staged && pass) ? pass : __builtin_amdgcn_readfirstlane(td.pass);
-      const uint32_t *qr = P.qres + td.res_base + lane;
+      if (!cur_ok)
+        cur = load_tile_data(L, nvalid, tres, t, tpass);
+      /* the next tile's data, in flight while this one is worked on */
+      if (block_phase) {
+        const uint32_t kn = k + NW;
+        cur_ok = false;
+        if (kn < ck.ntiles) {
+          const TileDesc tn = tref_lds[kn].td;
+          nxt = load_tile_data(__builtin_amdgcn_readfirstlane(tn.len),
+                               __builtin_amdgcn_readfirstlane(tn.nvalid),
+                               __builtin_amdgcn_readfirstlane(tn.res_base),
+                               __builtin_amdgcn_readfirstlane(tref_lds[kn].t),
+                               pass ? pass : __builtin_amdgcn_readfirstlane(tn.pass));
+          cur_ok = true;
+        } else if (nref_ok) {
+          nxt = load_tile_data(nref.td.len, nref.td.nvalid, nref.td.res_base, nref.t,
+                               ck_next.pass ? ck_next.pass : nref.td.pass);
+          pre_ok = true;
+        }
+        k = kn;
+      }
+      const uint32_t *qr = P.qres + tres + lane;
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
-      W.qslot = t * WAVE + lane;
       const bool class_tile = tpass >= 3;
       /* a class-row tile carries, per lane, the row's blanked hash, the query's slot
          in pass 0 and its residue at the class position (query_layout.hip) */
-      const uint32_t cs = td.res_base + lane;
-      uint64_t cW = 0;
-      uint32_t cr = 0;
-      if (class_tile) {
-        if (valid) {
-          cW = P.cw[cs];
-          W.qslot = P.cmain[cs];
-          cr = P.cres[cs];
-        }
-      }
-      const uint32_t Ll = (valid && !class_tile) ? (uint32_t)P.qlen[W.qslot] : 0u;
+      W.qslot = class_tile ? cur.b : t * WAVE + lane;
+      const uint64_t cW = cur.a;
+      const uint32_t cr = cur.c;
+      const uint32_t Ll = (valid && !class_tile) ? cur.b : 0u;
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 
       auto woff_of = [&](uint64_t Wk) -> uint32_t {
-        return __umulhi((uint32_t)(Wk >> 32), nwords) << 4;
+        return __umulhi((uint32_t)(Wk >> 32), nwords) << 5;
+      };
+      auto word_lds = [&](uint32_t wo) -> RowWord {
+        RowWord w;
+        w.a = lds_u128(wo);
+        w.b = lds_u128(wo + 16u);
+        return w;
+      };
+      auto word_glob = [&](const unsigned char *base, uint32_t wo) -> RowWord {
+        RowWord w;
+        w.a = *(const u32x4 *)(base + wo);
+        w.b = *(const u32x4 *)(base + wo + 16u);
+        return w;
       };
       /* the tile's slice: the staged copy, or where it lies */
-      auto fetch_own = [&](uint64_t Wk) -> u32x4 {
+      auto fetch_own = [&](uint64_t Wk) -> RowWord {
         const uint32_t wo = woff_of(Wk);
         reads += valid ? 1u : 0u;
         if (staged)
-          return lds_u128(wo);
-        return *(const u32x4 *)(own_glob + wo);
+          return word_lds(wo);
+        return word_glob(own_glob, wo);
       };
       /* a slice of the lane's own */
-      auto fetch_at = [&](uint64_t Wk, uint32_t slice, bool in_lds) -> u32x4 {
+      auto fetch_at = [&](uint64_t Wk, uint32_t slice, bool in_lds) -> RowWord {
         const uint32_t wo = woff_of(Wk);
         reads += valid ? 1u : 0u;
-        u32x4 w;
+        RowWord w;
         if (in_lds)
-          w = lds_u128(wo);
+          w = word_lds(wo);
         else
-          w = *(const u32x4 *)(filter + (size_t)slice * slice_bytes + wo);
+          w = word_glob(filter + (size_t)slice * slice_bytes, wo);
         return w;
       };
       auto res_at = [&](uint32_t p) -> uint32_t {
@@ -364,7 +469,7 @@ probe_rows_kernel(const ProbeParams P)
               computed when the set was laid out, like the reference's
               seqinfo hash; with -i also the two shifted hashes of the rolling
               indel enumeration (zobrist.cc:90-104, 122-136) ---- */
-      const uint64_t h = (valid && !class_tile) ? P.qgh[W.qslot] : 0ull;
+      const uint64_t h = cur.a;        /* (pass 1, 2: the shifted hash of that pass) */
 
       /* class positions of this length (wave-uniform), as a bit set */
       uint32_t m[MCR];
@@ -424,7 +529,7 @@ probe_rows_kernel(const ProbeParams P)
           const uint32_t r = (rpack >> (RBITS * j)) & RMASK;
           const uint32_t za = zl_addr + ZS * p * 8u;
           const uint64_t hv = h ^ lds_u64(za + r * 8u) ^ lds_u64(za + v * 8u);
-          s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+          s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB, p, v), 0);
           if (first)
             m0 &= m0 - 1ull;
           else
@@ -435,9 +540,9 @@ probe_rows_kernel(const ProbeParams P)
       if (tpass == 0) {
         /* ---- the unchanged sequence (variants.cc:260-268) ---- */
         {
-          const u32x4 w = fetch_own(h);
-          const bool hit = ((row_bits(w, (uint32_t)h) >> A) & 1u) != 0;
-          s_push<GENES>(W, valid && hit, h, pack_a(K_SAME, 0, 0), 0);
+          const RowWord w = fetch_own(h);
+          const bool hit = ((row_bits(w, h) >> A) & 1u) != 0;
+          s_push<GENES, INLINE>(W, valid && hit, h, pack_a(K_SAME, 0, 0), 0);
           nvar += 1;
         }
 
@@ -456,8 +561,8 @@ probe_rows_kernel(const ProbeParams P)
             dn0 = qr[w0 * WAVE];
             dn1 = qr[(w0 + 1u < nd ? w0 + 1u : w0) * WAVE];
           };
-          if (L)
-            request(0);
+          dn0 = cur.c;                       /* block 0 came with the tile's data */
+          dn1 = cur.d;
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < L; p0 += RB) {
@@ -476,20 +581,31 @@ probe_rows_kernel(const ProbeParams P)
             uint64_t m0 = 0, m1 = 0;
             uint32_t rpack = 0;
             uint64_t Wk[RB];
-            uint32_t rj[RB];
+            uint32_t rj[RB], wo[RB];
+            /* the rows' own keys, all RB reads in flight together ... */
 #pragma unroll
             for (int j = 0; j < RB; j++) {
               rj[j] = (uint32_t)(rr >> (8 * j)) & 31u;
               rpack |= (rj[j] & RMASK) << (RBITS * j);
-              Wk[j] = h ^ lds_u64(zl_addr + (ZS * (p0 + (uint32_t)j) + rj[j]) * 8u);
+              Wk[j] = lds_u64(zl_addr + (ZS * (p0 + (uint32_t)j) + rj[j]) * 8u);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+              Wk[j] ^= h;
+              wo[j] = woff_of(Wk[j]);
+            }
+            /* ... then the filter words, one row ahead of the row being tested */
+            RowWord wc = STAGED ? word_lds(wo[0]) : word_glob(own_glob, wo[0]);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
               const uint32_t p = p0 + (uint32_t)j;
-              const uint32_t wo = woff_of(Wk[j]);
-              const u32x4 w = STAGED ? lds_u128(wo) : *(const u32x4 *)(own_glob + wo);
+              RowWord wn = wc;
+              if (j + 1 < RB)
+                wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
+              __builtin_amdgcn_sched_barrier(0);
               reads += valid ? 1u : 0u;
-              uint32_t x = row_bits(w, (uint32_t)Wk[j]) & AMASK & ~(1u << rj[j]);
+              uint32_t x = row_bits(wc, Wk[j]) & AMASK & ~(1u << rj[j]);
               const bool live = (p < Ll) & !((cbits >> j) & 1u);
               x = live ? x : 0u;
               nvar += live ? (uint64_t)(A - 1) : 0ull;
@@ -497,6 +613,7 @@ probe_rows_kernel(const ProbeParams P)
                 m0 |= (uint64_t)x << (A * j);
               else
                 m1 |= (uint64_t)x << (A * (j - RPW));
+              wc = wn;
             }
             emit_sub_rows(m0, m1, p0, rpack);
           }
@@ -537,7 +654,7 @@ probe_rows_kernel(const ProbeParams P)
                   const uint32_t k = k0 + (uint32_t)j;
                   if (k < (uint32_t)A) {
                     const uint64_t Wk = hb ^ lds_u64(ea + 8u * k);     /* e <- (re + k) mod A */
-                    u32x4 w;
+                    RowWord w;
                     if (own) {
                       w = fetch_own(Wk);
                     } else {
@@ -547,7 +664,7 @@ probe_rows_kernel(const ProbeParams P)
                       const uint32_t sl = key & smask;
                       w = fetch_at(Wk, sl, staged && sl == tslice);
                     }
-                    uint32_t x = row_bits(w, (uint32_t)Wk) & AMASK & ~(1u << rb);
+                    uint32_t x = row_bits(w, Wk) & AMASK & ~(1u << rb);
                     x = live ? x : 0u;
                     if (j < RPW)
                       m0 |= (uint64_t)x << (A * j);
@@ -570,7 +687,7 @@ probe_rows_kernel(const ProbeParams P)
                   /* (position, residue) pairs in increasing position order */
                   const uint32_t p1 = swap ? e : b, r1 = swap ? wres : v;
                   const uint32_t p2 = swap ? b : e, r2 = swap ? v : wres;
-                  s_push<GENES>(W, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24));
+                  s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24));
                   if (first)
                     m0 &= m0 - 1ull;
                   else
@@ -596,15 +713,15 @@ probe_rows_kernel(const ProbeParams P)
           if (i < ci && i < K && m[i] == p)
             dup = true;
         if (!dup && D >= 1 && L > 0) {
-          const u32x4 w = fetch_own(cW);
-          uint32_t x = row_bits(w, (uint32_t)cW) & AMASK & ~(1u << cr) & vmask;
+          const RowWord w = fetch_own(cW);
+          uint32_t x = row_bits(w, cW) & AMASK & ~(1u << cr) & vmask;
           nvar += (uint64_t)(A - 1);
           const uint32_t za = zl_addr + ZS * p * 8u;
           while (__ballot(x != 0)) {
             const bool pos = x != 0;
             const uint32_t v = pos ? (uint32_t)__ffs((int)x) - 1u : 0u;
             const uint64_t hv = cW ^ lds_u64(za + v * 8u);
-            s_push<GENES>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+            s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB, p, v), 0);
             x &= x - 1u;
           }
         }
@@ -646,7 +763,7 @@ probe_rows_kernel(const ProbeParams P)
               hi[i] = cr_lds[i * A + res_at(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
             }
           }
-          uint64_t hd = P.qhdel[W.qslot];
+          uint64_t hd = h;                        /* zobrist_hash_delete_first */
           uint32_t gone = 0;
           for (uint32_t p0 = 0; p0 < L; p0 += 32) {
             const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
@@ -666,8 +783,8 @@ probe_rows_kernel(const ProbeParams P)
               for (uint32_t i = 0; i < MCR; i++)
                 key ^= md[i] < p ? lo[i] : hi[i];
               const uint32_t sl = key & smask;
-              const u32x4 w = fetch_at(hd, sl, !valid || sl == ck.slice);
-              const bool hit = ((row_bits(w, (uint32_t)hd) >> A) & 1u) != 0;
+              const RowWord w = fetch_at(hd, sl, !valid || sl == ck.slice);
+              const bool hit = ((row_bits(w, hd) >> A) & 1u) != 0;
               nvar += fresh ? 1u : 0u;
               mask |= (fresh && hit) ? (1u << (p - p0)) : 0u;
               gone = r;
@@ -681,7 +798,7 @@ probe_rows_kernel(const ProbeParams P)
                 const uint32_t r = res_at(p);
                 if (p > 0 && r != g)
                   hr ^= zl[ZS * (p - 1) + g] ^ zl[ZS * (p - 1) + r];
-                s_push<GENES>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
+                s_push<GENES, INLINE>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
                 g = r;
               }
             }
@@ -706,7 +823,7 @@ probe_rows_kernel(const ProbeParams P)
                 hi[i] = cr_lds[i * A + res_at(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
             }
           }
-          uint64_t hg = P.qhins[W.qslot];         /* hash of q with a gap at ip */
+          uint64_t hg = h;                        /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
           uint32_t r = 0;
           ResStream rs;
           rs.start(qr, L);
@@ -730,8 +847,8 @@ probe_rows_kernel(const ProbeParams P)
                   if (i < KH && mi[i] != ip)
                     key ^= mi[i] < ip ? lo[i] : hi[i];
                 const uint32_t sl = key & smask;
-                const u32x4 w = fetch_at(hg, sl, !valid || sl == ck.slice);
-                uint32_t x = row_bits(w, (uint32_t)hg) & AMASK & vmask;
+                const RowWord w = fetch_at(hg, sl, !valid || sl == ck.slice);
+                uint32_t x = row_bits(w, hg) & AMASK & vmask;
                 if (ip > 0)
                   x &= ~(1u << r);                              /* v != q[ip - 1] */
                 nvar += ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A;
@@ -755,7 +872,7 @@ probe_rows_kernel(const ProbeParams P)
                 hw = j == (uint32_t)jj ? hrow[jj] : hw;
               const uint32_t ip = ip0 + j;
               const uint64_t hv = hw ^ lds_u64(zl_addr + (ZS * ip + v) * 8u);
-              s_push<GENES>(W, pos, hv, pack_a(K_INS, ip, v), 0);
+              s_push<GENES, INLINE>(W, pos, hv, pack_a(K_INS, ip, v), 0);
               if (first)
                 m0 &= m0 - 1ull;
               else
@@ -766,6 +883,13 @@ probe_rows_kernel(const ProbeParams P)
       }
 
       W.st.variants += valid ? nvar : 0ull;
+      cur = nxt;
+    }
+    /* a wave without a tile in this chunk still fetches its first one of the next */
+    if (nref_ok && !pre_ok) {
+      nxt = load_tile_data(nref.td.len, nref.td.nvalid, nref.td.res_base, nref.t,
+                           ck_next.pass ? ck_next.pass : nref.td.pass);
+      pre_ok = true;
     }
     if (all_done)
       break;
@@ -774,7 +898,7 @@ probe_rows_kernel(const ProbeParams P)
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (W.qn > 0)
-    flush_or_resolve<GENES>(W, 0, W.qn);
+    flush_or_resolve<GENES, INLINE>(W, 0, W.qn);
 
   {
     unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,

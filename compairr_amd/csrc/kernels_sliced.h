@@ -114,11 +114,15 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
   }
 }
 
-template <bool GENES>
+/* FALLBACK = false (the fast form of kernels_rows.h): entries that do not fit are
+   dropped and the launch is flagged (ProbeParams::overflow); resolve_kernel then
+   does nothing and a second launch of the kernel's FALLBACK = true form redoes the
+   whole step resolving inline, so that capacity is never a limit either way. */
+template <bool GENES, bool FALLBACK = true>
 __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
 {
   const ProbeParams &P = W.P;
-  bool inline_resolve = P.pos_buf == nullptr;
+  bool inline_resolve = FALLBACK && P.pos_buf == nullptr;
   if (!inline_resolve) {
     const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
     unsigned long long *ctr = P.pos_ctr + (size_t)seg * POS_CTR_STRIDE;
@@ -138,18 +142,19 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
         P.pos_buf[(size_t)seg * (P.pos_cap + WAVE) + base + W.lane] = e;
       }
     } else {
-      if (W.lane == 0)
+      if (W.lane == 0) {
         atomicMax(ctr + 1, ~base);
-      inline_resolve = true;
+        if (!FALLBACK)
+          atomicOr(P.overflow, 1ull);
+      }
+      inline_resolve = FALLBACK;
     }
   }
-#ifndef EXPERIMENT_NO_INLINE_RESOLVE
-  if (inline_resolve)
+  if (FALLBACK && inline_resolve)
     resolve_inline_slow<GENES>(W, first, n);
-#endif
 }
 
-template <bool GENES>
+template <bool GENES, bool FALLBACK = true>
 __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
                                        uint32_t ca, uint32_t cb)
 {
@@ -168,7 +173,7 @@ __device__ __forceinline__ void s_push(SProber &W, bool pos, uint64_t hv,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       W.qn -= WAVE;
       if (!CMPR_DBG(W.P, DBG_SKIP_RESOLVE))
-        flush_or_resolve<GENES>(W, W.qn, WAVE);
+        flush_or_resolve<GENES, FALLBACK>(W, W.qn, WAVE);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
@@ -364,13 +369,6 @@ __device__ __forceinline__ const uint64_t *hbm_word(const SProber &W, uint64_t h
   return (const uint64_t *)((const char *)W.P.bloom + ((uint64_t)vslice << W.slice_shift) + woff);
 }
 
-/* tile descriptor + tile number, staged in LDS per chunk */
-struct TileRef {
-  TileDesc td;
-  uint32_t t;
-  uint32_t pad;
-};
-
 /* The residues of a tile, streamed one dword (4 positions x 64 lanes) ahead of
    use so that the HBM/L2 latency of the next dword hides behind the rows of
    the current one. */
@@ -488,11 +486,8 @@ probe_sliced_kernel(const ProbeParams P)
         const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
         for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
           slice_lds[i] = src[i];
-        for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT) {
-          const uint32_t t = P.tile_list[ck.first_tile + i];
-          tref_lds[i].td = P.tiles[t];
-          tref_lds[i].t = t;
-        }
+        for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT)
+          tref_lds[i] = P.tile_refs[ck.first_tile + i];
         __syncthreads();
       }
     }

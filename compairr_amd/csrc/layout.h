@@ -82,7 +82,8 @@ constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 3 for aa (20^3
                                                  K <= 8 for nt (4^8 splits)            */
 __host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 3u; }
 constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
-constexpr uint32_t MAX_ROW_SLICE_WORDS = 2048; /* variant 2: 32 KiB of 16-byte words per slice */
+constexpr uint32_t ROW_WORD_BYTES      = 32;   /* variant 2: filter word = 8 dwords, one bit of each per entry */
+constexpr uint32_t MAX_ROW_SLICE_WORDS = 1280; /* variant 2: at most 40 KiB per slice */
 constexpr uint32_t HEAVY_BUCKETS_LOG2 = 16;
 constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
 
@@ -96,7 +97,7 @@ struct SliceGeom {
   const uint32_t *ctab;
   uint32_t off_cv, off_cj, off_cr, off_hv;
   uint32_t c0;             /* first class position                          */
-  uint32_t rw_words;       /* variant 2 (kernels_rows.h): 16-byte words per
+  uint32_t rw_words;       /* variant 2 (kernels_rows.h): 32-byte words per
                               slice, any count <= MAX_ROW_SLICE_WORDS          */
 };
 
@@ -137,10 +138,17 @@ __host__ __device__ inline uint32_t class_key_of(const uint32_t *t, const SliceG
   return ck;
 }
 
+/* tile descriptor + tile number: the unit the chunks list, staged in LDS per chunk */
+struct TileRef {
+  TileDesc td;
+  uint32_t t;            /* tile number: slot = t * 64 + lane                */
+  uint32_t pad;
+};
+
 /* one block-level work item of the sliced kernel: tiles of one slice */
 struct Chunk {
   uint32_t slice;        /* slice to stage in LDS                            */
-  uint32_t first_tile;   /* index into ProbeParams::tile_list                */
+  uint32_t first_tile;   /* index into ProbeParams::tile_refs                */
   uint32_t ntiles;
   uint32_t pass;         /* 0: all rows of the tiles' own slice; 1: insertion
                             rows, 2: deletion rows, with the
@@ -249,7 +257,11 @@ struct ProbeParams {
   uint32_t            pos_segments; /* power of two; workgroup b appends to
                                        segment b % pos_segments: claims are
                                        same-address atomics, which serialise    */
-  uint32_t            pos_pad;
+  uint32_t            redo;         /* 1: this launch is the redo pass (see overflow) */
+  unsigned long long *overflow;     /* set by a fast-form probe launch (kernels_rows.h)
+                                       whose positives did not fit: resolve_kernel
+                                       skips, the redo launch does the step inline;
+                                       NULL for kernels that resolve inline instead  */
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
   unsigned long long *pair_count;   /* NULL: matrix mode                        */
@@ -260,7 +272,7 @@ struct ProbeParams {
   const uint32_t *small_tiles;     /* tiles handled by single waves, unstaged      */
   uint32_t        nsmall;
   uint32_t        pad3;
-  const uint32_t *tile_list;       /* chunk c covers tiles tile_list[first .. first+n) */
+  const TileRef  *tile_refs;       /* chunk c covers tile_refs[first .. first+n)       */
   uint32_t        nchunks;
   uint32_t        debug;           /* ablation switches, 0 in production      */
   /* work distribution + statistics */

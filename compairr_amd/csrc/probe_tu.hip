@@ -1,6 +1,7 @@
 /*
  * probe_tu.hip -- one translation unit per (kernel variant, workgroup size):
- * compiled with -DTU_VARIANT=0|1|2|9 and -DTU_NW=4|8|16 (variants 1, 2).
+ * compiled with -DTU_VARIANT=0|1|2|9, -DTU_NW=4|8|16 (variants 1, 2) and
+ * -DTU_INLINE=0|1 (variant 2: the fast form / the form that resolves inline).
  * TU_VARIANT 9 = resolve_kernel.
  */
 #include "select.h"
@@ -23,8 +24,11 @@ namespace cmpr {
 #elif TU_VARIANT == 1
 #define KERNEL(A_, D_, I_, G_) probe_sliced_kernel<A_, D_, I_, G_, TU_NW>
 #define SELECT_NAME CAT(select_probe_v1_nw, TU_NW)
+#elif TU_VARIANT == 2 && TU_INLINE
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true>
+#define SELECT_NAME CAT(select_probe_v2_inline_nw, TU_NW)
 #elif TU_VARIANT == 2
-#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW>
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false>
 #define SELECT_NAME CAT(select_probe_v2_nw, TU_NW)
 #endif
 

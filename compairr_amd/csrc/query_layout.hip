@@ -78,7 +78,7 @@ struct QL {
   SliceGeom       geom;
   uint32_t        npass;             /* 1 + class-row passes (variant 2) */
   uint32_t        min_mixed;         /* lengths >= this share tiles; ~0: none do */
-  uint32_t        chunk_tiles, small_max;
+  uint32_t        chunk_tiles, small_max, class_unstaged;
   uint64_t        nbuckets;          /* (slice, heavy) buckets */
   uint64_t        nslices;
   /* per pass */
@@ -93,7 +93,8 @@ struct QL {
   /* outputs */
   TileDesc *tiles;
   Chunk    *chunks;
-  uint32_t *tile_list, *small_tiles, *chunk_work;
+  TileRef  *tile_refs;
+  uint32_t *small_tiles, *chunk_work;
   uint32_t *qres, *qv, *qj, *qrep, *qorig, *qck;
   uint64_t *qgh, *qhins, *qhdel, *qcnt;
   uint16_t *qlen;
@@ -376,7 +377,7 @@ slices_kernel(const QL Q, uint32_t pi)
      that single waves work through, probing the slice in HBM / L2. */
   uint32_t nchunks = 0, nsmall = 0, nlist = 0;
   if (Q.sliced && ntiles) {
-    if (!Q.indels && ntiles <= Q.small_max) {
+    if (!Q.indels && (ntiles <= Q.small_max || (pi > 0 && Q.class_unstaged))) {
       nsmall = ntiles;
       if (WRITE)
         for (uint32_t t = 0; t < ntiles; t++)
@@ -385,8 +386,13 @@ slices_kernel(const QL Q, uint32_t pi)
       nchunks = (ntiles + Q.chunk_tiles - 1) / Q.chunk_tiles;
       nlist = ntiles;
       if (WRITE) {
-        for (uint32_t t = 0; t < ntiles; t++)
-          Q.tile_list[Q.list0[pi] + at.list + t] = tile_base + t;
+        for (uint32_t t = 0; t < ntiles; t++) {
+          TileRef r;
+          r.td = Q.tiles[tile_base + t];
+          r.t = tile_base + t;
+          r.pad = 0;
+          Q.tile_refs[Q.list0[pi] + at.list + t] = r;
+        }
         for (uint32_t k = 0; k < nchunks; k++) {
           Chunk ck;
           ck.slice = (uint32_t)sl;
@@ -531,8 +537,13 @@ sibling_fill_kernel(const QL Q, uint64_t G, const uint32_t *list_pre, uint32_t *
       continue;
     const uint64_t k = (uint64_t)(ip - 1) * Q.nslices + sib;
     const uint32_t at = list_base + list_pre[k] + atomicAdd(sib_fill + k, nt);
-    for (uint32_t t = 0; t < nt; t++)
-      Q.tile_list[at + t] = Q.tfirst_g[g] + t;
+    for (uint32_t t = 0; t < nt; t++) {
+      TileRef r;
+      r.t = Q.tfirst_g[g] + t;
+      r.td = Q.tiles[r.t];
+      r.pad = 0;
+      Q.tile_refs[at + t] = r;
+    }
   }
 }
 
@@ -566,7 +577,7 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   const Chunk ck = Q.chunks[k];
   uint64_t w = 0;
   for (uint32_t t = 0; t < ck.ntiles; t++) {
-    const TileDesc td = Q.tiles[Q.tile_list[ck.first_tile + t]];
+    const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
     w += (uint64_t)(ck.pass == 0 ? td.len + 1 : ck.pass == 1 ? td.len + 2 : 2) * td.nvalid;
   }
   work[k] = (uint32_t)min(w, (uint64_t)0xffffffffu);
@@ -759,6 +770,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.min_mixed = mixed_ok ? c->geom.c0 + c->geom.k : 0xffffffffu;
   Q.chunk_tiles = (uint32_t)chunk_tiles;
   Q.small_max = (uint32_t)c->small_slice_tiles;
+  Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
 
@@ -913,7 +925,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, c->tiles, (size_t)ntiles))) return rc;
   if ((rc = dev_alloc(c, chunks_unsorted.b, (size_t)nchunks))) return rc;
   if ((rc = dev_alloc(c, c->chunks, (size_t)nchunks))) return rc;
-  if ((rc = dev_alloc(c, c->tile_list, (size_t)nlist))) return rc;
+  if ((rc = dev_alloc(c, c->tile_refs, (size_t)nlist))) return rc;
   if ((rc = dev_alloc(c, c->small_tiles, (size_t)nsmall))) return rc;
   /* + 9 rows: verify_candidate reads nine dwords per query whatever its length */
   if ((rc = dev_alloc(c, c->qres, (size_t)res_words + 9 * WAVE))) return rc;
@@ -960,7 +972,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   }
   Q.tiles = c->tiles.p;
   Q.chunks = chunks_unsorted.b.p;
-  Q.tile_list = c->tile_list.p;
+  Q.tile_refs = c->tile_refs.p;
   Q.small_tiles = c->small_tiles.p;
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;

@@ -19,10 +19,14 @@ ProbeFn select_probe_v0(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v1_nw4(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v1_nw8(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v1_nw16(int A, int D, bool indels, bool genes);
-/* variant 2 (kernels_rows.h probe_rows_kernel) */
+/* variant 2 (kernels_rows.h probe_rows_kernel): the fast form, and the form that
+   resolves its Bloom positives inline (deferred_resolve = 0, redo pass) */
 ProbeFn select_probe_v2_nw4(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_nw8(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_nw16(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_inline_nw4(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_inline_nw8(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_inline_nw16(int A, int D, bool indels, bool genes);
 /* resolve_kernel (kernels.h) */
 ProbeFn select_resolve(bool genes);
 
