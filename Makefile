@@ -32,7 +32,7 @@ TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o \
 all: lib cli oracle
 
 lib:
-	$(MAKE) -j8 $(LIB)
+	$(MAKE) -j8 $(LIB) LIB=$(LIB) OBJ_DIR=$(OBJ_DIR)
 
 $(OBJ_DIR)/main.o: $(KERN_DIR)/compairr_hip.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
@@ -64,6 +64,17 @@ $(OBJ_DIR)/probe_v2i_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 
 $(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
+
+# diagnostic build with per-phase cycle counters in the probe kernel (tools/phase_timing.py)
+timing:
+	$(MAKE) -j8 lib LIB=compairr_amd/lib/libcompairr_hip_timing.so OBJ_DIR=compairr_amd/lib/obj_timing \
+	    HIPFLAGS="$(HIPFLAGS) -DCMPR_PHASE_TIMING"
+
+# ablation build: the "debug" tunable skips parts of the kernels (timing experiments only,
+# results become wrong; tools/ablation.sh)
+ablation:
+	$(MAKE) -j8 lib LIB=compairr_amd/lib/libcompairr_hip_ablation.so OBJ_DIR=compairr_amd/lib/obj_ablation \
+	    HIPFLAGS="$(HIPFLAGS) -DCMPR_ABLATION"
 
 cli: $(CLI)
 

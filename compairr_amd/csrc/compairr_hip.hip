@@ -470,6 +470,15 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "pos_segments") *value = c->pos_segments;
   else if (n == "resolve_blocks_per_cu") *value = c->resolve_blocks_per_cu;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
+#ifdef CMPR_PHASE_TIMING
+  else if (n.size() == 3 && n[0] == 'p' && n[1] == 't' && n[2] >= '0' && n[2] <= '7') {
+    /* diagnostic build: wave cycles of phase n of the last launch (kernels_rows.h PT_*) */
+    unsigned long long x = 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(&x, c->d_stats + 8 + (n[2] - '0'), sizeof x, hipMemcpyDeviceToHost));
+    *value = (int64_t)x;
+  }
+#endif
   else
     return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
   return CMPR_OK;
@@ -556,24 +565,29 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
   int64_t swl = c->slice_words_log2;
   if (swl < 0)
     swl = SLICE_WORDS_LOG2;
-  /* variant 2: the largest slice in 32-byte words -- 40 KiB by default (two
-     workgroups of slice + tables + queues per CU), a power of two on request */
+  /* variant 2: the largest slice in 32-byte words -- 40 KiB by default (a ring of
+     two slices + tables + the queues of 16 waves in one workgroup per CU), a power
+     of two on request */
   uint64_t row_max_words = c->slice_words_log2 < 0
-      ? MAX_ROW_SLICE_WORDS : std::min<uint64_t>(1ull << c->slice_words_log2, 1024);
+      ? MAX_ROW_SLICE_WORDS : std::min<uint64_t>(1ull << c->slice_words_log2, MAX_ROW_SLICE_WORDS);
   if (c->sliced) {
     const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
-    /* everything but the slice */
+    /* everything but the slice(s), with the fewest waves a workgroup may have */
     const size_t fixed = zrow * c->zpos * sizeof(uint64_t) +
                          4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
                          MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
-                         64 * sizeof(TileRef);
+                         64 * sizeof(TileRef) + (c->rows ? RING * (sizeof(RingSlot) + 64 * sizeof(TileRef)) : 0);
     if (c->rows && c->slice_words_log2 < 0) {
-      /* long sequences: a smaller slice next to the bigger Zobrist table */
-      const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
-      row_max_words = std::min<uint64_t>(row_max_words, room / ROW_WORD_BYTES);
+      /* the default slice leaves room for the queues of 16 waves; long sequences: a
+         smaller slice next to the bigger Zobrist table */
+      const size_t fixed16 = fixed + 12 * sizeof(WaveQueue);
+      const size_t room = fixed16 < 160 * 1024 ? 160 * 1024 - fixed16 : 0;
+      row_max_words = std::min<uint64_t>(row_max_words, room / (RING * ROW_WORD_BYTES));
+      row_max_words -= row_max_words % 32;               /* whole KiB: LDS-DMA pieces */
     }
-    const size_t need = fixed + (c->rows ? (size_t)row_max_words * ROW_WORD_BYTES : ((size_t)8 << swl));
-    if (need > 160 * 1024 || (c->rows && row_max_words < 32)) {
+    const size_t need = fixed + (c->rows ? RING * (size_t)row_max_words * ROW_WORD_BYTES
+                                         : ((size_t)8 << swl));
+    if (need > 160 * 1024 || (c->rows && row_max_words < 1)) {
       c->sliced = false;
       c->rows = false;
     }
@@ -593,9 +607,11 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
     /* S slices (a power of two: sibling slices are XORs of slice numbers) of
        rw_words <= row_max_words words each */
     uint64_t S = 1;
-    while (S * row_max_words * ROW_WORD_BYTES < bloom_bytes)
+    while (S * row_max_words * ROW_WORD_BYTES * 17 / 16 < bloom_bytes)    /* (up to 6 % denser) */
       S <<= 1;
     uint64_t words = (bloom_bytes + S * ROW_WORD_BYTES - 1) / (S * ROW_WORD_BYTES);
+    if (words >= 64)
+      words = (words + 31) / 32 * 32;                  /* whole KiB: LDS-DMA pieces */
     words = std::max<uint64_t>(1, std::min<uint64_t>(words, row_max_words));
     if (S > (1ull << 31))
       return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
@@ -1106,10 +1122,14 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       P.pos_segments = (uint32_t)c->pos_segments;
     }
 
-    /* workgroups of 8 waves share one staged slice; when the chunks are short
-       (many slices, few queries each) 4 waves keep more of them busy */
+    /* variant 1: workgroups of 8 waves share one staged slice; when the chunks are
+       short (many slices, few queries each) 4 waves keep more of them busy.
+       variant 2: one workgroup per CU, 15 compute waves + the loader wave around a
+       ring of two slices */
     int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
-    if (c->sliced && !c->waves_per_block_forced && c->nchunks > 0 &&
+    if (c->rows && !c->waves_per_block_forced)
+      nw = 16;
+    if (c->sliced && !c->rows && !c->waves_per_block_forced && c->nchunks > 0 &&
         (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
       nw = 4;
     auto lds_for = [&](int waves) -> size_t {
@@ -1120,9 +1140,9 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
                  (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
                  (size_t)waves * sizeof(WaveQueue);
       if (c->rows)
-        b += (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
-             (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) + 16 +
-             (size_t)c->chunk_cap * sizeof(TileRef);
+        b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
+             (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) +
+             RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef));
       else if (c->sliced)
         b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
              MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
@@ -1130,22 +1150,14 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       return b;
     };
     size_t lds = lds_for(nw);
-    if (lds > 160 * 1024 && c->sliced && nw > 4) {
-      nw = 4;                              /* long sequences: fewer wave queues */
+    while (lds > 160 * 1024 && c->sliced && nw > 4) {
+      nw /= 2;                             /* long sequences: fewer wave queues */
       lds = lds_for(nw);
     }
     if (lds > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED,
                   "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    /* a chunk's tile descriptors are staged one per thread (kernels_rows.h) */
-    if (c->rows && c->chunk_cap > (uint32_t)nw * WAVE)
-      nw = c->chunk_cap > 8 * WAVE ? 16 : 8;
-    if (c->rows && c->chunk_cap > (uint32_t)nw * WAVE)
-      return fail(c, CMPR_EINVAL, "chunk_tiles exceeds the threads of a workgroup (variant 2)");
-    lds = lds_for(nw);
-    if (lds > 160 * 1024)
-      return fail(c, CMPR_EUNSUPPORTED,
-                  "sequences too long: Zobrist table does not fit the 160 KiB LDS");
+    P.chunk_cap = c->chunk_cap;
     /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
        that resolves inline is deferred_resolve = 0 and the redo pass below */
     ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !deferred)

@@ -52,6 +52,8 @@ namespace cmpr {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u32x4 lds_u128_t;
 typedef __attribute__((address_space(3))) u32x4 lds_u128_w_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glob_void_t;
 
 __device__ __forceinline__ u32x4 lds_u128(uint32_t byte_addr)
 {
@@ -165,13 +167,54 @@ template <int A> struct RowCfg {
  *   1, 2   insertion rows / deletion variants, the tiles grouped by the slice
  *          most of those variants fall into (as in variant 1)
  *   3 + i  the substitution row of class position i of the heavy queries, the
- *          tiles grouped by that row's slice
+ *          tiles grouped by that row's slice (in class part i of the filter)
  * TileDesc::slice is the slice the tile's rows of this pass are filed under;
  * for a staged chunk it is the slice in LDS.
  *
- * LDS: [slice, rw_words x 16 B][ZS x zpos Zobrist keys][R1 x R2 matrix (optional)]
- *      [NW WaveQueues][CR tables][heavy bitmap (-i)][chunk broadcast][tile refs]
+ * Workgroup = NW waves around a ring of RING slice buffers in LDS.  Chunks are
+ * dealt to the workgroups statically (workgroup b: chunks b, b + G, ... of the
+ * list, heaviest first).  A wave that finds no tile to work on stages the next
+ * chunk: it copies slice and tile references into the next free buffer with
+ * LDS-DMA (global_load_lds: no registers, asynchronous) and publishes it; waves
+ * claim tiles from the published buffers in order, one tile at a time with an LDS
+ * atomic, and a buffer is free again when its tiles are finished.  Nothing in the
+ * steady state is a workgroup barrier: staging overlaps the rows, several chunks
+ * are copied at once, and no wave idles at the end of a chunk while another still
+ * works on it.
+ *
+ * LDS: [RING slices, rw_words x 32 B each][ZS x zpos Zobrist keys]
+ *      [R1 x R2 matrix (optional)][NW WaveQueues][CR tables][heavy bitmap (-i)]
+ *      [RING ring slots][RING x chunk_cap tile refs]
  */
+constexpr uint32_t RING = 4;
+constexpr uint32_t RING_END = 0xffffffffu;
+
+/* -DCMPR_PHASE_TIMING (tools/phase_timing.sh): every wave sums the shader cycles
+   (s_memtime) it spends per phase and adds them to ProbeParams::stats[8 + phase];
+   a diagnostic build, never the shipped one */
+#ifdef CMPR_PHASE_TIMING
+#define PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime();
+#define PT_MARK(i) do { const unsigned long long pt_n = __builtin_amdgcn_s_memtime(); pt_acc[i] += pt_n - pt_t; pt_t = pt_n; } while (0)
+#define PT_FLUSH do { if (lane == 0) for (int pt_k = 0; pt_k < 8; pt_k++) atomicAdd(P.stats + 8 + pt_k, pt_acc[pt_k]); } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i) do { } while (0)
+#define PT_FLUSH do { } while (0)
+#endif
+enum { PT_CLAIM = 0, PT_TILE_DATA = 1, PT_ROWS = 2, PT_EMIT = 3, PT_OTHER = 4, PT_LOADER_WAIT = 5,
+       PT_LOADER_DMA = 6, PT_TAIL = 7 };
+
+/* one buffer of the ring */
+struct RingSlot {
+  /* tag << 32 | ntiles << 16 | tiles handed out: claimed with ONE 64-bit LDS add,
+     so that a claim names the tenant it belongs to; tag 0 = nothing yet, tags
+     grow by one per tenant, RING_END = no more chunks */
+  unsigned long long claim;
+  uint32_t done;             /* tiles of the tenant finished */
+  uint32_t slice, pass;
+  uint32_t pad[3];
+};
+
 template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE>
 __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_rows_kernel(const ProbeParams P)
@@ -190,24 +233,24 @@ probe_rows_kernel(const ProbeParams P)
   constexpr uint32_t RBITS = RowCfg<A>::RBITS;
   constexpr uint32_t RMASK = (1u << RBITS) - 1u;
   constexpr uint32_t AMASK = (1u << A) - 1u;
-  constexpr uint32_t PF = (MAX_ROW_SLICE_WORDS * 2 + NT - 1) / NT;   /* staged 16-byte pieces per thread */
 
   extern __shared__ __align__(16) unsigned char smem[];
   if ((uint32_t)(uintptr_t)smem != 0u)
-    __builtin_trap();                       /* the slice is read at absolute LDS addresses */
+    __builtin_trap();                       /* the slices are read at absolute LDS addresses */
   const uint32_t nwords = P.geom.rw_words;
-  const uint32_t slice_bytes = nwords * ROW_WORD_BYTES;
-  const uint32_t npieces = nwords * 2u;     /* 16-byte pieces of a slice */
+  const uint32_t slice_bytes = nwords * ROW_WORD_BYTES;     /* a multiple of 1 KiB */
   const unsigned char *filter = (const unsigned char *)P.bloom;
-  uint64_t *zl = (uint64_t *)(smem + slice_bytes);
+  const uint32_t zl_addr = RING * slice_bytes;              /* LDS address of zl */
+  uint64_t *zl = (uint64_t *)(smem + zl_addr);
   const uint32_t nz = ZS * P.zpos;
   unsigned long long *mat_all = (unsigned long long *)(zl + nz);
   const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
   uint32_t *cr_lds = (uint32_t *)(queues + NW);
   uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;
-  uint32_t *bcast = hv_lds + (INDELS ? HEAVY_WORDS : 0u);
-  TileRef *tref_lds = (TileRef *)(bcast + 4);
+  RingSlot *ring = (RingSlot *)(hv_lds + (INDELS ? HEAVY_WORDS : 0u));
+  TileRef *tref_lds = (TileRef *)(ring + RING);             /* RING x chunk_cap */
+  const uint32_t chunk_cap = P.chunk_cap;
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
@@ -219,6 +262,8 @@ probe_rows_kernel(const ProbeParams P)
   if (INDELS)
     for (uint32_t i = threadIdx.x; i < HEAVY_WORDS; i += NT)
       hv_lds[i] = P.geom.ctab[P.geom.off_hv + i];
+  for (uint32_t i = threadIdx.x; i < RING * (uint32_t)(sizeof(RingSlot) / 4); i += NT)
+    ((uint32_t *)ring)[i] = 0;
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
@@ -226,47 +271,69 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t smask = P.geom.smask;
   SProber W{P, (const uint64_t *)smem, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, 0u, 0u, smask, 0u, 0, {0ull, 0u, 0u, 0u}};
-  const uint32_t zl_addr = slice_bytes;           /* LDS address of zl */
   unsigned long long reads = 0;                   /* filter words read by this lane */
+  __syncthreads();                                /* tables and ring slots are in place */
 
-  /* Chunks are dealt out statically: workgroup b takes chunks b, b + G, b + 2G, ...
-     of the list (sorted heaviest first, so the sums even out).  Knowing its
-     chunks in advance, a workgroup has the descriptor of the chunk after the next
-     and the slice + tile descriptors of the next chunk in flight while it works
-     on the current one; nothing on the way to a chunk waits for an atomic. */
   const uint32_t G = gridDim.x;
-  uint32_t ci = blockIdx.x;                       /* index of the NEXT chunk */
-  Chunk ck_next, ck_next2;
-  ck_next.slice = ck_next.first_tile = ck_next.ntiles = ck_next.pass = 0;
-  ck_next2 = ck_next;
-  u32x4 pf[PF];
-  uint32_t pft_t = 0;                             /* this thread's tile of the next chunk */
-  u32x4 pft_a = {0, 0, 0, 0};                     /* its descriptor: len, nvalid, res_base, pass */
-  uint32_t pft_slice = 0, pft_k = 0;
-  auto load_chunk = [&]() {                       /* slice + tile descriptors of ck_next */
-    const u32x4 *src = (const u32x4 *)(filter + (size_t)ck_next.slice * slice_bytes);
-#pragma unroll
-    for (uint32_t k = 0; k < PF; k++) {
-      const uint32_t idx = threadIdx.x + k * NT;
-      if (idx < npieces)
-        pf[k] = src[idx];
+  const bool have_chunks = blockIdx.x < P.nchunks;
+  PT_DECL
+
+  /* ---------------- staging: any wave without a tile to work on ---------------- */
+  /* Chunk number T of this workgroup (its chunks: blockIdx.x + (T - 1) G) goes into
+     buffer (T - 1) % RING once that buffer's tenant T - RING is finished.  The
+     wave that wins the compare-and-swap on the issue counter copies slice and tile
+     references with LDS-DMA (no registers, nothing it issues depends on an earlier
+     load of its own), waits for them and publishes the tenant.  Several waves can
+     be staging different chunks at the same time, so the copies of up to RING
+     chunks overlap -- and a workgroup short of tiles turns more of its waves into
+     loaders by itself. */
+  const uint32_t my_chunks = have_chunks ? (P.nchunks - blockIdx.x + G - 1u) / G : 0u;
+  uint32_t *issue = (uint32_t *)&ring[0].pad[1];            /* next tag to stage, starts at 1 */
+  auto try_stage = [&]() -> bool {
+    const uint32_t T = *(volatile uint32_t *)issue + 1u;     /* (stored as T - 1: zero-initialised) */
+    if (T > my_chunks + 1u)
+      return false;                           /* everything, the end marker included, is issued */
+    const uint32_t b = (T - 1u) % RING;
+    volatile RingSlot *rs = ring + b;
+    const unsigned long long cl = rs->claim;
+    const uint32_t hi = (uint32_t)(cl >> 32);
+    if (hi != (T > RING ? T - RING : 0u) || rs->done != (uint32_t)((cl >> 16) & 0xffffu))
+      return false;                           /* the buffer's tenant is not finished (or not even there) */
+    uint32_t won = 0;
+    if (lane == 0)
+      won = atomicCAS(issue, T - 1u, T) == T - 1u ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane(won))
+      return false;
+    if (T == my_chunks + 1u) {
+      /* the end marker goes where the next chunk would */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      rs->claim = ((unsigned long long)RING_END << 32) | ((unsigned long long)(T & 0xffffu) << 16);
+      return true;
     }
-    if (threadIdx.x < ck_next.ntiles) {
-      const TileRef *tp = P.tile_refs + ck_next.first_tile + threadIdx.x;
-      pft_a = *(const u32x4 *)tp;
-      pft_slice = tp->td.slice;
-      pft_k = tp->td.k;
-      pft_t = tp->t;
-    }
+    const Chunk ck = P.chunks[blockIdx.x + (T - 1u) * G];
+    const unsigned char *src = filter + (size_t)ck.slice * slice_bytes + lane * 16u;
+    const uint32_t dst = b * slice_bytes;
+    /* one wave-instruction copies 1 KiB: lane l its 16 bytes to (uniform base) +
+       16 l; lanes past the end of a slice that is no whole KiB stay out of it */
+    for (uint32_t off = 0; off < slice_bytes; off += 1024u)
+      if (off + lane * 16u < slice_bytes)
+        __builtin_amdgcn_global_load_lds((glob_void_t *)(src + off),
+                                         (lds_void_t *)(uintptr_t)(dst + off), 16, 0, 0);
+    const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + lane * 16u;
+    const uint32_t tdst = (uint32_t)(uintptr_t)(tref_lds + b * chunk_cap);
+    const uint32_t tbytes = ck.ntiles * (uint32_t)sizeof(TileRef);
+    for (uint32_t off = 0; off < tbytes; off += 1024u)
+      if (off + lane * 16u < tbytes)
+        __builtin_amdgcn_global_load_lds((glob_void_t *)(tsrc + off),
+                                         (lds_void_t *)(uintptr_t)(tdst + off), 16, 0, 0);
+    rs->done = 0;
+    rs->slice = ck.slice;
+    rs->pass = ck.pass;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the copies have landed */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    rs->claim = ((unsigned long long)T << 32) | ((unsigned long long)ck.ntiles << 16);
+    return true;
   };
-  bool have_next = ci < P.nchunks;
-  if (have_next) {
-    ck_next = P.chunks[ci];
-    load_chunk();
-  }
-  if (ci + G < P.nchunks)
-    ck_next2 = P.chunks[ci + G];
-  __syncthreads();                                /* the tables above are in place */
 
   /* what a tile needs per lane before its first row: pass 0 -- the query's hash, its
      length and the residues of the first block; passes 1, 2 -- the shifted hash
@@ -303,118 +370,157 @@ probe_rows_kernel(const ProbeParams P)
     }
     return x;
   };
-  const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
-  TileData nxt;
-  nxt.a = 0;
-  nxt.b = nxt.c = nxt.d = 0;
-  bool pre_ok = false;                      /* nxt holds my first tile of the next chunk */
 
-  bool block_phase = true;
-  for (;;) {
-    Chunk ck;
-    ck.slice = ck.first_tile = ck.ntiles = ck.pass = 0;
-    if (block_phase) {
-      if (!have_next) {
-        block_phase = false;                      /* the same for every thread of the block */
-      } else {
-        __syncthreads();                          /* everyone is done with the old slice */
-        ck = ck_next;
-#pragma unroll
-        for (uint32_t k = 0; k < PF; k++) {
-          const uint32_t idx = threadIdx.x + k * NT;
-          if (idx < npieces)
-            *(lds_u128_w_t *)(uintptr_t)(idx * 16u) = pf[k];
-        }
-        if (threadIdx.x < ck.ntiles) {
-          TileRef *tr = tref_lds + threadIdx.x;
-          tr->td.len = pft_a.x;
-          tr->td.nvalid = pft_a.y;
-          tr->td.res_base = pft_a.z;
-          tr->td.pass = pft_a.w;
-          tr->td.slice = pft_slice;
-          tr->td.k = pft_k;
-          tr->t = pft_t;
-        }
-        __syncthreads();
-        ci += G;
-        have_next = ci < P.nchunks;
-        ck_next = ck_next2;
-        if (have_next)
-          load_chunk();
-        if (ci + G < P.nchunks)
-          ck_next2 = P.chunks[ci + G];
-      }
-    }
-    const bool staged = block_phase;
-    const uint32_t pass = ck.pass;
-
-    /* The tiles of a chunk are dealt to the waves round-robin (wave w: tiles w,
-       w + NW, ...), so a wave knows its next tile while it works on the current one
-       and has that tile's per-lane data in flight -- also across the chunk
-       boundary: the reference of its first tile of the next chunk is a scalar
-       load issued as soon as that chunk's descriptor is known. */
-    const bool nref_ok = block_phase && have_next && wave_u < ck_next.ntiles;
-    TileRef nref;
-    nref.t = 0;
-    nref.pad = 0;
-    nref.td = TileDesc{0, 0, 0, 0, 0, 0};
-    if (nref_ok)
-      nref = P.tile_refs[ck_next.first_tile + wave_u];
-    uint32_t k = wave_u;                    /* my tile of the chunk being worked on */
-    TileData cur = nxt;                     /* fetched while the previous chunk was worked on */
-    bool cur_ok = pre_ok;
-    pre_ok = false;
-
-    bool all_done = false;
+  /* ---------------- the compute waves ---------------- */
+  /* A wave works through the tenants in tag order: tag T lives in buffer
+     (T - 1) % RING.  A claim is one 64-bit LDS add on the buffer's claim word; it
+     returns the tenant's tag, its tile count and the tile handed out, all of the
+     same instant. */
+  uint32_t my_tag = 1;
+  struct Claim {
+    bool ok;
+    uint32_t b, k;
+  };
+  /* blocking = false: give up instead of waiting for the loader */
+  auto claim_tile = [&](bool blocking) -> Claim {
+    Claim c;
+    c.ok = false;
+    c.b = c.k = 0;
     for (;;) {
-      uint32_t t;
-      TileDesc td;
-      if (block_phase) {
-        if (k >= ck.ntiles)
-          break;
-        t = __builtin_amdgcn_readfirstlane(tref_lds[k].t);
-        td = tref_lds[k].td;
-      } else {
-        uint32_t i = 0;
-        if (lane == 0)
-          i = atomicAdd(P.tile_counter + 1, 1u);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= P.nsmall) {
-          all_done = true;
-          break;
-        }
-        t = P.small_tiles[i];
-        td = P.tiles[t];
-        cur_ok = false;
+      const uint32_t b = (my_tag - 1u) % RING;
+      const unsigned long long cl = ((volatile RingSlot *)ring)[b].claim;
+      const uint32_t hi = (uint32_t)(cl >> 32);
+      if (hi == RING_END) {
+        if ((((uint32_t)cl >> 16) & 0xffffu) == (my_tag & 0xffffu))
+          return c;                           /* the end */
+        my_tag++;                             /* that tenant came and went */
+        continue;
       }
+      if (hi < my_tag) {                      /* not published yet */
+        if (!blocking)
+          return c;
+        PT_MARK(PT_CLAIM);
+        const bool staged_one = try_stage();  /* nothing to work on: stage a chunk */
+        PT_MARK(PT_LOADER_DMA);
+        if (!staged_one)
+          __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      if (hi > my_tag) {                      /* came and went */
+        my_tag++;
+        continue;
+      }
+      unsigned long long v = 0;
+      if (lane == 0)
+        v = atomicAdd((unsigned long long *)&ring[b].claim, 1ull);
+      const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+      const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+      if (tag == RING_END)
+        continue;                             /* (the add touched only its count bits) */
+      const uint32_t nt = (vlo >> 16) & 0xffffu, k = vlo & 0xffffu;
+      if (k < nt) {                           /* a tile of tenant `tag` (>= my_tag) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        c.ok = true;
+        c.b = b;
+        c.k = k;
+        return c;
+      }
+      if (tag == my_tag)
+        my_tag++;                             /* it has run out */
+    }
+  };
+
+  const bool compute_wave = have_chunks;
+  bool block_phase = compute_wave;
+  Claim cur_c, nxt_c;
+  cur_c.ok = nxt_c.ok = false;
+  cur_c.b = cur_c.k = nxt_c.b = nxt_c.k = 0;
+  TileData cur, nxt;
+  cur.a = nxt.a = 0;
+  cur.b = cur.c = cur.d = nxt.b = nxt.c = nxt.d = 0;
+  bool nxt_loaded = false;
+
+  for (;;) {
+    uint32_t t;
+    TileDesc td;
+    uint32_t sbase = 0, pass = 0, cslice = 0;    /* staged: LDS address of the slice, the chunk's pass and slice */
+    bool staged = false;
+    PT_MARK(PT_OTHER);
+    if (block_phase) {
+      /* my tile: the one claimed (and fetched) while the previous was worked on, or a
+         fresh claim */
+      bool have = nxt_c.ok;
+      cur_c = nxt_c;
+      cur = nxt;
+      bool cur_loaded = nxt_loaded;
+      if (!have) {
+        cur_c = claim_tile(true);
+        have = cur_c.ok;
+        cur_loaded = false;
+      }
+      PT_MARK(PT_CLAIM);
+      if (!have) {
+        block_phase = false;
+        continue;
+      }
+      const TileRef *tr = tref_lds + cur_c.b * chunk_cap + cur_c.k;
+      t = __builtin_amdgcn_readfirstlane(tr->t);
+      td = tr->td;
+      sbase = cur_c.b * slice_bytes;
+      pass = __builtin_amdgcn_readfirstlane(ring[cur_c.b].pass);
+      cslice = __builtin_amdgcn_readfirstlane(ring[cur_c.b].slice);
+      staged = true;
+      if (!cur_loaded)
+        cur = load_tile_data(__builtin_amdgcn_readfirstlane(td.len),
+                             __builtin_amdgcn_readfirstlane(td.nvalid),
+                             __builtin_amdgcn_readfirstlane(td.res_base), t,
+                             pass ? pass : __builtin_amdgcn_readfirstlane(td.pass));
+      /* the next tile, if one can be had without waiting: its data is in flight
+         while this one is worked on */
+      nxt_c = claim_tile(false);
+      nxt_loaded = false;
+      if (nxt_c.ok) {
+        const TileRef *tn = tref_lds + nxt_c.b * chunk_cap + nxt_c.k;
+        const uint32_t np = __builtin_amdgcn_readfirstlane(ring[nxt_c.b].pass);
+        nxt = load_tile_data(__builtin_amdgcn_readfirstlane(tn->td.len),
+                             __builtin_amdgcn_readfirstlane(tn->td.nvalid),
+                             __builtin_amdgcn_readfirstlane(tn->td.res_base),
+                             __builtin_amdgcn_readfirstlane(tn->t),
+                             np ? np : __builtin_amdgcn_readfirstlane(tn->td.pass));
+        nxt_loaded = true;
+      }
+    } else {
+      /* tiles whose slice holds too few queries to be worth staging: claimed one
+         at a time, the filter read where it lies */
+      uint32_t i = 0;
+      if (lane == 0)
+        i = atomicAdd(P.tile_counter + 1, 1u);
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i >= P.nsmall)
+        break;
+      t = P.small_tiles[i];
+      td = P.tiles[t];
+      cur = load_tile_data(__builtin_amdgcn_readfirstlane(td.len),
+                           __builtin_amdgcn_readfirstlane(td.nvalid),
+                           __builtin_amdgcn_readfirstlane(td.res_base), t,
+                           __builtin_amdgcn_readfirstlane(td.pass));
+    }
+    {
       const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);       /* 0: light tile */
       const uint32_t tslice = __builtin_amdgcn_readfirstlane(td.slice);
       const uint32_t tres = __builtin_amdgcn_readfirstlane(td.res_base);
       /* the indel passes reuse the tiles of pass 0 and are named by their chunk */
-      const uint32_t tpass = (staged && pass) ? pass : __builtin_amdgcn_readfirstlane(td.pass);
-      if (!cur_ok)
-        cur = load_tile_data(L, nvalid, tres, t, tpass);
-      /* the next tile's data, in flight while this one is worked on */
-      if (block_phase) {
-        const uint32_t kn = k + NW;
-        cur_ok = false;
-        if (kn < ck.ntiles) {
-          const TileDesc tn = tref_lds[kn].td;
-          nxt = load_tile_data(__builtin_amdgcn_readfirstlane(tn.len),
-                               __builtin_amdgcn_readfirstlane(tn.nvalid),
-                               __builtin_amdgcn_readfirstlane(tn.res_base),
-                               __builtin_amdgcn_readfirstlane(tref_lds[kn].t),
-                               pass ? pass : __builtin_amdgcn_readfirstlane(tn.pass));
-          cur_ok = true;
-        } else if (nref_ok) {
-          nxt = load_tile_data(nref.td.len, nref.td.nvalid, nref.td.res_base, nref.t,
-                               ck_next.pass ? ck_next.pass : nref.td.pass);
-          pre_ok = true;
-        }
-        k = kn;
-      }
+      const uint32_t tpass_real = (staged && pass) ? pass : __builtin_amdgcn_readfirstlane(td.pass);
+      /* (ablation builds: a skipped tile gets a pass number no branch below takes) */
+      const uint32_t tpass = (CMPR_DBG(P, DBG_SKIP_TILES) ||
+                              (CMPR_DBG(P, DBG_SKIP_CLASS_TILES) && tpass_real >= 3) ||
+                              (CMPR_DBG(P, DBG_SKIP_MAIN_TILES) && tpass_real < 3)) ? 0xffu : tpass_real;
+#ifdef CMPR_PHASE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT_MARK(PT_TILE_DATA);
+#endif
       const uint32_t *qr = P.qres + tres + lane;
       const bool valid = lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
@@ -432,8 +538,8 @@ probe_rows_kernel(const ProbeParams P)
       };
       auto word_lds = [&](uint32_t wo) -> RowWord {
         RowWord w;
-        w.a = lds_u128(wo);
-        w.b = lds_u128(wo + 16u);
+        w.a = lds_u128(sbase + wo);
+        w.b = lds_u128(sbase + wo + 16u);
         return w;
       };
       auto word_glob = [&](const unsigned char *base, uint32_t wo) -> RowWord {
@@ -615,7 +721,9 @@ probe_rows_kernel(const ProbeParams P)
                 m1 |= (uint64_t)x << (A * (j - RPW));
               wc = wn;
             }
+            PT_MARK(PT_ROWS);
             emit_sub_rows(m0, m1, p0, rpack);
+            PT_MARK(PT_EMIT);
           }
           };
           if (staged)
@@ -783,7 +891,7 @@ probe_rows_kernel(const ProbeParams P)
               for (uint32_t i = 0; i < MCR; i++)
                 key ^= md[i] < p ? lo[i] : hi[i];
               const uint32_t sl = key & smask;
-              const RowWord w = fetch_at(hd, sl, !valid || sl == ck.slice);
+              const RowWord w = fetch_at(hd, sl, !valid || sl == cslice);
               const bool hit = ((row_bits(w, hd) >> A) & 1u) != 0;
               nvar += fresh ? 1u : 0u;
               mask |= (fresh && hit) ? (1u << (p - p0)) : 0u;
@@ -847,7 +955,7 @@ probe_rows_kernel(const ProbeParams P)
                   if (i < KH && mi[i] != ip)
                     key ^= mi[i] < ip ? lo[i] : hi[i];
                 const uint32_t sl = key & smask;
-                const RowWord w = fetch_at(hg, sl, !valid || sl == ck.slice);
+                const RowWord w = fetch_at(hg, sl, !valid || sl == cslice);
                 uint32_t x = row_bits(w, hg) & AMASK & vmask;
                 if (ip > 0)
                   x &= ~(1u << r);                              /* v != q[ip - 1] */
@@ -883,22 +991,22 @@ probe_rows_kernel(const ProbeParams P)
       }
 
       W.st.variants += valid ? nvar : 0ull;
-      cur = nxt;
     }
-    /* a wave without a tile in this chunk still fetches its first one of the next */
-    if (nref_ok && !pre_ok) {
-      nxt = load_tile_data(nref.td.len, nref.td.nvalid, nref.td.res_base, nref.t,
-                           ck_next.pass ? ck_next.pass : nref.td.pass);
-      pre_ok = true;
+    if (staged) {
+      /* this tile's reads of the slice are done: one step towards handing the
+         buffer back to the loader */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        atomicAdd(&ring[cur_c.b].done, 1u);
     }
-    if (all_done)
-      break;
   }
 
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (W.qn > 0)
     flush_or_resolve<GENES, INLINE>(W, 0, W.qn);
+  PT_MARK(PT_TAIL);
+  PT_FLUSH;
 
   {
     unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,

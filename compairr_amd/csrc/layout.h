@@ -83,7 +83,7 @@ constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 3 for aa (20^3
 __host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 3u; }
 constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
 constexpr uint32_t ROW_WORD_BYTES      = 32;   /* variant 2: filter word = 8 dwords, one bit of each per entry */
-constexpr uint32_t MAX_ROW_SLICE_WORDS = 1280; /* variant 2: at most 40 KiB per slice */
+constexpr uint32_t MAX_ROW_SLICE_WORDS = 640;  /* variant 2: at most 20 KiB per slice (a ring of 4 in LDS) */
 constexpr uint32_t HEAVY_BUCKETS_LOG2 = 16;
 constexpr uint32_t HEAVY_WORDS        = (1u << HEAVY_BUCKETS_LOG2) / 32;
 
@@ -274,6 +274,7 @@ struct ProbeParams {
   uint32_t        pad3;
   const TileRef  *tile_refs;       /* chunk c covers tile_refs[first .. first+n)       */
   uint32_t        nchunks;
+  uint32_t        chunk_cap;       /* tiles per chunk at most (variant 2: LDS tile refs per ring slot) */
   uint32_t        debug;           /* ablation switches, 0 in production      */
   /* work distribution + statistics */
   uint32_t           *tile_counter;  /* [0] chunks, [1] small tiles                  */
@@ -286,7 +287,7 @@ struct ProbeParams {
    rejected. */
 enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
                   DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32,
-                  DBG_SKIP_TILES = 64 };
+                  DBG_SKIP_TILES = 64, DBG_SKIP_CLASS_TILES = 128, DBG_SKIP_MAIN_TILES = 256 };
 #ifdef CMPR_ABLATION
 #define CMPR_DBG(P, bit) (((P).debug & (bit)) != 0)
 #else
@@ -295,8 +296,13 @@ enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4
 
 /* STAT_VARIANTS counts the variant tests the kernel executed (one per variant
    hash held against the filter); STAT_READS the filter words read for them */
+#ifdef CMPR_PHASE_TIMING
+enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
+       STAT_READS = 4, STAT_COUNT = 16 };      /* [8..15]: per-phase wave cycles (kernels_rows.h) */
+#else
 enum { STAT_VARIANTS = 0, STAT_BLOOM_POS = 1, STAT_HASH_EQ = 2, STAT_MATCHES = 3,
        STAT_READS = 4, STAT_COUNT = 5 };
+#endif
 
 }  // namespace cmpr
 #endif

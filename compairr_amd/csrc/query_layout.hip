@@ -735,7 +735,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       1 + ((c->rows && c->geom.k > 0 && c->opt.differences >= 1) ? c->geom.k : 0u);
   c->npasses = npass;
   const uint64_t chunk_tiles =
-      c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : 8 * (uint64_t)c->waves_per_block;
+      c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : c->rows ? 64 : 8 * (uint64_t)c->waves_per_block;
   c->chunk_cap = (uint32_t)chunk_tiles;
   /* Without -i, queries long enough to contain all class positions unwrapped
      (len >= c0 + K) may share a tile with queries of other lengths: inside a
