@@ -296,7 +296,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->cres.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -617,8 +617,14 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
       return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
     c->geom.rw_words = (uint32_t)words;
     c->geom.words_log2 = 0;
-    c->bloom_words = S * words * (ROW_WORD_BYTES / 8);       /* 8-byte units */
+    c->bloom_words = S * words * (ROW_WORD_BYTES / 8);       /* 8-byte units; + the class parts, below */
     c->geom.smask = (uint32_t)(S - 1);
+    /* class parts (layout.h row_slice): each holds one entry per split sequence,
+       the main part L + 1 - K per sequence: S n / entries slices, a power of two */
+    uint64_t Sc = 1;
+    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1))
+      Sc <<= 1;
+    c->geom.cmask = (uint32_t)(Sc - 1);
   } else {
     /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
        whatever the total), so it takes 4 bytes per table slot: with the 2^20
@@ -743,7 +749,10 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
             bucket[b] += part[t][b];
       }
       /* heavy = would take more than half of a slice's budget on its own */
-      const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold : slice_cap / 2;
+      /* (row filter: an eighth -- its 8-bit tests are sensitive to an overfull slice,
+         and a split class costs its queries one cheap class row per class residue) */
+      const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold
+                                                 : slice_cap / (c->rows ? 8 : 2);
       bool any_heavy = false;
       for (uint32_t b = 0; b < bucket.size(); b++)
         if ((double)bucket[b] > thr) {
@@ -791,6 +800,9 @@ static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
     if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
     g.ctab = c->d_ctab.p;
   }
+  if (c->rows)          /* main part + one class part per class residue */
+    c->bloom_words = ((uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1)) *
+                     c->geom.rw_words * (ROW_WORD_BYTES / 8);
   if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
@@ -1092,7 +1104,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qhdel = c->qhdel.p;
     P.cw = c->cw.p;
     P.cmain = c->cmain.p;
-    P.cres = c->cres.p;
+    P.crp = c->crp.p;
     P.pair_q = c->pair_q;
     P.pair_h = c->pair_h;
     P.pair_count = c->pair_count;

@@ -129,11 +129,10 @@ struct cmpr_context {
   DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
   DevBuf<uint32_t>  qorig, qck;
-  /* variant 2, class-row passes: per class slot the row's blanked hash, the
-     query's slot in pass 0 and its residue at the class position */
+  /* variant 2, class rows: per item the row's blanked hash, the query's slot in
+     pass 0 (~0: padding) and its residue at the class position | position << 8 */
   DevBuf<uint64_t>  cw;
-  DevBuf<uint32_t>  cmain;
-  DevBuf<uint8_t>   cres;
+  DevBuf<uint32_t>  cmain, crp;
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;

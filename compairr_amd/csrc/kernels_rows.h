@@ -129,22 +129,26 @@ build_rows_kernel(const BuildParams B)
                                    B.use_genes ? B.v[i] : 0u, B.use_genes ? B.j[i] : 0u, &heavy);
   const uint32_t nwords = g.rw_words;
   unsigned long long *words = (unsigned long long *)B.bloom;
-  auto enter = [&](uint64_t Wk, uint32_t code, uint32_t key) {
-    const uint64_t w = (uint64_t)(key & g.smask) * nwords + row_word(Wk, nwords);
+  auto enter = [&](uint64_t Wk, uint32_t code, uint32_t slice) {
+    const uint64_t w = (uint64_t)slice * nwords + row_word(Wk, nwords);
     uint64_t q[4];
     row_entry_bits(Wk, code, q);
 #pragma unroll
     for (int k = 0; k < 4; k++)
       atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
   };
-  enter(h, B.A, ck);
+  enter(h, B.A, row_slice(g, ck, -1));
   for (uint32_t p = 0; p < L; p++) {
     uint32_t key = ck;
+    int ci = -1;                               /* first class residue at p, if any */
     if (heavy)
       for (uint32_t k = 0; k < g.k; k++)
-        if (class_pos(L, k, g.c0) == p)
+        if (class_pos(L, k, g.c0) == p) {
           key ^= g.ctab[g.off_cr + k * B.A + s[p]];
-    enter(h ^ B.zob[B.A * p + s[p]], s[p], key);
+          if (ci < 0)
+            ci = (int)k;
+        }
+    enter(h ^ B.zob[B.A * p + s[p]], s[p], row_slice(g, key, ci));
   }
 }
 
@@ -212,7 +216,8 @@ struct RingSlot {
   unsigned long long claim;
   uint32_t done;             /* tiles of the tenant finished */
   uint32_t slice, pass;
-  uint32_t pad[3];
+  uint32_t first;            /* class-row chunk: its first item (blocks of 64 items, no tile refs) */
+  uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter) */
 };
 
 template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE>
@@ -288,7 +293,7 @@ probe_rows_kernel(const ProbeParams P)
      chunks overlap -- and a workgroup short of tiles turns more of its waves into
      loaders by itself. */
   const uint32_t my_chunks = have_chunks ? (P.nchunks - blockIdx.x + G - 1u) / G : 0u;
-  uint32_t *issue = (uint32_t *)&ring[0].pad[1];            /* next tag to stage, starts at 1 */
+  uint32_t *issue = (uint32_t *)&ring[0].pad[0];            /* next tag to stage, starts at 1 */
   auto try_stage = [&]() -> bool {
     const uint32_t T = *(volatile uint32_t *)issue + 1u;     /* (stored as T - 1: zero-initialised) */
     if (T > my_chunks + 1u)
@@ -321,7 +326,8 @@ probe_rows_kernel(const ProbeParams P)
                                          (lds_void_t *)(uintptr_t)(dst + off), 16, 0, 0);
     const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + lane * 16u;
     const uint32_t tdst = (uint32_t)(uintptr_t)(tref_lds + b * chunk_cap);
-    const uint32_t tbytes = ck.ntiles * (uint32_t)sizeof(TileRef);
+    /* (a class-row chunk has no tile references: its "tiles" are blocks of 64 items) */
+    const uint32_t tbytes = ck.pass >= 3 ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
     for (uint32_t off = 0; off < tbytes; off += 1024u)
       if (off + lane * 16u < tbytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(tsrc + off),
@@ -329,6 +335,7 @@ probe_rows_kernel(const ProbeParams P)
     rs->done = 0;
     rs->slice = ck.slice;
     rs->pass = ck.pass;
+    rs->first = ck.first_tile;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the copies have landed */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     rs->claim = ((unsigned long long)T << 32) | ((unsigned long long)ck.ntiles << 16);
@@ -337,8 +344,8 @@ probe_rows_kernel(const ProbeParams P)
 
   /* what a tile needs per lane before its first row: pass 0 -- the query's hash, its
      length and the residues of the first block; passes 1, 2 -- the shifted hash
-     instead; class-row tiles -- the row's blanked hash, the query's slot in pass 0
-     and its residue there */
+     instead; class-row blocks -- per item the row's blanked hash, the query's slot
+     in pass 0 (~0: padding) and its residue | position << 8 */
   struct TileData {
     uint64_t a;
     uint32_t b, c, d;
@@ -350,12 +357,11 @@ probe_rows_kernel(const ProbeParams P)
     x.b = x.c = x.d = 0;
     const bool valid = lane < nvalid;
     if (tpass >= 3) {
+      /* a block of 64 class-row items, from item res_base on */
       const uint32_t cs = res_base + lane;
-      if (valid) {
-        x.a = P.cw[cs];
-        x.b = P.cmain[cs];
-        x.c = P.cres[cs];
-      }
+      x.a = P.cw[cs];
+      x.b = P.cmain[cs];
+      x.c = P.crp[cs];
     } else {
       const uint32_t slot = t * WAVE + lane;
       if (valid) {
@@ -463,13 +469,30 @@ probe_rows_kernel(const ProbeParams P)
         block_phase = false;
         continue;
       }
-      const TileRef *tr = tref_lds + cur_c.b * chunk_cap + cur_c.k;
-      t = __builtin_amdgcn_readfirstlane(tr->t);
-      td = tr->td;
       sbase = cur_c.b * slice_bytes;
       pass = __builtin_amdgcn_readfirstlane(ring[cur_c.b].pass);
       cslice = __builtin_amdgcn_readfirstlane(ring[cur_c.b].slice);
       staged = true;
+      /* a tile of the chunk: its reference is in LDS; a block of a class-row chunk:
+         64 consecutive items */
+      auto tile_of = [&](const Claim &cc, uint32_t cpass, uint32_t &tt) -> TileDesc {
+        TileDesc x;
+        if (cpass >= 3) {
+          x.len = 0;
+          x.nvalid = WAVE;
+          x.res_base = __builtin_amdgcn_readfirstlane(ring[cc.b].first) + cc.k * WAVE;
+          x.pass = cpass;
+          x.slice = __builtin_amdgcn_readfirstlane(ring[cc.b].slice);
+          x.k = 0;
+          tt = 0;
+        } else {
+          const TileRef *tr = tref_lds + cc.b * chunk_cap + cc.k;
+          tt = __builtin_amdgcn_readfirstlane(tr->t);
+          x = tr->td;
+        }
+        return x;
+      };
+      td = tile_of(cur_c, pass, t);
       if (!cur_loaded)
         cur = load_tile_data(__builtin_amdgcn_readfirstlane(td.len),
                              __builtin_amdgcn_readfirstlane(td.nvalid),
@@ -480,13 +503,13 @@ probe_rows_kernel(const ProbeParams P)
       nxt_c = claim_tile(false);
       nxt_loaded = false;
       if (nxt_c.ok) {
-        const TileRef *tn = tref_lds + nxt_c.b * chunk_cap + nxt_c.k;
         const uint32_t np = __builtin_amdgcn_readfirstlane(ring[nxt_c.b].pass);
-        nxt = load_tile_data(__builtin_amdgcn_readfirstlane(tn->td.len),
-                             __builtin_amdgcn_readfirstlane(tn->td.nvalid),
-                             __builtin_amdgcn_readfirstlane(tn->td.res_base),
-                             __builtin_amdgcn_readfirstlane(tn->t),
-                             np ? np : __builtin_amdgcn_readfirstlane(tn->td.pass));
+        uint32_t tn = 0;
+        const TileDesc dn = tile_of(nxt_c, np, tn);
+        nxt = load_tile_data(__builtin_amdgcn_readfirstlane(dn.len),
+                             __builtin_amdgcn_readfirstlane(dn.nvalid),
+                             __builtin_amdgcn_readfirstlane(dn.res_base), tn,
+                             np ? np : __builtin_amdgcn_readfirstlane(dn.pass));
         nxt_loaded = true;
       }
     } else {
@@ -522,14 +545,15 @@ probe_rows_kernel(const ProbeParams P)
       PT_MARK(PT_TILE_DATA);
 #endif
       const uint32_t *qr = P.qres + tres + lane;
-      const bool valid = lane < nvalid;
+      const bool class_tile = tpass_real >= 3;
+      /* a class-row item carries the row's blanked hash, the query's slot in pass 0
+         (~0: padding behind the items of a slice) and its residue | position << 8
+         (query_layout.hip) */
+      const bool valid = class_tile ? cur.b != 0xffffffffu : lane < nvalid;
       const uint32_t vmask = valid ? ~0u : 0u;
-      const bool class_tile = tpass >= 3;
-      /* a class-row tile carries, per lane, the row's blanked hash, the query's slot
-         in pass 0 and its residue at the class position (query_layout.hip) */
       W.qslot = class_tile ? cur.b : t * WAVE + lane;
       const uint64_t cW = cur.a;
-      const uint32_t cr = cur.c;
+      const uint32_t cr = cur.c & 0xffu;
       const uint32_t Ll = (valid && !class_tile) ? cur.b : 0u;
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 
@@ -752,6 +776,11 @@ probe_rows_kernel(const ProbeParams P)
               const uint64_t hb = h ^ lds_u64(zl_addr + (ZS * b + rb) * 8u) ^ lds_u64(ea);
               const bool own = !b_cls && !e_cls;
               const uint32_t key_b = b_cls ? qck ^ class_term(b, rb) : qck;
+              int ci_b = -1;                           /* class part of a row blanked at b */
+#pragma unroll
+              for (uint32_t i = 0; i < MCR; i++)
+                if (b_cls && ci_b < 0 && i < K && m[i] == b)
+                  ci_b = (int)i;
               const uint32_t te_own = e_cls ? class_term(e, re) : 0u;
               const bool live = pb < Ll;                          /* pb < Ll implies pa < Ll */
               nvar += live ? (uint64_t)(A - 1) * (A - 1) : 0ull;
@@ -769,7 +798,7 @@ probe_rows_kernel(const ProbeParams P)
                       uint32_t wres = re + k;
                       wres = wres >= (uint32_t)A ? wres - (uint32_t)A : wres;
                       const uint32_t key = key_b ^ (e_cls ? te_own ^ class_term(e, wres) : 0u);
-                      const uint32_t sl = key & smask;
+                      const uint32_t sl = row_slice(P.geom, key, ci_b);
                       w = fetch_at(Wk, sl, staged && sl == tslice);
                     }
                     uint32_t x = row_bits(w, Wk) & AMASK & ~(1u << rb);
@@ -805,22 +834,12 @@ probe_rows_kernel(const ProbeParams P)
             }
           }
         }
-      } else if (tpass >= 3) {
-        /* ---- the substitution row of class position i = pass - 3 (heavy queries
-                only); the tile is grouped by that row's slice.  A position that
-                carries several class residues is handled by the first of them. ---- */
-        const uint32_t ci = tpass - 3u;
-        bool dup = ci >= K;
-        uint32_t p = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < MCR; i++)
-          if (i == ci)
-            p = m[i];
-#pragma unroll
-        for (uint32_t i = 0; i < MCR; i++)
-          if (i < ci && i < K && m[i] == p)
-            dup = true;
-        if (!dup && D >= 1 && L > 0) {
+      } else if (tpass >= 3 && tpass != 0xffu) {
+        /* ---- substitution rows at class positions (heavy queries only): 64 items of
+                the chunk's slice of class part pass - 3; the row's position comes
+                with the item ---- */
+        if (D >= 1) {
+          const uint32_t p = cur.c >> 8;
           const RowWord w = fetch_own(cW);
           uint32_t x = row_bits(w, cW) & AMASK & ~(1u << cr) & vmask;
           nvar += (uint64_t)(A - 1);
@@ -950,11 +969,16 @@ probe_rows_kernel(const ProbeParams P)
                 }
                 hrow[j] = hg;
                 uint32_t key = base_t;
+                int ci_u = -1;                         /* first class residue of t at the blanked position */
 #pragma unroll
                 for (uint32_t i = 0; i < MCR; i++)
-                  if (i < KH && mi[i] != ip)
-                    key ^= mi[i] < ip ? lo[i] : hi[i];
-                const uint32_t sl = key & smask;
+                  if (i < KH) {
+                    if (mi[i] != ip)
+                      key ^= mi[i] < ip ? lo[i] : hi[i];
+                    else if (ci_u < 0)
+                      ci_u = (int)i;
+                  }
+                const uint32_t sl = row_slice(P.geom, key, hvy ? ci_u : -1);
                 const RowWord w = fetch_at(hg, sl, !valid || sl == cslice);
                 uint32_t x = row_bits(w, hg) & AMASK & vmask;
                 if (ip > 0)

@@ -99,7 +99,20 @@ struct SliceGeom {
   uint32_t c0;             /* first class position                          */
   uint32_t rw_words;       /* variant 2 (kernels_rows.h): 32-byte words per
                               slice, any count <= MAX_ROW_SLICE_WORDS          */
+  uint32_t cmask;          /* variant 2: slices per class part - 1 (row_slice)  */
+  uint32_t pad2;
 };
+
+/* Variant 2 files the entries of a row under the class key WITHOUT the terms of
+   the blanked position.  Rows whose blanked position is class position i of a
+   split class live in "class part" i of the filter, a run of cmask + 1 slices
+   behind the smask + 1 slices of the main part: those rows are 1 / (L + 1) of the
+   entries, and a pass over them stages only its own part. */
+__host__ __device__ inline uint32_t row_slice(const SliceGeom &g, uint32_t key, int class_index)
+{
+  return class_index < 0 ? (key & g.smask)
+                         : g.smask + 1u + (uint32_t)class_index * (g.cmask + 1u) + (key & g.cmask);
+}
 
 __host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i, uint32_t c0)
 {
@@ -229,9 +242,9 @@ struct ProbeParams {
                                       the query's Zobrist hash                   */
   const uint64_t *qhins, *qhdel;   /* variant 2 with -i: the shifted hashes that seed
                                       the rolling indel enumeration              */
-  const uint64_t *cw;              /* variant 2, class-row tiles, per class slot: the  */
-  const uint32_t *cmain;           /* row's blanked hash, the query's slot in pass 0,  */
-  const uint8_t  *cres;            /* its residue at the class position               */
+  const uint64_t *cw;              /* variant 2, class rows, per item: the row's blanked   */
+  const uint32_t *cmain;           /* hash, the query's slot in pass 0 (~0: padding),      */
+  const uint32_t *crp;             /* its residue at the class position | position << 8    */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */

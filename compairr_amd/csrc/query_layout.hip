@@ -98,9 +98,17 @@ struct QL {
   uint32_t *qres, *qv, *qj, *qrep, *qorig, *qck;
   uint64_t *qgh, *qhins, *qhdel, *qcnt;
   uint16_t *qlen;
+  /* variant 2, class rows: flat items grouped by the slice of their class part,
+     every group padded to whole blocks of 64 */
+  uint32_t  nclass;                  /* class-row passes */
+  uint32_t  cslices;                 /* slices per class part */
+  uint32_t  cblocks;                 /* blocks of 64 items per chunk at most */
+  uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nclass * cslices] */
+  uint32_t *cgrp[MAX_CLASS_RES];     /* per query: slice within the class part, or NO_GROUP */
+  uint32_t  cchunk0;                 /* first class chunk in the chunk list */
   uint64_t *cw;
   uint32_t *cmain;
-  uint8_t  *cres;
+  uint32_t *crp;
   /* validation / statistics */
   uint32_t           *verr;          /* [0] first error kind, [1] longest */
   double             *rep_total;
@@ -249,23 +257,33 @@ keys_kernel(const QL Q)
       Q.ck_tmp[i] = ck;
     }
     const uint64_t gl = Q.longest - L;
-    for (uint32_t pi = 0; pi < Q.npass; pi++) {
-      uint32_t g = NO_GROUP;
-      if (pi == 0) {
-        const uint64_t bucket = Q.sliced ? 2 * (uint64_t)(ck & Q.geom.smask) + (heavy ? 1 : 0) : 0;
-        g = (uint32_t)(bucket * Q.per_slice + gl);
-      } else if (heavy && L > 0) {
-        /* the row of class position pi - 1: the key without the terms of that position */
-        const uint32_t pos = class_pos(L, pi - 1, Q.geom.c0);
+    {
+      const uint64_t bucket = Q.sliced ? 2 * (uint64_t)(ck & Q.geom.smask) + (heavy ? 1 : 0) : 0;
+      const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
+      Q.grp[0][i] = g;
+      atomicAdd(Q.cnt_g[0] + g, 1u);
+    }
+    for (uint32_t ci = 0; ci < Q.nclass; ci++) {
+      /* the row of class position ci: filed under the key without the terms of that
+         position, in class part ci; a position that carries several class residues
+         is handled by the first of them */
+      uint32_t cs = NO_GROUP;
+      if (heavy && L > 0) {
+        const uint32_t pos = class_pos(L, ci, Q.geom.c0);
+        bool first = true;
         uint32_t key = ck;
         for (uint32_t k = 0; k < Q.geom.k; k++)
-          if (class_pos(L, k, Q.geom.c0) == pos)
+          if (class_pos(L, k, Q.geom.c0) == pos) {
+            if (k < ci)
+              first = false;
             key ^= Q.geom.ctab[Q.geom.off_cr + k * Q.A + s[pos]];
-        g = (uint32_t)((2 * (uint64_t)(key & Q.geom.smask) + 1) * Q.per_slice + gl);
+          }
+        if (first)
+          cs = key & Q.geom.cmask;
       }
-      Q.grp[pi][i] = g;
-      if (g != NO_GROUP)
-        atomicAdd(Q.cnt_g[pi] + g, 1u);
+      Q.cgrp[ci][i] = cs;
+      if (cs != NO_GROUP)
+        atomicAdd(Q.ccnt + (size_t)ci * Q.cslices + cs, 1u);
     }
     alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
   }
@@ -463,27 +481,58 @@ place_kernel(const QL Q)
   }
 }
 
-/* variant 2, class-row pass pi - 1: the row's blanked hash, the residue there and
-   the query's slot in pass 0 are all its kernel needs */
+/* variant 2, class rows: per (class part, slice) the items padded to whole blocks
+   of 64, and the chunks (at most cblocks blocks each) they make */
 __global__ void __launch_bounds__(256)
-place_class_kernel(const QL Q, uint32_t pi)
+class_pad_kernel(const QL Q, uint32_t *padded)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (uint64_t)Q.nclass * Q.cslices)
+    return;
+  const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
+  padded[k] = blocks * WAVE;
+  Q.cnch[k] = (blocks + Q.cblocks - 1) / Q.cblocks;
+}
+
+__global__ void __launch_bounds__(256)
+class_chunks_kernel(const QL Q)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (uint64_t)Q.nclass * Q.cslices)
+    return;
+  const uint32_t ci = (uint32_t)(k / Q.cslices), cs = (uint32_t)(k % Q.cslices);
+  const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
+  const uint32_t nc = (blocks + Q.cblocks - 1) / Q.cblocks;
+  for (uint32_t q = 0; q < nc; q++) {
+    Chunk ck;
+    ck.slice = row_slice(Q.geom, cs, (int)ci);
+    ck.first_tile = Q.cbase[k] + q * Q.cblocks * WAVE;      /* first item */
+    ck.ntiles = min(Q.cblocks, blocks - q * Q.cblocks);     /* blocks of 64 items */
+    ck.pass = 3 + ci;
+    Q.chunks[Q.cchunk0 + Q.cchpre[k] + q] = ck;
+  }
+}
+
+/* the row's blanked hash, the residue there with its position, and the query's
+   slot in pass 0 are all its kernel needs */
+__global__ void __launch_bounds__(256)
+place_class_kernel(const QL Q, uint32_t ci)
 {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= Q.n)
     return;
-  const uint32_t g = Q.grp[pi][i];
-  if (g == NO_GROUP)
+  const uint32_t cs = Q.cgrp[ci][i];
+  if (cs == NO_GROUP)
     return;
-  const uint32_t slot = Q.base_g[pi][g] + atomicAdd(Q.fill_g[pi] + g, 1u);
-  const uint32_t tile = slot / WAVE, lane = slot % WAVE;
-  const uint32_t cs = Q.tiles[tile].res_base + lane;
+  const size_t k = (size_t)ci * Q.cslices + cs;
+  const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
   const uint64_t b = Q.off[i];
   const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-  const uint32_t pos = class_pos(L, pi - 1, Q.geom.c0);
+  const uint32_t pos = class_pos(L, ci, Q.geom.c0);
   const uint32_t r = Q.res[b + pos];
-  Q.cw[cs] = Q.h_tmp[i] ^ Q.zob[Q.A * pos + r];
-  Q.cmain[cs] = Q.slot_of[i];
-  Q.cres[cs] = (uint8_t)r;
+  Q.cw[item] = Q.h_tmp[i] ^ Q.zob[Q.A * pos + r];
+  Q.cmain[item] = Q.slot_of[i];
+  Q.crp[item] = r | (pos << 8);
 }
 
 /* ---- -i: tiles regrouped by the slice their indel variants fall into ------- */
@@ -575,8 +624,8 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   if (k >= nchunks)
     return;
   const Chunk ck = Q.chunks[k];
-  uint64_t w = 0;
-  for (uint32_t t = 0; t < ck.ntiles; t++) {
+  uint64_t w = ck.pass >= 3 ? (uint64_t)ck.ntiles * WAVE * 2 : 0;
+  for (uint32_t t = 0; ck.pass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
     w += (uint64_t)(ck.pass == 0 ? td.len + 1 : ck.pass == 1 ? td.len + 2 : 2) * td.nvalid;
   }
@@ -731,9 +780,12 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if (nbuckets * per_slice >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
   const uint64_t G = nbuckets * per_slice;
-  const uint32_t npass =
-      1 + ((c->rows && c->geom.k > 0 && c->opt.differences >= 1) ? c->geom.k : 0u);
-  c->npasses = npass;
+  /* class-row passes of variant 2 (flat items, not tiles) */
+  const uint32_t nclass = (c->rows && c->geom.k > 0 && c->opt.differences >= 1) ? c->geom.k : 0u;
+  const uint32_t npass = 1;                  /* passes laid out as tiles */
+  c->npasses = 1 + nclass;
+  const uint32_t cslices = c->geom.cmask + 1;
+  const uint64_t ncs = (uint64_t)nclass * cslices;
   const uint64_t chunk_tiles =
       c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : c->rows ? 64 : 8 * (uint64_t)c->waves_per_block;
   c->chunk_cap = (uint32_t)chunk_tiles;
@@ -773,12 +825,34 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
+  Q.nclass = nclass;
+  Q.cslices = cslices;
+  Q.cblocks = 4096;                          /* (a claim word counts tiles in 16 bits) */
 
   /* ---- scratch: group counters, per-query keys ---- */
   Tmp<uint32_t> gcnt, gbase, gfill, grp, tfirst, ck_tmp, slot_of;
   Tmp<uint64_t> h_tmp, hins_tmp, hdel_tmp;
   Tmp<SliceTot> tot, pre;
   Tmp<unsigned long long> alg;
+  Tmp<uint32_t> ccnt, cbase, cfill, cnch, cchpre, cpad, cgrp;
+  if (nclass) {
+    if ((rc = dev_alloc(c, ccnt.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cbase.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cfill.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cnch.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cchpre.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cpad.b, (size_t)ncs))) return rc;
+    if ((rc = dev_alloc(c, cgrp.b, (size_t)s->n * nclass))) return rc;
+    HIP_TRY(c, hipMemsetAsync(ccnt.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(cfill.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
+    Q.ccnt = ccnt.b.p;
+    Q.cbase = cbase.b.p;
+    Q.cfill = cfill.b.p;
+    Q.cnch = cnch.b.p;
+    Q.cchpre = cchpre.b.p;
+    for (uint32_t ci = 0; ci < nclass; ci++)
+      Q.cgrp[ci] = cgrp.b.p + (size_t)s->n * ci;
+  }
   if ((rc = dev_alloc(c, gcnt.b, (size_t)G * npass))) return rc;
   if ((rc = dev_alloc(c, gbase.b, (size_t)G * npass))) return rc;
   if ((rc = dev_alloc(c, gfill.b, (size_t)G * npass))) return rc;
@@ -869,9 +943,31 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     if (pi == 0)
       c->nmain_tiles = t.tiles;
   }
+  /* ---- class rows: items per (class part, slice), padded to blocks of 64 ---- */
+  uint64_t class_chunks = 0;
+  if (nclass) {
+    hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad.b.p);
+    HIP_TRY(c, hipGetLastError());
+    size_t b2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, cpad.b.p, cbase.b.p, (int)ncs, c->stream);
+    Tmp<char> t2;
+    if ((rc = dev_alloc(c, t2.b, b2))) return rc;
+    size_t bb = b2;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, cpad.b.p, cbase.b.p, (int)ncs, c->stream));
+    bb = b2;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, cnch.b.p, cchpre.b.p, (int)ncs, c->stream));
+    uint32_t last[4];
+    HIP_TRY(c, hipMemcpyAsync(&last[0], cpad.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&last[1], cbase.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&last[2], cnch.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&last[3], cchpre.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    cslots = (uint64_t)last[0] + last[1];
+    class_chunks = (uint64_t)last[2] + last[3];
+  }
   if (ntiles * WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
-  if (res_words + 9 * WAVE >= 0xffffffffull || cslots >= 0xffffffffull)
+  if (res_words + 9 * WAVE >= 0xffffffffull || cslots + WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "query set too large for 32-bit residue positions");
   const uint64_t main_chunks = nchunks, main_list = nlist;
 
@@ -913,6 +1009,8 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     nchunks += sib_chunks;
     nlist += sib_list;
   }
+  Q.cchunk0 = (uint32_t)nchunks;
+  nchunks += class_chunks;
   if (nchunks >= 0xffffffffull || nlist >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many chunks");
 
@@ -937,7 +1035,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   HIP_TRY(c, hipMemsetAsync(c->qlen.p, 0, std::max<size_t>(slots, 1) * sizeof(uint16_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qorig.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
   c->qv.release(); c->qj.release(); c->qgh.release(); c->qcnt.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->cres.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release();
   if (!c->opt.ignore_genes) {
     if ((rc = dev_alloc(c, c->qv, slots))) return rc;
     if ((rc = dev_alloc(c, c->qj, slots))) return rc;
@@ -961,13 +1059,15 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       HIP_TRY(c, hipMemsetAsync(c->qhins.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
       HIP_TRY(c, hipMemsetAsync(c->qhdel.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
     }
-    if (npass > 1) {
-      if ((rc = dev_alloc(c, c->cw, (size_t)cslots))) return rc;
-      if ((rc = dev_alloc(c, c->cmain, (size_t)cslots))) return rc;
-      if ((rc = dev_alloc(c, c->cres, (size_t)cslots))) return rc;
-      HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, std::max<size_t>((size_t)cslots, 1) * sizeof(uint64_t), c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0, std::max<size_t>((size_t)cslots, 1) * sizeof(uint32_t), c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->cres.p, 0, std::max<size_t>((size_t)cslots, 1), c->stream));
+    if (nclass) {
+      /* (+ 64: a block read past the last item stays inside) */
+      const size_t ni = (size_t)cslots + WAVE;
+      if ((rc = dev_alloc(c, c->cw, ni))) return rc;
+      if ((rc = dev_alloc(c, c->cmain, ni))) return rc;
+      if ((rc = dev_alloc(c, c->crp, ni))) return rc;
+      HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, ni * sizeof(uint64_t), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0xff, ni * sizeof(uint32_t), c->stream));   /* ~0: padding */
+      HIP_TRY(c, hipMemsetAsync(c->crp.p, 0, ni * sizeof(uint32_t), c->stream));
     }
   }
   Q.tiles = c->tiles.p;
@@ -977,7 +1077,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
   Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p;
-  Q.cw = c->cw.p; Q.cmain = c->cmain.p; Q.cres = c->cres.p;
+  Q.cw = c->cw.p; Q.cmain = c->cmain.p; Q.crp = c->crp.p;
 
   for (uint32_t pi = 0; pi < npass; pi++) {
     hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, pi);
@@ -986,10 +1086,14 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if (s->n) {
     hipLaunchKernelGGL(place_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
-    for (uint32_t pi = 1; pi < npass; pi++) {
-      hipLaunchKernelGGL(place_class_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q, pi);
+    for (uint32_t ci = 0; ci < nclass; ci++) {
+      hipLaunchKernelGGL(place_class_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q, ci);
       HIP_TRY(c, hipGetLastError());
     }
+  }
+  if (nclass) {
+    hipLaunchKernelGGL(class_chunks_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
   }
   if (indel_passes) {
     hipLaunchKernelGGL(sibling_fill_kernel, dim3(blocks_for(G)), dim3(256), 0, c->stream, Q, G,
