@@ -2,20 +2,27 @@
 """bench.py -- query sequences/sec through the --matrix hot path on MI355X.
 
 One "step" = one pass of the hot path (variant enumeration -> Zobrist hash ->
-Bloom probe -> hash-table walk -> verify -> matrix accumulate) over one batch of
+Bloom test -> hash-table walk -> verify -> matrix accumulate) over one batch of
 synthetic queries that is already resident in HBM, plus -- at N > 1 -- the RCCL
 all-reduce of the repertoire matrix.  Default workload = BASELINE.json
 configs[2]: synthetic 10M-vs-10M CDR3aa, d = 1, substitutions only.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
-(hash table + Bloom) is replicated, every rank holds its own 10M-query shard
-(rank 0's shard is the N = 1 workload; weak scaling: the job's query set is
-N x 10M), and the only collective is one all-reduce of the R1 x R2 matrix.
+(hash table + filter) is replicated on every GPU; the query set is sharded:
+  --scaling strong (default)  the SAME seeded 10M queries, split into N contiguous
+                              shards (overlap.cc:421-433 hands out query chunks the
+                              same way): total work fixed, BASELINE configs[3];
+  --scaling weak              every rank its own 10M-query shard.
+The only collective is one all-reduce (sum, int64) of the R1 x R2 matrix per
+step, on the same stream as the kernels.  In strong mode the reduced matrix is
+the N = 1 matrix; its checksum is compared with the recorded N = 1 checksum at
+every N ("parity_vs_n1").
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), with
-`roofline` (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM peak) and
-`cpu_baseline` (the reference algorithm timed on this box's host cores on a
-bounded sample of the same workload).
+`roofline` (the dominant kernel against its binding unit, from the committed
+rocprofv3 counters and the live HIP-event time) and `cpu_baseline` (the
+reference program timed on this box's host cores on a bounded sample of the same
+workload).
 """
 
 import argparse
@@ -30,15 +37,24 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# N = 1 matrix checksums of the recorded workloads (synth.checksum), the parity
+# anchor of the strong-scaling runs; each was confirmed digit for digit against the
+# reference binary by this script's cpu_baseline leg
+KNOWN_CHECKSUMS = {
+    "synthetic 10M-vs-10M CDR3aa, d=1 substitutions only, V/J matched":
+        "fc9769626ca2bcf2c84e8473864b8853",
+}
 
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--refs", type=int, default=10_000_000, help="set-2 sequences")
-    p.add_argument("--queries", type=int, default=10_000_000, help="set-1 sequences per GPU")
+    p.add_argument("--queries", type=int, default=10_000_000,
+                   help="set-1 sequences (strong: in total; weak: per GPU)")
+    p.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     p.add_argument("--differences", "-d", type=int, default=1)
     p.add_argument("--indels", action="store_true")
     p.add_argument("--nucleotides", action="store_true")
@@ -119,6 +135,68 @@ def cpu_baseline(ref, queries, opt, sample, args):
             _oracle.integer_cells(m, opt).astype(np.float64), q, None)
 
 
+def roofline(workload, st, probe_ms, kernel_ms):
+    """The dominant kernel (the probe kernel) against the unit that binds it.
+
+    Per-launch work of each unit comes from the committed rocprofv3 counter summary
+    of this workload (profiles/roofline_inputs.json, written by tools/pmc_summary.py:
+    wave-level VALU / SALU instructions, LDS-array cycles, HBM bytes per the guide's
+    FETCH_SIZE / WRITE_SIZE recipe); the unit rates are the calibrated ones of
+    profiles/*/calibration.json (tools/calib.hip, same chip); the time is the live
+    HIP-event time of the kernel.  `bound` is the unit with the highest utilisation,
+    `frac` that utilisation (<= 1).  `algorithmic_equiv` keeps SURVEY 8d's figure
+    (8 bytes per variant, as the reference reads its filter) for comparison with
+    round 1: it is not a physical rate -- this kernel answers a row of variants
+    with one LDS read."""
+    t = probe_ms * 1e-3
+    out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+           "traffic": None, "kernel": "probe_rows_kernel",
+           "kernel_ms": probe_ms, "step_kernels_ms": kernel_ms,
+           "resolve_kernel_ms": kernel_ms - probe_ms,
+           "algorithmic_bytes_per_launch": st.algorithmic_bytes,
+           "algorithmic_equiv": {"GB/s": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,
+                                 "of_hbm_peak": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "SURVEY 8d bytes (8 B per variant) / probe + resolve time; "
+                                         "exceeds 1 because variants are not answered by HBM reads"},
+           "variants_per_launch": st.variants, "filter_reads_per_launch": st.filter_reads,
+           "bloom_positive_per_launch": st.bloom_positive, "pairs_per_launch": st.matches}
+    path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+    try:
+        with open(path) as fh:
+            inp = json.load(fh)
+    except Exception:
+        inp = None
+    if not inp or inp.get("workload") != workload:
+        out["note"] = "no committed counter summary for this workload: utilisation not priced"
+        return out
+    cal = inp["calibration"]
+    k = inp["probe_kernel"]
+    units = {}
+    if k.get("valu_insts"):
+        peak = cal["valu_wave_insts_per_s"]
+        units["valu"] = (k["valu_insts"] / t, peak, "wave-instructions/s")
+    if k.get("lds_active_cycles"):
+        peak = cal["lds_cycles_per_s"]
+        units["lds"] = (k["lds_active_cycles"] / t, peak, "LDS-array cycles/s")
+    if k.get("salu_insts"):
+        peak = cal["salu_insts_per_s"]
+        units["salu"] = (k["salu_insts"] / t, peak, "scalar instructions/s")
+    if k.get("hbm_bytes"):
+        units["hbm"] = (k["hbm_bytes"] / t / 1e9, HBM_PEAK_GBS, "GB/s")
+        out["traffic"] = k["hbm_bytes"]
+    if not units:
+        return out
+    best = max(units, key=lambda u: units[u][0] / units[u][1])
+    a, p, unit = units[best]
+    out.update({"bound": best, "achieved": a, "peak": p, "unit": unit, "frac": a / p,
+                "utilisation": {u: v[0] / v[1] for u, v in units.items()},
+                "counters_from": inp.get("source"),
+                "note": "achieved = per-launch work of the binding unit (committed rocprofv3 PMC "
+                        "summary of this workload) / live HIP-event time of the probe kernel; peak = "
+                        "the calibrated rate of that unit (tools/calib.hip)"})
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +206,7 @@ def main():
     import torch
     import torch.distributed as dist
     from compairr_amd import HipOverlap, Options, synth
-    from compairr_amd.dist import allreduce_matrix
+    from compairr_amd.dist import allreduce_matrix, shard_bounds
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -150,11 +228,18 @@ def main():
     t0 = time.time()
     ref = synth.make_set(args.refs, 2, prefix="B", nucleotides=args.nucleotides,
                          pool_size=args.refs // 4)
-    qry = ref if args.self_cmp else synth.make_set(
-        args.queries, 1 + 1000 * rank, prefix="A", nucleotides=args.nucleotides,
-        pool_size=args.refs // 4)
+    strong = args.scaling == "strong"
     if args.self_cmp:
+        full = ref
         args.queries = ref.n
+    else:
+        full = synth.make_set(args.queries, 1 + (0 if strong else 1000 * rank), prefix="A",
+                              nucleotides=args.nucleotides, pool_size=args.refs // 4)
+    if strong and world > 1:
+        lo, hi = shard_bounds(full.n, rank, world)
+        qry = full.subset(slice(lo, hi))      # keeps the full set's repertoire numbering
+    else:
+        qry = full
     t_gen = time.time() - t0
 
     # ---- resident in HBM before the timed region ----
@@ -163,53 +248,57 @@ def main():
         k, v = kv.split("=")
         h.set_tunable(k, int(v))
     t0 = time.time()
-    h.set_reference(ref, qry.longest)
+    h.set_reference(ref, full.longest)
     t_index = time.time() - t0
     t0 = time.time()
     h.set_queries(qry)
     t_layout = time.time() - t0
     R1, R2 = h.shape
     layout = h.layout()
-    # every rank must use the same R1 x R2 (16 x 16 for the synthetic law)
+    # every rank uses the same R1 x R2 (16 x 16 for the synthetic law)
     matrix = torch.zeros(R1 * R2, dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream()
+    # one explicit stream for the kernels AND the collective: nothing in a step is
+    # ordered by the host
+    stream = torch.cuda.Stream()
 
     def step():
         h.overlap_matrix_device(matrix.data_ptr(), stream.cuda_stream)
         allreduce_matrix(matrix)               # RCCL sum over xGMI, R1*R2 int64 (no-op at N=1)
 
-    kernel_ms, probe_ms = [], []
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
     st = h.stats()
     # HIP events recorded by the library on the kernels' stream, one set per step of
     # the timed region (ring of the last 64 launches: no synchronisation inside the loop)
     kernel_ms, probe_ms = h.kernel_times(args.steps)
 
-    total_queries = args.queries * world
+    total_queries = args.queries if strong else args.queries * world
     value = total_queries * args.steps / elapsed
     k_avg_ms = float(np.mean(kernel_ms))
-    achieved = st.algorithmic_bytes / (k_avg_ms * 1e-3) / 1e9
+    p_avg_ms = float(np.mean(probe_ms))
 
     result_matrix = matrix.cpu().numpy().astype(np.uint64).reshape(R1, R2)
+    checksum = synth.checksum(result_matrix)
 
     if rank == 0:
+        wl = workload_name(args)
         baseline = None
         parity = None
         if world == 1 and args.cpu_sample >= 0:
@@ -227,16 +316,11 @@ def main():
             if not parity:
                 print("PARITY FAILURE: HIP matrix differs from the CPU %s on the sample"
                       % baseline["kind"], file=sys.stderr)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    t = json.load(fh)
-                if t.get("workload") == workload_name(args):
-                    traffic = t.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        known = KNOWN_CHECKSUMS.get(wl) if strong else None
+        parity_vs_n1 = None if known is None else bool(checksum == known)
+        if parity_vs_n1 is False:
+            print("PARITY FAILURE: reduced matrix checksum %s != recorded N=1 checksum %s"
+                  % (checksum, known), file=sys.stderr)
         out = {
             "metric": "query sequences/sec for --matrix d=%d%s, %s-vs-%s %s" % (
                 args.differences, " --indels" if args.indels else "",
@@ -249,35 +333,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": workload_name(args),
-                       "queries_per_gpu": args.queries, "reference_sequences": args.refs,
+            "config": {"workload": wl,
+                       "queries_total": total_queries, "queries_this_gpu": qry.n,
+                       "reference_sequences": args.refs,
                        "repertoires": [int(R1), int(R2)],
-                       "sharding": "queries sharded per GPU, reference index replicated, "
-                                   "one RCCL all-reduce of the matrix" if world > 1 else "single GPU",
-                       "matrix_checksum": synth.checksum(result_matrix),
+                       "sharding": ("%s scaling: queries sharded over %d GPUs, reference index "
+                                    "replicated, one RCCL all-reduce of the matrix per step"
+                                    % (args.scaling, world)) if world > 1 else "single GPU",
+                       "matrix_checksum": checksum,
                        "layout": layout,
                        "setup_seconds": {"generate": round(t_gen, 2), "index_build+upload": round(t_index, 3),
                                          "query_layout+upload": round(t_layout, 3)}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "probe_sliced_kernel" if layout.get("variant") == 1
-                         else "probe_kernel",
-                         # probe + resolve kernels (the figure `achieved` is priced on)
-                         "kernel_ms": k_avg_ms,
-                         "probe_kernel_ms": float(np.mean(probe_ms)),
-                         "resolve_kernel_ms": k_avg_ms - float(np.mean(probe_ms)),
-                         "algorithmic_bytes_per_launch": st.algorithmic_bytes,
-                         "variants_per_launch": st.variants,
-                         "bloom_positive_per_launch": st.bloom_positive,
-                         "pairs_per_launch": st.matches,
-                         "note": "achieved = SURVEY 8d algorithmic bytes (8 B per variant, as the "
-                                 "reference reads its filter) / HIP-event time of the probe + "
-                                 "resolve kernels; it can exceed the HBM peak because the filter "
-                                 "words come from LDS; `traffic` is the measured HBM bytes"},
+            # from cmpr_set_view in host memory to the matrix: upload + device-side layout
+            # of the queries (once per query set) + one step
+            "value_incl_layout": total_queries / (t_layout + elapsed / args.steps),
+            "parity_vs_n1": parity_vs_n1,
+            "roofline": roofline(wl, st, p_avg_ms, k_avg_ms),
             "cpu_baseline": baseline,
             "parity_on_cpu_sample": parity,
         }

@@ -296,7 +296,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1024,7 +1024,7 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
      does not fit is resolved inline by the probe kernel */
   {
     const uint64_t total = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
-                                               : std::max<uint64_t>(1u << 20, 2 * c->n1);
+                                               : std::max<uint64_t>(1u << 20, 4 * c->n1);
     const uint64_t S = (uint64_t)c->pos_segments;
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
     if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
@@ -1100,6 +1100,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qlen = c->qlen.p;
     P.qorig = c->qorig.p;
     P.qck = c->qck.p;
+    P.qrec = c->qrec.p;
     P.qhins = c->qhins.p;
     P.qhdel = c->qhdel.p;
     P.cw = c->cw.p;

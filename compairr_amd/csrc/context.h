@@ -129,6 +129,7 @@ struct cmpr_context {
   DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
   DevBuf<uint32_t>  qorig, qck;
+  DevBuf<cmpr::QueryRec> qrec;     /* per slot: what verification reads, 64 bytes */
   /* variant 2, class rows: per item the row's blanked hash, the query's slot in
      pass 0 (~0: padding) and its residue at the class position | position << 8 */
   DevBuf<uint64_t>  cw;

@@ -506,10 +506,10 @@ __device__ __forceinline__ uint32_t block_mismatch(uint32_t c, const uint32_t q[
 }
 
 /* Verification + scoring of one candidate per lane.  Everything a candidate
-   needs is requested at once -- the hit's record with its first 32 residues
-   (one 64-byte piece), the query's fields and its first 36 residues -- so a
-   CDR3 is verified after ONE memory round trip; sequences longer than 32 take
-   one more per 16 residues. */
+   needs is requested at once -- the hit's record with its first 32 residues and
+   the query's record with its first 36, one 64-byte piece each -- so a CDR3 is
+   verified after ONE memory round trip of two requests; sequences longer than
+   32 take one more per 16 residues. */
 template <bool GENES>
 __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t qbase,
                                                  uint32_t ca, uint32_t cb, uint32_t hit,
@@ -517,16 +517,19 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
 {
   const uint4 *rp = (const uint4 *)(P.rec2 + (size_t)hit * REC_UNIT);
   const uint4 h0 = rp[0], h1 = rp[1], t0 = rp[2], t1 = rp[3];
-  const uint32_t *qr = P.qres + qbase + (qs & 63u);
+  /* the query's record (layout.h QueryRec): count, genes, repertoire, length and
+     its first 36 residues in ONE 64-byte piece, like the hit's */
+  const uint4 *qp = (const uint4 *)P.qrec + (size_t)qs * 4;
+  const uint4 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  const uint32_t *qr = P.qres + qbase + (qs & 63u);        /* residues past the 36th */
   uint32_t q[10];
   q[0] = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++)
-    q[k + 1] = qr[(size_t)k * WAVE];
-  const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
-  const uint32_t q_rep = P.qrep[qs];
-  const uint32_t L = P.qlen[qs];
-  const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
+  q[1] = a1.z; q[2] = a1.w; q[3] = a2.x; q[4] = a2.y; q[5] = a2.z; q[6] = a2.w;
+  q[7] = a3.x; q[8] = a3.y; q[9] = a3.z;
+  const uint32_t q_v = GENES ? a0.z : 0u, q_j = GENES ? a0.w : 0u;
+  const uint32_t q_rep = a1.x;
+  const uint32_t L = a1.y;
+  const unsigned long long q_cnt = ((unsigned long long)a0.y << 32) | a0.x;
 
   RefRec rec;
   rec.cnt = ((unsigned long long)h0.y << 32) | h0.x;
@@ -565,7 +568,7 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
    walk free of the verification's dependent loads is what matters: the kernel
    is bound by memory round trips per wave, not by bytes. */
 template <bool GENES>
-__global__ void __launch_bounds__(BLOCK_THREADS)
+__global__ void __launch_bounds__(BLOCK_THREADS, 4)      /* <= 128 VGPRs: 4 waves per SIMD */
 resolve_kernel(const ProbeParams P)
 {
   extern __shared__ __align__(16) unsigned char smem[];

@@ -207,6 +207,18 @@ struct RefRec {
 };
 constexpr uint32_t REC_UNIT = 16;
 
+/* One set-1 sequence as the verification step reads it (resolve_kernel): 64 bytes
+   per query slot -- a verified candidate costs one request for the hit's record
+   and one for the query's. */
+struct QueryRec {
+  uint64_t cnt;       /* duplicate_count (1 with -f)                        */
+  uint32_t v, j;      /* 0 with -g                                          */
+  uint32_t rep;       /* matrix row                                         */
+  uint32_t len;
+  uint32_t res[9];    /* residues 0..35, four to a dword                    */
+  uint32_t pad;
+};
+
 __host__ __device__ inline uint32_t rec_units(uint32_t len)
 {
   return (uint32_t)(sizeof(RefRec) / REC_UNIT) + (len + REC_UNIT - 1) / REC_UNIT;
@@ -250,6 +262,7 @@ struct ProbeParams {
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
   const uint32_t *qorig;           /* per slot: index in the caller's set 1       */
   const uint32_t *qck;             /* per slot: class key (variant 2)             */
+  const QueryRec *qrec;            /* per slot: what verification reads            */
   uint32_t        ntiles;
   uint32_t        first_tile;
   /* output */

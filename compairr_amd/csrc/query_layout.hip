@@ -98,6 +98,7 @@ struct QL {
   uint32_t *qres, *qv, *qj, *qrep, *qorig, *qck;
   uint64_t *qgh, *qhins, *qhdel, *qcnt;
   uint16_t *qlen;
+  QueryRec *qrec;
   /* variant 2, class rows: flat items grouped by the slice of their class part,
      every group padded to whole blocks of 64 */
   uint32_t  nclass;                  /* class-row passes */
@@ -468,9 +469,20 @@ place_kernel(const QL Q)
     const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
     Q.qgh[slot] = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
   }
-  /* residues four to a dword, position-major / lane-minor (layout.h TileDesc) */
+  /* residues four to a dword, position-major / lane-minor (layout.h TileDesc), and
+     the first nine dwords once more in the query's record */
   uint32_t *dst = Q.qres + Q.tiles[tile].res_base + lane;
   const uint8_t *s = Q.res + b;
+  QueryRec qr;
+  qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
+  qr.v = Q.genes ? Q.v[i] : 0u;
+  qr.j = Q.genes ? Q.j[i] : 0u;
+  qr.rep = Q.existence ? (uint32_t)i : Q.rep[i];
+  qr.len = L;
+  qr.pad = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 9; w++)
+    qr.res[w] = 0;
   for (uint32_t w = 0; 4 * w < L; w++) {
     uint32_t d = 0;
 #pragma unroll
@@ -478,7 +490,10 @@ place_kernel(const QL Q)
       if (4 * w + k < L)
         d |= (uint32_t)s[4 * w + k] << (8 * k);
     dst[(size_t)w * WAVE] = d;
+    if (w < 9)
+      qr.res[w] = d;
   }
+  Q.qrec[slot] = qr;
 }
 
 /* variant 2, class rows: per (class part, slice) the items padded to whole blocks
@@ -1030,6 +1045,8 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, c->qrep, slots))) return rc;
   if ((rc = dev_alloc(c, c->qlen, slots))) return rc;
   if ((rc = dev_alloc(c, c->qorig, slots))) return rc;
+  if ((rc = dev_alloc(c, c->qrec, slots))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->qrec.p, 0, std::max<size_t>(slots, 1) * sizeof(QueryRec), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qres.p, 0, ((size_t)res_words + 9 * WAVE) * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qrep.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qlen.p, 0, std::max<size_t>(slots, 1) * sizeof(uint16_t), c->stream));
@@ -1076,7 +1093,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.small_tiles = c->small_tiles.p;
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
-  Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p;
+  Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
   Q.cw = c->cw.p; Q.cmain = c->cmain.p; Q.crp = c->crp.p;
 
   for (uint32_t pi = 0; pi < npass; pi++) {

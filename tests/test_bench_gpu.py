@@ -1,0 +1,58 @@
+"""bench.py itself, on the GPU box: the JSON contract, and the RCCL path (process
+group on backend nccl + all-reduce of the matrix on the kernels' stream) executed
+at world size 1 under torch.distributed.run -- the code the driver runs at N > 1."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["--steps", "3", "--warmup", "1", "--queries", "300000", "--refs", "300000",
+         "--cpu-sample", "-1"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_and_rccl_path_at_world_1():
+    plain = _run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline", "value_incl_layout", "parity_vs_n1"):
+        assert key in plain, key
+    assert plain["n_gpus"] == 1 and plain["steps"] == 3 and plain["value"] > 0
+    assert plain["scaling"] == "strong" and plain["dtype"] == "u64"
+    assert set(plain["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # the same workload through torch.distributed.run: process group on nccl (= RCCL),
+    # all-reduce of the matrix inside every step
+    dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                 "bench.py", "--gpus", "1"] + SMALL)
+    assert dist["n_gpus"] == 1
+    assert dist["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    # weak scaling keeps the same shard at N = 1
+    weak = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "weak"] + SMALL)
+    assert weak["scaling"] == "weak"
+    assert weak["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]

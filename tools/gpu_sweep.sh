@@ -16,7 +16,7 @@ try:
     d=json.loads(open(sys.argv[2]).read())
     r=d["roofline"]; l=d["config"]["layout"]
     print("%-60s step %.3f ms probe %.3f resolve %.3f | K=%s slices=%s tiles=%s chunks=%s small=%s pos=%s setup=%s cs=%s" % (
-        sys.argv[1], d["ms_per_step"], r["probe_kernel_ms"], r["resolve_kernel_ms"], l.get("class_residues"), l.get("slices"),
+        sys.argv[1], d["ms_per_step"], r["kernel_ms"], r["resolve_kernel_ms"], l.get("class_residues"), l.get("slices"),
         l.get("tiles"), l.get("chunks"), l.get("small_tiles"), r["bloom_positive_per_launch"], d["config"]["setup_seconds"]["query_layout+upload"], d["config"]["matrix_checksum"][:8]))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output of tools/profile_round.sh (kernel stats + separate --pmc
-passes) for the probe and resolve kernels into profiles/<round>/ and profiles/traffic.json.
+passes) into profiles/<round>/<tag>_pmc_summary.json, profiles/traffic.json and
+profiles/roofline_inputs.json (what bench.py prices its `roofline` object on).
 
 usage: tools/pmc_summary.py <gpurun_out/tag dir> <profiles/rNN dir> <tag> "<workload name>"
+
+Kernels are kept apart by their full name (the fast and the redo form of the probe
+kernel are different instantiations); "probe" below is the probe kernel with the
+longest mean duration, "resolve" likewise.
 
 HBM traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are
 in KiB, collected in separate passes; on gfx950 FETCH_SIZE tallies 128-byte
@@ -18,56 +23,65 @@ import sys
 
 src, dst, tag, workload = sys.argv[1:5]
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("probe", "resolve")
+
+per = collections.defaultdict(lambda: {"dur": [], "ctr": collections.defaultdict(list), "dispatch": None})
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        d = per[name]
+        d["ctr"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = (name, r.get("Dispatch_Id"))
+        if key not in seen:
+            seen.add(key)
+            d["dur"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        d["dispatch"] = {"grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]),
+                         "vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                         "lds": int(r.get("LDS_Block_Size", 0) or 0)}
 
 
-def which(name):
-    for k in KERNELS:
-        if k in name:
-            return k
-    return None
+def pick(word):
+    best = None
+    for name, d in per.items():
+        if word in name and d["dur"]:
+            m = sum(d["dur"]) / len(d["dur"])
+            if best is None or m > best[1]:
+                best = (name, m)
+    return best
 
 
 out = {"workload": workload, "kernels": {}}
 for f in glob.glob(os.path.join(src, "prof_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % tag))
-    for r in csv.DictReader(open(f)):
-        k = which(r["Name"])
-        if k:
-            out["kernels"].setdefault(k, {})["stats"] = {
-                "name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
-                "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    stats = {r["Name"]: r for r in csv.DictReader(open(f))}
+else:
+    stats = locals().get("stats", {})
 
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        k = which(r["Kernel_Name"])
-        if not k:
-            continue
-        acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-        out["kernels"].setdefault(k, {})["dispatch"] = {
-            "grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]),
-            "vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
-            "lds": int(r.get("LDS_Block_Size", 0) or 0)}
-    for (k, c), v in acc.items():
-        out["kernels"][k].setdefault("counters", {})[c] = {
-            "per_launch_mean": sum(v) / len(v), "launches": len(v)}
-
-total = 0.0
-have = True
-for k, d in out["kernels"].items():
-    c = d.get("counters", {})
+for k in ("probe", "resolve"):
+    b = pick(k)
+    if not b:
+        continue
+    name, mean_us = b
+    d = per[name]
+    e = {"name": name, "dispatch": d["dispatch"], "pmc_pass_mean_duration_us": mean_us,
+         "counters": {c: {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+                      for c, v in d["ctr"].items()}}
+    if name in stats:
+        r = stats[name]
+        e["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                      "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    c = e["counters"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch = c["FETCH_SIZE"]["per_launch_mean"] * 1024
         write = c["WRITE_SIZE"]["per_launch_mean"] * 1024
-        d["hbm_bytes_per_launch"] = 2 * fetch + write
-        d["raw_fetch_bytes"] = fetch
-        d["raw_write_bytes"] = write
-        total += d["hbm_bytes_per_launch"]
-    else:
-        have = False
-if have and out["kernels"]:
-    out["hbm_bytes_per_step"] = total
+        e["hbm_bytes_per_launch"] = 2 * fetch + write
+        e["raw_fetch_bytes"] = fetch
+        e["raw_write_bytes"] = write
+    out["kernels"][k] = e
+
+tot = [e.get("hbm_bytes_per_launch") for e in out["kernels"].values()]
+if tot and all(x is not None for x in tot):
+    out["hbm_bytes_per_step"] = sum(tot)
     out["hbm_bytes_note"] = ("sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1024: "
                              "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md")
 for name in ("bench.json", "stats_bench.json"):
@@ -76,10 +90,50 @@ for name in ("bench.json", "stats_bench.json"):
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
 with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
+root = os.path.dirname(dst.rstrip("/"))
 if "hbm_bytes_per_step" in out:
-    with open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json"), "w") as fh:
+    with open(os.path.join(root, "traffic.json"), "w") as fh:
         json.dump({"workload": workload, "hbm_bytes_per_launch": out["hbm_bytes_per_step"],
                    "per_kernel": {k: d.get("hbm_bytes_per_launch") for k, d in out["kernels"].items()},
                    "source": os.path.join(dst, "%s_pmc_summary.json" % tag),
                    "note": out["hbm_bytes_note"]}, fh, indent=1)
-print(json.dumps(out, indent=1))
+
+# ---- what bench.py's roofline object is priced on ----
+cal_path = os.path.join(dst, "calibration.json")
+if "probe" in out["kernels"] and os.path.exists(cal_path):
+    cal = json.load(open(cal_path))
+    c = out["kernels"]["probe"]["counters"]
+    g = lambda n: c[n]["per_launch_mean"] if n in c else None
+    valu4 = [v for v in cal["valu"] if v["waves_per_simd"] == 4][0]
+    simds = cal["cus"] * 4
+    nominal = cal["clock_mhz"] * 1e6
+    # effective shader clock of this kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    f_eff = None
+    if g("GRBM_GUI_ACTIVE"):
+        f_eff = g("GRBM_GUI_ACTIVE") / 8 / (out["kernels"]["probe"]["pmc_pass_mean_duration_us"] * 1e-6)
+    inputs = {
+        "workload": workload,
+        "source": os.path.join(dst, "%s_pmc_summary.json" % tag),
+        "probe_kernel": {
+            "name": out["kernels"]["probe"]["name"],
+            "valu_insts": g("SQ_INSTS_VALU"), "salu_insts": None,
+            "salu_insts_reported": g("SQ_INSTS_SALU"),
+            "lds_active_cycles": g("SQ_LDS_IDX_ACTIVE"),
+            "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
+            "hbm_bytes": out["kernels"]["probe"].get("hbm_bytes_per_launch"),
+            "effective_clock_hz": f_eff,
+        },
+        "calibration": {
+            "from": cal_path,
+            # wave64 VALU instructions per second, all SIMDs, 4 waves per SIMD: the wall
+            # time of tools/calib.hip's stream at the nominal clock (folds in the clock
+            # the chip holds under a dense VALU stream)
+            "valu_wave_insts_per_s": simds * nominal / valu4["cycles_per_instr_per_simd_at_nominal_clock"],
+            # one LDS array per CU, cycles at the effective clock of this kernel
+            "lds_cycles_per_s": cal["cus"] * (f_eff or nominal),
+            "salu_insts_per_s": None,
+        },
+    }
+    with open(os.path.join(root, "roofline_inputs.json"), "w") as fh:
+        json.dump(inputs, fh, indent=1)
+print(json.dumps(out, indent=1)[:3000])
