@@ -42,6 +42,10 @@ $(OBJ_DIR)/query_layout.o: $(KERN_DIR)/query_layout.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
+$(OBJ_DIR)/ref_index.o: $(KERN_DIR)/ref_index.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
 $(OBJ_DIR)/probe_v0.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=0 -c -o $@ $<
@@ -62,7 +66,7 @@ $(OBJ_DIR)/probe_v2i_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=1 -c -o $@ $<
 
-$(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(TU_OBJS)
+$(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(OBJ_DIR)/ref_index.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
 # diagnostic build with per-phase cycle counters in the probe kernel (tools/phase_timing.py)

@@ -85,86 +85,6 @@ int validate_options(const cmpr_options *o, std::string &why)
 }
 
 
-/* Runs fn(t, begin, end) on `threads` host threads over [0, n) cut into equal
-   contiguous ranges (thread t gets range t): the per-sequence passes of the
-   layout code are independent or become so with per-thread histograms. */
-template <typename F>
-void parallel_ranges(uint64_t n, unsigned threads, F fn)
-{
-  if (threads <= 1 || n < 65536) {
-    fn(0u, (uint64_t)0, n);
-    return;
-  }
-  std::vector<std::thread> pool;
-  for (unsigned t = 0; t < threads; t++)
-    pool.emplace_back([=]() { fn(t, n * t / threads, n * (t + 1) / threads); });
-  for (std::thread &th : pool)
-    th.join();
-}
-
-/* residue codes, gene and repertoire numbers in range; lengths >= 1 */
-int scan_view(const cmpr_options &o, const cmpr_set_view *s, uint32_t &longest,
-              std::vector<double> &rep_total, std::string &why, unsigned threads)
-{
-  longest = 0;
-  rep_total.assign(s->n_repertoires, 0.0);
-  if (s->n < 65536)
-    threads = 1;
-  threads = std::max(1u, threads);
-  std::vector<int> rcs(threads, CMPR_OK);
-  std::vector<const char *> whys(threads, "");
-  std::vector<uint32_t> longs(threads, 0);
-  std::vector<std::vector<double> > tots(threads, std::vector<double>(s->n_repertoires, 0.0));
-  const uint8_t A = (uint8_t)o.alphabet_size;
-  parallel_ranges(s->n, threads, [&](unsigned t, uint64_t b, uint64_t e) {
-    auto bad = [&](int rc, const char *w) { rcs[t] = rc; whys[t] = w; };
-    for (uint64_t i = b; i < e; i++) {
-      if (s->offsets[i + 1] < s->offsets[i]) return bad(CMPR_EINVAL, "offsets not monotone");
-      const uint64_t L = s->offsets[i + 1] - s->offsets[i];
-      if (L > 0xffffu) return bad(CMPR_EUNSUPPORTED, "sequence longer than 65535 residues");
-      longs[t] = std::max<uint32_t>(longs[t], (uint32_t)L);
-      if (s->repertoire[i] >= s->n_repertoires) return bad(CMPR_EINVAL, "repertoire number out of range");
-      if (!o.ignore_genes && (s->v_gene[i] >= o.n_v_genes || s->j_gene[i] >= o.n_j_genes))
-        return bad(CMPR_EINVAL, "gene number out of range");
-      if (!o.ignore_counts && s->count[i] < 1) return bad(CMPR_EINVAL, "duplicate_count must be >= 1");
-      tots[t][s->repertoire[i]] += o.ignore_counts ? 1.0 : (double)s->count[i];
-    }
-    /* the residues of this range of sequences (offsets are monotone here) */
-    for (uint64_t k = s->offsets[b]; k < s->offsets[e]; k++)
-      if (s->residues[k] >= A) return bad(CMPR_EINVAL, "residue code out of range");
-  });
-  for (unsigned t = 0; t < threads; t++) {
-    if (rcs[t] != CMPR_OK) { why = whys[t]; return rcs[t]; }
-    longest = std::max(longest, longs[t]);
-    for (uint32_t r = 0; r < s->n_repertoires; r++)
-      rep_total[r] += tots[t][r];
-  }
-  return CMPR_OK;
-}
-
-/* number of variants the reference enumerates for one query
-   (generate_variants, variants.cc:260-428) */
-uint64_t variants_of(const cmpr_options &o, const uint8_t *s, uint32_t L)
-{
-  const uint64_t A = (uint64_t)o.alphabet_size;
-  uint64_t n = 1;
-  if (o.differences >= 1) {
-    n += (A - 1) * L;
-    if (o.indels) {
-      if (L > 1) {
-        uint64_t runs = 1;
-        for (uint32_t p = 1; p < L; p++)
-          runs += s[p] != s[p - 1];
-        n += runs;
-      }
-      n += A + (A - 1) * (uint64_t)L;
-    }
-  }
-  if (o.differences >= 2)
-    n += (A - 1) * (A - 1) * (uint64_t)L * (L ? L - 1 : 0) / 2;
-  return n;
-}
-
 ProbeFn select_sliced_kernel(const cmpr_options &o, int nw)
 {
   const int A = o.alphabet_size, D = o.differences;
@@ -484,400 +404,6 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   return CMPR_OK;
 }
 
-/* ------------------------------------------------------------------ */
-/* set 2: upload + index build on the device                            */
-/* ------------------------------------------------------------------ */
-
-static int cmpr_set_reference_impl(cmpr_context *c, const cmpr_set_view *s,
-                                  uint32_t longest_query)
-{
-  if (!c)
-    return CMPR_EINVAL;
-  std::string why;
-  int rc = validate_view(c->opt, s, why);
-  if (rc)
-    return fail(c, rc, why);
-  HIP_TRY(c, hipSetDevice(c->device));
-  c->have_ref = false;
-  c->have_q = false;
-
-  uint32_t longest = 0;
-  rc = scan_view(c->opt, s, longest, c->tot2, why, (unsigned)c->host_threads);
-  if (rc)
-    return fail(c, rc, why);
-  c->longest2 = longest;
-  c->n2 = s->n;
-  c->R2 = s->n_repertoires;
-
-  /* Zobrist table for max(longest1, longest2) + 3 positions (overlap.cc:840) */
-  const uint32_t A = (uint32_t)c->opt.alphabet_size;
-  c->zpos = std::max(longest, longest_query) + EXTRA_POSITIONS;
-  const uint32_t n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
-  const uint32_t n_j = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
-  {
-    std::vector<uint64_t> z((size_t)A * c->zpos + n_v + n_j);
-    SplitMix64 rng(0x636f6d7061697272ull);   /* "compairr" */
-    for (auto &x : z)
-      x = rng.next();
-    rc = dev_upload(c, c->zob, z.data(), z.size());
-    if (rc)
-      return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
-  }
-
-  /* records */
-  const uint64_t total = s->n ? s->offsets[s->n] : 0;
-  static const uint64_t zero_off[1] = {0};
-  if ((rc = dev_upload(c, c->res2, s->residues, (size_t)total))) return rc;
-  if ((rc = dev_upload(c, c->off2, s->n ? s->offsets : zero_off, (size_t)s->n + 1))) return rc;
-  if ((rc = dev_upload(c, c->rep2, s->repertoire, (size_t)s->n))) return rc;
-  if (!c->opt.ignore_genes) {
-    if ((rc = dev_upload(c, c->v2, s->v_gene, (size_t)s->n))) return rc;
-    if ((rc = dev_upload(c, c->j2, s->j_gene, (size_t)s->n))) return rc;
-  } else {
-    c->v2.release();
-    c->j2.release();
-  }
-  if (!c->opt.ignore_counts) {
-    if ((rc = dev_upload(c, c->cnt2, s->count, (size_t)s->n))) return rc;
-  } else {
-    c->cnt2.release();
-  }
-
-  /* table: smallest power of two with fill <= 70 % (hash_init, hashtable.cc:31-54);
-     Bloom: one byte per slot (bloom_init(tablesize), overlap.cc:863) */
-  c->slots = 1;
-  while (FILL_PERCENT * c->slots < 100 * s->n)
-    c->slots <<= 1;
-  uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
-  /* results do not depend on the table size (every hit is verified), only the
-     length of the probe chains does: HBM is plentiful, round trips are not */
-  c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
-  /* Kernel variant: the row filter (2) for amino acids -- one word read answers
-     the 19 substitutions of a position; nucleotides (3 per position, and L + 1
-     entries per sequence to pay for them) keep the per-variant filter (1). */
-  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 ? 2 : 1);
-  /* The staged layouts keep a slice, the Zobrist tables and the wave queues in
-     LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
-     no longer fits and the un-sliced filter is probed where it lies (variant 0). */
-  c->sliced = variant >= 1;
-  c->rows = variant == 2;
-  int64_t swl = c->slice_words_log2;
-  if (swl < 0)
-    swl = SLICE_WORDS_LOG2;
-  /* variant 2: the largest slice in 32-byte words -- 40 KiB by default (a ring of
-     two slices + tables + the queues of 16 waves in one workgroup per CU), a power
-     of two on request */
-  uint64_t row_max_words = c->slice_words_log2 < 0
-      ? MAX_ROW_SLICE_WORDS : std::min<uint64_t>(1ull << c->slice_words_log2, MAX_ROW_SLICE_WORDS);
-  if (c->sliced) {
-    const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
-    /* everything but the slice(s), with the fewest waves a workgroup may have */
-    const size_t fixed = zrow * c->zpos * sizeof(uint64_t) +
-                         4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
-                         MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
-                         64 * sizeof(TileRef) + (c->rows ? RING * (sizeof(RingSlot) + 64 * sizeof(TileRef)) : 0);
-    if (c->rows && c->slice_words_log2 < 0) {
-      /* the default slice leaves room for the queues of 16 waves; long sequences: a
-         smaller slice next to the bigger Zobrist table */
-      const size_t fixed16 = fixed + 12 * sizeof(WaveQueue);
-      const size_t room = fixed16 < 160 * 1024 ? 160 * 1024 - fixed16 : 0;
-      row_max_words = std::min<uint64_t>(row_max_words, room / (RING * ROW_WORD_BYTES));
-      row_max_words -= row_max_words % 32;               /* whole KiB: LDS-DMA pieces */
-    }
-    const size_t need = fixed + (c->rows ? RING * (size_t)row_max_words * ROW_WORD_BYTES
-                                         : ((size_t)8 << swl));
-    if (need > 160 * 1024 || (c->rows && row_max_words < 1)) {
-      c->sliced = false;
-      c->rows = false;
-    }
-  }
-  const uint64_t entries = (s->n ? s->offsets[s->n] : 0) + s->n;   /* row filter: L + 1 per sequence */
-  if (c->rows) {
-    /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a
-       word then has ~40 % of its bits set and a test of eight of them passes by
-       chance ~6e-4 of the time -- the optimum of a Bloom filter at 16 bits per
-       entry), x 2^delta */
-    bloom_bytes = std::max<uint64_t>(entries * 2, ROW_WORD_BYTES);
-    const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
-    if (delta > 0)
-      bloom_bytes <<= delta;
-    else if (delta < 0)
-      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), ROW_WORD_BYTES);
-    /* S slices (a power of two: sibling slices are XORs of slice numbers) of
-       rw_words <= row_max_words words each */
-    uint64_t S = 1;
-    while (S * row_max_words * ROW_WORD_BYTES * 17 / 16 < bloom_bytes)    /* (up to 6 % denser) */
-      S <<= 1;
-    uint64_t words = (bloom_bytes + S * ROW_WORD_BYTES - 1) / (S * ROW_WORD_BYTES);
-    if (words >= 64)
-      words = (words + 31) / 32 * 32;                  /* whole KiB: LDS-DMA pieces */
-    words = std::max<uint64_t>(1, std::min<uint64_t>(words, row_max_words));
-    if (S > (1ull << 31))
-      return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
-    c->geom.rw_words = (uint32_t)words;
-    c->geom.words_log2 = 0;
-    c->bloom_words = S * words * (ROW_WORD_BYTES / 8);       /* 8-byte units; + the class parts, below */
-    c->geom.smask = (uint32_t)(S - 1);
-    /* class parts (layout.h row_slice): each holds one entry per split sequence,
-       the main part L + 1 - K per sequence: S n / entries slices, a power of two */
-    uint64_t Sc = 1;
-    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1))
-      Sc <<= 1;
-    c->geom.cmask = (uint32_t)(Sc - 1);
-  } else {
-    /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
-       whatever the total), so it takes 4 bytes per table slot: with the 2^20
-       pattern space that leaves almost only true positives for the table walk. */
-    const int64_t delta = c->bloom_log2_delta == -100 ? (c->sliced ? 2 : 0)
-                                                      : c->bloom_log2_delta;
-    if (delta > 0)
-      bloom_bytes <<= delta;
-    else if (delta < 0)
-      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 8);
-    if (bloom_bytes > (1ull << 32))
-      return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
-    c->bloom_words = bloom_bytes / 8;
-    c->geom.rw_words = 0;
-  }
-
-  /* ---- variants 1, 2: cut the filter into class-keyed slices (layout.h) ---- */
-  if (c->sliced) {
-    SliceGeom &g = c->geom;
-    if (!c->rows) {
-      uint32_t wl = 0;
-      while ((1ull << (wl + 1)) <= c->bloom_words && wl + 1 <= (uint32_t)swl)
-        wl++;
-      g.words_log2 = wl;
-      g.smask = (uint32_t)(c->bloom_words >> wl) - 1;
-    }
-    g.ncl = c->zpos + 1;
-    g.off_cv = g.ncl;
-    g.off_cj = g.off_cv + n_v;
-    g.off_cr = g.off_cj + n_j;
-    g.off_hv = g.off_cr + MAX_CLASS_RES * A;
-    c->ctab.assign((size_t)g.off_hv + HEAVY_WORDS, 0);
-    SplitMix64 crng(0x736c69636573ull);     /* "slices" */
-    for (size_t i = 0; i < g.off_hv; i++)
-      c->ctab[i] = (uint32_t)(crng.next() >> 32);
-    const bool genes = !c->opt.ignore_genes;
-    const uint64_t S = (uint64_t)g.smask + 1;
-    const double slice_bits = (double)(64ull << g.words_log2);
-    /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
-       bits per key, false-positive rate <= 6e-3 there and far less elsewhere.
-       Row filter: sequences per slice at 24 entries per word (1.5 x the average). */
-    const double slice_cap = c->rows
-        ? (double)g.rw_words * 24.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
-        : slice_bits / 12.0;
-    g.k = 0;
-    /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
-       (<= 5th-percentile length of set 2) and be informative (a conserved
-       position splits nothing); the closer to the start, the more insertion /
-       deletion variants keep their class residues in place.  So: the first
-       window of max_class_res positions whose residue entropy in set 2 is at
-       least 70 % of the maximum. */
-    {
-      std::vector<uint64_t> hist((size_t)longest + 2, 0);
-      for (uint64_t i = 0; i < s->n; i++)
-        hist[s->offsets[i + 1] - s->offsets[i]]++;
-      uint64_t acc = 0;
-      uint32_t l5 = longest;
-      for (uint32_t L = 0; L <= longest; L++) {
-        acc += hist[L];
-        if (acc * 20 >= s->n) {
-          l5 = L;
-          break;
-        }
-      }
-      const uint32_t mcr = max_class_res(A);
-      g.c0 = 0;
-      if (l5 > mcr && s->n > 0) {
-        const uint32_t npos = l5;
-        std::vector<uint64_t> cnt((size_t)npos * A, 0);
-        const uint64_t stride = std::max<uint64_t>(1, s->n / 200000);   /* a sample is enough */
-        for (uint64_t i = 0; i < s->n; i += stride) {
-          const uint64_t b = s->offsets[i];
-          const uint32_t L = (uint32_t)std::min<uint64_t>(s->offsets[i + 1] - b, npos);
-          for (uint32_t p = 0; p < L; p++)
-            cnt[(size_t)p * A + s->residues[b + p]]++;
-        }
-        std::vector<double> ent(npos, 0.0);
-        for (uint32_t p = 0; p < npos; p++) {
-          double tot = 0;
-          for (uint32_t r = 0; r < A; r++)
-            tot += (double)cnt[(size_t)p * A + r];
-          for (uint32_t r = 0; r < A && tot > 0; r++) {
-            const double q = (double)cnt[(size_t)p * A + r] / tot;
-            if (q > 0)
-              ent[p] -= q * std::log2(q);
-          }
-        }
-        const double need = 0.7 * std::log2((double)A);
-        uint32_t best = (l5 - mcr) / 2;
-        for (uint32_t c0 = 0; c0 + mcr <= npos; c0++) {
-          bool ok = true;
-          for (uint32_t i = 0; i < mcr; i++)
-            ok = ok && ent[c0 + i] >= need;
-          if (ok) {
-            best = c0;
-            break;
-          }
-        }
-        g.c0 = best;
-      }
-      if (c->class_anchor >= 0)
-        g.c0 = (uint32_t)c->class_anchor;
-    }
-    if (S > 1 && s->n > 0) {
-      /* population of every (length, V, J) class bucket */
-      const unsigned T = s->n < 65536 ? 1u : (unsigned)std::max<int64_t>(1, c->host_threads);
-      std::vector<uint32_t> bucket((size_t)1 << HEAVY_BUCKETS_LOG2, 0);
-      std::vector<uint32_t> base_of((size_t)s->n);
-      {
-        std::vector<std::vector<uint32_t> > part(T, std::vector<uint32_t>(bucket.size(), 0));
-        parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-          for (uint64_t i = lo; i < hi; i++) {
-            const uint32_t L = (uint32_t)(s->offsets[i + 1] - s->offsets[i]);
-            const uint32_t b = class_base(c->ctab.data(), g, genes, L, genes ? s->v_gene[i] : 0,
-                                          genes ? s->j_gene[i] : 0);
-            base_of[i] = b;
-            part[t][b >> (32 - HEAVY_BUCKETS_LOG2)]++;
-          }
-        });
-        for (unsigned t = 0; t < T; t++)
-          for (size_t b = 0; b < bucket.size(); b++)
-            bucket[b] += part[t][b];
-      }
-      /* heavy = would take more than half of a slice's budget on its own */
-      /* (row filter: an eighth -- its 8-bit tests are sensitive to an overfull slice,
-         and a split class costs its queries one cheap class row per class residue) */
-      const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold
-                                                 : slice_cap / (c->rows ? 8 : 2);
-      bool any_heavy = false;
-      for (uint32_t b = 0; b < bucket.size(); b++)
-        if ((double)bucket[b] > thr) {
-          c->ctab[g.off_hv + (b >> 5)] |= 1u << (b & 31);
-          any_heavy = true;
-        }
-      if (c->class_residues >= 0) {
-        g.k = (uint32_t)c->class_residues;
-      } else if (any_heavy) {
-        /* K = fewest class residues that bring the fullest slice under the cap;
-           every one costs the heavy queries one HBM-probed row */
-        double best_max = -1;
-        uint32_t best_k = 1;
-        std::vector<uint32_t> pop;
-        for (uint32_t k = 1; k <= max_class_res(A); k++) {
-          pop.assign((size_t)S, 0);
-          {
-            std::vector<std::vector<uint32_t> > part(T, std::vector<uint32_t>((size_t)S, 0));
-            parallel_ranges(s->n, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
-              for (uint64_t i = lo; i < hi; i++) {
-                const uint64_t b = s->offsets[i];
-                const uint32_t L = (uint32_t)(s->offsets[i + 1] - b);
-                uint32_t ck = base_of[i];
-                if (L > 0 && class_is_heavy(c->ctab.data(), g, ck))
-                  for (uint32_t r = 0; r < k; r++)
-                    ck ^= c->ctab[g.off_cr + r * A + s->residues[b + class_pos(L, r, g.c0)]];
-                part[t][ck & g.smask]++;
-              }
-            });
-            for (unsigned t = 0; t < T; t++)
-              for (size_t x = 0; x < (size_t)S; x++)
-                pop[x] += part[t][x];
-          }
-          const double mx = *std::max_element(pop.begin(), pop.end());
-          if (best_max < 0 || mx < best_max) {
-            best_max = mx;
-            best_k = k;
-          }
-          if (mx <= slice_cap)
-            break;
-        }
-        g.k = best_k;
-      }
-    }
-    if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
-    g.ctab = c->d_ctab.p;
-  }
-  if (c->rows)          /* main part + one class part per class residue */
-    c->bloom_words = ((uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1)) *
-                     c->geom.rw_words * (ROW_WORD_BYTES / 8);
-  if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
-  if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
-  /* inverted polarity (bloompat.cc:54-57) for variants 0, 1; the row filter sets bits */
-  HIP_TRY(c, hipMemsetAsync(c->bloom.p, c->rows ? 0 : 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
-
-  {
-    /* positions in the verification stream (layout.h RefRec) */
-    std::vector<uint32_t> voff((size_t)s->n + 1);
-    uint64_t units = 0;
-    for (uint64_t i = 0; i < s->n; i++) {
-      /* a record of at most 64 bytes never straddles a 64-byte boundary, and no
-         header does: one memory request fetches it */
-      const uint64_t u = rec_units((uint32_t)(s->offsets[i + 1] - s->offsets[i]));
-      const uint64_t room = 4 - (units & 3);
-      if (std::min<uint64_t>(u, 4) > room)
-        units += room;
-      voff[i] = (uint32_t)units;
-      units += u;
-    }
-    units += 8;                 /* verify_candidate reads 64 bytes whatever the length */
-    if (units >> 32)
-      return fail(c, CMPR_EUNSUPPORTED, "reference set too large for 32-bit record positions");
-    if ((rc = dev_upload(c, c->voff2, voff.data(), std::max<size_t>((size_t)s->n, 1)))) return rc;
-    if ((rc = dev_alloc(c, c->rec2, std::max<size_t>((size_t)units * REC_UNIT, REC_UNIT)))) return rc;
-  }
-  if (s->n) {
-    BuildParams B{};
-    B.zob = c->zob.p;
-    B.A = A;
-    B.zpos = c->zpos;
-    B.n_v = n_v;
-    B.use_genes = c->opt.ignore_genes ? 0u : 1u;
-    B.voff = c->voff2.p;
-    B.res = c->res2.p;
-    B.off = c->off2.p;
-    B.v = c->v2.p;
-    B.j = c->j2.p;
-    B.n = s->n;
-    B.table = c->table.p;
-    B.slot_mask = c->slots - 1;
-    B.bloom = c->rows ? nullptr : c->bloom.p;
-    B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
-    B.sliced = c->sliced ? 1u : 0u;
-    B.geom = c->geom;
-    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
-    hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
-                       c->stream, B);
-    HIP_TRY(c, hipGetLastError());
-    if (c->rows) {
-      B.bloom = c->bloom.p;
-      hipLaunchKernelGGL(build_rows_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
-      HIP_TRY(c, hipGetLastError());
-    }
-  }
-  if (s->n) {
-    PackParams K{};
-    K.voff = c->voff2.p;
-    K.res = c->res2.p;
-    K.off = c->off2.p;
-    K.cnt = c->opt.ignore_counts ? nullptr : c->cnt2.p;
-    K.v = c->opt.ignore_genes ? nullptr : c->v2.p;
-    K.j = c->opt.ignore_genes ? nullptr : c->j2.p;
-    K.rep = c->rep2.p;
-    K.n = s->n;
-    K.out = c->rec2.p;
-    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
-    hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, K);
-    HIP_TRY(c, hipGetLastError());
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->have_ref = true;
-  return CMPR_OK;
-}
-
 static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
 {
   if (!c || !out)
@@ -919,10 +445,13 @@ static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, u
     std::string why;
     if ((rc = validate_view(c->opt, s, why)))
       return fail(c, rc, why);
+    /* upload + validation on the device (query_layout.hip) */
     uint32_t longest = 0;
     std::vector<double> tot;
-    if ((rc = scan_view(c->opt, s, longest, tot, why, (unsigned)c->host_threads)))
-      return fail(c, rc, why);
+    DevBuf<uint64_t> cnt_tmp;
+    struct Ct { DevBuf<uint64_t> &z; ~Ct() { z.release(); } } ctclean{cnt_tmp};
+    if ((rc = cmpr_upload_and_validate(c, s, res, off, v, j, rep, cnt_tmp, longest, tot)))
+      return rc;
     /* own Zobrist keys when no reference set is resident or it is too short */
     DevBuf<uint64_t> zob_own;
     struct Z { DevBuf<uint64_t> &z; ~Z() { z.release(); } } zclean{zob_own};
@@ -938,15 +467,6 @@ static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, u
       if ((rc = dev_upload(c, zob_own, z.data(), z.size()))) return rc;
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       zob = zob_own.p;
-    }
-    const uint64_t total = s->n ? s->offsets[s->n] : 0;
-    static const uint64_t zero_off[1] = {0};
-    if ((rc = dev_upload(c, res, s->residues, (size_t)total))) return rc;
-    if ((rc = dev_upload(c, off, s->n ? s->offsets : zero_off, (size_t)s->n + 1))) return rc;
-    if ((rc = dev_upload(c, rep, s->repertoire, (size_t)s->n))) return rc;
-    if (!c->opt.ignore_genes) {
-      if ((rc = dev_upload(c, v, s->v_gene, (size_t)s->n))) return rc;
-      if ((rc = dev_upload(c, j, s->j_gene, (size_t)s->n))) return rc;
     }
     uint64_t slots = 1;
     while (FILL_PERCENT * slots < 100 * s->n)
@@ -1432,7 +952,7 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
 {
   /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
   try {
-    return cmpr_set_reference_impl(c, s, longest_query);
+    return cmpr_set_reference_device(c, s, longest_query);
   } catch (const std::bad_alloc &) {
     return fail(c, CMPR_ENOMEM, "out of host memory");
   }

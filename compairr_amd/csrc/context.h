@@ -214,4 +214,15 @@ int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &wh
    all on the device (cmpr_set_queries) */
 int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s);
 
+/* query_layout.hip: the caller's arrays into the given device buffers, validated
+   there (what a host pass over the set would check); longest sequence and count
+   total per repertoire */
+int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uint8_t> &res,
+                             DevBuf<uint64_t> &off, DevBuf<uint32_t> &v, DevBuf<uint32_t> &j,
+                             DevBuf<uint32_t> &rep, DevBuf<uint64_t> &cnt, uint32_t &longest,
+                             std::vector<double> &rep_total);
+
+/* ref_index.hip: cmpr_set_reference */
+int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query);
+
 #endif

@@ -1,0 +1,510 @@
+/*
+ * ref_index.hip -- cmpr_set_reference on the device: upload of set 2, its
+ * validation, the geometry of the sliced filter (class positions, heavy classes,
+ * number of class residues), record positions, hash table, filter and records.
+ *
+ * What the reference does serially before its per-query loop (db_hash,
+ * db.cc:903-916; hash_init / bloom_init / hash_insert, overlap.cc:861-873,
+ * hashtable.cc:31-54) is one upload and a handful of kernels here; the host
+ * touches nothing per sequence, only histograms of a few thousand counters.
+ */
+#include "context.h"
+#include "kernels_rows.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace cmpr;
+
+namespace {
+
+inline uint32_t blocks_for(uint64_t n)
+{
+  return (uint32_t)std::max<uint64_t>(1, (n + 255) / 256);
+}
+
+template <typename T>
+struct Tmp {
+  DevBuf<T> b;
+  ~Tmp() { b.release(); }
+};
+
+/* lengths: one counter per length (LDS copy per workgroup when they fit) */
+__global__ void __launch_bounds__(256)
+length_hist_kernel(const uint64_t *off, uint64_t n, uint32_t nh, uint32_t *hist)
+{
+  extern __shared__ uint32_t h_lds[];
+  const bool lds = nh <= 8192;
+  if (lds) {
+    for (uint32_t k = threadIdx.x; k < nh; k += 256)
+      h_lds[k] = 0;
+    __syncthreads();
+  }
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const uint32_t L = (uint32_t)(off[i + 1] - off[i]);
+    atomicAdd((lds ? h_lds : hist) + min(L, nh - 1), 1u);
+  }
+  if (lds) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nh; k += 256)
+      if (h_lds[k])
+        atomicAdd(hist + k, h_lds[k]);
+  }
+}
+
+/* residue counts per position over a sample of the set (every stride-th sequence) */
+__global__ void __launch_bounds__(256)
+residue_sample_kernel(const uint8_t *res, const uint64_t *off, uint64_t n, uint64_t stride,
+                      uint32_t npos, uint32_t A, uint32_t *cnt)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i = k * stride;
+  if (i >= n)
+    return;
+  const uint64_t b = off[i];
+  const uint32_t L = (uint32_t)min((uint64_t)npos, off[i + 1] - b);
+  for (uint32_t p = 0; p < L; p++)
+    atomicAdd(cnt + (size_t)p * A + res[b + p], 1u);
+}
+
+/* (length, V, J) class key of every sequence and the population of its bucket */
+__global__ void __launch_bounds__(256)
+class_base_kernel(const uint64_t *off, const uint32_t *v, const uint32_t *j, uint64_t n,
+                  SliceGeom g, uint32_t genes, uint32_t *base_of, uint32_t *bucket)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint32_t L = (uint32_t)(off[i + 1] - off[i]);
+  const uint32_t b = class_base(g.ctab, g, genes != 0, L, genes ? v[i] : 0u, genes ? j[i] : 0u);
+  base_of[i] = b;
+  atomicAdd(bucket + (b >> (32 - HEAVY_BUCKETS_LOG2)), 1u);
+}
+
+/* sequences per slice if the heavy classes are split by k class residues */
+__global__ void __launch_bounds__(256)
+slice_population_kernel(const uint8_t *res, const uint64_t *off, const uint32_t *base_of, uint64_t n,
+                        SliceGeom g, uint32_t A, uint32_t k, uint32_t *pop)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint64_t b = off[i];
+  const uint32_t L = (uint32_t)(off[i + 1] - b);
+  uint32_t ck = base_of[i];
+  if (L > 0 && class_is_heavy(g.ctab, g, ck))
+    for (uint32_t r = 0; r < k; r++)
+      ck ^= g.ctab[g.off_cr + r * A + res[b + class_pos(L, r, g.c0)]];
+  atomicAdd(pop + (ck & g.smask), 1u);
+}
+
+/* 64-byte pieces of a sequence's record (layout.h RefRec): header + residues,
+   rounded up -- every record starts a 64-byte piece, so a verified hit of a
+   CDR3 costs one request */
+__global__ void __launch_bounds__(256)
+record_pieces_kernel(const uint64_t *off, uint64_t n, uint32_t *pieces)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n)
+    pieces[i] = (rec_units((uint32_t)(off[i + 1] - off[i])) + 3u) / 4u;
+}
+
+__global__ void __launch_bounds__(256)
+record_positions_kernel(const uint32_t *piece_pre, uint64_t n, uint32_t *voff)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n)
+    voff[i] = piece_pre[i] * 4u;              /* in 16-byte units */
+}
+
+}  // namespace
+
+int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  std::string why;
+  int rc = validate_view(c->opt, s, why);
+  if (rc)
+    return fail(c, rc, why);
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->have_ref = false;
+  c->have_q = false;
+
+  /* ---- the set as the caller has it, validated on the device ---- */
+  uint32_t longest = 0;
+  if ((rc = cmpr_upload_and_validate(c, s, c->res2, c->off2, c->v2, c->j2, c->rep2, c->cnt2, longest,
+                                     c->tot2)))
+    return rc;
+  c->longest2 = longest;
+  c->n2 = s->n;
+  c->R2 = s->n_repertoires;
+
+  /* Zobrist table for max(longest1, longest2) + 3 positions (overlap.cc:840) */
+  const uint32_t A = (uint32_t)c->opt.alphabet_size;
+  c->zpos = std::max(longest, longest_query) + EXTRA_POSITIONS;
+  const uint32_t n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+  const uint32_t n_j = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
+  {
+    std::vector<uint64_t> z((size_t)A * c->zpos + n_v + n_j);
+    SplitMix64 rng(0x636f6d7061697272ull);   /* "compairr" */
+    for (auto &x : z)
+      x = rng.next();
+    rc = dev_upload(c, c->zob, z.data(), z.size());
+    if (rc)
+      return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   /* host vectors go away */
+  }
+
+  /* table: smallest power of two with fill <= 70 % (hash_init, hashtable.cc:31-54);
+     Bloom: one byte per slot (bloom_init(tablesize), overlap.cc:863) */
+  c->slots = 1;
+  while (FILL_PERCENT * c->slots < 100 * s->n)
+    c->slots <<= 1;
+  uint64_t bloom_bytes = std::max<uint64_t>(c->slots, 8);
+  /* results do not depend on the table size (every hit is verified), only the
+     length of the probe chains does: HBM is plentiful, round trips are not */
+  c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
+  /* Kernel variant: the row filter (2) for amino acids -- one word read answers
+     the 19 substitutions of a position; nucleotides (3 per position, and L + 1
+     entries per sequence to pay for them) keep the per-variant filter (1). */
+  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 ? 2 : 1);
+  /* The staged layouts keep a slice, the Zobrist tables and the wave queues in
+     LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
+     no longer fits and the un-sliced filter is probed where it lies (variant 0). */
+  c->sliced = variant >= 1;
+  c->rows = variant == 2;
+  int64_t swl = c->slice_words_log2;
+  if (swl < 0)
+    swl = SLICE_WORDS_LOG2;
+  /* variant 2: the largest slice in 32-byte words -- 40 KiB by default (a ring of
+     two slices + tables + the queues of 16 waves in one workgroup per CU), a power
+     of two on request */
+  uint64_t row_max_words = c->slice_words_log2 < 0
+      ? MAX_ROW_SLICE_WORDS : std::min<uint64_t>(1ull << c->slice_words_log2, MAX_ROW_SLICE_WORDS);
+  if (c->sliced) {
+    const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
+    /* everything but the slice(s), with the fewest waves a workgroup may have */
+    const size_t fixed = zrow * c->zpos * sizeof(uint64_t) +
+                         4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
+                         MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
+                         64 * sizeof(TileRef) + (c->rows ? RING * (sizeof(RingSlot) + 64 * sizeof(TileRef)) : 0);
+    if (c->rows && c->slice_words_log2 < 0) {
+      /* the default slice leaves room for the queues of 16 waves; long sequences: a
+         smaller slice next to the bigger Zobrist table */
+      const size_t fixed16 = fixed + 12 * sizeof(WaveQueue);
+      const size_t room = fixed16 < 160 * 1024 ? 160 * 1024 - fixed16 : 0;
+      row_max_words = std::min<uint64_t>(row_max_words, room / (RING * ROW_WORD_BYTES));
+      row_max_words -= row_max_words % 32;               /* whole KiB: LDS-DMA pieces */
+    }
+    const size_t need = fixed + (c->rows ? RING * (size_t)row_max_words * ROW_WORD_BYTES
+                                         : ((size_t)8 << swl));
+    if (need > 160 * 1024 || (c->rows && row_max_words < 1)) {
+      c->sliced = false;
+      c->rows = false;
+    }
+  }
+  const uint64_t entries = (s->n ? s->offsets[s->n] : 0) + s->n;   /* row filter: L + 1 per sequence */
+  if (c->rows) {
+    /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a
+       word then has ~40 % of its bits set and a test of eight of them passes by
+       chance ~6e-4 of the time -- the optimum of a Bloom filter at 16 bits per
+       entry), x 2^delta */
+    bloom_bytes = std::max<uint64_t>(entries * 2, ROW_WORD_BYTES);
+    const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
+    if (delta > 0)
+      bloom_bytes <<= delta;
+    else if (delta < 0)
+      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), ROW_WORD_BYTES);
+    /* S slices (a power of two: sibling slices are XORs of slice numbers) of
+       rw_words <= row_max_words words each */
+    uint64_t S = 1;
+    while (S * row_max_words * ROW_WORD_BYTES * 17 / 16 < bloom_bytes)    /* (up to 6 % denser) */
+      S <<= 1;
+    uint64_t words = (bloom_bytes + S * ROW_WORD_BYTES - 1) / (S * ROW_WORD_BYTES);
+    if (words >= 64)
+      words = (words + 31) / 32 * 32;                  /* whole KiB: LDS-DMA pieces */
+    words = std::max<uint64_t>(1, std::min<uint64_t>(words, row_max_words));
+    if (S > (1ull << 31))
+      return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
+    c->geom.rw_words = (uint32_t)words;
+    c->geom.words_log2 = 0;
+    c->bloom_words = S * words * (ROW_WORD_BYTES / 8);       /* 8-byte units; + the class parts, below */
+    c->geom.smask = (uint32_t)(S - 1);
+    /* class parts (layout.h row_slice): each holds one entry per split sequence,
+       the main part L + 1 - K per sequence: S n / entries slices, a power of two */
+    uint64_t Sc = 1;
+    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1))
+      Sc <<= 1;
+    c->geom.cmask = (uint32_t)(Sc - 1);
+  } else {
+    /* The LDS-staged layout pays nothing for a sparser filter (a slice is 32 KiB
+       whatever the total), so it takes 4 bytes per table slot: with the 2^20
+       pattern space that leaves almost only true positives for the table walk. */
+    const int64_t delta = c->bloom_log2_delta == -100 ? (c->sliced ? 2 : 0)
+                                                      : c->bloom_log2_delta;
+    if (delta > 0)
+      bloom_bytes <<= delta;
+    else if (delta < 0)
+      bloom_bytes = std::max<uint64_t>(bloom_bytes >> (-delta), 8);
+    if (bloom_bytes > (1ull << 32))
+      return fail(c, CMPR_EUNSUPPORTED, "Bloom filter larger than 4 GiB");
+    c->bloom_words = bloom_bytes / 8;
+    c->geom.rw_words = 0;
+  }
+
+
+  /* ---- variants 1, 2: cut the filter into class-keyed slices (layout.h) ---- */
+  if (c->sliced) {
+    SliceGeom &g = c->geom;
+    if (!c->rows) {
+      uint32_t wl = 0;
+      while ((1ull << (wl + 1)) <= c->bloom_words && wl + 1 <= (uint32_t)swl)
+        wl++;
+      g.words_log2 = wl;
+      g.smask = (uint32_t)(c->bloom_words >> wl) - 1;
+    }
+    g.ncl = c->zpos + 1;
+    g.off_cv = g.ncl;
+    g.off_cj = g.off_cv + n_v;
+    g.off_cr = g.off_cj + n_j;
+    g.off_hv = g.off_cr + MAX_CLASS_RES * A;
+    c->ctab.assign((size_t)g.off_hv + HEAVY_WORDS, 0);
+    SplitMix64 crng(0x736c69636573ull);     /* "slices" */
+    for (size_t i = 0; i < g.off_hv; i++)
+      c->ctab[i] = (uint32_t)(crng.next() >> 32);
+    /* the tables go to the device now (heavy bitmap still empty): the kernels below
+       read them there */
+    if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
+    g.ctab = c->d_ctab.p;
+    const bool genes = !c->opt.ignore_genes;
+    const uint64_t S = (uint64_t)g.smask + 1;
+    const double slice_bits = (double)(64ull << g.words_log2);
+    /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
+       bits per key, false-positive rate <= 6e-3 there and far less elsewhere.
+       Row filter: sequences per slice at 24 entries per word (1.5 x the average). */
+    const double slice_cap = c->rows
+        ? (double)g.rw_words * 24.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
+        : slice_bits / 12.0;
+    g.k = 0;
+    /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
+       (<= 5th-percentile length of set 2) and be informative (a conserved
+       position splits nothing); the closer to the start, the more insertion /
+       deletion variants keep their class residues in place.  So: the first
+       window of max_class_res positions whose residue entropy in set 2 is at
+       least 70 % of the maximum. */
+    g.c0 = 0;
+    if (s->n > 0) {
+      const uint32_t nh = longest + 2;
+      Tmp<uint32_t> d_hist;
+      if ((rc = dev_alloc(c, d_hist.b, nh))) return rc;
+      HIP_TRY(c, hipMemsetAsync(d_hist.b.p, 0, nh * sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(length_hist_kernel, dim3(blocks_for(s->n)), dim3(256),
+                         nh <= 8192 ? nh * sizeof(uint32_t) : 0, c->stream, c->off2.p, s->n, nh,
+                         d_hist.b.p);
+      HIP_TRY(c, hipGetLastError());
+      std::vector<uint32_t> hist(nh);
+      HIP_TRY(c, hipMemcpyAsync(hist.data(), d_hist.b.p, nh * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      uint64_t acc = 0;
+      uint32_t l5 = longest;
+      for (uint32_t L = 0; L <= longest; L++) {
+        acc += hist[L];
+        if (acc * 20 >= s->n) {
+          l5 = L;
+          break;
+        }
+      }
+      const uint32_t mcr = max_class_res(A);
+      if (l5 > mcr) {
+        const uint32_t npos = l5;
+        const uint64_t stride = std::max<uint64_t>(1, s->n / 200000);   /* a sample is enough */
+        Tmp<uint32_t> d_cnt;
+        if ((rc = dev_alloc(c, d_cnt.b, (size_t)npos * A))) return rc;
+        HIP_TRY(c, hipMemsetAsync(d_cnt.b.p, 0, (size_t)npos * A * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(residue_sample_kernel, dim3(blocks_for((s->n + stride - 1) / stride)),
+                           dim3(256), 0, c->stream, c->res2.p, c->off2.p, s->n, stride, npos, A,
+                           d_cnt.b.p);
+        HIP_TRY(c, hipGetLastError());
+        std::vector<uint32_t> cnt((size_t)npos * A);
+        HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt.b.p, cnt.size() * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<double> ent(npos, 0.0);
+        for (uint32_t p = 0; p < npos; p++) {
+          double tot = 0;
+          for (uint32_t r = 0; r < A; r++)
+            tot += (double)cnt[(size_t)p * A + r];
+          for (uint32_t r = 0; r < A && tot > 0; r++) {
+            const double q = (double)cnt[(size_t)p * A + r] / tot;
+            if (q > 0)
+              ent[p] -= q * std::log2(q);
+          }
+        }
+        const double need = 0.7 * std::log2((double)A);
+        uint32_t best = (l5 - mcr) / 2;
+        for (uint32_t c0 = 0; c0 + mcr <= npos; c0++) {
+          bool ok = true;
+          for (uint32_t i = 0; i < mcr; i++)
+            ok = ok && ent[c0 + i] >= need;
+          if (ok) {
+            best = c0;
+            break;
+          }
+        }
+        g.c0 = best;
+      }
+    }
+    if (c->class_anchor >= 0)
+      g.c0 = (uint32_t)c->class_anchor;
+    if (S > 1 && s->n > 0) {
+      /* population of every (length, V, J) class bucket */
+      const size_t nb = (size_t)1 << HEAVY_BUCKETS_LOG2;
+      Tmp<uint32_t> d_bucket, d_base, d_pop;
+      if ((rc = dev_alloc(c, d_bucket.b, nb))) return rc;
+      if ((rc = dev_alloc(c, d_base.b, (size_t)s->n))) return rc;
+      HIP_TRY(c, hipMemsetAsync(d_bucket.b.p, 0, nb * sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(class_base_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, c->off2.p,
+                         c->v2.p, c->j2.p, s->n, g, genes ? 1u : 0u, d_base.b.p, d_bucket.b.p);
+      HIP_TRY(c, hipGetLastError());
+      std::vector<uint32_t> bucket(nb);
+      HIP_TRY(c, hipMemcpyAsync(bucket.data(), d_bucket.b.p, nb * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      /* heavy = would take more than half of a slice's budget on its own */
+      /* (row filter: an eighth -- its 8-bit tests are sensitive to an overfull slice,
+         and a split class costs its queries one cheap class row per class residue) */
+      const double thr = c->heavy_threshold >= 0 ? (double)c->heavy_threshold
+                                                 : slice_cap / (c->rows ? 8 : 2);
+      bool any_heavy = false;
+      for (uint32_t b = 0; b < bucket.size(); b++)
+        if ((double)bucket[b] > thr) {
+          c->ctab[g.off_hv + (b >> 5)] |= 1u << (b & 31);
+          any_heavy = true;
+        }
+      HIP_TRY(c, hipMemcpyAsync(c->d_ctab.p + g.off_hv, c->ctab.data() + g.off_hv,
+                                HEAVY_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      if (c->class_residues >= 0) {
+        g.k = (uint32_t)c->class_residues;
+      } else if (any_heavy) {
+        /* K = fewest class residues that bring the fullest slice under the cap;
+           every one costs the heavy queries one more row elsewhere */
+        if ((rc = dev_alloc(c, d_pop.b, (size_t)S))) return rc;
+        std::vector<uint32_t> pop((size_t)S);
+        double best_max = -1;
+        uint32_t best_k = 1;
+        for (uint32_t k = 1; k <= max_class_res(A); k++) {
+          HIP_TRY(c, hipMemsetAsync(d_pop.b.p, 0, (size_t)S * sizeof(uint32_t), c->stream));
+          hipLaunchKernelGGL(slice_population_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
+                             c->res2.p, c->off2.p, d_base.b.p, s->n, g, A, k, d_pop.b.p);
+          HIP_TRY(c, hipGetLastError());
+          HIP_TRY(c, hipMemcpyAsync(pop.data(), d_pop.b.p, (size_t)S * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+          const double mx = *std::max_element(pop.begin(), pop.end());
+          if (best_max < 0 || mx < best_max) {
+            best_max = mx;
+            best_k = k;
+          }
+          if (mx <= slice_cap)
+            break;
+        }
+        g.k = best_k;
+      }
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  if (c->rows)          /* main part + one class part per class residue */
+    c->bloom_words = ((uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1)) *
+                     c->geom.rw_words * (ROW_WORD_BYTES / 8);
+  if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
+  if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
+  /* inverted polarity (bloompat.cc:54-57) for variants 0, 1; the row filter sets bits */
+  HIP_TRY(c, hipMemsetAsync(c->bloom.p, c->rows ? 0 : 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
+
+  {
+    /* positions in the verification stream (layout.h RefRec): every record starts a
+       64-byte piece -- an exclusive scan of the pieces per record */
+    Tmp<uint32_t> pieces, pre;
+    Tmp<char> tmp;
+    uint64_t units = 0;
+    if ((rc = dev_alloc(c, c->voff2, std::max<size_t>((size_t)s->n, 1)))) return rc;
+    if (s->n) {
+      if ((rc = dev_alloc(c, pieces.b, (size_t)s->n))) return rc;
+      if ((rc = dev_alloc(c, pre.b, (size_t)s->n))) return rc;
+      hipLaunchKernelGGL(record_pieces_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
+                         c->off2.p, s->n, pieces.b.p);
+      HIP_TRY(c, hipGetLastError());
+      size_t tb = 0;
+      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.b.p, pre.b.p, (int)s->n, c->stream);
+      if ((rc = dev_alloc(c, tmp.b, tb))) return rc;
+      HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.b.p, tb, pieces.b.p, pre.b.p, (int)s->n, c->stream));
+      hipLaunchKernelGGL(record_positions_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
+                         pre.b.p, s->n, c->voff2.p);
+      HIP_TRY(c, hipGetLastError());
+      uint32_t lastp = 0, lastn = 0;
+      HIP_TRY(c, hipMemcpyAsync(&lastp, pre.b.p + (s->n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&lastn, pieces.b.p + (s->n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      units = ((uint64_t)lastp + lastn) * 4;
+    }
+    units += 8;                 /* verify_candidate reads 64 bytes whatever the length */
+    if (units >> 32)
+      return fail(c, CMPR_EUNSUPPORTED, "reference set too large for 32-bit record positions");
+    if ((rc = dev_alloc(c, c->rec2, std::max<size_t>((size_t)units * REC_UNIT, REC_UNIT)))) return rc;
+  }
+  if (s->n) {
+    BuildParams B{};
+    B.zob = c->zob.p;
+    B.A = A;
+    B.zpos = c->zpos;
+    B.n_v = n_v;
+    B.use_genes = c->opt.ignore_genes ? 0u : 1u;
+    B.voff = c->voff2.p;
+    B.res = c->res2.p;
+    B.off = c->off2.p;
+    B.v = c->v2.p;
+    B.j = c->j2.p;
+    B.n = s->n;
+    B.table = c->table.p;
+    B.slot_mask = c->slots - 1;
+    B.bloom = c->rows ? nullptr : c->bloom.p;
+    B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
+    B.sliced = c->sliced ? 1u : 0u;
+    B.geom = c->geom;
+    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+    hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
+                       c->stream, B);
+    HIP_TRY(c, hipGetLastError());
+    if (c->rows) {
+      B.bloom = c->bloom.p;
+      hipLaunchKernelGGL(build_rows_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
+  if (s->n) {
+    PackParams K{};
+    K.voff = c->voff2.p;
+    K.res = c->res2.p;
+    K.off = c->off2.p;
+    K.cnt = c->opt.ignore_counts ? nullptr : c->cnt2.p;
+    K.v = c->opt.ignore_genes ? nullptr : c->v2.p;
+    K.j = c->opt.ignore_genes ? nullptr : c->j2.p;
+    K.rep = c->rep2.p;
+    K.n = s->n;
+    K.out = c->rec2.p;
+    const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, K);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_ref = true;
+  return CMPR_OK;
+}
+
