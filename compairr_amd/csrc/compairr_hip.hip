@@ -544,7 +544,7 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
      does not fit is resolved inline by the probe kernel */
   {
     const uint64_t total = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
-                                               : std::max<uint64_t>(1u << 20, 4 * c->n1);
+                                               : std::max<uint64_t>(1u << 20, (c->rows && c->opt.differences == 2 ? 32 : 4) * c->n1);
     const uint64_t S = (uint64_t)c->pos_segments;
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
     if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;

@@ -171,8 +171,9 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
   c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
   /* Kernel variant: the row filter (2) for amino acids -- one word read answers
      the 19 substitutions of a position; nucleotides (3 per position, and L + 1
-     entries per sequence to pay for them) keep the per-variant filter (1). */
-  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 ? 2 : 1);
+     entries per sequence to pay for them) and d = 0 (one test per query, no rows
+     at all) keep the per-variant filter (1). */
+  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 && c->opt.differences >= 1 ? 2 : 1);
   /* The staged layouts keep a slice, the Zobrist tables and the wave queues in
      LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
      no longer fits and the un-sliced filter is probed where it lies (variant 0). */

@@ -414,6 +414,37 @@ def test_full_size_properties_10m(indels):
     assert int(mf.sum()) == stf.matches == st.matches
 
 
+def test_full_size_properties_cfg5():
+    """BASELINE config 5 at the size one of its 8 GPUs sees: 100M nucleotide
+    references (--cdr3 -n), the per-GPU shard of 12.5M queries, d = 2,
+    --ignore-genes.  No oracle at this size: query-shard linearity (what the
+    multi-GPU reduce relies on), the closed-form count of variant tests, and with -f
+    the matrix total = number of pairs.  (Symmetry would need a 100M-query run.)"""
+    n2, n1 = 100_000_000, 12_500_000
+    b = synth.make_set(n2, 4, prefix="B", pool_size=n2 // 4, nucleotides=True)
+    a = synth.make_set(n1, 3, prefix="A", pool_size=n2 // 4, nucleotides=True)
+    o = Options(differences=2, nucleotides=True, ignore_genes=True, **FULL)
+    with HipOverlap(o) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        full = h.overlap_matrix()
+        st = h.stats()
+        L = a.lengths.astype(np.int64)
+        assert st.variants == int((1 + 3 * L + 9 * L * (L - 1) // 2).sum())
+        assert st.matches > 0 and st.hash_equal >= st.matches
+        parts = []
+        for k in range(2):
+            h.set_queries(a.subset(slice(k * n1 // 2, (k + 1) * n1 // 2)))
+            parts.append(h.overlap_matrix())
+        assert np.array_equal(parts[0] + parts[1], full)
+    with HipOverlap(Options(differences=2, nucleotides=True, ignore_genes=True,
+                            ignore_counts=True, **FULL)) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        mf = h.overlap_matrix()
+        assert int(mf.sum()) == h.stats().matches == st.matches
+
+
 def test_kernel_times_ring():
     """cmpr_get_kernel_times: one HIP-event pair per launch, the last 64 kept."""
     a = synth.make_set(20000, 3, prefix="A", pool_size=3000)
