@@ -89,7 +89,18 @@ $(CLI): $(HOST_SRC) $(HOST_HDR) compairr_amd/host/main/compairr_main.cc
 
 oracle:
 	$(MAKE) -C oracle all
-	$(MAKE) tests/bin/compairr_oracle_cli
+	$(MAKE) tests/bin/compairr_oracle_cli tests/bin/compairr_oracle_cli_asan
+
+asan: tests/bin/compairr_oracle_cli_asan
+
+# the same TEST binary under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only:
+# SURVEY section 5; the golden cases run through it in the CPU suite)
+SAN = -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -g -O1
+tests/bin/compairr_oracle_cli_asan: $(HOST_CORE) $(HOST_HDR) tests/oracle_cli_main.cc oracle/compairr_oracle.c oracle/compairr_oracle.h
+	@mkdir -p tests/bin
+	gcc $(SAN) -std=c11 -pthread -c -o tests/bin/compairr_oracle_asan.o oracle/compairr_oracle.c
+	$(CXX) $(SAN) -std=c++11 -Wall -Wextra -pedantic -Iinclude -Icompairr_amd/host -Ioracle -o $@ $(HOST_CORE) \
+	    tests/oracle_cli_main.cc tests/bin/compairr_oracle_asan.o -lpthread
 
 # host logic + oracle backend: a TEST binary (lives under tests/, never shipped)
 tests/bin/compairr_oracle_cli: $(HOST_CORE) $(HOST_HDR) tests/oracle_cli_main.cc oracle/compairr_oracle.c oracle/compairr_oracle.h
@@ -102,4 +113,4 @@ clean:
 	rm -rf compairr_amd/lib bin tests/bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean
+.PHONY: all lib cli oracle asan timing ablation clean

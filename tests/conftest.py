@@ -18,6 +18,7 @@ ARTIFACTS = [
     "bin/compairr",
     "oracle/liboracle.so",
     "tests/bin/compairr_oracle_cli",
+    "tests/bin/compairr_oracle_cli_asan",
 ]
 
 

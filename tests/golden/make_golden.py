@@ -119,6 +119,30 @@ def random_files():
     return out
 
 
+def late_file(n, seed, prefix):
+    """A file of ~450 KB whose repertoire ids, V and J genes make their FIRST
+    appearance spread over the whole file, i.e. in different 64-KiB ranges of a
+    threaded reader: first-appearance numbering (db.cc:510-520, 592-631) defines
+    the matrix layout, so a reader that cuts the file into ranges has to merge
+    them in file order."""
+    import numpy as np
+    s = synth.make_set(n, seed, pool_seed=4242, prefix=prefix, n_repertoires=14, pool_size=3500)
+    rng = np.random.default_rng(seed)
+    # a sequence may only appear once "its" repertoire / genes are unlocked: rank
+    # every row by the latest of its three ranks, then order rows by that rank
+    rank = np.maximum.reduce([s.repertoire.astype(np.int64) * n // 14,
+                              (s.v_gene.astype(np.int64) % 20) * n // 20,
+                              s.j_gene.astype(np.int64) * n // 13])
+    order = np.argsort(rank + rng.integers(0, n // 40, size=n), kind="stable")
+    lines = []
+    for k, i in enumerate(order):
+        seq = "".join(s.alphabet[c] for c in s.residues[int(s.offsets[i]):int(s.offsets[i + 1])])
+        lines.append("%s%02d\t%s%d\t%d\t%s\t%s\t%s" % (
+            prefix, int(s.repertoire[i]), prefix.lower(), k, int(s.count[i]),
+            s.v_names[int(s.v_gene[i])], s.j_names[int(s.j_gene[i])], seq))
+    return rows(lines, header="repertoire_id\tsequence_id\tduplicate_count\tv_call\tj_call\tjunction_aa\n")
+
+
 def cases():
     c = []
 
@@ -250,6 +274,12 @@ def cases():
             add("c_%s_%s" % (fam, tag), (d + n).strip(), [fam + ".tsv"], cmd="-c")
         add("c_%s_d1i_g_t3" % fam, ("-d 1 -i -g -t 3" + n).strip(), [fam + ".tsv"], cmd="-c")
         add("c_%s_d2_g" % fam, ("-d 2 -g" + n).strip(), [fam + ".tsv"], cmd="-c")
+    # (g) files of several 64-KiB reader ranges, ids and genes appearing late (db.cc:510-520):
+    #     the threaded reader's merge, at -t 1 / 3 / 8
+    for t in (1, 3, 8):
+        add("late_aa_d1i_t%d" % t, "-d 1 -i -t %d" % t, ["late_a.tsv", "late_b.tsv"])
+    add("late_aa_d1_self_t8", "-d 1 -t 8", ["late_b.tsv"])
+    add("late_aa_d0_g_t3", "-g -t 3 -s min", ["late_b.tsv", "late_a.tsv"])
     add("err_c_two_files", "-d 1", ["seta.tsv", "setb.tsv"], "exit 1", cmd="-c")
     add("err_c_pairs", "-d 1", ["seta.tsv"], "exit 1", cmd="-c", pairs=True)
     add("err_c_alternative", "-d 1 -a", ["seta.tsv"], "exit 1", cmd="-c")
@@ -278,6 +308,10 @@ def main():
     for name, (s, nt) in random_files().items():
         # both junction and junction_aa columns are not needed: one file per alphabet
         s.write_tsv(os.path.join(INPUTS, name), nucleotides=nt)
+
+    for name, (n, seed, prefix) in {"late_a.tsv": (11000, 71, "A"), "late_b.tsv": (10000, 72, "B")}.items():
+        with open(os.path.join(INPUTS, name), "w", newline="") as fh:
+            fh.write(late_file(n, seed, prefix))
 
     manifest = []
     for case in cases():

@@ -30,6 +30,21 @@ def test_oracle_cli_matches_reference(case, tmp_path):
         assert sorted_pairs(pairs) == expected_pairs_of(case)
 
 
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_host_code_under_sanitizers(case, tmp_path):
+    """The host program (option table, threaded AIRR-TSV reader, matrix / pairs /
+    cluster output) + the oracle backend built with -fsanitize=address,undefined
+    (make asan): every golden case once more, and no report from either sanitizer."""
+    log = str(tmp_path / "log.txt")
+    pairs = str(tmp_path / "pairs.tsv")
+    p = run_cli("tests/bin/compairr_oracle_cli_asan", case, log=log, pairs=pairs, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert "AddressSanitizer" not in err and "runtime error" not in err and "LeakSanitizer" not in err, err[-3000:]
+    assert p.returncode == case["exit"], err[-2000:]
+    if case["exit"] == 0:
+        assert p.stdout == expected_of(case)
+
+
 def test_reference_own_golden_file():
     """test/test.sh:9-11 of the reference: -m seta.tsv setb.tsv -d 1 -i."""
     case = next(c for c in CASES if c["name"] == "ref_test_sh")
