@@ -346,15 +346,18 @@ probe_rows_kernel(const ProbeParams P)
      length and the residues of the first block; passes 1, 2 -- the shifted hash
      instead; class-row blocks -- per item the row's blanked hash, the query's slot
      in pass 0 (~0: padding) and its residue | position << 8 */
+  constexpr uint32_t TDW = 6;                 /* residue dwords that travel with a tile: 24 positions */
   struct TileData {
     uint64_t a;
-    uint32_t b, c, d;
+    uint32_t b, c;
+    uint32_t r0, r1, r2, r3, r4, r5;
   };
   auto load_tile_data = [&](uint32_t len, uint32_t nvalid, uint32_t res_base, uint32_t t,
                             uint32_t tpass) -> TileData {
     TileData x;
     x.a = 0;
-    x.b = x.c = x.d = 0;
+    x.b = x.c = 0;
+    x.r0 = x.r1 = x.r2 = x.r3 = x.r4 = x.r5 = 0;
     const bool valid = lane < nvalid;
     if (tpass >= 3) {
       /* a block of 64 class-row items, from item res_base on */
@@ -368,11 +371,17 @@ probe_rows_kernel(const ProbeParams P)
         x.a = tpass == 1 ? P.qhins[slot] : tpass == 2 ? P.qhdel[slot] : P.qgh[slot];
         x.b = P.qlen[slot];
       }
+      /* the residues of its first 24 positions: the rows then issue no load of
+         their own (vmcnt retires in order -- a wait for one would also wait for
+         the next tile's data, requested before) */
       const uint32_t nd = (len + 3u) >> 2;
-      if (nd) {
-        x.c = P.qres[res_base + lane];
-        x.d = P.qres[res_base + (nd > 1u ? WAVE : 0u) + lane];
-      }
+      const uint32_t *qp = P.qres + res_base + lane;
+      if (nd > 0) x.r0 = qp[0];
+      if (nd > 1) x.r1 = qp[WAVE];
+      if (nd > 2) x.r2 = qp[2 * WAVE];
+      if (nd > 3) x.r3 = qp[3 * WAVE];
+      if (nd > 4) x.r4 = qp[4 * WAVE];
+      if (nd > 5) x.r5 = qp[5 * WAVE];
     }
     return x;
   };
@@ -443,7 +452,9 @@ probe_rows_kernel(const ProbeParams P)
   cur_c.b = cur_c.k = nxt_c.b = nxt_c.k = 0;
   TileData cur, nxt;
   cur.a = nxt.a = 0;
-  cur.b = cur.c = cur.d = nxt.b = nxt.c = nxt.d = 0;
+  cur.b = cur.c = nxt.b = nxt.c = 0;
+  cur.r0 = cur.r1 = cur.r2 = cur.r3 = cur.r4 = cur.r5 = 0;
+  nxt.r0 = nxt.r1 = nxt.r2 = nxt.r3 = nxt.r4 = nxt.r5 = 0;
   bool nxt_loaded = false;
 
   for (;;) {
@@ -685,20 +696,35 @@ probe_rows_kernel(const ProbeParams P)
           const uint32_t nd = (L + 3u) >> 2;
           /* the residues of positions p0 .. p0 + RB - 1 lie in two dwords (RB = 6:
              p0 % 4 is 0 or 2; RB = 8: aligned); requested one block ahead */
-          uint32_t dn0 = 0, dn1 = 0;
-          auto request = [&](uint32_t p0) {
-            const uint32_t w0 = p0 >> 2;
-            dn0 = qr[w0 * WAVE];
-            dn1 = qr[(w0 + 1u < nd ? w0 + 1u : w0) * WAVE];
-          };
-          dn0 = cur.c;                       /* block 0 came with the tile's data */
-          dn1 = cur.d;
+          /* the residues travel with the tile's data, 24 positions at a time: six
+             dwords used as one shift register, the block's residues always in the low
+             bytes of the first (no indexing, no load inside the rows; sequences longer
+             than 24 refill it where their residues lie) */
+          uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < L; p0 += RB) {
-            const uint64_t rr = (((uint64_t)dn1 << 32) | dn0) >> ((p0 & 3u) * 8u);
-            if (p0 + RB < L)
-              request(p0 + RB);
+            if (p0 && p0 % (4u * TDW) == 0) {
+              const uint32_t w0 = p0 >> 2;
+              s0 = qr[w0 * WAVE];
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+            }
+            const uint64_t rr = ((uint64_t)s1 << 32) | s0;
+            if constexpr (RB == 4) {
+              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+            } else {
+              constexpr uint32_t SH = 8u * (RB & 3);
+              s0 = __builtin_amdgcn_alignbit(s1, s0, SH);
+              s1 = __builtin_amdgcn_alignbit(s2, s1, SH);
+              s2 = __builtin_amdgcn_alignbit(s3, s2, SH);
+              s3 = __builtin_amdgcn_alignbit(s4, s3, SH);
+              s4 = __builtin_amdgcn_alignbit(s5, s4, SH);
+              s5 >>= SH;
+            }
             /* class positions among the rows of the block (wave-uniform bits) */
             uint32_t cbits = 0;
             if (K) {
@@ -835,20 +861,24 @@ probe_rows_kernel(const ProbeParams P)
           }
         }
       } else if (tpass >= 3 && tpass != 0xffu) {
-        /* ---- substitution rows at class positions (heavy queries only): 64 items of
-                the chunk's slice of class part pass - 3; the row's position comes
-                with the item ---- */
+        /* ---- items: rows and variants that are not filed under the slice staged for
+                their tile, 64 of them per block, grouped by the slice they ARE filed
+                under (query_layout.hip for_each_item): the substitution row of a class
+                position (K_SUB) and the insertion row blanked at one (K_INS), in that
+                position's class part; a deletion variant (K_DEL), a whole sequence
+                looked up by its code-A entry in the main part ---- */
         if (D >= 1) {
-          const uint32_t p = cur.c >> 8;
+          const uint32_t kind = cur.c >> 24, p = (cur.c >> 8) & 0xffffu;
           const RowWord w = fetch_own(cW);
-          uint32_t x = row_bits(w, cW) & AMASK & ~(1u << cr) & vmask;
-          nvar += (uint64_t)(A - 1);
+          const uint32_t bits = row_bits(w, cW);
+          uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << cr)) & vmask;
+          nvar += kind == K_DEL ? 1ull : (cr == 31u ? (uint64_t)A : (uint64_t)(A - 1));
           const uint32_t za = zl_addr + ZS * p * 8u;
           while (__ballot(x != 0)) {
             const bool pos = x != 0;
-            const uint32_t v = pos ? (uint32_t)__ffs((int)x) - 1u : 0u;
-            const uint64_t hv = cW ^ lds_u64(za + v * 8u);
-            s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB, p, v), 0);
+            const uint32_t v = (pos && kind != K_DEL) ? (uint32_t)__ffs((int)x) - 1u : 0u;
+            const uint64_t hv = kind == K_DEL ? cW : cW ^ lds_u64(za + v * 8u);
+            s_push<GENES, INLINE>(W, pos, hv, pack_a(kind, p, v), 0);
             x &= x - 1u;
           }
         }
@@ -859,24 +889,47 @@ probe_rows_kernel(const ProbeParams P)
              base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
            and its rows are filed under base(t) ^ (class residues of t other than
            the blanked position).  Most of them fall into the slice staged for
-           this pass; a lane whose row lands elsewhere reads the filter where it
-           lies. */
+           this pass; what does not is an item of a later pass (query_layout.hip
+           for_each_item) or, rarely, read where it lies. */
         const uint32_t cl_L = P.geom.ctab[L];
         const uint32_t qck = P.qck[W.qslot];     /* the query's class key */
+        /* residue of a wave-uniform position: from the tile's data (a select chain kept
+           opaque, or the compiler turns it into an indexed read of a scratch copy) */
+        auto res_reg = [&](uint32_t pp) -> uint32_t {
+          if (pp >= 4u * TDW)
+            return res_at(pp);
+          const uint32_t wq = pp >> 2;
+          uint32_t x = cur.r0;
+          asm volatile("" : "+v"(x));
+          x = wq == 1u ? cur.r1 : x;
+          asm volatile("" : "+v"(x));
+          x = wq == 2u ? cur.r2 : x;
+          asm volatile("" : "+v"(x));
+          x = wq == 3u ? cur.r3 : x;
+          asm volatile("" : "+v"(x));
+          x = wq == 4u ? cur.r4 : x;
+          asm volatile("" : "+v"(x));
+          x = wq == 5u ? cur.r5 : x;
+          return (x >> ((pp & 3u) * 8u)) & 0xffu;
+        };
         uint32_t cbase = 0;                      /* XOR_i CR[i][q[m_i]], heavy tiles */
 #pragma unroll
         for (uint32_t i = 0; i < MCR; i++)
           if (i < K && L > 0)
-            cbase ^= cr_lds[i * A + res_at(m[i])];
+            cbase ^= cr_lds[i * A + res_reg(m[i])];
         const uint32_t base_q = qck ^ cbase;
         auto heavy_of = [&](uint32_t bs) -> uint32_t {
           const uint32_t b = bs >> (32 - HEAVY_BUCKETS_LOG2);
           return (KH > 0 && ((hv_lds[b >> 5] >> (b & 31u)) & 1u)) ? ~0u : 0u;
         };
+        /* the tile's residue dwords as a shift register (as in the substitution rows) */
+        uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
+        const uint32_t nd = (L + 3u) >> 2;
 
         /* ---- deletions (variants.cc:301-325): t = q without position p, one
                 per run of equal residues; t is looked up as a whole sequence
-                (code A).  Blocks of up to 32 positions. ---- */
+                (code A).  Four positions (a residue dword) at a time: their rolling
+                keys are read together, the filter words one position ahead. ---- */
         if (tpass == 2 && L > 1) {
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hvy = heavy_of(base_t);
@@ -886,8 +939,8 @@ probe_rows_kernel(const ProbeParams P)
             md[i] = class_pos(L - 1, i, P.geom.c0);
             lo[i] = hi[i] = 0;
             if (i < KH) {
-              lo[i] = cr_lds[i * A + res_at(md[i])] & hvy;        /* t[md] = q[md],     md < p  */
-              hi[i] = cr_lds[i * A + res_at(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
+              lo[i] = cr_lds[i * A + res_reg(md[i])] & hvy;        /* t[md] = q[md],     md < p  */
+              hi[i] = cr_lds[i * A + res_reg(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
             }
           }
           uint64_t hd = h;                        /* zobrist_hash_delete_first */
@@ -896,36 +949,80 @@ probe_rows_kernel(const ProbeParams P)
             const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
             const uint64_t hd0 = hd;
             const uint32_t gone0 = gone;
-            uint32_t mask = 0, wd = 0;
-#pragma unroll 4
-            for (uint32_t p = p0; p < pe; p++) {
-              if ((p & 3u) == 0 || p == p0)
-                wd = qr[(p >> 2) * WAVE];
-              const uint32_t r = (wd >> ((p & 3u) * 8)) & 0xffu;
-              const bool fresh = (p == 0) || (r != gone);
-              if (p > 0 && fresh)
-                hd ^= zl[ZS * (p - 1) + gone] ^ zl[ZS * (p - 1) + r];
-              uint32_t key = base_t;
+            uint32_t mask = 0;
+            for (uint32_t pq = p0; pq < pe; pq += 4) {
+              uint32_t wd;
+              if (pq < 4u * TDW) {
+                wd = s0;
+                s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+              } else {
+                wd = qr[(pq >> 2) * WAVE];
+              }
+              uint32_t r4[4];
+              uint64_t ka[4], kb[4];
 #pragma unroll
-              for (uint32_t i = 0; i < MCR; i++)
-                key ^= md[i] < p ? lo[i] : hi[i];
-              const uint32_t sl = key & smask;
-              const RowWord w = fetch_at(hd, sl, !valid || sl == cslice);
-              const bool hit = ((row_bits(w, hd) >> A) & 1u) != 0;
-              nvar += fresh ? 1u : 0u;
-              mask |= (fresh && hit) ? (1u << (p - p0)) : 0u;
-              gone = r;
+              for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t pp = pq + k;
+                r4[k] = (wd >> (8u * k)) & 31u;
+                const uint32_t g = k == 0 ? gone : r4[k - 1];
+                ka[k] = kb[k] = 0;
+                if (pp > 0 && pp < pe) {                       /* wave-uniform */
+                  ka[k] = lds_u64(zl_addr + (ZS * (pp - 1u) + g) * 8u);
+                  kb[k] = lds_u64(zl_addr + (ZS * (pp - 1u) + r4[k]) * 8u);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              uint64_t hp[4];
+              uint32_t woq[4];
+              bool fr[4];
+#pragma unroll
+              for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t pp = pq + k;
+                const uint32_t g = k == 0 ? gone : r4[k - 1];
+                fr[k] = (pp == 0) || (r4[k] != g);
+                if (pp > 0 && pp < pe && fr[k])
+                  hd ^= ka[k] ^ kb[k];
+                hp[k] = hd;
+                woq[k] = woff_of(hd);
+              }
+              if (pq + 4u <= pe)
+                gone = r4[3];
+              else
+                gone = pe - pq == 1u ? r4[0] : pe - pq == 2u ? r4[1] : r4[2];
+              RowWord wc = word_lds(woq[0]);
+#pragma unroll
+              for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t pp = pq + k;
+                RowWord wn = wc;
+                if (k + 1 < 4)
+                  wn = word_lds(woq[k + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp < pe) {                                 /* wave-uniform */
+                  uint32_t key = base_t;
+#pragma unroll
+                  for (uint32_t i = 0; i < MCR; i++)
+                    key ^= md[i] < pp ? lo[i] : hi[i];
+                  /* a variant filed under another slice is an item of the deletion-item
+                     pass (query_layout.hip), not looked up here */
+                  const bool here = (key & smask) == cslice;
+                  const bool hit = ((row_bits(wc, hp[k]) >> A) & 1u) != 0;
+                  reads += valid ? 1u : 0u;
+                  nvar += (fr[k] && here) ? 1u : 0u;
+                  mask |= (fr[k] && here && hit) ? (1u << (pp - p0)) : 0u;
+                }
+                wc = wn;
+              }
             }
             mask &= vmask;
             if (__ballot(mask != 0)) {
               uint64_t hr = hd0;
               uint32_t g = gone0;
 #pragma unroll 1
-              for (uint32_t p = p0; p < pe; p++) {
-                const uint32_t r = res_at(p);
-                if (p > 0 && r != g)
-                  hr ^= zl[ZS * (p - 1) + g] ^ zl[ZS * (p - 1) + r];
-                s_push<GENES, INLINE>(W, (mask >> (p - p0)) & 1u, hr, pack_a(K_DEL, p, 0), 0);
+              for (uint32_t pp = p0; pp < pe; pp++) {
+                const uint32_t r = res_reg(pp);
+                if (pp > 0 && r != g)
+                  hr ^= zl[ZS * (pp - 1) + g] ^ zl[ZS * (pp - 1) + r];
+                s_push<GENES, INLINE>(W, (mask >> (pp - p0)) & 1u, hr, pack_a(K_DEL, pp, 0), 0);
                 g = r;
               }
             }
@@ -934,7 +1031,8 @@ probe_rows_kernel(const ProbeParams P)
 
         /* ---- insertions (variants.cc:329-353): t = q with v in front of
                 position ip; blanked at ip it is q with a gap there, whose rolling
-                hash addresses the row of all A residues. ---- */
+                hash addresses the row of all A residues.  RB rows per block: the
+                rolling keys are read together, the filter words one row ahead. ---- */
         if (tpass == 1) {
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hvy = heavy_of(base_t);
@@ -945,50 +1043,105 @@ probe_rows_kernel(const ProbeParams P)
             lo[i] = hi[i] = 0;
             if (i < KH) {
               if (mi[i] < L)
-                lo[i] = cr_lds[i * A + res_at(mi[i])] & hvy;      /* t[mi] = q[mi],     mi < ip */
+                lo[i] = cr_lds[i * A + res_reg(mi[i])] & hvy;      /* t[mi] = q[mi],     mi < ip */
               if (mi[i] >= 1)
-                hi[i] = cr_lds[i * A + res_at(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
+                hi[i] = cr_lds[i * A + res_reg(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
             }
           }
           uint64_t hg = h;                        /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
-          uint32_t r = 0;
-          ResStream rs;
-          rs.start(qr, L);
+          uint32_t carry = 31u;                   /* q[ip0 - 1]: the residue behind which block ip0 starts */
           for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
-            uint64_t m0 = 0, m1 = 0;
-            uint64_t hrow[RB];
+            if (ip0 && ip0 % (4u * TDW) == 0) {
+              const uint32_t w0 = ip0 >> 2;
+              s0 = w0 < nd ? qr[w0 * WAVE] : 0u;
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+            }
+            /* residues of positions ip0 .. ip0 + RB - 1 in the low bytes of s0 (s1) */
+            const uint64_t rr = ((uint64_t)s1 << 32) | s0;
+            if constexpr (RB == 4) {
+              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+            } else {
+              constexpr uint32_t SH = 8u * (RB & 3);
+              s0 = __builtin_amdgcn_alignbit(s1, s0, SH);
+              s1 = __builtin_amdgcn_alignbit(s2, s1, SH);
+              s2 = __builtin_amdgcn_alignbit(s3, s2, SH);
+              s3 = __builtin_amdgcn_alignbit(s4, s3, SH);
+              s4 = __builtin_amdgcn_alignbit(s5, s4, SH);
+              s5 >>= SH;
+            }
+            /* row ip moves q[ip - 1] from position ip to ip - 1 */
+            uint32_t rprev[RB];
+            uint64_t ka[RB], kb[RB];
 #pragma unroll
             for (int j = 0; j < RB; j++) {
               const uint32_t ip = ip0 + (uint32_t)j;
-              hrow[j] = 0;
-              if (ip <= L) {                                  /* wave-uniform */
-                if (ip > 0) {
-                  const uint32_t p = ip - 1;
-                  r = rs.at(p);
-                  hg ^= zl[ZS * p + r] ^ zl[ZS * ip + r];
-                }
-                hrow[j] = hg;
-                uint32_t key = base_t;
-                int ci_u = -1;                         /* first class residue of t at the blanked position */
+              rprev[j] = j == 0 ? carry : (uint32_t)(rr >> (8 * (j - 1))) & 31u;
+              ka[j] = kb[j] = 0;
+              if (ip > 0 && ip <= L) {                         /* wave-uniform */
+                ka[j] = lds_u64(zl_addr + (ZS * (ip - 1u) + rprev[j]) * 8u);
+                kb[j] = lds_u64(zl_addr + (ZS * ip + rprev[j]) * 8u);
+              }
+            }
+            carry = (uint32_t)(rr >> (8 * (RB - 1))) & 31u;
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t m0 = 0, m1 = 0;
+            uint64_t hrow[RB];
+            uint32_t wor[RB], slr[RB];
+            bool itr[RB];
+            bool any_glob = false;
 #pragma unroll
-                for (uint32_t i = 0; i < MCR; i++)
-                  if (i < KH) {
-                    if (mi[i] != ip)
-                      key ^= mi[i] < ip ? lo[i] : hi[i];
-                    else if (ci_u < 0)
-                      ci_u = (int)i;
-                  }
-                const uint32_t sl = row_slice(P.geom, key, hvy ? ci_u : -1);
-                const RowWord w = fetch_at(hg, sl, !valid || sl == cslice);
-                uint32_t x = row_bits(w, hg) & AMASK & vmask;
+            for (int j = 0; j < RB; j++) {
+              const uint32_t ip = ip0 + (uint32_t)j;
+              if (ip > 0 && ip <= L)
+                hg ^= ka[j] ^ kb[j];
+              hrow[j] = hg;
+              wor[j] = woff_of(hg);
+              uint32_t key = base_t;
+              int ci_u = -1;                           /* first class residue of t at the blanked position */
+#pragma unroll
+              for (uint32_t i = 0; i < MCR; i++)
+                if (i < KH) {
+                  if (mi[i] != ip)
+                    key ^= mi[i] < ip ? lo[i] : hi[i];
+                  else if (ci_u < 0)
+                    ci_u = (int)i;
+                }
+              /* a row blanked at a class position of a split variant class is an
+                 item of that position's class part (query_layout.hip) */
+              itr[j] = hvy && ci_u >= 0;
+              slr[j] = row_slice(P.geom, key, -1);
+              any_glob = any_glob || (ip <= L && __ballot(valid && !itr[j] && slr[j] != cslice) != 0);
+            }
+            RowWord wc = word_lds(wor[0]);
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+              const uint32_t ip = ip0 + (uint32_t)j;
+              RowWord wn = wc;
+              if (j + 1 < RB)
+                wn = word_lds(wor[j + 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (ip <= L) {                                   /* wave-uniform */
+                RowWord w = wc;
+                if (any_glob) {                                /* rare: a lane's row lies in another slice */
+                  if (valid && !itr[j] && slr[j] != cslice)
+                    w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
+                }
+                reads += valid ? 1u : 0u;
+                uint32_t x = row_bits(w, hrow[j]) & AMASK & vmask;
                 if (ip > 0)
-                  x &= ~(1u << r);                              /* v != q[ip - 1] */
-                nvar += ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A;
+                  x &= ~(1u << rprev[j]);                       /* v != q[ip - 1] */
+                x = itr[j] ? 0u : x;
+                nvar += itr[j] ? 0ull : (ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A);
                 if (j < RPW)
                   m0 |= (uint64_t)x << (A * j);
                 else
                   m1 |= (uint64_t)x << (A * (j - RPW));
               }
+              wc = wn;
             }
             while (__ballot((m0 | m1) != 0)) {
               const bool pos = (m0 | m1) != 0;

@@ -40,7 +40,6 @@ using namespace cmpr;
 
 namespace {
 
-constexpr uint32_t NO_GROUP = 0xffffffffu;
 constexpr uint32_t MAXP = 1 + MAX_CLASS_RES;     /* passes with a layout of their own */
 
 enum : uint32_t { VERR_OFFSETS = 1, VERR_LONG = 2, VERR_REP = 3, VERR_GENE = 4, VERR_COUNT = 5,
@@ -99,14 +98,21 @@ struct QL {
   uint64_t *qgh, *qhins, *qhdel, *qcnt;
   uint16_t *qlen;
   QueryRec *qrec;
-  /* variant 2, class rows: flat items grouped by the slice of their class part,
-     every group padded to whole blocks of 64 */
-  uint32_t  nclass;                  /* class-row passes */
-  uint32_t  cslices;                 /* slices per class part */
-  uint32_t  cblocks;                 /* blocks of 64 items per chunk at most */
-  uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nclass * cslices] */
-  uint32_t *cgrp[MAX_CLASS_RES];     /* per query: slice within the class part, or NO_GROUP */
-  uint32_t  cchunk0;                 /* first class chunk in the chunk list */
+  /* variant 2: rows that cannot be answered from the slice staged for their tile
+     become flat ITEMS, grouped by the slice they are filed under and padded to
+     whole blocks of 64 per slice (kernels_rows.h, passes >= 3).  Item group g < K:
+     class part g of the filter -- the substitution row of class position g of every
+     split query and, with -i, its insertion row blanked at class position g of
+     the variant.  Group K (with -i): deletion variants whose slice of the main
+     part is not the one staged for their tile's deletion pass. */
+  uint32_t  ngroups;
+  uint32_t  goff[MAX_CLASS_RES + 1];      /* first counter of the group */
+  uint32_t  gslices[MAX_CLASS_RES + 1];   /* slices of the group */
+  uint32_t  gslice0[MAX_CLASS_RES + 1];   /* its first slice in the filter */
+  uint32_t  nitem_slices;                 /* counters in all */
+  uint32_t  cblocks;                      /* blocks of 64 items per chunk at most */
+  uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
+  uint32_t  cchunk0;                      /* first item chunk in the chunk list */
   uint64_t *cw;
   uint32_t *cmain;
   uint32_t *crp;
@@ -218,6 +224,116 @@ __device__ inline uint64_t variants_of(const QL &Q, const uint8_t *s, uint32_t L
   return n;
 }
 
+/* item kinds = the variant kinds of layout.h */
+enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_DEL = K_DEL };
+
+__device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
+{
+  const uint32_t L = (uint32_t)(Q.off[i + 1] - Q.off[i]);
+  return class_base(Q.geom.ctab, Q.geom, Q.genes != 0, L, Q.genes ? Q.v[i] : 0u,
+                    Q.genes ? Q.j[i] : 0u);
+}
+
+/* The items of query i (see QL): f(counter index, the row's / variant's hash,
+   excluded residue | position << 8 | kind << 24).  Called once to count (HASH =
+   false: the hash argument is not computed) and once to place, so both see the
+   same items. */
+template <bool HASH, typename F>
+__device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool heavy, F f)
+{
+  const SliceGeom &g = Q.geom;
+  const uint64_t b = Q.off[i];
+  const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
+  const uint8_t *s = Q.res + b;
+  const uint32_t K = g.k, A = Q.A;
+  if (L == 0 || K == 0 || Q.differences < 1)
+    return;
+  /* ---- substitution rows at class positions: class part ci, key without the terms
+          of that position; a position that carries several class residues is
+          handled by the first of them ---- */
+  if (heavy) {
+    const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
+    for (uint32_t ci = 0; ci < K; ci++) {
+      const uint32_t pos = class_pos(L, ci, g.c0);
+      bool first = true;
+      uint32_t key = ck;
+      for (uint32_t k = 0; k < K; k++)
+        if (class_pos(L, k, g.c0) == pos) {
+          if (k < ci)
+            first = false;
+          key ^= g.ctab[g.off_cr + k * A + s[pos]];
+        }
+      if (first)
+        f(Q.goff[ci] + (key & g.cmask), HASH ? h ^ Q.zob[A * pos + s[pos]] : 0ull,
+          (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24));
+    }
+  }
+  if (!Q.indels)
+    return;
+  /* (length, V, J) key of the query: its class key without the class residues */
+  uint32_t base = ck;
+  if (heavy)
+    for (uint32_t k = 0; k < K; k++)
+      base ^= g.ctab[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
+  const uint32_t base_i = base ^ g.ctab[L] ^ g.ctab[L + 1];          /* insertion variants */
+  const bool heavy_i = class_is_heavy(g.ctab, g, base_i);
+  const uint32_t dlen = L > 1 ? g.ctab[L] ^ g.ctab[L - 1] : 0u;
+  const uint32_t base_d = base ^ dlen;                               /* deletion variants */
+  const bool heavy_d = L > 1 && class_is_heavy(g.ctab, g, base_d);
+  const uint32_t sibling = (ck ^ dlen) & g.smask;
+  /* One walk over the positions.  With P(x) = XOR_{y<x} Z[y][q[y]], P+(x) and P-(x)
+     the same over Z[y+1] / Z[y-1], and the query's two shifted hashes from the keys
+     kernel:   gap at ip:  P(ip) ^ hins ^ P+(ip);   q without p:  P(p) ^ hdel ^ P-(p+1). */
+  const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull, hdel = HASH ? Q.hdel_tmp[i] : 0ull;
+  uint64_t P0 = 0, Pp = 0, Pm = 0;
+  for (uint32_t x = 0; x <= L; x++) {
+    /* ---- insertion row blanked at x, if x is a class position of the variant t
+            (length L + 1, t[y] = y < x ? q[y] : q[y - 1] around the gap) and t's
+            class is split: class part of that position ---- */
+    if (heavy_i) {
+      int ci = -1;
+      uint32_t key = base_i;
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t mk = class_pos(L + 1, k, g.c0);
+        if (mk == x) {
+          if (ci < 0)
+            ci = (int)k;
+        } else {
+          key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk - 1]];
+        }
+      }
+      if (ci >= 0)
+        f(Q.goff[ci] + (key & g.cmask), P0 ^ hins ^ Pp,
+          (x > 0 ? (uint32_t)s[x - 1] : 31u) | (x << 8) | (ITEM_INS << 24));
+    }
+    if (x == L)
+      break;
+    /* ---- deletion variant t = q without x (one per run of equal residues) whose
+            slice of the main part is not the sibling staged for the tile's
+            deletion pass ---- */
+    if (L > 1 && (x == 0 || s[x] != s[x - 1])) {
+      uint32_t key = base_d;
+      if (heavy_d)
+        for (uint32_t k = 0; k < K; k++) {
+          const uint32_t mk = class_pos(L - 1, k, g.c0);
+          key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk + 1]];
+        }
+      if ((key & g.smask) != sibling) {
+        uint64_t w = 0;
+        if (HASH)
+          w = P0 ^ hdel ^ (x > 0 ? Pm ^ Q.zob[A * (x - 1) + s[x]] : 0ull);
+        f(Q.goff[K] + (key & g.smask), w, 31u | (x << 8) | (ITEM_DEL << 24));
+      }
+    }
+    if (HASH) {
+      P0 ^= Q.zob[A * x + s[x]];
+      Pp ^= Q.zob[A * (x + 1) + s[x]];
+      if (x > 0)
+        Pm ^= Q.zob[A * (x - 1) + s[x]];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 keys_kernel(const QL Q)
 {
@@ -264,28 +380,8 @@ keys_kernel(const QL Q)
       Q.grp[0][i] = g;
       atomicAdd(Q.cnt_g[0] + g, 1u);
     }
-    for (uint32_t ci = 0; ci < Q.nclass; ci++) {
-      /* the row of class position ci: filed under the key without the terms of that
-         position, in class part ci; a position that carries several class residues
-         is handled by the first of them */
-      uint32_t cs = NO_GROUP;
-      if (heavy && L > 0) {
-        const uint32_t pos = class_pos(L, ci, Q.geom.c0);
-        bool first = true;
-        uint32_t key = ck;
-        for (uint32_t k = 0; k < Q.geom.k; k++)
-          if (class_pos(L, k, Q.geom.c0) == pos) {
-            if (k < ci)
-              first = false;
-            key ^= Q.geom.ctab[Q.geom.off_cr + k * Q.A + s[pos]];
-          }
-        if (first)
-          cs = key & Q.geom.cmask;
-      }
-      Q.cgrp[ci][i] = cs;
-      if (cs != NO_GROUP)
-        atomicAdd(Q.ccnt + (size_t)ci * Q.cslices + cs, 1u);
-    }
+    if (Q.ngroups)
+      for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) { atomicAdd(Q.ccnt + k, 1u); });
     alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
   }
   for (int o = 32; o > 0; o >>= 1)
@@ -502,7 +598,7 @@ __global__ void __launch_bounds__(256)
 class_pad_kernel(const QL Q, uint32_t *padded)
 {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= (uint64_t)Q.nclass * Q.cslices)
+  if (k >= (uint64_t)Q.nitem_slices)
     return;
   const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
   padded[k] = blocks * WAVE;
@@ -513,41 +609,41 @@ __global__ void __launch_bounds__(256)
 class_chunks_kernel(const QL Q)
 {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= (uint64_t)Q.nclass * Q.cslices)
+  if (k >= (uint64_t)Q.nitem_slices)
     return;
-  const uint32_t ci = (uint32_t)(k / Q.cslices), cs = (uint32_t)(k % Q.cslices);
+  uint32_t gi = 0;
+  for (uint32_t x = 1; x < Q.ngroups; x++)
+    if (k >= Q.goff[x])
+      gi = x;
   const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
   const uint32_t nc = (blocks + Q.cblocks - 1) / Q.cblocks;
   for (uint32_t q = 0; q < nc; q++) {
     Chunk ck;
-    ck.slice = row_slice(Q.geom, cs, (int)ci);
+    ck.slice = Q.gslice0[gi] + (uint32_t)(k - Q.goff[gi]);
     ck.first_tile = Q.cbase[k] + q * Q.cblocks * WAVE;      /* first item */
     ck.ntiles = min(Q.cblocks, blocks - q * Q.cblocks);     /* blocks of 64 items */
-    ck.pass = 3 + ci;
+    ck.pass = 3 + gi;
     Q.chunks[Q.cchunk0 + Q.cchpre[k] + q] = ck;
   }
 }
 
-/* the row's blanked hash, the residue there with its position, and the query's
-   slot in pass 0 are all its kernel needs */
+/* an item: the row's (variant's) hash, what to exclude / where / what kind, and the
+   query's slot in pass 0 */
 __global__ void __launch_bounds__(256)
-place_class_kernel(const QL Q, uint32_t ci)
+place_items_kernel(const QL Q)
 {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= Q.n)
     return;
-  const uint32_t cs = Q.cgrp[ci][i];
-  if (cs == NO_GROUP)
-    return;
-  const size_t k = (size_t)ci * Q.cslices + cs;
-  const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
-  const uint64_t b = Q.off[i];
-  const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-  const uint32_t pos = class_pos(L, ci, Q.geom.c0);
-  const uint32_t r = Q.res[b + pos];
-  Q.cw[item] = Q.h_tmp[i] ^ Q.zob[Q.A * pos + r];
-  Q.cmain[item] = Q.slot_of[i];
-  Q.crp[item] = r | (pos << 8);
+  const uint32_t slot = Q.slot_of[i];
+  const uint32_t ck = Q.ck_tmp[i];
+  const bool heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, class_base_of(Q, i));
+  for_each_item<true>(Q, i, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
+    const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
+    Q.cw[item] = w;
+    Q.cmain[item] = slot;
+    Q.crp[item] = crp;
+  });
 }
 
 /* ---- -i: tiles regrouped by the slice their indel variants fall into ------- */
@@ -796,11 +892,30 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
   const uint64_t G = nbuckets * per_slice;
   /* class-row passes of variant 2 (flat items, not tiles) */
-  const uint32_t nclass = (c->rows && c->geom.k > 0 && c->opt.differences >= 1) ? c->geom.k : 0u;
+  /* item groups of variant 2 (flat items, not tiles; see QL) */
   const uint32_t npass = 1;                  /* passes laid out as tiles */
-  c->npasses = 1 + nclass;
-  const uint32_t cslices = c->geom.cmask + 1;
-  const uint64_t ncs = (uint64_t)nclass * cslices;
+  uint32_t ngroups = 0;
+  uint32_t goff[MAX_CLASS_RES + 1] = {0}, gslices[MAX_CLASS_RES + 1] = {0}, gslice0[MAX_CLASS_RES + 1] = {0};
+  uint64_t ncs = 0;                          /* counters over all groups */
+  if (c->rows && c->geom.k > 0 && c->opt.differences >= 1) {
+    for (uint32_t g = 0; g < c->geom.k; g++) {
+      goff[g] = (uint32_t)ncs;
+      gslices[g] = c->geom.cmask + 1;
+      gslice0[g] = row_slice(c->geom, 0, (int)g);
+      ncs += gslices[g];
+    }
+    ngroups = c->geom.k;
+    if (c->opt.indels) {
+      goff[ngroups] = (uint32_t)ncs;
+      gslices[ngroups] = c->geom.smask + 1;
+      gslice0[ngroups] = 0;
+      ncs += gslices[ngroups];
+      ngroups++;
+    }
+  }
+  if (ncs >= 0x7fffffffull)
+    return fail(c, CMPR_EUNSUPPORTED, "too many item slices");
+  c->npasses = 1 + ngroups;
   const uint64_t chunk_tiles =
       c->chunk_tiles > 0 ? (uint64_t)c->chunk_tiles : c->rows ? 64 : 8 * (uint64_t)c->waves_per_block;
   c->chunk_cap = (uint32_t)chunk_tiles;
@@ -840,8 +955,13 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
-  Q.nclass = nclass;
-  Q.cslices = cslices;
+  Q.ngroups = ngroups;
+  for (uint32_t g = 0; g <= MAX_CLASS_RES; g++) {
+    Q.goff[g] = goff[g];
+    Q.gslices[g] = gslices[g];
+    Q.gslice0[g] = gslice0[g];
+  }
+  Q.nitem_slices = (uint32_t)ncs;
   Q.cblocks = 4096;                          /* (a claim word counts tiles in 16 bits) */
 
   /* ---- scratch: group counters, per-query keys ---- */
@@ -849,15 +969,14 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Tmp<uint64_t> h_tmp, hins_tmp, hdel_tmp;
   Tmp<SliceTot> tot, pre;
   Tmp<unsigned long long> alg;
-  Tmp<uint32_t> ccnt, cbase, cfill, cnch, cchpre, cpad, cgrp;
-  if (nclass) {
+  Tmp<uint32_t> ccnt, cbase, cfill, cnch, cchpre, cpad;
+  if (ngroups) {
     if ((rc = dev_alloc(c, ccnt.b, (size_t)ncs))) return rc;
     if ((rc = dev_alloc(c, cbase.b, (size_t)ncs))) return rc;
     if ((rc = dev_alloc(c, cfill.b, (size_t)ncs))) return rc;
     if ((rc = dev_alloc(c, cnch.b, (size_t)ncs))) return rc;
     if ((rc = dev_alloc(c, cchpre.b, (size_t)ncs))) return rc;
     if ((rc = dev_alloc(c, cpad.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cgrp.b, (size_t)s->n * nclass))) return rc;
     HIP_TRY(c, hipMemsetAsync(ccnt.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(cfill.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
     Q.ccnt = ccnt.b.p;
@@ -865,8 +984,6 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     Q.cfill = cfill.b.p;
     Q.cnch = cnch.b.p;
     Q.cchpre = cchpre.b.p;
-    for (uint32_t ci = 0; ci < nclass; ci++)
-      Q.cgrp[ci] = cgrp.b.p + (size_t)s->n * ci;
   }
   if ((rc = dev_alloc(c, gcnt.b, (size_t)G * npass))) return rc;
   if ((rc = dev_alloc(c, gbase.b, (size_t)G * npass))) return rc;
@@ -960,7 +1077,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   }
   /* ---- class rows: items per (class part, slice), padded to blocks of 64 ---- */
   uint64_t class_chunks = 0;
-  if (nclass) {
+  if (ngroups) {
     hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad.b.p);
     HIP_TRY(c, hipGetLastError());
     size_t b2 = 0;
@@ -1076,7 +1193,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       HIP_TRY(c, hipMemsetAsync(c->qhins.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
       HIP_TRY(c, hipMemsetAsync(c->qhdel.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
     }
-    if (nclass) {
+    if (ngroups) {
       /* (+ 64: a block read past the last item stays inside) */
       const size_t ni = (size_t)cslots + WAVE;
       if ((rc = dev_alloc(c, c->cw, ni))) return rc;
@@ -1103,12 +1220,12 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if (s->n) {
     hipLaunchKernelGGL(place_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
-    for (uint32_t ci = 0; ci < nclass; ci++) {
-      hipLaunchKernelGGL(place_class_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q, ci);
+    if (ngroups) {
+      hipLaunchKernelGGL(place_items_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
       HIP_TRY(c, hipGetLastError());
     }
   }
-  if (nclass) {
+  if (ngroups) {
     hipLaunchKernelGGL(class_chunks_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
   }
