@@ -658,6 +658,8 @@ probe_rows_kernel(const ProbeParams P)
          (m0, m1) <-> residue v at row j of the block; rpack holds the lanes' own
          residues of those rows */
       auto emit_sub_rows = [&](uint64_t m0, uint64_t m1, uint32_t p0, uint32_t rpack) {
+        if (CMPR_DBG(P, DBG_SKIP_EMIT))
+          m0 = m1 = 0;
         while (__ballot((m0 | m1) != 0)) {
           const bool pos = (m0 | m1) != 0;
           const bool first = m0 != 0;
@@ -703,7 +705,7 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
-          for (uint32_t p0 = 0; p0 < L; p0 += RB) {
+          for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += RB) {
             if (p0 && p0 % (4u * TDW) == 0) {
               const uint32_t w0 = p0 >> 2;
               s0 = qr[w0 * WAVE];
@@ -1006,9 +1008,10 @@ probe_rows_kernel(const ProbeParams P)
                      pass (query_layout.hip), not looked up here */
                   const bool here = (key & smask) == cslice;
                   const bool hit = ((row_bits(wc, hp[k]) >> A) & 1u) != 0;
+                  const bool lives = fr[k] && here && pp < Ll && Ll > 1u;   /* (the lane's own length) */
                   reads += valid ? 1u : 0u;
-                  nvar += (fr[k] && here) ? 1u : 0u;
-                  mask |= (fr[k] && here && hit) ? (1u << (pp - p0)) : 0u;
+                  nvar += lives ? 1u : 0u;
+                  mask |= (lives && hit) ? (1u << (pp - p0)) : 0u;
                 }
                 wc = wn;
               }
@@ -1134,8 +1137,9 @@ probe_rows_kernel(const ProbeParams P)
                 uint32_t x = row_bits(w, hrow[j]) & AMASK & vmask;
                 if (ip > 0)
                   x &= ~(1u << rprev[j]);                       /* v != q[ip - 1] */
-                x = itr[j] ? 0u : x;
-                nvar += itr[j] ? 0ull : (ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A);
+                const bool lives = !itr[j] && ip <= Ll;               /* (the lane's own length) */
+                x = lives ? x : 0u;
+                nvar += lives ? (ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A) : 0ull;
                 if (j < RPW)
                   m0 |= (uint64_t)x << (A * j);
                 else

@@ -492,13 +492,15 @@ slices_kernel(const QL Q, uint32_t pi)
      that single waves work through, probing the slice in HBM / L2. */
   uint32_t nchunks = 0, nsmall = 0, nlist = 0;
   if (Q.sliced && ntiles) {
+    const uint32_t reps = (Q.rows && Q.indels) ? 3u : 1u;     /* variant 2 with -i: passes 0, 1, 2 */
     if (!Q.indels && (ntiles <= Q.small_max || (pi > 0 && Q.class_unstaged))) {
       nsmall = ntiles;
       if (WRITE)
         for (uint32_t t = 0; t < ntiles; t++)
           Q.small_tiles[Q.small0[pi] + at.small + t] = tile_base + t;
     } else {
-      nchunks = (ntiles + Q.chunk_tiles - 1) / Q.chunk_tiles;
+      const uint32_t nc1 = (ntiles + Q.chunk_tiles - 1) / Q.chunk_tiles;
+      nchunks = nc1 * reps;
       nlist = ntiles;
       if (WRITE) {
         for (uint32_t t = 0; t < ntiles; t++) {
@@ -508,14 +510,15 @@ slices_kernel(const QL Q, uint32_t pi)
           r.pad = 0;
           Q.tile_refs[Q.list0[pi] + at.list + t] = r;
         }
-        for (uint32_t k = 0; k < nchunks; k++) {
-          Chunk ck;
-          ck.slice = (uint32_t)sl;
-          ck.first_tile = Q.list0[pi] + at.list + k * Q.chunk_tiles;
-          ck.ntiles = min(Q.chunk_tiles, ntiles - k * Q.chunk_tiles);
-          ck.pass = pass;
-          Q.chunks[Q.chunk0[pi] + at.chunks + k] = ck;
-        }
+        for (uint32_t k = 0; k < nc1; k++)
+          for (uint32_t rp = 0; rp < reps; rp++) {
+            Chunk ck;
+            ck.slice = (uint32_t)sl;
+            ck.first_tile = Q.list0[pi] + at.list + k * Q.chunk_tiles;
+            ck.ntiles = min(Q.chunk_tiles, ntiles - k * Q.chunk_tiles);
+            ck.pass = pass + rp;
+            Q.chunks[Q.chunk0[pi] + at.chunks + k * reps + rp] = ck;
+          }
       }
     }
   }
@@ -927,7 +930,9 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
      (100M references x 49 nucleotide lengths = 1.6M groups).  Shorter queries,
      and all queries with -i (the indel passes stage one sibling slice per
      length), keep one tile group per length. */
-  const bool mixed_ok = c->sliced && !c->opt.indels;
+  /* (variant 2 mixes lengths with -i too: its class keys then carry no length term,
+     ref_index.hip, and its indel rows mask every lane by its own length) */
+  const bool mixed_ok = c->sliced && (!c->opt.indels || c->rows);
 
   QL Q;
   memset(&Q, 0, sizeof Q);
@@ -949,7 +954,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.zob = c->zob.p;
   Q.geom = c->geom;
   Q.npass = npass;
-  Q.min_mixed = mixed_ok ? c->geom.c0 + c->geom.k : 0xffffffffu;
+  Q.min_mixed = mixed_ok ? c->geom.c0 + c->geom.k + (c->opt.indels ? 1u : 0u) : 0xffffffffu;
   Q.chunk_tiles = (uint32_t)chunk_tiles;
   Q.small_max = (uint32_t)c->small_slice_tiles;
   Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
@@ -1106,7 +1111,9 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   /* ---- -i: sibling lists of the two indel passes ---- */
   Tmp<uint32_t> sib_cnt, sib_nch, sib_lpre, sib_cpre, sib_fill;
   uint64_t sib_chunks = 0, sib_list = 0;
-  const bool indel_passes = c->sliced && c->opt.indels;
+  /* variant 1: the indel passes list the tiles by sibling slice; variant 2: the same
+     tiles, the same slice, three chunks per chunk (slices_kernel) */
+  const bool indel_passes = c->sliced && c->opt.indels && !c->rows;
   if (indel_passes) {
     const uint64_t n2s = 2 * nslices;
     if ((rc = dev_alloc(c, sib_cnt.b, (size_t)n2s))) return rc;

@@ -278,6 +278,13 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     SplitMix64 crng(0x736c69636573ull);     /* "slices" */
     for (size_t i = 0; i < g.off_hv; i++)
       c->ctab[i] = (uint32_t)(crng.next() >> 32);
+    /* With -i the class key carries no length term: an insertion / deletion variant
+       then stays in the class of its query (up to the class residues it shifts), so
+       the indel rows are answered from the query's own slice and its tiles may mix
+       lengths. */
+    if (c->opt.indels)
+      for (uint32_t L = 0; L < g.ncl; L++)
+        c->ctab[L] = 0;
     /* the tables go to the device now (heavy bitmap still empty): the kernels below
        read them there */
     if ((rc = dev_upload(c, c->d_ctab, c->ctab.data(), c->ctab.size()))) return rc;
