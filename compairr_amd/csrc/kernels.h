@@ -521,7 +521,7 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
      its first 36 residues in ONE 64-byte piece, like the hit's */
   const uint4 *qp = (const uint4 *)P.qrec + (size_t)qs * 4;
   const uint4 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
-  const uint32_t *qr = P.qres + qbase + (qs & 63u);        /* residues past the 36th */
+  (void)qbase;
   uint32_t q[10];
   q[0] = 0;
   q[1] = a1.z; q[2] = a1.w; q[3] = a2.x; q[4] = a2.y; q[5] = a2.z; q[6] = a2.w;
@@ -545,6 +545,8 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
   uint32_t bad = block_mismatch(0, q, r0, kind, p1, r1, p2, r2, M) |
                  block_mismatch(1, q + 4, r1w, kind, p1, r1, p2, r2, M);
   if (ok && M > 32) {
+    /* residues past the 36th: from the query's tile (rare -- a CDR3 is shorter) */
+    const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
     for (uint32_t c = 2; 16 * c < M; c++) {
       const uint4 t = rp[2 + c];
       uint32_t qq[6];
@@ -608,6 +610,7 @@ resolve_kernel(const ProbeParams P)
     PosEntry e{};
     if (active)
       e = pos[base + lane];
+    active = active && e.slot != POS_NULL_SLOT;      /* padding of a block of 64 */
     const uint64_t key = table_key(e.hash);
     uint64_t s = table_home(key, P.slot_mask);
     while (__ballot(active)) {

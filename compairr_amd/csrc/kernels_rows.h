@@ -275,7 +275,8 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t KH = P.geom.k;
   const uint32_t smask = P.geom.smask;
   SProber W{P, (const uint64_t *)smem, queues[wave], P.lds_matrix ? mat_all : nullptr,
-            lane, 0u, 0u, 0u, smask, 0u, 0, {0ull, 0u, 0u, 0u}};
+            lane, 0u, 0u, 0u, smask, 0u, 0, {0ull, 0u, 0u, 0u}, 0ull};
+  claim_pos_block(W);
   unsigned long long reads = 0;                   /* filter words read by this lane */
   __syncthreads();                                /* tables and ring slots are in place */
 
@@ -1184,8 +1185,7 @@ probe_rows_kernel(const ProbeParams P)
 
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (W.qn > 0)
-    flush_or_resolve<GENES, INLINE>(W, 0, W.qn);
+  flush_or_resolve<GENES, INLINE>(W, 0, W.qn, true);
   PT_MARK(PT_TAIL);
   PT_FLUSH;
 

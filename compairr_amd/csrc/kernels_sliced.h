@@ -50,6 +50,7 @@ struct SProber {
   uint32_t            tile_slice;
   int                 qn;
   LaneStats           st;
+  unsigned long long  held;        /* lane 0: the block of the positives buffer claimed ahead */
 };
 
 /* `n` queue entries starting at `first` leave the wave: in deferred mode they
@@ -118,29 +119,46 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
    dropped and the launch is flagged (ProbeParams::overflow); resolve_kernel then
    does nothing and a second launch of the kernel's FALLBACK = true form redoes the
    whole step resolving inline, so that capacity is never a limit either way. */
+/* The positives buffer is claimed one block of 64 entries AHEAD: the claim (a
+   device-scope atomic, 1-2 us until its answer is back) is issued when the
+   previous block is written and waited for only when the next is, so a flush costs
+   no round trip.  The last flush of a wave (`last`) claims nothing and pads its
+   block with null entries (POS_NULL_SLOT). */
+__device__ __forceinline__ void claim_pos_block(SProber &W)
+{
+  const ProbeParams &P = W.P;
+  if (P.pos_buf == nullptr)
+    return;
+  const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
+  if (W.lane == 0)
+    W.held = atomicAdd(P.pos_ctr + (size_t)seg * POS_CTR_STRIDE, (unsigned long long)WAVE);
+}
+
 template <bool GENES, bool FALLBACK = true>
-__device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n)
+__device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n, bool last = false)
 {
   const ProbeParams &P = W.P;
   bool inline_resolve = FALLBACK && P.pos_buf == nullptr;
   if (!inline_resolve) {
     const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
     unsigned long long *ctr = P.pos_ctr + (size_t)seg * POS_CTR_STRIDE;
-    unsigned long long base = 0;
-    if (W.lane == 0)
-      base = atomicAdd(ctr, (unsigned long long)n);
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-           __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const unsigned long long base =
+        ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(W.held >> 32)) << 32) |
+        __builtin_amdgcn_readfirstlane((uint32_t)W.held);
+    if (!last)
+      claim_pos_block(W);
     if (base < P.pos_cap) {                   /* the segment has 64 entries of slack */
+      PosEntry e;
+      e.hash = 0;
+      e.slot = POS_NULL_SLOT;
+      e.ca = e.cb = e.qbase = 0;
       if ((int)W.lane < n) {
-        PosEntry e;
         e.hash = W.q.hash[first + W.lane];
         e.slot = W.q.slot[first + W.lane];
         e.ca = W.q.ca[first + W.lane];
         e.cb = W.q.cb[first + W.lane];
-        e.qbase = (uint32_t)P.tiles[e.slot >> 6].res_base;
-        P.pos_buf[(size_t)seg * (P.pos_cap + WAVE) + base + W.lane] = e;
       }
+      P.pos_buf[(size_t)seg * (P.pos_cap + WAVE) + base + W.lane] = e;
     } else {
       if (W.lane == 0) {
         atomicMax(ctr + 1, ~base);
@@ -453,7 +471,8 @@ probe_sliced_kernel(const ProbeParams P)
   const uint32_t KH = P.geom.k;           /* class residues of heavy classes */
   SProber W{P, slice_lds, queues[wave], P.lds_matrix ? mat_all : nullptr,
             lane, 0u, (slice_words - 1u) << 3, P.geom.words_log2 + 3u, P.geom.smask,
-            0u, 0, {0ull, 0u, 0u, 0u}};
+            0u, 0, {0ull, 0u, 0u, 0u}, 0ull};
+  claim_pos_block(W);
   const uint32_t zl_addr = slice_words * 8u;       /* LDS address of zl */
   const uint32_t ze_addr = zl_addr + nz * 8u;      /* ... and of ze */
   const uint32_t zlane = lane < (uint32_t)A ? lane : 0u;   /* lane r <-> residue r */
@@ -1011,8 +1030,7 @@ probe_sliced_kernel(const ProbeParams P)
 
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (W.qn > 0)
-    flush_or_resolve<GENES>(W, 0, W.qn);
+  flush_or_resolve<GENES>(W, 0, W.qn, true);
 
   {
     unsigned long long s[STAT_COUNT] = {W.st.variants, W.st.bloom_pos,

@@ -189,8 +189,11 @@ struct PosEntry {
   uint64_t hash;
   uint32_t slot;     /* query: tile * 64 + lane                         */
   uint32_t ca, cb;   /* variant: kind | p1 << 3 | r1 << 24 ; p2 | r2 << 24 */
-  uint32_t qbase;    /* res_base of the query's tile (dword index in qres) */
+  uint32_t qbase;    /* (unused: the verification looks a long query's tile up itself) */
 };
+/* The positives buffer is written in blocks of 64 entries; the entries a wave
+   has no positive for carry this slot */
+constexpr uint32_t POS_NULL_SLOT = 0xffffffffu;
 
 /* One set-2 sequence as the verification step reads it: a 32-byte header
    followed by its residues (one byte each, padded to 16): header + residues of

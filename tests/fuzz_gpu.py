@@ -72,8 +72,15 @@ def random_case(rng):
         tun["deferred_resolve"] = 0
     if rng.random() < 0.2:
         tun["table_log2_delta"] = int(rng.integers(0, 3))
-    if rng.random() < 0.1:
+    r = rng.random()
+    if r < 0.1:
         tun["variant"] = 0
+    elif r < 0.3:
+        tun["variant"] = 1
+    elif r < 0.6:
+        tun["variant"] = 2                                # the row filter, also where it is not the default
+    if rng.random() < 0.2:
+        tun["class_rows_unstaged"] = 1
     if rng.random() < 0.3:
         tun["host_threads"] = int(rng.integers(1, 9))
     same = rng.random() < 0.2

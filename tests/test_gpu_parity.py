@@ -349,6 +349,24 @@ def test_errors_through_the_abi():
             h.overlap_matrix()         # ratio needs the f64 entry point
 
 
+def test_debug_switches_absent_from_the_shipped_library():
+    """The ablation switches (ProbeParams::debug) are compiled out of
+    libcompairr_hip.so: the tunable is refused, and so are values no kernel has."""
+    with HipOverlap(Options(differences=1, **FULL)) as h:
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_tunable("debug", 1)
+        assert e.value.code == 1                                  # CMPR_EINVAL
+        for name, value in (("variant", 3), ("waves_per_block", 5), ("slice_words_log2", 0),
+                            ("no_such_tunable", 1)):
+            with pytest.raises(hipmod.HipError) as e:
+                h.set_tunable(name, value)
+            assert e.value.code == 1
+        h.set_reference(synth.make_set(100, 1), 0)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_tunable("variant", 1)                           # after the index is built
+        assert e.value.code == 5                                  # CMPR_ESTATE
+
+
 def test_repeatable_and_device_output():
     import torch
     a = synth.make_set(50000, 1, prefix="A")
