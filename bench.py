@@ -8,10 +8,18 @@ all-reduce of the repertoire matrix.  Default workload = BASELINE.json
 configs[2]: synthetic 10M-vs-10M CDR3aa, d = 1, substitutions only.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
-(hash table + filter) is replicated on every GPU; the query set is sharded:
-  --scaling strong (default)  the SAME seeded 10M queries, split into N contiguous
-                              shards (overlap.cc:421-433 hands out query chunks the
-                              same way): total work fixed, BASELINE configs[3];
+(hash table + filter) is replicated on every GPU and the step is sharded:
+  --scaling strong (default)  the SAME seeded 10M queries, total work fixed
+                              (BASELINE configs[3]).  --shard-by work (default):
+                              every rank holds all queries and takes every N-th
+                              work item of the step (a filter slice with the tiles
+                              of queries that probe it; library tunables
+                              work_shard_index / _count) -- the per-step cost of
+                              streaming the filter through LDS divides by N too.
+                              --shard-by queries: N contiguous query shards, the
+                              way overlap.cc:421-433 hands out query chunks; every
+                              rank then streams the whole filter for 1/N of the
+                              queries.
   --scaling weak              every rank its own 10M-query shard.
 The only collective is one all-reduce (sum, int64) of the R1 x R2 matrix per
 step, on the same stream as the kernels.  In strong mode the reduced matrix is
@@ -55,6 +63,8 @@ def parse_args():
     p.add_argument("--queries", type=int, default=10_000_000,
                    help="set-1 sequences (strong: in total; weak: per GPU)")
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    p.add_argument("--shard-by", choices=["work", "queries"], default="work",
+                   help="strong scaling at N > 1: what the ranks divide (see the module docstring)")
     p.add_argument("--differences", "-d", type=int, default=1)
     p.add_argument("--indels", action="store_true")
     p.add_argument("--nucleotides", action="store_true")
@@ -235,7 +245,8 @@ def main():
     else:
         full = synth.make_set(args.queries, 1 + (0 if strong else 1000 * rank), prefix="A",
                               nucleotides=args.nucleotides, pool_size=args.refs // 4)
-    if strong and world > 1:
+    by_work = strong and world > 1 and args.shard_by == "work"
+    if strong and world > 1 and not by_work:
         lo, hi = shard_bounds(full.n, rank, world)
         qry = full.subset(slice(lo, hi))      # keeps the full set's repertoire numbering
     else:
@@ -247,6 +258,9 @@ def main():
     for kv in args.tunable:
         k, v = kv.split("=")
         h.set_tunable(k, int(v))
+    if by_work:
+        h.set_tunable("work_shard_count", world)
+        h.set_tunable("work_shard_index", rank)
     t0 = time.time()
     h.set_reference(ref, full.longest)
     t_index = time.time() - t0
@@ -341,9 +355,12 @@ def main():
                        "queries_total": total_queries, "queries_this_gpu": qry.n,
                        "reference_sequences": args.refs,
                        "repertoires": [int(R1), int(R2)],
-                       "sharding": ("%s scaling: queries sharded over %d GPUs, reference index "
+                       "sharding": ("%s scaling: %s over %d GPUs, reference index "
                                     "replicated, one RCCL all-reduce of the matrix per step"
-                                    % (args.scaling, world)) if world > 1 else "single GPU",
+                                    % (args.scaling,
+                                       "the step's work items (filter slice + the tiles that probe it) "
+                                       "dealt round-robin, all queries resident on every GPU" if by_work
+                                       else "queries sharded", world)) if world > 1 else "single GPU",
                        "matrix_checksum": checksum,
                        "layout": layout,
                        "setup_seconds": {"generate": round(t_gen, 2), "index_build+upload": round(t_index, 3),

@@ -319,6 +319,12 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (c->have_q)
       return fail(c, CMPR_ESTATE, "set pos_capacity before cmpr_set_queries");
     c->pos_capacity = value;
+  } else if (n == "work_shard_count" || n == "work_shard_index") {
+    if (value < 0 || value > 65535 || (n == "work_shard_count" && value < 1))
+      return fail(c, CMPR_EINVAL, "work_shard_count must be 1..65535, work_shard_index 0..count-1");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set the work shard before cmpr_set_queries");
+    (n == "work_shard_count" ? c->work_shard_count : c->work_shard_index) = value;
   } else if (n == "small_slice_tiles") {
     if (value < 0 || value > 64)
       return fail(c, CMPR_EINVAL, "small_slice_tiles must be 0..64");
@@ -382,6 +388,8 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunks") *value = c->nchunks;
   else if (n == "small_tiles") *value = c->nsmall;
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
+  else if (n == "work_shard_count") *value = c->work_shard_count;
+  else if (n == "work_shard_index") *value = c->work_shard_index;
   else if (n == "class_rows_unstaged") *value = c->class_rows_unstaged;
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
@@ -557,6 +565,13 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
     c->d_overflow = c->d_stats + STAT_COUNT + 1;
     c->d_stats2 = c->d_overflow + 1;
     c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
+    /* partial results of the workgroups (ProbeParams::part); cleared here, and by
+       reduce_partials_kernel after every launch */
+    const size_t cells = (size_t)c->R1 * c->R2;
+    c->part_stride = (uint32_t)((cells <= 2048 && !is_f64_score(c->opt) ? cells : 0) + STAT_COUNT);
+    if ((rc = dev_alloc(c, c->part, (size_t)NPART * c->part_stride))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long),
+                              c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_q = true;
@@ -632,6 +647,10 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.pair_cap = c->pair_cap;
     P.ntiles = c->ntiles;
     P.first_tile = 0;
+    P.part = c->part.p;
+    P.part_stride = c->part_stride;
+    P.work_first = (uint32_t)c->work_shard_index;
+    P.work_step = (uint32_t)c->work_shard_count;
     P.matrix = d_out;
     P.matrix_f64 = c->matrix_f64.p;
     P.R1 = c->R1;
@@ -725,6 +744,14 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     c->launches = 1;
     launched = true;
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
+    auto reduce_partials = [&]() {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((P.part_stride + 255) / 256), dim3(256), 0, st, P,
+                         (uint32_t)(P.lds_matrix ? cells : 0));
+    };
+    if (!(deferred && !(c->debug & DBG_SKIP_RESOLVE))) {
+      reduce_partials();
+      HIP_TRY(c, hipGetLastError());
+    }
     if (deferred && !(c->debug & DBG_SKIP_RESOLVE)) {
       const size_t rlds = (BLOCK_THREADS / WAVE) * sizeof(CandQueue) +
                           (P.lds_matrix ? cells * sizeof(unsigned long long) : 0);
@@ -733,6 +760,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
       hipLaunchKernelGGL(select_resolve(!c->opt.ignore_genes), dim3(rgrid), dim3(BLOCK_THREADS),
                          rlds, st, P);
+      reduce_partials();
       HIP_TRY(c, hipGetLastError());
       c->launches = 2;
       if (c->rows) {
@@ -749,6 +777,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
         }
         ProbeParams P2 = P;
         P2.pos_buf = nullptr;
+        P2.part = nullptr;                  /* (straight into matrix and stats2) */
         P2.redo = 1;
         P2.stats = c->d_stats2;
         P2.tile_counter = c->d_tile_counter2;
@@ -939,7 +968,8 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   out->hash_equal = st[STAT_HASH_EQ];
   out->matches = st[STAT_MATCHES];
   out->filter_reads = st[STAT_READS];
-  out->algorithmic_bytes = c->algorithmic_bytes;
+  /* (a work shard does its share of every query's variants) */
+  out->algorithmic_bytes = c->algorithmic_bytes / (uint64_t)c->work_shard_count;
   out->kernel_ms = k_ms;
   out->probe_ms = p_ms;
   out->total_ms = t_ms;

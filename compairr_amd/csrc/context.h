@@ -72,6 +72,8 @@ struct cmpr_context {
                                      -1: from the slice size, 0: every class   */
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
+  int64_t work_shard_index = 0;   /* this context works on every work_shard_count-th work   */
+  int64_t work_shard_count = 1;   /* item (chunk / small tile / tile) of the step, from here */
   int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
   int64_t class_rows_unstaged = 0; /* variant 2: class-row tiles read the filter where it lies */
   int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
@@ -147,6 +149,8 @@ struct cmpr_context {
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */
   uint32_t                  *d_tile_counter2 = nullptr;
+  DevBuf<unsigned long long> part;           /* NPART x part_stride partial results */
+  uint32_t                   part_stride = 0;
   const void                *attr_fn2 = nullptr;
   size_t                     attr_lds2 = 0;
   uint64_t                   pos_cap = 0;

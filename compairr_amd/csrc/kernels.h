@@ -563,6 +563,41 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
   }
 }
 
+/* destinations of a workgroup's results (ProbeParams::part) */
+__device__ __forceinline__ unsigned long long *stats_dst(const ProbeParams &P)
+{
+  return P.part ? P.part + (size_t)(blockIdx.x % NPART) * P.part_stride + (P.part_stride - STAT_COUNT)
+                : P.stats;
+}
+__device__ __forceinline__ unsigned long long *matrix_dst(const ProbeParams &P)
+{
+  return P.part ? P.part + (size_t)(blockIdx.x % NPART) * P.part_stride : P.matrix;
+}
+
+/* Sums the NPART partial results into the matrix and the counters and clears them
+   for the next launch; one thread per cell / counter. */
+static __global__ void __launch_bounds__(256)
+reduce_partials_kernel(const ProbeParams P, uint32_t cells)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.part_stride)
+    return;
+  unsigned long long sum = 0;
+  for (uint32_t s = 0; s < NPART; s++) {
+    const unsigned long long x = P.part[(size_t)s * P.part_stride + i];
+    if (x) {
+      sum += x;
+      P.part[(size_t)s * P.part_stride + i] = 0;
+    }
+  }
+  if (!sum)
+    return;
+  if (i < cells)
+    P.matrix[i] += sum;
+  else if (i >= P.part_stride - STAT_COUNT)
+    P.stats[i - (P.part_stride - STAT_COUNT)] += sum;
+}
+
 /* Second kernel of the deferred mode.  Phase A, one lane per queued Bloom
    positive: walk the probe chain comparing keys only (find_variant_matches,
    overlap.cc:168-251) and queue every key match; phase B, whenever 64
@@ -661,7 +696,7 @@ resolve_kernel(const ProbeParams P)
       for (int off = 32; off > 0; off >>= 1)
         x += __shfl_down(x, off, WAVE);
       if (lane == 0 && x)
-        atomicAdd(P.stats + (k == 0 ? STAT_HASH_EQ : STAT_MATCHES), x);
+        atomicAdd(stats_dst(P) + (k == 0 ? STAT_HASH_EQ : STAT_MATCHES), x);
     }
   }
   if (P.lds_matrix) {
@@ -669,7 +704,7 @@ resolve_kernel(const ProbeParams P)
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS) {
       const unsigned long long x = mat_lds[i];
       if (x)
-        atomicAdd(P.matrix + i, x);
+        atomicAdd(matrix_dst(P) + i, x);
     }
   }
 }
@@ -764,7 +799,7 @@ probe_kernel(const ProbeParams P)
     uint32_t t = 0;
     if (lane == 0)
       t = atomicAdd(P.tile_counter, 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
+    t = __builtin_amdgcn_readfirstlane(t) * P.work_step + P.work_first;
     if (t >= P.ntiles)
       break;
     t += P.first_tile;
@@ -895,7 +930,7 @@ probe_kernel(const ProbeParams P)
       for (int off = 32; off > 0; off >>= 1)
         x += __shfl_down(x, off, WAVE);
       if (lane == 0 && x)
-        atomicAdd(P.stats + k, x);
+        atomicAdd(stats_dst(P) + k, x);
     }
   }
 
@@ -904,7 +939,7 @@ probe_kernel(const ProbeParams P)
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS) {
       const unsigned long long x = mat_all[i];
       if (x)
-        atomicAdd(P.matrix + i, x);
+        atomicAdd(matrix_dst(P) + i, x);
     }
   }
 }

@@ -1041,7 +1041,7 @@ probe_sliced_kernel(const ProbeParams P)
       for (int off = 32; off > 0; off >>= 1)
         x += __shfl_down(x, off, WAVE);
       if (lane == 0 && x)
-        atomicAdd(P.stats + k, x);
+        atomicAdd(stats_dst(P) + k, x);
     }
   }
 
@@ -1050,7 +1050,7 @@ probe_sliced_kernel(const ProbeParams P)
     for (uint32_t i = threadIdx.x; i < cells; i += NT) {
       const unsigned long long x = mat_all[i];
       if (x)
-        atomicAdd(P.matrix + i, x);
+        atomicAdd(matrix_dst(P) + i, x);
     }
   }
 }

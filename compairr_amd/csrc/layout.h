@@ -168,6 +168,7 @@ struct Chunk {
                             sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
 };
 
+constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
 
 /* entries per position of the sliced kernel's LDS copy of the Zobrist table:
@@ -268,6 +269,14 @@ struct ProbeParams {
   const QueryRec *qrec;            /* per slot: what verification reads            */
   uint32_t        ntiles;
   uint32_t        first_tile;
+  /* Where a workgroup leaves its counters and its LDS copy of the matrix: slot
+     blockIdx % NPART of `part` (part_stride u64 each: the matrix cells, then STAT_COUNT
+     counters), summed into matrix / stats by reduce_partials_kernel.  Thousands of
+     workgroups adding to the same 16 memory lines serialise (~8 ns per atomic and
+     line: 150 us of a 260 us resolve kernel); NULL = add to matrix / stats directly. */
+  unsigned long long *part;
+  uint32_t        part_stride;
+  uint32_t        work_first, work_step;   /* variant 0: this launch takes tiles work_first + k work_step */
   /* output */
   unsigned long long *matrix;      /* R1 * R2 integer sums                   */
   double             *matrix_f64;  /* ratio score only                       */

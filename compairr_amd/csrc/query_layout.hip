@@ -763,6 +763,38 @@ gather_chunks_kernel(const Chunk *src, const uint32_t *idx, uint32_t n, Chunk *d
     dst[k] = src[idx[k]];
 }
 
+/* Work sharding (tunables work_shard_index / _count): which context of `step` takes
+   the work filed under a slice in a pass.  By slice, not by position in the work
+   list: WHICH queries a slice holds is a property of the input, how they are cut
+   into tiles and chunks is decided by atomics and differs from one layout run (one
+   GPU) to the next. */
+__host__ __device__ inline uint32_t work_owner(uint32_t slice, uint32_t pass, uint32_t step)
+{
+  return (uint32_t)((((uint64_t)slice * 2654435761u + pass * 40503u) >> 7) % step);
+}
+
+__global__ void __launch_bounds__(256)
+chunk_mine_kernel(const Chunk *chunks, const uint32_t *idx, uint32_t n, uint32_t first, uint32_t step,
+                  unsigned char *flag)
+{
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) {
+    const Chunk ck = chunks[idx[k]];
+    flag[k] = work_owner(ck.slice, ck.pass, step) == first ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+small_mine_kernel(const QL Q, const uint32_t *small, uint32_t n, uint32_t first, uint32_t step,
+                  unsigned char *flag)
+{
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) {
+    const TileDesc td = Q.tiles[small[k]];
+    flag[k] = work_owner(td.slice, td.pass, step) == first ? 1 : 0;
+  }
+}
+
 template <typename T>
 struct Tmp {
   DevBuf<T> b;
@@ -856,6 +888,31 @@ int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uin
   if (hv[0])
     return fail(c, CMPR_EINVAL, verr_message(hv[0]));
   longest = hv[1];
+  return CMPR_OK;
+}
+
+/* the entries of `list` (n of them) whose flag -- set by `mark` -- is 1, order kept */
+template <typename Mark>
+static int select_mine(cmpr_context *c, const uint32_t *list, uint32_t n, Tmp<uint32_t> &sel, uint64_t &count,
+                       Mark mark)
+{
+  int rc;
+  Tmp<unsigned char> flag;
+  Tmp<uint32_t> nsel;
+  if ((rc = dev_alloc(c, flag.b, (size_t)n))) return rc;
+  if ((rc = dev_alloc(c, sel.b, (size_t)n))) return rc;
+  if ((rc = dev_alloc(c, nsel.b, 1))) return rc;
+  mark(flag.b.p);
+  HIP_TRY(c, hipGetLastError());
+  size_t sb = 0;
+  (void)hipcub::DeviceSelect::Flagged(nullptr, sb, list, flag.b.p, sel.b.p, nsel.b.p, (int)n, c->stream);
+  Tmp<char> st;
+  if ((rc = dev_alloc(c, st.b, sb))) return rc;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(st.b.p, sb, list, flag.b.p, sel.b.p, nsel.b.p, (int)n, c->stream));
+  uint32_t h = 0;
+  HIP_TRY(c, hipMemcpyAsync(&h, nsel.b.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  count = h;
   return CMPR_OK;
 }
 
@@ -1246,6 +1303,12 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     HIP_TRY(c, hipGetLastError());
   }
 
+  const uint32_t wstep = (uint32_t)c->work_shard_count;
+  const uint32_t wfirst = (uint32_t)c->work_shard_index;
+  if (wfirst >= wstep)
+    return fail(c, CMPR_EINVAL, "work_shard_index must be below work_shard_count");
+  if (wstep > 1 && !c->sliced)
+    return fail(c, CMPR_EUNSUPPORTED, "work shards need a sliced layout (kernel variant 1 or 2)");
   /* ---- heaviest chunks first: the tail of the launch is made of light ones;
           single-wave tiles longest first ---- */
   if (nchunks) {
@@ -1264,10 +1327,24 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     if ((rc = dev_alloc(c, st.b, sb))) return rc;
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(st.b.p, sb, wk.b.p, wk2.b.p, ix.b.p,
                                                             ix2.b.p, (int)nchunks, 0, 32, c->stream));
-    hipLaunchKernelGGL(gather_chunks_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream,
-                       chunks_unsorted.b.p, ix2.b.p, (uint32_t)nchunks, c->chunks.p);
+    uint64_t mine = nchunks;
+    const uint32_t *order = ix2.b.p;
+    Tmp<uint32_t> sel;
+    if (wstep > 1) {
+      /* the context's share of the sorted list */
+      if ((rc = select_mine(c, ix2.b.p, (uint32_t)nchunks, sel, mine, [&](unsigned char *flag) {
+            hipLaunchKernelGGL(chunk_mine_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream,
+                               chunks_unsorted.b.p, ix2.b.p, (uint32_t)nchunks, wfirst, wstep, flag);
+          })))
+        return rc;
+      order = sel.b.p;
+    }
+    if (mine)
+      hipLaunchKernelGGL(gather_chunks_kernel, dim3(blocks_for(mine)), dim3(256), 0, c->stream,
+                         chunks_unsorted.b.p, order, (uint32_t)mine, c->chunks.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->nchunks = (uint32_t)mine;
   }
   if (nsmall) {
     Tmp<uint32_t> ln, ln2, out;
@@ -1285,9 +1362,22 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(st.b.p, sb, ln.b.p, ln2.b.p,
                                                             c->small_tiles.p, out.b.p, (int)nsmall,
                                                             0, 17, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->small_tiles.p, out.b.p, (size_t)nsmall * sizeof(uint32_t),
-                              hipMemcpyDeviceToDevice, c->stream));
+    uint64_t mine = nsmall;
+    const uint32_t *keep = out.b.p;
+    Tmp<uint32_t> sel;
+    if (wstep > 1) {
+      if ((rc = select_mine(c, out.b.p, (uint32_t)nsmall, sel, mine, [&](unsigned char *flag) {
+            hipLaunchKernelGGL(small_mine_kernel, dim3(blocks_for(nsmall)), dim3(256), 0, c->stream, Q,
+                               out.b.p, (uint32_t)nsmall, wfirst, wstep, flag);
+          })))
+        return rc;
+      keep = sel.b.p;
+    }
+    if (mine)
+      HIP_TRY(c, hipMemcpyAsync(c->small_tiles.p, keep, (size_t)mine * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->nsmall = (uint32_t)mine;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMPR_OK;

@@ -349,6 +349,57 @@ def test_errors_through_the_abi():
             h.overlap_matrix()         # ratio needs the f64 entry point
 
 
+@pytest.mark.parametrize("name,opt,nt,tun", [
+    ("aa_d1", dict(differences=1), False, {}),
+    ("aa_d1_indels", dict(differences=1, indels=True), False, {}),
+    ("aa_d2", dict(differences=2), False, {}),
+    ("nt_d1_sliced", dict(differences=1, nucleotides=True, ignore_genes=True), True, {}),
+    ("aa_d1_sliced", dict(differences=1), False, {"variant": 1}),
+    ("aa_d1_small_slices", dict(differences=1), False, {"small_slice_tiles": 64}),
+])
+def test_work_shards_add_up(name, opt, nt, tun):
+    """bench.py --shard-by work: a context with work_shard_count = N does the work filed
+    under its share of the filter slices; the N matrices add up to the whole one, and
+    so do the counters -- although every context lays the queries out by itself."""
+    n = 3000 if opt.get("differences") == 2 else 60000
+    a = synth.make_set(n, 11, prefix="A", nucleotides=nt, pool_size=n // 2)
+    b = synth.make_set(n, 12, prefix="B", nucleotides=nt, pool_size=n // 2)
+    o = Options(**opt, **FULL)
+
+    def run(index, count):
+        with HipOverlap(o) as h:
+            for k, v in tun.items():
+                h.set_tunable(k, v)
+            h.set_tunable("work_shard_count", count)
+            h.set_tunable("work_shard_index", index)
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            m = h.overlap_matrix()
+            return m, h.stats().matches
+
+    whole, pairs = run(0, 1)
+    want, _ = _oracle.overlap(a, b, o, threads=8)
+    assert np.array_equal(whole, _oracle.integer_cells(want, o))
+    for count in (2, 5):
+        parts = [run(i, count) for i in range(count)]
+        assert np.array_equal(sum(p[0] for p in parts), whole), (name, count)
+        assert sum(p[1] for p in parts) == pairs
+        assert all(p[1] < pairs for p in parts)                  # nobody did everything
+    with HipOverlap(o) as h:
+        h.set_tunable("work_shard_count", 2)
+        h.set_tunable("work_shard_index", 2)
+        h.set_reference(b, a.longest)
+        with pytest.raises(hipmod.HipError):
+            h.set_queries(a)
+    with HipOverlap(o) as h:                   # the unsliced baseline kernel has no slices to deal out
+        h.set_tunable("variant", 0)
+        h.set_tunable("work_shard_count", 2)
+        h.set_reference(b, a.longest)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_queries(a)
+        assert e.value.code == 4               # CMPR_EUNSUPPORTED
+
+
 def test_debug_switches_absent_from_the_shipped_library():
     """The ablation switches (ProbeParams::debug) are compiled out of
     libcompairr_hip.so: the tunable is refused, and so are values no kernel has."""
