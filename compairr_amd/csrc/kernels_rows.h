@@ -456,106 +456,127 @@ probe_rows_kernel(const ProbeParams P)
   cur.b = cur.c = nxt.b = nxt.c = 0;
   cur.r0 = cur.r1 = cur.r2 = cur.r3 = cur.r4 = cur.r5 = 0;
   nxt.r0 = nxt.r1 = nxt.r2 = nxt.r3 = nxt.r4 = nxt.r5 = 0;
-  bool nxt_loaded = false;
 
-  for (;;) {
-    uint32_t t;
-    TileDesc td;
-    uint32_t sbase = 0, pass = 0, cslice = 0;    /* staged: LDS address of the slice, the chunk's pass and slice */
-    bool staged = false;
-    PT_MARK(PT_OTHER);
-    if (block_phase) {
-      /* my tile: the one claimed (and fetched) while the previous was worked on, or a
-         fresh claim */
-      bool have = nxt_c.ok;
-      cur_c = nxt_c;
-      cur = nxt;
-      bool cur_loaded = nxt_loaded;
-      if (!have) {
-        cur_c = claim_tile(true);
-        have = cur_c.ok;
-        cur_loaded = false;
-      }
-      PT_MARK(PT_CLAIM);
-      if (!have) {
-        block_phase = false;
-        continue;
-      }
-      sbase = cur_c.b * slice_bytes;
-      pass = __builtin_amdgcn_readfirstlane(ring[cur_c.b].pass);
-      cslice = __builtin_amdgcn_readfirstlane(ring[cur_c.b].slice);
-      staged = true;
-      /* a tile of the chunk: its reference is in LDS; a block of a class-row chunk:
-         64 consecutive items */
-      auto tile_of = [&](const Claim &cc, uint32_t cpass, uint32_t &tt) -> TileDesc {
-        TileDesc x;
-        if (cpass >= 3) {
-          x.len = 0;
-          x.nvalid = WAVE;
-          x.res_base = __builtin_amdgcn_readfirstlane(ring[cc.b].first) + cc.k * WAVE;
-          x.pass = cpass;
-          x.slice = __builtin_amdgcn_readfirstlane(ring[cc.b].slice);
-          x.k = 0;
-          tt = 0;
-        } else {
-          const TileRef *tr = tref_lds + cc.b * chunk_cap + cc.k;
-          tt = __builtin_amdgcn_readfirstlane(tr->t);
-          x = tr->td;
-        }
-        return x;
-      };
-      td = tile_of(cur_c, pass, t);
-      if (!cur_loaded)
-        cur = load_tile_data(__builtin_amdgcn_readfirstlane(td.len),
-                             __builtin_amdgcn_readfirstlane(td.nvalid),
-                             __builtin_amdgcn_readfirstlane(td.res_base), t,
-                             pass ? pass : __builtin_amdgcn_readfirstlane(td.pass));
-      /* the next tile, if one can be had without waiting: its data is in flight
-         while this one is worked on */
-      nxt_c = claim_tile(false);
-      nxt_loaded = false;
-      if (nxt_c.ok) {
-        const uint32_t np = __builtin_amdgcn_readfirstlane(ring[nxt_c.b].pass);
-        uint32_t tn = 0;
-        const TileDesc dn = tile_of(nxt_c, np, tn);
-        nxt = load_tile_data(__builtin_amdgcn_readfirstlane(dn.len),
-                             __builtin_amdgcn_readfirstlane(dn.nvalid),
-                             __builtin_amdgcn_readfirstlane(dn.res_base), tn,
-                             np ? np : __builtin_amdgcn_readfirstlane(dn.pass));
-        nxt_loaded = true;
-      }
+  /* What is known of the tile at hand, all wave-uniform: `staged` = it came from a
+     chunk (slice in LDS at sbase; pass and cslice are the chunk's), else one of the
+     tiles whose slice holds too few queries to be worth staging (claimed one at a
+     time, the filter read where it lies). */
+  struct Unit {
+    bool staged;
+    uint32_t sbase, pass, cslice;
+    uint32_t t, L, nvalid, K, tslice, tres, tpass;
+  };
+  /* a tile of a chunk: its reference is in LDS; a block of a class-row chunk: 64
+     consecutive items */
+  auto unit_of = [&](const Claim &cc) -> Unit {
+    Unit u;
+    u.staged = true;
+    u.sbase = cc.b * slice_bytes;
+    u.pass = __builtin_amdgcn_readfirstlane(ring[cc.b].pass);
+    u.cslice = __builtin_amdgcn_readfirstlane(ring[cc.b].slice);
+    if (u.pass >= 3) {
+      u.t = 0;
+      u.L = 0;
+      u.nvalid = WAVE;
+      u.K = 0;
+      u.tslice = u.cslice;
+      u.tres = __builtin_amdgcn_readfirstlane(ring[cc.b].first) + cc.k * WAVE;
+      u.tpass = u.pass;
     } else {
-      /* tiles whose slice holds too few queries to be worth staging: claimed one
-         at a time, the filter read where it lies */
-      uint32_t i = 0;
-      if (lane == 0)
-        i = atomicAdd(P.tile_counter + 1, 1u);
-      i = __builtin_amdgcn_readfirstlane(i);
-      if (i >= P.nsmall)
-        break;
-      t = P.small_tiles[i];
-      td = P.tiles[t];
-      cur = load_tile_data(__builtin_amdgcn_readfirstlane(td.len),
-                           __builtin_amdgcn_readfirstlane(td.nvalid),
-                           __builtin_amdgcn_readfirstlane(td.res_base), t,
-                           __builtin_amdgcn_readfirstlane(td.pass));
+      const TileRef *tr = tref_lds + cc.b * chunk_cap + cc.k;
+      const TileDesc td = tr->td;
+      u.t = __builtin_amdgcn_readfirstlane(tr->t);
+      u.L = __builtin_amdgcn_readfirstlane(td.len);
+      u.nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
+      u.K = __builtin_amdgcn_readfirstlane(td.k);
+      u.tslice = __builtin_amdgcn_readfirstlane(td.slice);
+      u.tres = __builtin_amdgcn_readfirstlane(td.res_base);
+      /* the indel passes reuse the tiles of pass 0 and are named by their chunk */
+      u.tpass = u.pass ? u.pass : __builtin_amdgcn_readfirstlane(td.pass);
+    }
+    return u;
+  };
+  /* The next thing to do when nothing was claimed ahead: a tile of a chunk (waiting
+     for the loader if need be), and when the chunks are through, the unstaged tiles.
+     Its data is requested here and awaited at once -- the rare way in. */
+  auto unit_small = [&](uint32_t t) -> Unit {
+    const TileDesc td = P.tiles[t];
+    Unit u;
+    u.staged = false;
+    u.sbase = u.pass = u.cslice = 0;
+    u.t = t;
+    u.L = __builtin_amdgcn_readfirstlane(td.len);
+    u.nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
+    u.K = __builtin_amdgcn_readfirstlane(td.k);
+    u.tslice = __builtin_amdgcn_readfirstlane(td.slice);
+    u.tres = __builtin_amdgcn_readfirstlane(td.res_base);
+    u.tpass = __builtin_amdgcn_readfirstlane(td.pass);
+    return u;
+  };
+  uint32_t small_t = 0;                   /* the unstaged tile at hand (cur_c.ok = false) */
+  auto next_unit = [&](TileData &d) -> bool {
+    if (block_phase) {
+      cur_c = claim_tile(true);
+      if (cur_c.ok) {
+        const Unit u = unit_of(cur_c);
+        d = load_tile_data(u.L, u.nvalid, u.tres, u.t, u.tpass);
+        return true;
+      }
+      block_phase = false;
+    }
+    cur_c.ok = false;
+    /* (no such tiles: not even the claim -- 4096 waves asking one counter at the end
+       of the launch wait ~30 ns each for one another) */
+    if (P.nsmall == 0)
+      return false;
+    uint32_t i = 0;
+    if (lane == 0)
+      i = atomicAdd(P.tile_counter + 1, 1u);
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= P.nsmall)
+      return false;
+    small_t = P.small_tiles[i];
+    const Unit u = unit_small(small_t);
+    d = load_tile_data(u.L, u.nvalid, u.tres, u.t, u.tpass);
+    return true;
+  };
+
+  PT_MARK(PT_OTHER);
+  bool have = next_unit(cur);
+  PT_MARK(PT_CLAIM);
+  /* The loop's shape is deliberate: the next tile is claimed and its data requested
+     at the TOP of the body, the registers change hands at the BOTTOM.  With the
+     hand-over at the top the compiler rotates the loop, the copy of the loaded
+     registers lands right behind the loads and waits for them -- nothing overlaps. */
+  while (have) {
+    /* (the descriptor is read again rather than carried round the loop: scalar
+       registers are scarce) */
+    const Unit un = cur_c.ok ? unit_of(cur_c) : unit_small(small_t);
+    const bool staged = un.staged;
+    const uint32_t sbase = un.sbase, pass = un.pass, cslice = un.cslice;
+    const uint32_t t = un.t;
+    /* the next tile, if one can be had without waiting: its data is in flight
+       while this one is worked on */
+    nxt_c.ok = false;
+    if (staged) {
+      nxt_c = claim_tile(false);
+      if (nxt_c.ok) {
+        const Unit n = unit_of(nxt_c);
+        nxt = load_tile_data(n.L, n.nvalid, n.tres, n.t, n.tpass);
+      }
     }
     {
-      const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
-      const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
-      const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);       /* 0: light tile */
-      const uint32_t tslice = __builtin_amdgcn_readfirstlane(td.slice);
-      const uint32_t tres = __builtin_amdgcn_readfirstlane(td.res_base);
-      /* the indel passes reuse the tiles of pass 0 and are named by their chunk */
-      const uint32_t tpass_real = (staged && pass) ? pass : __builtin_amdgcn_readfirstlane(td.pass);
+      const uint32_t L = un.L;
+      const uint32_t nvalid = un.nvalid;
+      const uint32_t K = un.K;       /* 0: light tile */
+      const uint32_t tslice = un.tslice;
+      const uint32_t tres = un.tres;
+      const uint32_t tpass_real = un.tpass;
       /* (ablation builds: a skipped tile gets a pass number no branch below takes) */
       const uint32_t tpass = (CMPR_DBG(P, DBG_SKIP_TILES) ||
                               (CMPR_DBG(P, DBG_SKIP_CLASS_TILES) && tpass_real >= 3) ||
                               (CMPR_DBG(P, DBG_SKIP_MAIN_TILES) && tpass_real < 3)) ? 0xffu : tpass_real;
-#ifdef CMPR_PHASE_TIMING
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PT_MARK(PT_TILE_DATA);
-#endif
       const uint32_t *qr = P.qres + tres + lane;
       const bool class_tile = tpass_real >= 3;
       /* a class-row item carries the row's blanked hash, the query's slot in pass 0
@@ -1181,6 +1202,16 @@ probe_rows_kernel(const ProbeParams P)
       if (lane == 0)
         atomicAdd(&ring[cur_c.b].done, 1u);
     }
+    PT_MARK(PT_OTHER);
+    /* hand-over: the tile claimed ahead, else a fresh claim */
+    if (nxt_c.ok) {
+      cur_c = nxt_c;
+      cur = nxt;
+      have = true;
+    } else {
+      have = next_unit(cur);
+    }
+    PT_MARK(PT_CLAIM);
   }
 
   /* leftovers: fewer than 64 entries */

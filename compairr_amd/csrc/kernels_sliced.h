@@ -527,8 +527,8 @@ probe_sliced_kernel(const ProbeParams P)
         t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
         td = tref_lds[tk].td;
       } else {
-        uint32_t i = 0;
-        if (lane == 0)
+        uint32_t i = P.nsmall;
+        if (lane == 0 && P.nsmall)             /* (none: not even the claim) */
           i = atomicAdd(P.tile_counter + 1, 1u);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= P.nsmall) {
