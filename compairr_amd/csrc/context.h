@@ -74,7 +74,7 @@ struct cmpr_context {
   int64_t waves_per_block = 8;
   int64_t work_shard_index = 0;   /* this context works on every work_shard_count-th work   */
   int64_t work_shard_count = 1;   /* item (chunk / small tile / tile) of the step, from here */
-  int64_t small_slice_tiles = 2;  /* slices with <= this many tiles: wave phase */
+  int64_t small_slice_tiles = 0;  /* slices with <= this many tiles are not staged (wave phase): never pays since round 2 */
   int64_t class_rows_unstaged = 0; /* variant 2: class-row tiles read the filter where it lies */
   int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
   int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */

@@ -229,13 +229,27 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              (default 0 for variant 0, +2 for variant 1)
      "class_residues"        -1 (default: from the data) or 0..3
      "slice_words_log2"      log2 of the (largest) slice in filter words: 64-bit
-                             words, default 12 (variant 1); 128-bit words,
-                             default and at most 11 (variant 2)
+                             words, default 12 (variant 1); 256-bit words,
+                             -1 = default: sized to the LDS (<= 640 words), or
+                             a power of two 1..13 (variant 2)
      "chunk_tiles"           tiles per workgroup work item (default 8 x waves)
-     "waves_per_block"       4, 8 (default) or 16 waves per workgroup (variants 1, 2)
+     "waves_per_block"       4, 8 or 16 waves per workgroup (variants 1, 2;
+                             default 8 / 16)
+     "small_slice_tiles"     slices with at most this many tiles are probed where
+                             they lie instead of being staged (default 0)
+     "work_shard_count",     this context does the work filed under every
+     "work_shard_index"      count-th share of the filter slices, share `index`
+                             (default 1, 0: everything).  N contexts -- e.g. one
+                             per GPU -- with the same sets and index 0..N-1
+                             produce matrices, pair lists and counters that add
+                             up to the unsharded ones (variants 1, 2).
+     "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
+     "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
+     "host_threads"          see compairr_amd/csrc/compairr_hip.hip
    "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
-   must be set before cmpr_set_reference(); "chunk_tiles" and "waves_per_block"
-   before cmpr_set_queries(). */
+   must be set before cmpr_set_reference(); "chunk_tiles", "waves_per_block",
+   "small_slice_tiles" and the work shard before cmpr_set_queries().  ("debug" exists
+   only in a -DCMPR_ABLATION build of the library.) */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 
 /* Current value of a tunable (for the data-dependent ones, the value in effect

@@ -77,6 +77,14 @@ for k in ("probe", "resolve"):
         e["hbm_bytes_per_launch"] = 2 * fetch + write
         e["raw_fetch_bytes"] = fetch
         e["raw_write_bytes"] = write
+    # issue-side utilisation straight from the counters: SQ_ACTIVE_INST_* count in units
+    # of 4 cycles per SIMD, SQ_BUSY_CU_CYCLES in cycles per CU (4 SIMDs): their ratio is
+    # the fraction of SIMD cycles in which the unit was executing an instruction
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CU_CYCLES" in c:
+        busy = c["SQ_BUSY_CU_CYCLES"]["per_launch_mean"]
+        e["busy_fraction"] = {u: c[n]["per_launch_mean"] / busy
+                              for u, n in (("valu", "SQ_ACTIVE_INST_VALU"), ("scalar", "SQ_ACTIVE_INST_SCA"),
+                                           ("lds", "SQ_ACTIVE_INST_LDS")) if n in c}
     out["kernels"][k] = e
 
 tot = [e.get("hbm_bytes_per_launch") for e in out["kernels"].values()]
@@ -122,6 +130,7 @@ if "probe" in out["kernels"] and os.path.exists(cal_path):
             "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
             "hbm_bytes": out["kernels"]["probe"].get("hbm_bytes_per_launch"),
             "effective_clock_hz": f_eff,
+            "busy_fraction_from_counters": out["kernels"]["probe"].get("busy_fraction"),
         },
         "calibration": {
             "from": cal_path,
