@@ -31,6 +31,7 @@ std::string &cmpr_create_error()
 /* u64s behind the segment counters of the positives buffer: statistics, cursors,
    overflow flag, and the statistics + cursors of the redo pass */
 static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
+namespace { void use_counter_block(cmpr_context *c, int which); }
 
 int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
 {
@@ -559,12 +560,11 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
     /* one block that is zeroed per launch with ONE memset: the segment counters,
        then the statistics, the two work cursors, the overflow flag, and the
        statistics + cursors of a redo pass (kernels_rows.h) */
-    if ((rc = dev_alloc(c, c->pos_ctr, S * POS_CTR_STRIDE + CTR_TAIL))) return rc;
-    c->d_stats = c->pos_ctr.p + S * POS_CTR_STRIDE;
-    c->d_tile_counter = (uint32_t *)(c->d_stats + STAT_COUNT);
-    c->d_overflow = c->d_stats + STAT_COUNT + 1;
-    c->d_stats2 = c->d_overflow + 1;
-    c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
+    /* (two of them: a launch uses one and clears the other for the next launch --
+       reduce_partials_kernel -- so that a step starts without a memset) */
+    if ((rc = dev_alloc(c, c->pos_ctr, 2 * (S * POS_CTR_STRIDE + CTR_TAIL)))) return rc;
+    c->ctr_clean = false;
+    use_counter_block(c, 0);
     /* partial results of the workgroups (ProbeParams::part); cleared here, and by
        reduce_partials_kernel after every launch */
     const size_t cells = (size_t)c->R1 * c->R2;
@@ -584,19 +584,47 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
 
 namespace {
 
+/* the counter block a launch works with (block 0 or 1 of pos_ctr's allocation) */
+void use_counter_block(cmpr_context *c, int which)
+{
+  const size_t blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
+  c->ctr_cur = c->pos_ctr.p + (size_t)which * blk;
+  c->ctr_other = c->pos_ctr.p + (size_t)(1 - which) * blk;
+  c->d_stats = c->ctr_cur + (size_t)c->pos_segments * POS_CTR_STRIDE;
+  c->d_tile_counter = (uint32_t *)(c->d_stats + STAT_COUNT);
+  c->d_overflow = c->d_stats + STAT_COUNT + 1;
+  c->d_stats2 = c->d_overflow + 1;
+  c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
+}
+
 /* enqueue: zero outputs, run the probe kernel over every tile.  `d_out` is the
    integer matrix to fill (ours or the caller's). */
 int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 {
   const size_t cells = (size_t)c->R1 * c->R2;
   HIP_TRY(c, hipEventRecord(c->ev_start, st));
-  if (cells)
+  /* A step normally starts without a memset: its counter block was cleared by the
+     previous launch's reduce kernel, and with the matrix privatised in LDS the reduce
+     kernel WRITES the cells.  Otherwise (first launch, a launch that failed half-way,
+     matrix too large for LDS, nothing to launch) everything is cleared here. */
+  const size_t ctr_blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
+  const bool will_launch = c->ntiles > 0 && cells > 0;
+  const bool reduce_writes = will_launch && cells <= 2048 && !is_f64_score(c->opt);
+  if (cells && !reduce_writes)
     HIP_TRY(c, hipMemsetAsync(d_out, 0, cells * sizeof(unsigned long long), st));
   if (cells && is_f64_score(c->opt))
     HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, cells * sizeof(double), st));
   const bool deferred = c->sliced && c->deferred_resolve;
-  HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, ((size_t)c->pos_segments * POS_CTR_STRIDE +
-                                              CTR_TAIL) * sizeof(unsigned long long), st));
+  if (!c->ctr_clean) {
+    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, 2 * ctr_blk * sizeof(unsigned long long), st));
+    HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long), st));
+    use_counter_block(c, 0);
+  } else {
+    use_counter_block(c, c->ctr_cur == c->pos_ctr.p ? 1 : 0);
+  }
+  c->ctr_clean = false;                     /* until this launch is through */
+  if (!will_launch)                         /* (nobody will clear the other block) */
+    HIP_TRY(c, hipMemsetAsync(c->ctr_other, 0, ctr_blk * sizeof(unsigned long long), st));
   c->launches = 0;
   bool launched = false;
 
@@ -669,7 +697,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.debug = (uint32_t)c->debug;
     if (deferred) {
       P.pos_buf = c->pos_buf.p;
-      P.pos_ctr = c->pos_ctr.p;
+      P.pos_ctr = c->ctr_cur;
       P.pos_cap = c->pos_cap;
       P.pos_segments = (uint32_t)c->pos_segments;
     }
@@ -746,7 +774,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
     auto reduce_partials = [&]() {
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((P.part_stride + 255) / 256), dim3(256), 0, st, P,
-                         (uint32_t)(P.lds_matrix ? cells : 0));
+                         (uint32_t)(P.lds_matrix ? cells : 0), reduce_writes ? 1u : 0u, c->ctr_other,
+                         (uint32_t)ctr_blk);
     };
     if (!(deferred && !(c->debug & DBG_SKIP_RESOLVE))) {
       reduce_partials();
@@ -790,6 +819,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   if (!launched)
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
+  c->ctr_clean = true;
   return CMPR_OK;
 }
 

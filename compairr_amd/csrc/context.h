@@ -145,6 +145,8 @@ struct cmpr_context {
   DevBuf<double>             matrix_f64;
   DevBuf<PosEntry>           pos_buf;      /* deferred resolve: queued Bloom positives */
   DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
+  unsigned long long        *ctr_cur = nullptr, *ctr_other = nullptr;   /* this launch's block / the next one's */
+  bool                       ctr_clean = false;        /* ctr_other and `part` are all zero */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */

@@ -575,11 +575,16 @@ __device__ __forceinline__ unsigned long long *matrix_dst(const ProbeParams &P)
 }
 
 /* Sums the NPART partial results into the matrix and the counters and clears them
-   for the next launch; one thread per cell / counter. */
+   for the next launch; one thread per cell / counter.  `overwrite`: the cells are
+   written, not added to (the matrix was not cleared before the launch).  Also clears
+   the counter block of the NEXT launch (`next_ctr`, n64 words). */
 static __global__ void __launch_bounds__(256)
-reduce_partials_kernel(const ProbeParams P, uint32_t cells)
+reduce_partials_kernel(const ProbeParams P, uint32_t cells, uint32_t overwrite,
+                       unsigned long long *next_ctr, uint32_t n64)
 {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  for (uint32_t k = i; k < n64; k += gridDim.x * 256)
+    next_ctr[k] = 0;
   if (i >= P.part_stride)
     return;
   unsigned long long sum = 0;
@@ -590,12 +595,14 @@ reduce_partials_kernel(const ProbeParams P, uint32_t cells)
       P.part[(size_t)s * P.part_stride + i] = 0;
     }
   }
-  if (!sum)
-    return;
-  if (i < cells)
-    P.matrix[i] += sum;
-  else if (i >= P.part_stride - STAT_COUNT)
+  if (i < cells) {
+    if (overwrite)
+      P.matrix[i] = sum;
+    else if (sum)
+      P.matrix[i] += sum;
+  } else if (sum && i >= P.part_stride - STAT_COUNT) {
     P.stats[i - (P.part_stride - STAT_COUNT)] += sum;
+  }
 }
 
 /* Second kernel of the deferred mode.  Phase A, one lane per queued Bloom

@@ -11,10 +11,10 @@
  *   Every set-2 sequence t is entered into the filter once per position p, under
  *   the hash of t WITH POSITION p BLANKED,  W = H(t) ^ Z[p][t[p]],  together with
  *   the residue it has there (code t[p] < A), and once more under H(t) itself
- *   with code A ("the sequence as it is").  An entry (W, code) sets four bits of
- *   the 128-bit filter word addressed by the high half of W: bit
+ *   with code A ("the sequence as it is").  An entry (W, code) sets eight bits of
+ *   the 256-bit filter word addressed by the high half of W: bit
  *   (a_k + code) mod 32 of dword k, a_0..a_3 being the low five bits of the four
- *   bytes of W's low half.
+ *   bytes of W's low half, a_4..a_7 four 5-bit fields of its high half.
  *
  *   A query q reads, for position p, the word of W = H(q) ^ Z[p][q[p]] -- the same
  *   W as every t that differs from q at most at p -- rotates dword k right by a_k
@@ -37,9 +37,9 @@
  * workgroup stages in LDS (layout.h), with one refinement the blanking makes
  * possible: the entry of (t, p) is filed under t's class key WITHOUT the term of
  * position p when p is a class position.  All A variants of a class-position
- * row therefore live in ONE slice (the "sibling" of the query's own), and the
- * host schedules those rows as separate passes whose tiles are grouped by that
- * sibling: no substitution probe of d = 1 goes to HBM.
+ * row therefore live in ONE slice of that position's "class part" of the filter,
+ * and the layout (query_layout.hip) lists those rows as items grouped by that
+ * slice: no substitution probe of d = 1 goes to HBM.
  */
 #ifndef COMPAIRR_AMD_KERNELS_ROWS_H
 #define COMPAIRR_AMD_KERNELS_ROWS_H
@@ -170,8 +170,10 @@ template <int A> struct RowCfg {
  *          position of a split ("heavy") tile (+ the double substitutions)
  *   1, 2   insertion rows / deletion variants, the tiles grouped by the slice
  *          most of those variants fall into (as in variant 1)
- *   3 + i  the substitution row of class position i of the heavy queries, the
- *          tiles grouped by that row's slice (in class part i of the filter)
+ *   3 + i  items: the substitution row of class position i of the heavy queries
+ *          (with -i also insertion rows blanked there; group K: deletion variants
+ *          that leave their query's slice), blocks of 64 grouped by the slice the
+ *          row is filed under (class part i of the filter), ITEM_BLOCKS per claim
  * TileDesc::slice is the slice the tile's rows of this pass are filed under;
  * for a staged chunk it is the slice in LDS.
  *
@@ -180,8 +182,9 @@ template <int A> struct RowCfg {
  * list, heaviest first).  A wave that finds no tile to work on stages the next
  * chunk: it copies slice and tile references into the next free buffer with
  * LDS-DMA (global_load_lds: no registers, asynchronous) and publishes it; waves
- * claim tiles from the published buffers in order, one tile at a time with an LDS
- * atomic, and a buffer is free again when its tiles are finished.  Nothing in the
+ * claim tiles from the published buffers in order, one tile (or ITEM_BLOCKS item
+ * blocks) at a time with an LDS atomic, and a buffer is free again when its tiles
+ * are finished.  Nothing in the
  * steady state is a workgroup barrier: staging overlaps the rows, several chunks
  * are copied at once, and no wave idles at the end of a chunk while another still
  * works on it.
@@ -192,6 +195,9 @@ template <int A> struct RowCfg {
  */
 constexpr uint32_t RING = 4;
 constexpr uint32_t RING_END = 0xffffffffu;
+/* blocks of 64 items a wave takes with one claim: an item is one row, and claiming,
+   descriptor and address arithmetic of a unit cost ~3 rows' worth of instructions */
+constexpr uint32_t ITEM_BLOCKS = 4;
 
 /* -DCMPR_PHASE_TIMING (tools/phase_timing.sh): every wave sums the shader cycles
    (s_memtime) it spends per phase and adds them to ProbeParams::stats[8 + phase];
@@ -217,7 +223,7 @@ struct RingSlot {
   uint32_t done;             /* tiles of the tenant finished */
   uint32_t slice, pass;
   uint32_t first;            /* class-row chunk: its first item (blocks of 64 items, no tile refs) */
-  uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter) */
+  uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter; [1]: item chunk: its blocks) */
 };
 
 template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE>
@@ -337,9 +343,12 @@ probe_rows_kernel(const ProbeParams P)
     rs->slice = ck.slice;
     rs->pass = ck.pass;
     rs->first = ck.first_tile;
+    rs->pad[1] = ck.ntiles;
+    /* what is claimed: a tile, or ITEM_BLOCKS blocks of an item chunk */
+    const uint32_t units = ck.pass >= 3 ? (ck.ntiles + ITEM_BLOCKS - 1u) / ITEM_BLOCKS : ck.ntiles;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the copies have landed */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    rs->claim = ((unsigned long long)T << 32) | ((unsigned long long)ck.ntiles << 16);
+    rs->claim = ((unsigned long long)T << 32) | ((unsigned long long)units << 16);
     return true;
   };
 
@@ -465,6 +474,7 @@ probe_rows_kernel(const ProbeParams P)
     bool staged;
     uint32_t sbase, pass, cslice;
     uint32_t t, L, nvalid, K, tslice, tres, tpass;
+    uint32_t nblk;                  /* item unit: its blocks of 64 (1 .. ITEM_BLOCKS) */
   };
   /* a tile of a chunk: its reference is in LDS; a block of a class-row chunk: 64
      consecutive items */
@@ -474,14 +484,17 @@ probe_rows_kernel(const ProbeParams P)
     u.sbase = cc.b * slice_bytes;
     u.pass = __builtin_amdgcn_readfirstlane(ring[cc.b].pass);
     u.cslice = __builtin_amdgcn_readfirstlane(ring[cc.b].slice);
+    u.nblk = 1;
     if (u.pass >= 3) {
       u.t = 0;
       u.L = 0;
       u.nvalid = WAVE;
       u.K = 0;
       u.tslice = u.cslice;
-      u.tres = __builtin_amdgcn_readfirstlane(ring[cc.b].first) + cc.k * WAVE;
+      u.tres = __builtin_amdgcn_readfirstlane(ring[cc.b].first) + cc.k * (ITEM_BLOCKS * WAVE);
       u.tpass = u.pass;
+      const uint32_t left = __builtin_amdgcn_readfirstlane(ring[cc.b].pad[1]) - cc.k * ITEM_BLOCKS;
+      u.nblk = left < ITEM_BLOCKS ? left : ITEM_BLOCKS;
     } else {
       const TileRef *tr = tref_lds + cc.b * chunk_cap + cc.k;
       const TileDesc td = tr->td;
@@ -504,6 +517,7 @@ probe_rows_kernel(const ProbeParams P)
     Unit u;
     u.staged = false;
     u.sbase = u.pass = u.cslice = 0;
+    u.nblk = 1;
     u.t = t;
     u.L = __builtin_amdgcn_readfirstlane(td.len);
     u.nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
@@ -555,6 +569,8 @@ probe_rows_kernel(const ProbeParams P)
     const bool staged = un.staged;
     const uint32_t sbase = un.sbase, pass = un.pass, cslice = un.cslice;
     const uint32_t t = un.t;
+    (void)pass;
+    (void)cslice;
     /* the next tile, if one can be had without waiting: its data is in flight
        while this one is worked on */
     nxt_c.ok = false;
@@ -892,18 +908,54 @@ probe_rows_kernel(const ProbeParams P)
                 position's class part; a deletion variant (K_DEL), a whole sequence
                 looked up by its code-A entry in the main part ---- */
         if (D >= 1) {
-          const uint32_t kind = cur.c >> 24, p = (cur.c >> 8) & 0xffffu;
-          const RowWord w = fetch_own(cW);
-          const uint32_t bits = row_bits(w, cW);
-          uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << cr)) & vmask;
-          nvar += kind == K_DEL ? 1ull : (cr == 31u ? (uint64_t)A : (uint64_t)(A - 1));
-          const uint32_t za = zl_addr + ZS * p * 8u;
-          while (__ballot(x != 0)) {
-            const bool pos = x != 0;
-            const uint32_t v = (pos && kind != K_DEL) ? (uint32_t)__ffs((int)x) - 1u : 0u;
-            const uint64_t hv = kind == K_DEL ? cW : cW ^ lds_u64(za + v * 8u);
-            s_push<GENES, INLINE>(W, pos, hv, pack_a(kind, p, v), 0);
-            x &= x - 1u;
+          /* the unit's further blocks: requested together now, worked on after the
+             first (whose data came with the claim) */
+          const uint32_t nblk = un.nblk;
+          uint64_t ea[ITEM_BLOCKS - 1];
+          uint32_t eb[ITEM_BLOCKS - 1], ec[ITEM_BLOCKS - 1];
+#pragma unroll
+          for (uint32_t r = 1; r < ITEM_BLOCKS; r++) {
+            ea[r - 1] = 0;
+            eb[r - 1] = 0xffffffffu;
+            ec[r - 1] = 0;
+            if (r < nblk) {
+              const uint32_t cs = tres + r * WAVE + lane;
+              ea[r - 1] = P.cw[cs];
+              eb[r - 1] = P.cmain[cs];
+              ec[r - 1] = P.crp[cs];
+            }
+          }
+          uint64_t iw = cW;
+          uint32_t im = cur.b, ic = cur.c;
+          for (uint32_t r = 0; r < nblk; r++) {
+            const bool ival = im != 0xffffffffu;          /* (~0: padding behind the items of a slice) */
+            const uint32_t icr = ic & 0xffu;
+            const uint32_t kind = ic >> 24, p = (ic >> 8) & 0xffffu;
+            W.qslot = im;
+            reads += ival ? 1u : 0u;
+            const uint32_t wo = woff_of(iw);
+            const RowWord w = staged ? word_lds(wo) : word_glob(own_glob, wo);
+            const uint32_t bits = row_bits(w, iw);
+            uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << icr)) & (ival ? ~0u : 0u);
+            nvar += !ival ? 0ull : kind == K_DEL ? 1ull : (icr == 31u ? (uint64_t)A : (uint64_t)(A - 1));
+            const uint32_t za = zl_addr + ZS * p * 8u;
+            while (__ballot(x != 0)) {
+              const bool pos = x != 0;
+              const uint32_t v = (pos && kind != K_DEL) ? (uint32_t)__ffs((int)x) - 1u : 0u;
+              const uint64_t hv = kind == K_DEL ? iw : iw ^ lds_u64(za + v * 8u);
+              s_push<GENES, INLINE>(W, pos, hv, pack_a(kind, p, v), 0);
+              x &= x - 1u;
+            }
+            /* next block's data moves up */
+            iw = ea[0];
+            im = eb[0];
+            ic = ec[0];
+#pragma unroll
+            for (uint32_t q = 0; q + 2 < ITEM_BLOCKS; q++) {
+              ea[q] = ea[q + 1];
+              eb[q] = eb[q + 1];
+              ec[q] = ec[q + 1];
+            }
           }
         }
       }
