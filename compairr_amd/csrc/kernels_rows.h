@@ -593,6 +593,9 @@ probe_rows_kernel(const ProbeParams P)
                               (CMPR_DBG(P, DBG_SKIP_CLASS_TILES) && tpass_real >= 3) ||
                               (CMPR_DBG(P, DBG_SKIP_MAIN_TILES) && tpass_real < 3)) ? 0xffu : tpass_real;
       PT_MARK(PT_TILE_DATA);
+      /* the tile's counters (nvar further down), 32 bits wide -- a lane's variants of
+         one tile fit -- and added to the 64-bit ones once per tile */
+      uint32_t treads = 0;
       const uint32_t *qr = P.qres + tres + lane;
       const bool class_tile = tpass_real >= 3;
       /* a class-row item carries the row's blanked hash, the query's slot in pass 0
@@ -624,7 +627,7 @@ probe_rows_kernel(const ProbeParams P)
       /* the tile's slice: the staged copy, or where it lies */
       auto fetch_own = [&](uint64_t Wk) -> RowWord {
         const uint32_t wo = woff_of(Wk);
-        reads += valid ? 1u : 0u;
+        treads += valid ? 1u : 0u;
         if (staged)
           return word_lds(wo);
         return word_glob(own_glob, wo);
@@ -632,7 +635,7 @@ probe_rows_kernel(const ProbeParams P)
       /* a slice of the lane's own */
       auto fetch_at = [&](uint64_t Wk, uint32_t slice, bool in_lds) -> RowWord {
         const uint32_t wo = woff_of(Wk);
-        reads += valid ? 1u : 0u;
+        treads += valid ? 1u : 0u;
         RowWord w;
         if (in_lds)
           w = word_lds(wo);
@@ -690,7 +693,7 @@ probe_rows_kernel(const ProbeParams P)
         return dk;
       };
 
-      uint64_t nvar = 0;
+      uint32_t nvar = 0;
 
       /* queue the positives of a block of substitution rows: bit A * j + v of
          (m0, m1) <-> residue v at row j of the block; rpack holds the lanes' own
@@ -741,6 +744,8 @@ probe_rows_kernel(const ProbeParams P)
              bytes of the first (no indexing, no load inside the rows; sequences longer
              than 24 refill it where their residues lie) */
           uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
+          uint32_t nlive = 0;                     /* rows of this lane that count (x A - 1 variants) */
+          uint32_t nrows = 0;                     /* rows read (wave-uniform) */
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += RB) {
@@ -800,17 +805,17 @@ probe_rows_kernel(const ProbeParams P)
               if (j + 1 < RB)
                 wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
               __builtin_amdgcn_sched_barrier(0);
-              reads += valid ? 1u : 0u;
               uint32_t x = row_bits(wc, Wk[j]) & AMASK & ~(1u << rj[j]);
               const bool live = (p < Ll) & !((cbits >> j) & 1u);
               x = live ? x : 0u;
-              nvar += live ? (uint64_t)(A - 1) : 0ull;
+              nlive += live ? 1u : 0u;
               if (j < RPW)
                 m0 |= (uint64_t)x << (A * j);
               else
                 m1 |= (uint64_t)x << (A * (j - RPW));
               wc = wn;
             }
+            nrows += (uint32_t)RB;
             PT_MARK(PT_ROWS);
             emit_sub_rows(m0, m1, p0, rpack);
             PT_MARK(PT_EMIT);
@@ -820,6 +825,8 @@ probe_rows_kernel(const ProbeParams P)
             sub_rows(std::true_type{});
           else
             sub_rows(std::false_type{});
+          nvar += nlive * (uint32_t)(A - 1);
+          treads += valid ? nrows : 0u;
         }
 
         if (D >= 2) {
@@ -849,7 +856,7 @@ probe_rows_kernel(const ProbeParams P)
                   ci_b = (int)i;
               const uint32_t te_own = e_cls ? class_term(e, re) : 0u;
               const bool live = pb < Ll;                          /* pb < Ll implies pa < Ll */
-              nvar += live ? (uint64_t)(A - 1) * (A - 1) : 0ull;
+              nvar += live ? (uint32_t)((A - 1) * (A - 1)) : 0u;
               for (uint32_t k0 = 1; k0 < (uint32_t)A; k0 += RB) {
                 uint64_t m0 = 0, m1 = 0;
 #pragma unroll
@@ -932,12 +939,12 @@ probe_rows_kernel(const ProbeParams P)
             const uint32_t icr = ic & 0xffu;
             const uint32_t kind = ic >> 24, p = (ic >> 8) & 0xffffu;
             W.qslot = im;
-            reads += ival ? 1u : 0u;
+            treads += ival ? 1u : 0u;
             const uint32_t wo = woff_of(iw);
             const RowWord w = staged ? word_lds(wo) : word_glob(own_glob, wo);
             const uint32_t bits = row_bits(w, iw);
             uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << icr)) & (ival ? ~0u : 0u);
-            nvar += !ival ? 0ull : kind == K_DEL ? 1ull : (icr == 31u ? (uint64_t)A : (uint64_t)(A - 1));
+            nvar += !ival ? 0u : kind == K_DEL ? 1u : (icr == 31u ? (uint32_t)A : (uint32_t)(A - 1));
             const uint32_t za = zl_addr + ZS * p * 8u;
             while (__ballot(x != 0)) {
               const bool pos = x != 0;
@@ -1083,7 +1090,7 @@ probe_rows_kernel(const ProbeParams P)
                   const bool here = (key & smask) == cslice;
                   const bool hit = ((row_bits(wc, hp[k]) >> A) & 1u) != 0;
                   const bool lives = fr[k] && here && pp < Ll && Ll > 1u;   /* (the lane's own length) */
-                  reads += valid ? 1u : 0u;
+                  treads += valid ? 1u : 0u;
                   nvar += lives ? 1u : 0u;
                   mask |= (lives && hit) ? (1u << (pp - p0)) : 0u;
                 }
@@ -1207,13 +1214,13 @@ probe_rows_kernel(const ProbeParams P)
                   if (valid && !itr[j] && slr[j] != cslice)
                     w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
                 }
-                reads += valid ? 1u : 0u;
+                treads += valid ? 1u : 0u;
                 uint32_t x = row_bits(w, hrow[j]) & AMASK & vmask;
                 if (ip > 0)
                   x &= ~(1u << rprev[j]);                       /* v != q[ip - 1] */
                 const bool lives = !itr[j] && ip <= Ll;               /* (the lane's own length) */
                 x = lives ? x : 0u;
-                nvar += lives ? (ip > 0 ? (uint64_t)(A - 1) : (uint64_t)A) : 0ull;
+                nvar += lives ? (ip > 0 ? (uint32_t)(A - 1) : (uint32_t)A) : 0u;
                 if (j < RPW)
                   m0 |= (uint64_t)x << (A * j);
                 else
@@ -1245,7 +1252,8 @@ probe_rows_kernel(const ProbeParams P)
         }
       }
 
-      W.st.variants += valid ? nvar : 0ull;
+      W.st.variants += valid ? (uint64_t)nvar : 0ull;
+      reads += treads;
     }
     if (staged) {
       /* this tile's reads of the slice are done: one step towards handing the
