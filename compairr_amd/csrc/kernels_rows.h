@@ -167,9 +167,11 @@ template <int A> struct RowCfg {
 /*
  * Chunk::pass of this kernel:
  *   0      the sequence itself + every substitution row that is not a class
- *          position of a split ("heavy") tile (+ the double substitutions)
- *   1, 2   insertion rows / deletion variants, the tiles grouped by the slice
- *          most of those variants fall into (as in variant 1)
+ *          position of a split ("heavy") tile (+ the double substitutions); with -i
+ *          also the tile's deletion variants and insertion rows, on the same staged
+ *          slice (the class keys of variant 2 have no length term with -i, so an
+ *          indel variant stays in its query's slice unless it touches a class
+ *          position -- those are items)
  *   3 + i  items: the substitution row of class position i of the heavy queries
  *          (with -i also insertion rows blanked there; group K: deletion variants
  *          that leave their query's slice), blocks of 64 grouped by the slice the
@@ -651,7 +653,14 @@ probe_rows_kernel(const ProbeParams P)
               computed when the set was laid out, like the reference's
               seqinfo hash; with -i also the two shifted hashes of the rolling
               indel enumeration (zobrist.cc:90-104, 122-136) ---- */
-      const uint64_t h = cur.a;        /* (pass 1, 2: the shifted hash of that pass) */
+      const uint64_t h = cur.a;
+      /* with -i also the two shifted hashes; requested now, needed behind the
+         substitution rows */
+      uint64_t h_ins = 0, h_del = 0;
+      if (INDELS && tpass == 0 && valid) {
+        h_ins = P.qhins[W.qslot];
+        h_del = P.qhdel[W.qslot];
+      }
 
       /* class positions of this length (wave-uniform), as a bit set */
       uint32_t m[MCR];
@@ -967,7 +976,7 @@ probe_rows_kernel(const ProbeParams P)
         }
       }
 
-      if (INDELS && (tpass == 1 || tpass == 2)) {
+      if (INDELS && tpass == 0) {
         /* Indel variants change the length, hence the class.  t = the variant:
              base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
            and its rows are filed under base(t) ^ (class residues of t other than
@@ -1013,7 +1022,7 @@ probe_rows_kernel(const ProbeParams P)
                 per run of equal residues; t is looked up as a whole sequence
                 (code A).  Four positions (a residue dword) at a time: their rolling
                 keys are read together, the filter words one position ahead. ---- */
-        if (tpass == 2 && L > 1) {
+        if (L > 1 && !CMPR_DBG(P, DBG_SKIP_DEL_ROWS)) {
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L - 1];
           const uint32_t hvy = heavy_of(base_t);
           uint32_t md[MCR], lo[MCR], hi[MCR];
@@ -1026,7 +1035,7 @@ probe_rows_kernel(const ProbeParams P)
               hi[i] = cr_lds[i * A + res_reg(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
             }
           }
-          uint64_t hd = h;                        /* zobrist_hash_delete_first */
+          uint64_t hd = h_del;                    /* zobrist_hash_delete_first */
           uint32_t gone = 0;
           for (uint32_t p0 = 0; p0 < L; p0 += 32) {
             const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
@@ -1117,7 +1126,9 @@ probe_rows_kernel(const ProbeParams P)
                 position ip; blanked at ip it is q with a gap there, whose rolling
                 hash addresses the row of all A residues.  RB rows per block: the
                 rolling keys are read together, the filter words one row ahead. ---- */
-        if (tpass == 1) {
+        if (!CMPR_DBG(P, DBG_SKIP_INS_ROWS)) {
+          /* (the residue shift register starts over) */
+          s0 = cur.r0; s1 = cur.r1; s2 = cur.r2; s3 = cur.r3; s4 = cur.r4; s5 = cur.r5;
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hvy = heavy_of(base_t);
           uint32_t mi[MCR], lo[MCR], hi[MCR];
@@ -1132,7 +1143,7 @@ probe_rows_kernel(const ProbeParams P)
                 hi[i] = cr_lds[i * A + res_reg(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
             }
           }
-          uint64_t hg = h;                        /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
+          uint64_t hg = h_ins;                    /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
           uint32_t carry = 31u;                   /* q[ip0 - 1]: the residue behind which block ip0 starts */
           for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
             if (ip0 && ip0 % (4u * TDW) == 0) {

@@ -492,7 +492,10 @@ slices_kernel(const QL Q, uint32_t pi)
      that single waves work through, probing the slice in HBM / L2. */
   uint32_t nchunks = 0, nsmall = 0, nlist = 0;
   if (Q.sliced && ntiles) {
-    const uint32_t reps = (Q.rows && Q.indels) ? 3u : 1u;     /* variant 2 with -i: passes 0, 1, 2 */
+    /* (variant 2 with -i: the deletion and insertion rows of a tile follow its
+       substitution rows in the same unit, on the same staged slice -- its class keys
+       have no length term -- so there is one chunk per slice, not one per pass) */
+    const uint32_t reps = 1u;
     if (!Q.indels && (ntiles <= Q.small_max || (pi > 0 && Q.class_unstaged))) {
       nsmall = ntiles;
       if (WRITE)
