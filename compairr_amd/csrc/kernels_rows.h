@@ -325,20 +325,24 @@ probe_rows_kernel(const ProbeParams P)
       return true;
     }
     const Chunk ck = P.chunks[blockIdx.x + (T - 1u) * G];
-    const unsigned char *src = filter + (size_t)ck.slice * slice_bytes + lane * 16u;
+    /* (opaque: or the per-lane source pointers are hoisted out of the tile loop and
+       live -- spilled -- across it for the sake of this rare path) */
+    uint32_t l16 = lane * 16u;
+    asm volatile("" : "+v"(l16));
+    const unsigned char *src = filter + (size_t)ck.slice * slice_bytes + l16;
     const uint32_t dst = b * slice_bytes;
     /* one wave-instruction copies 1 KiB: lane l its 16 bytes to (uniform base) +
        16 l; lanes past the end of a slice that is no whole KiB stay out of it */
     for (uint32_t off = 0; off < slice_bytes; off += 1024u)
-      if (off + lane * 16u < slice_bytes)
+      if (off + l16 < slice_bytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(src + off),
                                          (lds_void_t *)(uintptr_t)(dst + off), 16, 0, 0);
-    const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + lane * 16u;
+    const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + l16;
     const uint32_t tdst = (uint32_t)(uintptr_t)(tref_lds + b * chunk_cap);
     /* (a class-row chunk has no tile references: its "tiles" are blocks of 64 items) */
     const uint32_t tbytes = ck.pass >= 3 ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
     for (uint32_t off = 0; off < tbytes; off += 1024u)
-      if (off + lane * 16u < tbytes)
+      if (off + l16 < tbytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(tsrc + off),
                                          (lds_void_t *)(uintptr_t)(tdst + off), 16, 0, 0);
     rs->done = 0;
@@ -654,13 +658,6 @@ probe_rows_kernel(const ProbeParams P)
               seqinfo hash; with -i also the two shifted hashes of the rolling
               indel enumeration (zobrist.cc:90-104, 122-136) ---- */
       const uint64_t h = cur.a;
-      /* with -i also the two shifted hashes; requested now, needed behind the
-         substitution rows */
-      uint64_t h_ins = 0, h_del = 0;
-      if (INDELS && tpass == 0 && valid) {
-        h_ins = P.qhins[W.qslot];
-        h_del = P.qhdel[W.qslot];
-      }
 
       /* class positions of this length (wave-uniform), as a bit set */
       uint32_t m[MCR];
@@ -977,6 +974,13 @@ probe_rows_kernel(const ProbeParams P)
       }
 
       if (INDELS && tpass == 0) {
+        /* the two shifted hashes of the rolling enumeration (requested together: the
+           insertion one arrives while the deletions are worked on) */
+        uint64_t h_ins = 0, h_del = 0;
+        if (valid) {
+          h_del = P.qhdel[W.qslot];
+          h_ins = P.qhins[W.qslot];
+        }
         /* Indel variants change the length, hence the class.  t = the variant:
              base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
            and its rows are filed under base(t) ^ (class residues of t other than
