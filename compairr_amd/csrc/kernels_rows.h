@@ -358,10 +358,10 @@ probe_rows_kernel(const ProbeParams P)
     return true;
   };
 
-  /* what a tile needs per lane before its first row: pass 0 -- the query's hash, its
-     length and the residues of the first block; passes 1, 2 -- the shifted hash
-     instead; class-row blocks -- per item the row's blanked hash, the query's slot
-     in pass 0 (~0: padding) and its residue | position << 8 */
+  /* what a tile needs per lane before its first row: the query's hash, its length and
+     the residues of its first 24 positions; an item block -- per item the row's
+     blanked hash, the query's slot (~0: padding) and its residue | position << 8 |
+     kind << 24 */
   constexpr uint32_t TDW = 6;                 /* residue dwords that travel with a tile: 24 positions */
   struct TileData {
     uint64_t a;
@@ -384,7 +384,7 @@ probe_rows_kernel(const ProbeParams P)
     } else {
       const uint32_t slot = t * WAVE + lane;
       if (valid) {
-        x.a = tpass == 1 ? P.qhins[slot] : tpass == 2 ? P.qhdel[slot] : P.qgh[slot];
+        x.a = P.qgh[slot];
         x.b = P.qlen[slot];
       }
       /* the residues of its first 24 positions: the rows then issue no load of

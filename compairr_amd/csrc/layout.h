@@ -54,9 +54,8 @@ struct TileDesc {
   uint32_t len;       /* residues of the longest query of the tile          */
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
   uint32_t res_base;  /* dword offset of the tile's residues in qres         */
-  uint32_t pass;      /* variant 2: 0, or 3 + i for a tile of class-row pass i
-                         (kernels_rows.h); the indel passes 1, 2 reuse the
-                         tiles of pass 0 and are named by their Chunk         */
+  uint32_t pass;      /* 0 (variant 1: the indel passes 1, 2 reuse the tiles of
+                         pass 0 and are named by their Chunk)                 */
   uint32_t slice;     /* filter slice the tile's probes go to (sliced modes)  */
   uint32_t k;         /* class residues of the tile's queries: 0 (light) or K  */
 };
@@ -163,9 +162,11 @@ struct Chunk {
   uint32_t slice;        /* slice to stage in LDS                            */
   uint32_t first_tile;   /* index into ProbeParams::tile_refs                */
   uint32_t ntiles;
-  uint32_t pass;         /* 0: all rows of the tiles' own slice; 1: insertion
-                            rows, 2: deletion rows, with the
-                            sibling slice (own ^ CL[L] ^ CL[L+-1]) staged      */
+  uint32_t pass;         /* 0: all rows of the tiles' own slice; variant 1 with -i:
+                            1 insertion / 2 deletion rows with the sibling slice
+                            (own ^ CL[L] ^ CL[L+-1]) staged; variant 2: 3 + g = a
+                            chunk of items of group g (first_tile = first item,
+                            ntiles = blocks of 64 items)                        */
 };
 
 constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */

@@ -3,4 +3,4 @@
 # -DCMPR_ABLATION library (make ablation); debug bits: layout.h DBG_*
 cd "$(dirname "$0")/.." || exit 1
 export COMPAIRR_HIP_LIB=$PWD/compairr_amd/lib/libcompairr_hip_ablation.so
-bash tools/gpu_sweep2.sh "$@"
+bash tools/bench_sweep.sh "$@"

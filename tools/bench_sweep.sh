@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_sweep2.sh OUTDIR "bench args A" "bench args B" ...   (each: a full bench.py argument string)
+# usage: tools/bench_sweep.sh OUTDIR "bench args A" "bench args B" ...   (each: a full bench.py argument string)
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 i=0

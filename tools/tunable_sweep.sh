@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_sweep.sh OUTDIR "tunables A" "tunables B" ...   (each: space-separated NAME=VALUE, or extra bench flags)
+# usage: tools/tunable_sweep.sh OUTDIR "tunables A" "tunables B" ...   (each: space-separated NAME=VALUE and/or single-word bench flags such as --indels; flags that take a value need tools/bench_sweep.sh)
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 i=0
