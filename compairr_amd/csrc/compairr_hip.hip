@@ -217,7 +217,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->qrec.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -332,6 +332,12 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (c->have_q)
       return fail(c, CMPR_ESTATE, "set small_slice_tiles before cmpr_set_queries");
     c->small_slice_tiles = value;
+  } else if (n == "sub2_items") {
+    if (value < -1 || value > 1)
+      return fail(c, CMPR_EINVAL, "sub2_items must be -1 (default), 0 or 1");
+    if (c->have_q)
+      return fail(c, CMPR_ESTATE, "set sub2_items before cmpr_set_queries");
+    c->sub2_items = value;
   } else if (n == "class_rows_unstaged") {
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "class_rows_unstaged must be 0 or 1");
@@ -389,6 +395,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunks") *value = c->nchunks;
   else if (n == "small_tiles") *value = c->nsmall;
   else if (n == "small_slice_tiles") *value = c->small_slice_tiles;
+  else if (n == "sub2_items") *value = c->sub2_items;
   else if (n == "work_shard_count") *value = c->work_shard_count;
   else if (n == "work_shard_index") *value = c->work_shard_index;
   else if (n == "class_rows_unstaged") *value = c->class_rows_unstaged;
@@ -667,6 +674,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.qhins = c->qhins.p;
     P.qhdel = c->qhdel.p;
     P.cw = c->cw.p;
+    P.cpk = c->cpk.p;
     P.cmain = c->cmain.p;
     P.crp = c->crp.p;
     P.pair_q = c->pair_q;
@@ -675,6 +683,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     P.pair_cap = c->pair_cap;
     P.ntiles = c->ntiles;
     P.first_tile = 0;
+    P.sub2_items = c->sub2_active ? 1u : 0u;
     P.part = c->part.p;
     P.part_stride = c->part_stride;
     P.work_first = (uint32_t)c->work_shard_index;

@@ -72,6 +72,9 @@ struct cmpr_context {
                                      -1: from the slice size, 0: every class   */
   int64_t chunk_tiles = 0;        /* 0: 8 x waves_per_block                    */
   int64_t waves_per_block = 8;
+  bool    sub2_active = false;    /* ... and the query layout in effect lists them */
+  int64_t sub2_items = -1;        /* variant 1, nt, d = 2: class-changing double substitutions as items
+                                     (-1: when the filter is larger than the 256 MB last-level cache) */
   int64_t work_shard_index = 0;   /* this context works on every work_shard_count-th work   */
   int64_t work_shard_count = 1;   /* item (chunk / small tile / tile) of the step, from here */
   int64_t small_slice_tiles = 0;  /* slices with <= this many tiles are not staged (wave phase): never pays since round 2 */
@@ -136,6 +139,7 @@ struct cmpr_context {
      pass 0 (~0: padding) and its residue at the class position | position << 8 */
   DevBuf<uint64_t>  cw;
   DevBuf<uint32_t>  cmain, crp;
+  DevBuf<cmpr::ResPack> cpk;             /* sub2 items: the query's residues, 2 bits each */
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;

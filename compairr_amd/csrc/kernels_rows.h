@@ -611,7 +611,6 @@ probe_rows_kernel(const ProbeParams P)
       const uint32_t vmask = valid ? ~0u : 0u;
       W.qslot = class_tile ? cur.b : t * WAVE + lane;
       const uint64_t cW = cur.a;
-      const uint32_t cr = cur.c & 0xffu;
       const uint32_t Ll = (valid && !class_tile) ? cur.b : 0u;
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 

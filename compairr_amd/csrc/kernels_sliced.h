@@ -505,7 +505,9 @@ probe_sliced_kernel(const ProbeParams P)
         const uint64_t *src = P.bloom + ((uint64_t)ck.slice << P.geom.words_log2);
         for (uint32_t i = threadIdx.x; i < slice_words; i += NT)
           slice_lds[i] = src[i];
-        for (uint32_t i = threadIdx.x; i < ck.ntiles; i += NT)
+        /* (an item chunk -- pass >= 3 -- has no tile references: its "tiles" are
+           blocks of 64 items from item ck.first_tile on) */
+        for (uint32_t i = threadIdx.x; ck.pass < 3 && i < ck.ntiles; i += NT)
           tref_lds[i] = P.tile_refs[ck.first_tile + i];
         __syncthreads();
       }
@@ -517,6 +519,7 @@ probe_sliced_kernel(const ProbeParams P)
     for (;;) {
       uint32_t t;
       TileDesc td;
+      uint32_t item0 = 0;                  /* item tile: its first item */
       if (block_phase) {
         uint32_t tk = 0;
         if (lane == 0)
@@ -524,8 +527,19 @@ probe_sliced_kernel(const ProbeParams P)
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= ck.ntiles)
           break;
-        t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
-        td = tref_lds[tk].td;
+        if (D >= 2 && pass >= 3) {
+          item0 = ck.first_tile + tk * WAVE;
+          t = 0;
+          td.len = 0;
+          td.nvalid = WAVE;
+          td.res_base = 0;
+          td.pass = pass;
+          td.slice = ck.slice;
+          td.k = P.geom.k;
+        } else {
+          t = __builtin_amdgcn_readfirstlane(tref_lds[tk].t);
+          td = tref_lds[tk].td;
+        }
       } else {
         uint32_t i = P.nsmall;
         if (lane == 0 && P.nsmall)             /* (none: not even the claim) */
@@ -540,16 +554,34 @@ probe_sliced_kernel(const ProbeParams P)
       }
       if (CMPR_DBG(P, DBG_SKIP_TILES))
         continue;                          /* measures claiming + staging alone */
-      const uint32_t L = __builtin_amdgcn_readfirstlane(td.len);
+      /* An item tile (pass >= 3; nucleotides, d = 2: the double substitutions that put
+         residue + k on class position c0 + i, staged here is the slice THAT variant
+         lives in): 64 queries from anywhere, each lane with its own slot and its own
+         residues; L = the longest of them. */
+      const bool item_tile = D >= 2 && staged && pass >= 3;
+      uint32_t islot = 0xffffffffu;
+      uint64_t ihash = 0;                  /* the item's query: its hash and its */
+      ResPack ipk{};                       /* residues, 2 bits each              */
+      if (item_tile) {
+        islot = P.cmain[item0 + lane];
+        ihash = P.cw[item0 + lane];
+        ipk = P.cpk[item0 + lane];
+      }
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
       W.tile_slice = __builtin_amdgcn_readfirstlane(td.slice);
-      const uint32_t *qr = P.qres + td.res_base + lane;
-      const bool valid = lane < nvalid;
+      const bool valid = item_tile ? islot != 0xffffffffu : lane < nvalid;
+      const uint32_t *qr = P.qres + td.res_base + lane;       /* (item tiles: unused) */
       const uint32_t vmask = valid ? ~0u : 0u;
-      W.qslot = t * WAVE + lane;
+      W.qslot = item_tile ? islot : t * WAVE + lane;
       /* own length: tiles without -i may mix lengths (L = the longest one) */
       const uint32_t Ll = valid ? (uint32_t)P.qlen[W.qslot] : 0u;
+      uint32_t Lmax = Ll;
+      if (item_tile)
+        for (int off = 32; off > 0; off >>= 1)
+          Lmax = max(Lmax, (uint32_t)__shfl_xor((int)Lmax, off, WAVE));
+      const uint32_t L = item_tile ? __builtin_amdgcn_readfirstlane(Lmax)
+                                   : __builtin_amdgcn_readfirstlane(td.len);
       auto res_at = [&](uint32_t p) -> uint32_t {
         return (qr[(p >> 2) * WAVE] >> ((p & 3u) * 8)) & 0xffu;
       };
@@ -557,12 +589,14 @@ probe_sliced_kernel(const ProbeParams P)
       /* ---- query hash (zobrist.cc:74-88) and, with -i, the two shifted
               hashes of the rolling indel enumeration (:90-104, :122-136) ---- */
       ResStream rs;
-      rs.start(qr, L);
+      rs.start(qr, item_tile ? 0u : L);
       uint64_t h = 0;
-      if (GENES)
+      if (GENES && !item_tile)
         h = P.qgh[W.qslot];
       uint64_t hdel = h, hins = h;
-      {
+      if (item_tile) {
+        h = ihash;
+      } else {
         for (uint32_t p = 0; p < L; p++) {
           const uint32_t r = rs.at(p);
           h ^= p < Ll ? zl[ZS * p + r] : 0ull;
@@ -905,9 +939,17 @@ probe_sliced_kernel(const ProbeParams P)
              the lane ((r + k) & 3), so none of the 9 (instead of 16) probes per
              position pair is masked; the second position runs in blocks of NTB
              that share one 30-bit mask and one compaction loop. */
+          /* split queries that hold every class position unwrapped: their pairs with a
+             class position are items of a later pass (query_layout.hip for_each_item) */
+          const bool cls_items = P.sub2_items && K > 0 && L >= P.geom.c0 + K;
+          /* (an item holds RESPACK_MAX residues: longer queries of such a tile keep those pairs) */
+          const bool lane_items = cls_items && Ll <= RESPACK_MAX;
+          const bool all_items = cls_items && __ballot(valid && Ll > RESPACK_MAX) == 0;
           for (uint32_t p = 0; p + 1 < L; p++) {
             const uint32_t rp = res_at(p);
             const bool cp = is_class_pos(p);
+            if (cp && all_items)
+              continue;
             uint32_t crow_unused;
             const uint32_t dk_rp = cp ? class_terms(p, rp, crow_unused) : 0u;
             const bool fast = staged && !cp;       /* wave-uniform */
@@ -932,6 +974,8 @@ probe_sliced_kernel(const ProbeParams P)
                   const uint32_t rq = ((jj < 4 ? w0 : w1) >> ((jj & 3u) * 8)) & 0xffu;
                   const bool cq = ((cbits >> jj) & 1u) != 0;
                   uint32_t b3 = 0;
+                  if (cq && all_items)
+                    continue;                              /* wave-uniform */
                   if (fast && !cq) {
                     const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
                     if (!CMPR_DBG(P, DBG_SKIP_LDS_ROWS))
@@ -963,6 +1007,8 @@ probe_sliced_kernel(const ProbeParams P)
                       b3 |= bloom_hit(word[k - 1], pattern_fields(hq ^ zq[(rq + k) & 3u]))
                                 ? (1u << (k - 1)) : 0u;
                   }
+                  if ((cp || cq) && lane_items)
+                    b3 = 0;                                /* this lane's pair is an item */
                   mask |= (qq < Ll ? b3 : 0u) << (3u * jj);       /* qq < Ll implies p < Ll */
                 }
                 if (!valid || CMPR_DBG(P, DBG_SKIP_EMIT))
@@ -1017,6 +1063,83 @@ probe_sliced_kernel(const ProbeParams P)
               }
               mask &= pv & (qq < Ll ? ~0u : 0u) & ~(1u << rq);
               emit_row<GENES, false>(W, mask, hq, zl + ZS * qq, ca, qq);
+            }
+          }
+        }
+      }
+
+      if constexpr (D >= 2 && A == 4) {
+        if (item_tile) {
+          /* ---- items (see item_tile above): position p = c0 + i of every lane takes
+                  residue + kp; the second position runs over ALL the others.  A second
+                  position that is no class position leaves the variant in the staged
+                  slice: the same 9-probe blocks as the main pass.  Two class positions:
+                  handled once, from the lower one, where the filter lies. ---- */
+          const uint32_t g = pass - 3u, ci = g / 3u, kp = g % 3u + 1u;
+          const uint32_t p = P.geom.c0 + ci;
+          /* residues of 16 positions from x0 (a multiple of 16, wave-uniform) */
+          auto pk16 = [&](uint32_t x0) -> uint32_t {
+            static_assert(RESPACK_MAX == 96, "six words");
+            return x0 < 16u ? ipk.w[0] : x0 < 32u ? ipk.w[1] : x0 < 48u ? ipk.w[2]
+                 : x0 < 64u ? ipk.w[3] : x0 < 80u ? ipk.w[4] : ipk.w[5];
+          };
+          const uint32_t rp = (pk16(p & ~15u) >> ((p & 15u) * 2u)) & 3u;
+          const uint32_t vp = (rp + kp) & 3u;
+          const uint64_t hpv = h ^ ze[16u * p + 4u * rp + kp];
+          uint32_t crow_unused;
+          for (uint32_t q0 = 0; q0 < L; q0 += 8) {
+            uint32_t mask = 0;
+            const uint32_t cbits = class_bits8(q0);
+            const uint32_t w8 = pk16(q0 & ~15u) >> ((q0 & 8u) * 2u);     /* 8 positions x 2 bits */
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8; jj++) {
+              const uint32_t qq = q0 + jj;
+              if (qq == p || qq >= L)
+                continue;                                  /* wave-uniform */
+              const uint32_t rq = (w8 >> (2u * jj)) & 3u;
+              const bool cq = ((cbits >> jj) & 1u) != 0;
+              uint32_t b3 = 0;
+              if (!cq) {
+                const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
+#pragma unroll
+                for (uint32_t k = 1; k <= 3; k++) {
+                  const uint64_t hv = hpv ^ lds_u64(eaddr, (int)k);
+                  const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
+                  b3 |= bloom_hit(word, pattern_fields(hv)) ? (1u << (k - 1)) : 0u;
+                }
+              } else if (qq > p) {
+                /* (W.tile_slice is the staged slice = the query's own ^ the change at p) */
+                const uint64_t *zq = zl + 4 * qq;
+                const uint64_t hq = hpv ^ zq[rq];
+                const uint32_t dk_rq = class_terms(qq, rq, crow_unused);
+                uint64_t word[3];
+#pragma unroll
+                for (uint32_t k = 1; k <= 3; k++) {
+                  const uint32_t x = (rq + k) & 3u;
+                  word[k - 1] = *hbm_word(W, hq ^ zq[x], dk_rq ^ class_terms(qq, x, crow_unused));
+                }
+#pragma unroll
+                for (uint32_t k = 1; k <= 3; k++)
+                  b3 |= bloom_hit(word[k - 1], pattern_fields(hq ^ zq[(rq + k) & 3u]))
+                            ? (1u << (k - 1)) : 0u;
+              }
+              mask |= (qq < Ll ? b3 : 0u) << (3u * jj);
+            }
+            if (!valid || CMPR_DBG(P, DBG_SKIP_EMIT))
+              mask = 0;
+            while (__ballot(mask != 0)) {
+              const bool pos = mask != 0;
+              const uint32_t b = pos ? (uint32_t)__ffs((int)mask) - 1u : 0u;
+              const uint32_t qq = q0 + b / 3u;
+              const uint32_t rq = (w8 >> (2u * (b / 3u))) & 3u;
+              const uint32_t k = b % 3u + 1u;
+              const uint32_t vq = (rq + k) & 3u;
+              const uint64_t hv = hpv ^ ze[16u * qq + 4u * rq + k];
+              /* (the lower position first, as everywhere) */
+              const bool lower = qq < p;
+              s_push<GENES>(W, pos, hv, lower ? pack_a(K_SUB2, qq, vq) : pack_a(K_SUB2, p, vp),
+                            lower ? (p | (vp << 24)) : (qq | (vq << 24)));
+              mask &= mask - 1u;
             }
           }
         }

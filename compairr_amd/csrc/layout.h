@@ -50,6 +50,12 @@ enum : uint32_t { K_SAME = 0, K_SUB = 1, K_DEL = 2, K_INS = 3, K_SUB2 = 4 };
      qres[res_base + (p / 4) * 64 + lane]  byte (p % 4)
    so that one wave instruction reads four positions of all 64 queries as one
    256-byte coalesced access. */
+/* up to 96 nucleotides, 2 bits each (sub2 items of variant 1) */
+constexpr uint32_t RESPACK_MAX = 96;
+struct alignas(8) ResPack {
+  uint32_t w[RESPACK_MAX / 16];
+};
+
 struct TileDesc {
   uint32_t len;       /* residues of the longest query of the tile          */
   uint32_t nvalid;    /* lanes 0..nvalid-1 hold queries, the rest is padding */
@@ -262,6 +268,8 @@ struct ProbeParams {
   const uint64_t *cw;              /* variant 2, class rows, per item: the row's blanked   */
   const uint32_t *cmain;           /* hash, the query's slot in pass 0 (~0: padding),      */
   const uint32_t *crp;             /* its residue at the class position | position << 8    */
+  const ResPack  *cpk;             /* variant 1 sub2 items: the query's residues, 2 bits each
+                                      (<= RESPACK_MAX positions); cw then holds the query's hash     */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
@@ -277,6 +285,7 @@ struct ProbeParams {
      line: 150 us of a 260 us resolve kernel); NULL = add to matrix / stats directly. */
   unsigned long long *part;
   uint32_t        part_stride;
+  uint32_t        sub2_items;  /* variant 1, nt, d = 2: class-position pairs are items (passes >= 3) */
   uint32_t        work_first, work_step;   /* variant 0: this launch takes tiles work_first + k work_step */
   /* output */
   unsigned long long *matrix;      /* R1 * R2 integer sums                   */

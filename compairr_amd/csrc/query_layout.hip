@@ -63,6 +63,9 @@ struct SliceTotSum {
 };
 
 /* everything the layout kernels need (passed by value) */
+constexpr uint32_t MAX_GROUPS = 32;          /* item groups: >= MAX_CLASS_RES + 1, >= 8 class positions x 3 */
+static_assert(MAX_GROUPS >= MAX_CLASS_RES + 1 && MAX_GROUPS >= 8 * 3, "item groups");
+
 struct QL {
   /* the caller's set, uploaded as it is */
   const uint8_t  *res;
@@ -106,9 +109,15 @@ struct QL {
      the variant.  Group K (with -i): deletion variants whose slice of the main
      part is not the one staged for their tile's deletion pass. */
   uint32_t  ngroups;
-  uint32_t  goff[MAX_CLASS_RES + 1];      /* first counter of the group */
-  uint32_t  gslices[MAX_CLASS_RES + 1];   /* slices of the group */
-  uint32_t  gslice0[MAX_CLASS_RES + 1];   /* its first slice in the filter */
+  uint32_t  goff[MAX_GROUPS];             /* first counter of the group */
+  uint32_t  gslices[MAX_GROUPS];          /* slices of the group */
+  uint32_t  gslice0[MAX_GROUPS];          /* its first slice in the filter */
+  /* variant 1, nucleotides, d = 2: group (i, k) = the double substitutions whose one
+     position is class position i with its residue advanced by k (1 .. 3): that
+     variant lives in another slice, the same for every second position that is no
+     class position -- one item per (split query, i, k), grouped by that slice
+     (kernels_sliced.h, passes >= 3) */
+  uint32_t  sub2_items;
   uint32_t  nitem_slices;                 /* counters in all */
   uint32_t  cblocks;                      /* blocks of 64 items per chunk at most */
   uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
@@ -116,6 +125,7 @@ struct QL {
   uint64_t *cw;
   uint32_t *cmain;
   uint32_t *crp;
+  cmpr::ResPack *cpk;
   /* validation / statistics */
   uint32_t           *verr;          /* [0] first error kind, [1] longest */
   double             *rep_total;
@@ -225,7 +235,7 @@ __device__ inline uint64_t variants_of(const QL &Q, const uint8_t *s, uint32_t L
 }
 
 /* item kinds = the variant kinds of layout.h */
-enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_DEL = K_DEL };
+enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_DEL = K_DEL, ITEM_SUB2 = K_SUB2 };
 
 __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
 {
@@ -248,6 +258,21 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
   const uint32_t K = g.k, A = Q.A;
   if (L == 0 || K == 0 || Q.differences < 1)
     return;
+  if (Q.sub2_items) {
+    /* (only queries that hold every class position unwrapped -- position c0 + i is then
+       the same for all of them -- and whose residues fit an item (RESPACK_MAX): the
+       others keep their probes where the filter lies) */
+    if (heavy && L >= g.c0 + K && L <= RESPACK_MAX)
+      for (uint32_t ci = 0; ci < K; ci++) {
+        const uint32_t pos = g.c0 + ci, r = s[pos];
+        for (uint32_t kp = 1; kp < A; kp++) {
+          const uint32_t v = (r + kp) % A;
+          const uint32_t key = ck ^ g.ctab[g.off_cr + ci * A + r] ^ g.ctab[g.off_cr + ci * A + v];
+          f(Q.goff[ci * (A - 1) + kp - 1] + (key & g.smask), 0ull, kp | (pos << 8) | (ITEM_SUB2 << 24));
+        }
+      }
+    return;
+  }
   /* ---- substitution rows at class positions: class part ci, key without the terms
           of that position; a position that carries several class residues is
           handled by the first of them ---- */
@@ -371,6 +396,8 @@ keys_kernel(const QL Q)
         Q.hins_tmp[i] = hins;
         Q.hdel_tmp[i] = hdel;
       }
+      Q.ck_tmp[i] = ck;
+    } else if (Q.sub2_items) {
       Q.ck_tmp[i] = ck;
     }
     const uint64_t gl = Q.longest - L;
@@ -644,8 +671,29 @@ place_items_kernel(const QL Q)
   const uint32_t slot = Q.slot_of[i];
   const uint32_t ck = Q.ck_tmp[i];
   const bool heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, class_base_of(Q, i));
+  uint64_t hq = 0;
+  cmpr::ResPack pk{};
+  if (Q.sub2_items && heavy) {
+    const uint64_t b = Q.off[i];
+    const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
+    if (L <= RESPACK_MAX) {
+      if (Q.genes) {
+        const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+        hq = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
+      }
+      for (uint32_t x = 0; x < L; x++) {
+        const uint32_t r = Q.res[b + x];
+        hq ^= Q.zob[Q.A * x + r];
+        pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
+      }
+    }
+  }
   for_each_item<true>(Q, i, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
     const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
+    if (Q.sub2_items) {
+      w = hq;                                   /* the query's hash and residues travel with the item */
+      Q.cpk[item] = pk;
+    }
     Q.cw[item] = w;
     Q.cmain[item] = slot;
     Q.crp[item] = crp;
@@ -741,7 +789,7 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   if (k >= nchunks)
     return;
   const Chunk ck = Q.chunks[k];
-  uint64_t w = ck.pass >= 3 ? (uint64_t)ck.ntiles * WAVE * 2 : 0;
+  uint64_t w = ck.pass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : 2) : 0;
   for (uint32_t t = 0; ck.pass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
     w += (uint64_t)(ck.pass == 0 ? td.len + 1 : ck.pass == 1 ? td.len + 2 : 2) * td.nvalid;
@@ -958,7 +1006,11 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   /* item groups of variant 2 (flat items, not tiles; see QL) */
   const uint32_t npass = 1;                  /* passes laid out as tiles */
   uint32_t ngroups = 0;
-  uint32_t goff[MAX_CLASS_RES + 1] = {0}, gslices[MAX_CLASS_RES + 1] = {0}, gslice0[MAX_CLASS_RES + 1] = {0};
+  uint32_t goff[MAX_GROUPS] = {0}, gslices[MAX_GROUPS] = {0}, gslice0[MAX_GROUPS] = {0};
+  const bool sub2_items = !c->rows && c->sliced && c->geom.k > 0 && c->opt.differences == 2 &&
+                          c->opt.alphabet_size == 4 && !c->opt.indels &&
+                          (c->sub2_items == 1 ||
+                           (c->sub2_items < 0 && c->bloom_words * sizeof(uint64_t) > ((size_t)256 << 20)));
   uint64_t ncs = 0;                          /* counters over all groups */
   if (c->rows && c->geom.k > 0 && c->opt.differences >= 1) {
     for (uint32_t g = 0; g < c->geom.k; g++) {
@@ -974,6 +1026,15 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       gslice0[ngroups] = 0;
       ncs += gslices[ngroups];
       ngroups++;
+    }
+  }
+  if (sub2_items) {
+    ngroups = c->geom.k * 3;
+    for (uint32_t g = 0; g < ngroups; g++) {
+      goff[g] = (uint32_t)ncs;
+      gslices[g] = c->geom.smask + 1;
+      gslice0[g] = 0;
+      ncs += gslices[g];
     }
   }
   if (ncs >= 0x7fffffffull)
@@ -1021,7 +1082,9 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
   Q.ngroups = ngroups;
-  for (uint32_t g = 0; g <= MAX_CLASS_RES; g++) {
+  Q.sub2_items = sub2_items ? 1u : 0u;
+  c->sub2_active = sub2_items;
+  for (uint32_t g = 0; g < MAX_GROUPS; g++) {
     Q.goff[g] = goff[g];
     Q.gslices[g] = gslices[g];
     Q.gslice0[g] = gslice0[g];
@@ -1059,6 +1122,8 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if ((rc = dev_alloc(c, tot.b, (size_t)nslices * npass))) return rc;
   if ((rc = dev_alloc(c, pre.b, (size_t)nslices * npass))) return rc;
   if ((rc = dev_alloc(c, alg.b, 1))) return rc;
+  if (sub2_items)
+    if ((rc = dev_alloc(c, ck_tmp.b, (size_t)s->n))) return rc;
   if (c->rows) {
     if ((rc = dev_alloc(c, h_tmp.b, (size_t)s->n))) return rc;
     if ((rc = dev_alloc(c, ck_tmp.b, (size_t)s->n))) return rc;
@@ -1236,7 +1301,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   HIP_TRY(c, hipMemsetAsync(c->qlen.p, 0, std::max<size_t>(slots, 1) * sizeof(uint16_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qorig.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
   c->qv.release(); c->qj.release(); c->qgh.release(); c->qcnt.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release();
   if (!c->opt.ignore_genes) {
     if ((rc = dev_alloc(c, c->qv, slots))) return rc;
     if ((rc = dev_alloc(c, c->qj, slots))) return rc;
@@ -1260,21 +1325,23 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       HIP_TRY(c, hipMemsetAsync(c->qhins.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
       HIP_TRY(c, hipMemsetAsync(c->qhdel.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
     }
-    if (ngroups) {
-      /* (+ 64: a block read past the last item stays inside) */
-      const size_t ni = (size_t)cslots + WAVE;
-      if ((rc = dev_alloc(c, c->cw, ni))) return rc;
-      if ((rc = dev_alloc(c, c->cmain, ni))) return rc;
-      if ((rc = dev_alloc(c, c->crp, ni))) return rc;
-      HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, ni * sizeof(uint64_t), c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0xff, ni * sizeof(uint32_t), c->stream));   /* ~0: padding */
-      HIP_TRY(c, hipMemsetAsync(c->crp.p, 0, ni * sizeof(uint32_t), c->stream));
-    }
+  }
+  if (ngroups) {
+    /* (+ 64: a block read past the last item stays inside) */
+    const size_t ni = (size_t)cslots + WAVE;
+    if ((rc = dev_alloc(c, c->cw, ni))) return rc;
+    if ((rc = dev_alloc(c, c->cmain, ni))) return rc;
+    if ((rc = dev_alloc(c, c->crp, ni))) return rc;
+    if (sub2_items && (rc = dev_alloc(c, c->cpk, ni))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, ni * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0xff, ni * sizeof(uint32_t), c->stream));   /* ~0: padding */
+    HIP_TRY(c, hipMemsetAsync(c->crp.p, 0, ni * sizeof(uint32_t), c->stream));
   }
   Q.tiles = c->tiles.p;
   Q.chunks = chunks_unsorted.b.p;
   Q.tile_refs = c->tile_refs.p;
   Q.small_tiles = c->small_tiles.p;
+  Q.cpk = c->cpk.p;
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
   Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;

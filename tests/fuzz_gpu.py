@@ -81,6 +81,8 @@ def random_case(rng):
         tun["variant"] = 2                                # the row filter, also where it is not the default
     if rng.random() < 0.2:
         tun["class_rows_unstaged"] = 1
+    if rng.random() < 0.4:
+        tun["sub2_items"] = 1                             # (takes effect for nucleotides, d = 2, variant 1)
     if rng.random() < 0.3:
         tun["host_threads"] = int(rng.integers(1, 9))
     same = rng.random() < 0.2

@@ -85,6 +85,15 @@ NT_LAYOUTS["lds_tiny_k8"] = {"variant": 1, "slice_words_log2": 3, "class_residue
                              "heavy_threshold": 0, "chunk_tiles": 5}
 NT_LAYOUTS["lds_tiny_k5_mixed"] = {"variant": 1, "slice_words_log2": 4, "class_residues": 5,
                                    "heavy_threshold": 3}
+# nucleotides, d = 2: the double substitutions on class positions as items grouped by
+# the slice they land in (by default only with filters larger than the last-level cache)
+NT_LAYOUTS["lds_items_k3"] = {"variant": 1, "slice_words_log2": 3, "class_residues": 3, "chunk_tiles": 2,
+                              "heavy_threshold": 0, "sub2_items": 1}
+NT_LAYOUTS["lds_items_k8"] = {"variant": 1, "slice_words_log2": 3, "class_residues": 8,
+                              "heavy_threshold": 0, "chunk_tiles": 5, "sub2_items": 1}
+NT_LAYOUTS["lds_items_k5_mixed"] = {"variant": 1, "slice_words_log2": 4, "class_residues": 5,
+                                    "heavy_threshold": 3, "sub2_items": 1}
+NT_LAYOUTS["lds_items_auto"] = {"variant": 1, "slice_words_log2": 6, "sub2_items": 1}
 NT_LAYOUTS["rows_tiny_k8"] = {"variant": 2, "slice_words_log2": 2, "class_residues": 8,
                               "heavy_threshold": 0, "chunk_tiles": 5}
 NT_LAYOUTS["rows_tiny_k5_mixed"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 5,
@@ -263,6 +272,33 @@ def test_long_sequences():
     assert st.matches >= n + 2 * (n // 2)
 
 
+def test_items_next_to_sequences_too_long_for_an_item():
+    """Nucleotides, d = 2, class-position pairs as items: an item carries 96 residues, so
+    longer queries keep those pairs in the main pass -- lane by lane, in tiles that mix
+    both kinds.  Neighbours at distance 2 planted on and off the class positions."""
+    rng = np.random.default_rng(11)
+    from compairr_amd.sets import NT, RepertoireSet
+    lens = np.array([40, 70, 96, 97, 130] * 60)
+    n = len(lens)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    res = rng.integers(0, 4, size=int(offs[-1]), dtype=np.uint8)
+    for k in range(5, n):              # sequence k: a neighbour of k - 5 (same length), two changes
+        a0, b0, L = int(offs[k - 5]), int(offs[k]), int(lens[k])
+        res[b0:b0 + L] = res[a0:a0 + L]
+        p1, p2 = rng.choice(L if k % 2 else 12, size=2, replace=False)   # (even k: near the front)
+        res[b0 + p1] = (res[b0 + p1] + 1 + rng.integers(0, 3)) % 4
+        res[b0 + p2] = (res[b0 + p2] + 1 + rng.integers(0, 3)) % 4
+    s = RepertoireSet(res, offs, np.zeros(n, np.uint32), np.zeros(n, np.uint32),
+                      (np.arange(n) % 3).astype(np.uint32), np.full(n, 2, np.uint64),
+                      ["a", "b", "c"], ["V"], ["J"], NT)
+    o = Options(differences=2, nucleotides=True, ignore_genes=True, n_v_genes=1, n_j_genes=1)
+    layouts = {name: dict(tun, class_anchor=0) for name, tun in NT_LAYOUTS.items() if "items" in name}
+    layouts["no_items"] = {"variant": 1, "slice_words_log2": 3, "class_residues": 3, "heavy_threshold": 0,
+                           "class_anchor": 0, "sub2_items": 0}
+    st = check(s, s, o, layouts=layouts)
+    assert st.matches >= n + 2 * (n - 5)
+
+
 @pytest.mark.parametrize("d,indels", [(0, False), (1, False), (1, True), (2, False)])
 def test_existence_rows_are_sequences(d, indels):
     """-x: one matrix row per set-1 sequence, in input order (overlap.cc:226)."""
@@ -354,6 +390,8 @@ def test_errors_through_the_abi():
     ("aa_d1_indels", dict(differences=1, indels=True), False, {}),
     ("aa_d2", dict(differences=2), False, {}),
     ("nt_d1_sliced", dict(differences=1, nucleotides=True, ignore_genes=True), True, {}),
+    ("nt_d2_items", dict(differences=2, nucleotides=True, ignore_genes=True), True,
+     {"variant": 1, "slice_words_log2": 4, "class_residues": 4, "heavy_threshold": 2, "sub2_items": 1}),
     ("aa_d1_sliced", dict(differences=1), False, {"variant": 1}),
     ("aa_d1_small_slices", dict(differences=1), False, {"small_slice_tiles": 64}),
 ])
@@ -361,7 +399,7 @@ def test_work_shards_add_up(name, opt, nt, tun):
     """bench.py --shard-by work: a context with work_shard_count = N does the work filed
     under its share of the filter slices; the N matrices add up to the whole one, and
     so do the counters -- although every context lays the queries out by itself."""
-    n = 3000 if opt.get("differences") == 2 else 60000
+    n = (1500 if nt else 3000) if opt.get("differences") == 2 else 60000
     a = synth.make_set(n, 11, prefix="A", nucleotides=nt, pool_size=n // 2)
     b = synth.make_set(n, 12, prefix="B", nucleotides=nt, pool_size=n // 2)
     o = Options(**opt, **FULL)
