@@ -562,10 +562,12 @@ probe_sliced_kernel(const ProbeParams P)
       uint32_t islot = 0xffffffffu;
       uint64_t ihash = 0;                  /* the item's query: its hash and its */
       ResPack ipk{};                       /* residues, 2 bits each              */
+      uint32_t icrp = 0;
       if (item_tile) {
         islot = P.cmain[item0 + lane];
         ihash = P.cw[item0 + lane];
         ipk = P.cpk[item0 + lane];
+        icrp = P.crp[item0 + lane];
       }
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */
@@ -1075,8 +1077,13 @@ probe_sliced_kernel(const ProbeParams P)
                   position that is no class position leaves the variant in the staged
                   slice: the same 9-probe blocks as the main pass.  Two class positions:
                   handled once, from the lower one, where the filter lies. ---- */
-          const uint32_t g = pass - 3u, ci = g / 3u, kp = g % 3u + 1u;
-          const uint32_t p = P.geom.c0 + ci;
+          /* which class position, which residue step: the same for the 64 items of a
+             block, and written in each of them (residue step | position << 8) */
+          const uint64_t have = __ballot(valid);
+          const uint32_t crp1 = have ? (uint32_t)__builtin_amdgcn_readlane(
+                                           (int)icrp, (int)__builtin_ctzll(have)) : 0u;
+          const uint32_t kp = crp1 & 0xffu;
+          const uint32_t p = (crp1 >> 8) & 0xffffu;
           /* residues of 16 positions from x0 (a multiple of 16, wave-uniform) */
           auto pk16 = [&](uint32_t x0) -> uint32_t {
             static_assert(RESPACK_MAX == 96, "six words");
@@ -1087,7 +1094,7 @@ probe_sliced_kernel(const ProbeParams P)
           const uint32_t vp = (rp + kp) & 3u;
           const uint64_t hpv = h ^ ze[16u * p + 4u * rp + kp];
           uint32_t crow_unused;
-          for (uint32_t q0 = 0; q0 < L; q0 += 8) {
+          for (uint32_t q0 = 0; q0 < (have ? L : 0u); q0 += 8) {
             uint32_t mask = 0;
             const uint32_t cbits = class_bits8(q0);
             const uint32_t w8 = pk16(q0 & ~15u) >> ((q0 & 8u) * 2u);     /* 8 positions x 2 bits */

@@ -268,7 +268,9 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
         for (uint32_t kp = 1; kp < A; kp++) {
           const uint32_t v = (r + kp) % A;
           const uint32_t key = ck ^ g.ctab[g.off_cr + ci * A + r] ^ g.ctab[g.off_cr + ci * A + v];
-          f(Q.goff[ci * (A - 1) + kp - 1] + (key & g.smask), 0ull, kp | (pos << 8) | (ITEM_SUB2 << 24));
+          /* (counters slice-major: the blocks of all groups of a slice lie side by side
+             and make one chunk -- the slice is staged once for them) */
+          f((key & g.smask) * Q.ngroups + (ci * (A - 1) + kp - 1), 0ull, kp | (pos << 8) | (ITEM_SUB2 << 24));
         }
       }
     return;
@@ -633,8 +635,17 @@ class_pad_kernel(const QL Q, uint32_t *padded)
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= (uint64_t)Q.nitem_slices)
     return;
-  const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
+  uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
   padded[k] = blocks * WAVE;
+  if (Q.sub2_items) {
+    /* one chunk list per slice, written by its first group */
+    if (k % Q.ngroups != 0) {
+      Q.cnch[k] = 0;
+      return;
+    }
+    for (uint32_t g = 1; g < Q.ngroups; g++)
+      blocks += (Q.ccnt[k + g] + WAVE - 1) / WAVE;
+  }
   Q.cnch[k] = (blocks + Q.cblocks - 1) / Q.cblocks;
 }
 
@@ -648,11 +659,18 @@ class_chunks_kernel(const QL Q)
   for (uint32_t x = 1; x < Q.ngroups; x++)
     if (k >= Q.goff[x])
       gi = x;
-  const uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
+  uint32_t blocks = (Q.ccnt[k] + WAVE - 1) / WAVE;
+  if (Q.sub2_items) {
+    if (k % Q.ngroups != 0)
+      return;
+    for (uint32_t g = 1; g < Q.ngroups; g++)
+      blocks += (Q.ccnt[k + g] + WAVE - 1) / WAVE;
+    gi = 0;                                  /* (which group a block belongs to is in its items) */
+  }
   const uint32_t nc = (blocks + Q.cblocks - 1) / Q.cblocks;
   for (uint32_t q = 0; q < nc; q++) {
     Chunk ck;
-    ck.slice = Q.gslice0[gi] + (uint32_t)(k - Q.goff[gi]);
+    ck.slice = Q.sub2_items ? (uint32_t)(k / Q.ngroups) : Q.gslice0[gi] + (uint32_t)(k - Q.goff[gi]);
     ck.first_tile = Q.cbase[k] + q * Q.cblocks * WAVE;      /* first item */
     ck.ntiles = min(Q.cblocks, blocks - q * Q.cblocks);     /* blocks of 64 items */
     ck.pass = 3 + gi;
