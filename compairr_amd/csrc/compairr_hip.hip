@@ -173,7 +173,6 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->host_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  CREATE_TRY(hipEventCreate(&c->ev_start));
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
     CREATE_TRY(hipEventCreate(&c->ring_k0[i]));
     CREATE_TRY(hipEventCreate(&c->ring_km[i]));
@@ -220,7 +219,6 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
-  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
     if (c->ring_k0[i]) (void)hipEventDestroy(c->ring_k0[i]);
     if (c->ring_km[i]) (void)hipEventDestroy(c->ring_km[i]);
@@ -609,7 +607,15 @@ void use_counter_block(cmpr_context *c, int which)
 int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 {
   const size_t cells = (size_t)c->R1 * c->R2;
-  HIP_TRY(c, hipEventRecord(c->ev_start, st));
+  /* (three event records per step, not five: each is a packet the stream waits for) */
+  {
+    const uint32_t slot = (uint32_t)(c->calls % cmpr_context::TIME_RING);
+    c->ev_k0 = c->ring_k0[slot];
+    c->ev_km = c->ring_km[slot];
+    c->ev_k1 = c->ring_k1[slot];
+    c->calls++;
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
   /* A step normally starts without a memset: its counter block was cleared by the
      previous launch's reduce kernel, and with the matrix privatised in LDS the reduce
      kernel WRITES the cells.  Otherwise (first launch, a launch that failed half-way,
@@ -635,14 +641,6 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   c->launches = 0;
   bool launched = false;
 
-  {
-    const uint32_t slot = (uint32_t)(c->calls % cmpr_context::TIME_RING);
-    c->ev_k0 = c->ring_k0[slot];
-    c->ev_km = c->ring_km[slot];
-    c->ev_k1 = c->ring_k1[slot];
-    c->calls++;
-  }
-  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
   if (c->ntiles > 0 && cells > 0) {
     const uint32_t A = (uint32_t)c->opt.alphabet_size;
     ProbeParams P{};
@@ -782,7 +780,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     launched = true;
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
     auto reduce_partials = [&]() {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3((P.part_stride + 255) / 256), dim3(256), 0, st, P,
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
                          (uint32_t)(P.lds_matrix ? cells : 0), reduce_writes ? 1u : 0u, c->ctr_other,
                          (uint32_t)ctr_blk);
     };
@@ -857,7 +855,7 @@ extern "C" int cmpr_overlap_matrix_device(cmpr_context *c, void *d_matrix, void 
   rc = enqueue_overlap(c, (unsigned long long *)d_matrix, st);
   if (rc)
     return rc;
-  HIP_TRY(c, hipEventRecord(c->ev_stop, st));
+  c->stop_is_k1 = true;                     /* (nothing follows the kernels on this path) */
   c->events_valid = true;
   if (!stream)
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -881,6 +879,7 @@ extern "C" int cmpr_overlap_matrix(cmpr_context *c, uint64_t *out)
     HIP_TRY(c, hipMemcpyAsync(out, c->matrix.p, cells * sizeof(uint64_t),
                               hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->stop_is_k1 = false;
   c->events_valid = true;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMPR_OK;
@@ -907,6 +906,7 @@ static int cmpr_overlap_matrix_f64_impl(cmpr_context *c, double *out)
                                 hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->stop_is_k1 = false;
   c->events_valid = true;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (!is_f64_score(c->opt)) {
@@ -946,6 +946,7 @@ extern "C" int cmpr_overlap_pairs(cmpr_context *c, uint64_t capacity, uint32_t *
   unsigned long long n = 0;
   HIP_TRY(c, hipMemcpyAsync(&n, dn.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->stop_is_k1 = false;
   c->events_valid = true;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const uint64_t have = std::min<uint64_t>(n, capacity);
@@ -989,7 +990,8 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   if (!c->events_valid)
     return fail(c, CMPR_ESTATE, "no overlap call has been made");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+  hipEvent_t ev_end = c->stop_is_k1 ? c->ev_k1 : c->ev_stop;
+  HIP_TRY(c, hipEventSynchronize(ev_end));
   unsigned long long st[STAT_COUNT], ovf = 0;
   HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(&ovf, c->d_overflow, sizeof ovf, hipMemcpyDeviceToHost));
@@ -999,7 +1001,7 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
   float p_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&p_ms, c->ev_k0, c->ev_km));
-  HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_start, c->ev_stop));
+  HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_k0, ev_end));
   memset(out, 0, sizeof *out);
   out->queries = c->n1;
   out->variants = st[STAT_VARIANTS];

@@ -51,7 +51,7 @@ struct cmpr_context {
   int          device = 0;
   int          cus = 256;
   hipStream_t  stream = nullptr;
-  hipEvent_t   ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t   ev_stop = nullptr;
   /* kernel-time events of the last TIME_RING calls (cmpr_get_kernel_times), so
      that a caller can time many launches without synchronising after each */
   static const uint32_t TIME_RING = 64;
@@ -59,6 +59,7 @@ struct cmpr_context {
   uint64_t     calls = 0;            /* overlap launches so far */
   hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
   bool         events_valid = false;
+  bool         stop_is_k1 = false;   /* the last call ended with the kernels (ev_k1), no copy behind them */
   std::string  err;
 
   /* tunables */
