@@ -22,7 +22,8 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
                               queries.
   --scaling weak              every rank its own 10M-query shard.
 The only collective is one all-reduce (sum, int64) of the R1 x R2 matrix per
-step, on the same stream as the kernels.  In strong mode the reduced matrix is
+step; it runs on a second stream, ordered by events, so that the all-reduce of a
+step overlaps the kernels of the next (two matrices).  In strong mode the reduced matrix is
 the N = 1 matrix; its checksum is compared with the recorded N = 1 checksum at
 every N ("parity_vs_n1").
 
@@ -216,7 +217,7 @@ def main():
     import torch
     import torch.distributed as dist
     from compairr_amd import HipOverlap, Options, synth
-    from compairr_amd.dist import allreduce_matrix, shard_bounds
+    from compairr_amd.dist import shard_bounds
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -269,15 +270,34 @@ def main():
     t_layout = time.time() - t0
     R1, R2 = h.shape
     layout = h.layout()
-    # every rank uses the same R1 x R2 (16 x 16 for the synthetic law)
-    matrix = torch.zeros(R1 * R2, dtype=torch.int64, device="cuda")
-    # one explicit stream for the kernels AND the collective: nothing in a step is
-    # ordered by the host
+    # every rank uses the same R1 x R2 (16 x 16 for the synthetic law).  Two matrices:
+    # step i fills one while the all-reduce of step i - 1 still works on the other
+    mats = [torch.zeros(R1 * R2, dtype=torch.int64, device="cuda") for _ in range(2)]
+    # one explicit stream for the kernels, one for the collective: nothing in a step is
+    # ordered by the host, and the all-reduce of a step (latency-bound: 2 KiB) overlaps
+    # the kernels of the next
     stream = torch.cuda.Stream()
+    comm = torch.cuda.Stream()
+    filled = [torch.cuda.Event() for _ in range(2)]      # the kernels have written matrix b
+    reduced = [torch.cuda.Event() for _ in range(2)]     # ... and its all-reduce is through
+    for e in reduced:
+        e.record(stream)
+    nstep = [0]
 
     def step():
-        h.overlap_matrix_device(matrix.data_ptr(), stream.cuda_stream)
-        allreduce_matrix(matrix)               # RCCL sum over xGMI, R1*R2 int64 (no-op at N=1)
+        b = nstep[0] & 1
+        nstep[0] += 1
+        if use_dist:
+            stream.wait_event(reduced[b])      # (the all-reduce of two steps ago)
+        h.overlap_matrix_device(mats[b].data_ptr(), stream.cuda_stream)
+        if use_dist:
+            # RCCL sum over xGMI, R1*R2 int64 (executed at world size 1 too: `torchrun
+            # --nproc-per-node 1` exercises this very code)
+            filled[b].record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(filled[b])
+                dist.all_reduce(mats[b], op=dist.ReduceOp.SUM)
+                reduced[b].record(comm)
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
@@ -289,7 +309,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()               # (every stream: the last all-reduce included)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -298,6 +318,7 @@ def main():
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
+    matrix = mats[(nstep[0] - 1) & 1]
     st = h.stats()
     # HIP events recorded by the library on the kernels' stream, one set per step of
     # the timed region (ring of the last 64 launches: no synchronisation inside the loop)
