@@ -182,6 +182,9 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   c->ev_km = c->ring_km[0];
   c->ev_k1 = c->ring_k1[0];
   CREATE_TRY(hipEventCreate(&c->ev_stop));
+  CREATE_TRY(hipEventCreateWithFlags(&c->ev_usage, hipEventDisableTiming));
+  CREATE_TRY(hipMalloc((void **)&c->d_usage, sizeof(unsigned long long)));
+  CREATE_TRY(hipHostMalloc((void **)&c->h_usage, sizeof(unsigned long long), hipHostMallocDefault));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
   if (const char *e = getenv("COMPAIRR_HIP_VARIANT")) {
@@ -225,6 +228,9 @@ extern "C" void cmpr_destroy(cmpr_context *c)
     if (c->ring_k1[i]) (void)hipEventDestroy(c->ring_k1[i]);
   }
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->ev_usage) (void)hipEventDestroy(c->ev_usage);
+  if (c->d_usage) (void)hipFree(c->d_usage);
+  if (c->h_usage) (void)hipHostFree(c->h_usage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -302,6 +308,7 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
     c->deferred_resolve = value;
+    c->usage_pending = c->never_overflows = false;
   } else if (n == "resolve_blocks_per_cu") {
     if (value < 1 || value > 8)
       return fail(c, CMPR_EINVAL, "resolve_blocks_per_cu must be 1..8");
@@ -541,6 +548,7 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
     return fail(c, rc, why);
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_q = false;
+  c->usage_pending = c->never_overflows = false;
 
   /* upload, validation, grouping by slice, tiles, chunks: all on the device
      (query_layout.hip) */
@@ -779,10 +787,22 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     c->launches = 1;
     launched = true;
     HIP_TRY(c, hipEventRecord(c->ev_km, st));
+    /* the redo launch below: needed until a finished launch has shown the margin */
+    const bool redo_kind = c->rows && deferred && !(c->debug & DBG_SKIP_RESOLVE);
+    if (redo_kind && c->usage_pending && hipEventQuery(c->ev_usage) == hipSuccess) {
+      c->usage_pending = false;
+      const uint64_t waves_per_segment =
+          ((grid + P.pos_segments - 1) / P.pos_segments) * (uint64_t)nw;
+      const uint64_t margin = 2 * WAVE * (waves_per_segment + 1);
+      c->never_overflows = *c->h_usage + margin <= c->pos_cap;
+    }
+    const bool track_usage = redo_kind && !c->never_overflows && !c->usage_pending;
+    if (track_usage)
+      HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
     auto reduce_partials = [&]() {
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
                          (uint32_t)(P.lds_matrix ? cells : 0), reduce_writes ? 1u : 0u, c->ctr_other,
-                         (uint32_t)ctr_blk);
+                         (uint32_t)ctr_blk, track_usage ? c->d_usage : nullptr);
     };
     if (!(deferred && !(c->debug & DBG_SKIP_RESOLVE))) {
       reduce_partials();
@@ -799,7 +819,13 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
       reduce_partials();
       HIP_TRY(c, hipGetLastError());
       c->launches = 2;
-      if (c->rows) {
+      if (track_usage) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_usage, c->d_usage, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipEventRecord(c->ev_usage, st));
+        c->usage_pending = true;
+      }
+      if (c->rows && !c->never_overflows) {
         /* Redo pass: if the positives of the fast launch did not fit their buffer
            (flag set: resolve_kernel then did nothing), the same step with every
            positive resolved inline; otherwise its workgroups return at once.
@@ -995,6 +1021,12 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   unsigned long long st[STAT_COUNT], ovf = 0;
   HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(&ovf, c->d_overflow, sizeof ovf, hipMemcpyDeviceToHost));
+  if (ovf && c->never_overflows) {
+    /* (cannot happen while the margin argument of enqueue_overlap holds: be loud) */
+    c->never_overflows = false;
+    return fail(c, CMPR_ESTATE, "positives buffer overflowed in a launch without redo pass: result invalid, "
+                                "repeat the call");
+  }
   if (ovf)       /* the positives buffer overflowed: the redo pass did the step */
     HIP_TRY(c, hipMemcpy(st, c->d_stats2, sizeof st, hipMemcpyDeviceToHost));
   float k_ms = 0, t_ms = 0;

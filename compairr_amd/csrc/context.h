@@ -152,6 +152,14 @@ struct cmpr_context {
   DevBuf<unsigned long long> pos_ctr;      /* per segment: [0] claimed, [1] ~first claim that did not fit */
   unsigned long long        *ctr_cur = nullptr, *ctr_other = nullptr;   /* this launch's block / the next one's */
   bool                       ctr_clean = false;        /* ctr_other and `part` are all zero */
+  /* The redo launch of variant 2 (enqueue_overlap) is dropped once a finished launch on
+     these sets has shown that the fullest segment of the positives buffer stays clear
+     of its capacity by more than launches can differ (which wave ends up with which
+     tile only moves the number of part-filled 64-entry blocks): */
+  unsigned long long        *d_usage = nullptr;        /* fullest segment of a launch (reduce kernel) */
+  unsigned long long        *h_usage = nullptr;        /* pinned copy */
+  hipEvent_t                 ev_usage = nullptr;
+  bool                       usage_pending = false, never_overflows = false;
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */

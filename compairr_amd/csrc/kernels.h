@@ -582,11 +582,15 @@ __device__ __forceinline__ unsigned long long *matrix_dst(const ProbeParams &P)
    counter block of the NEXT launch (`next_ctr`, n64 words). */
 static __global__ void __launch_bounds__(NPART)
 reduce_partials_kernel(const ProbeParams P, uint32_t cells, uint32_t overwrite,
-                       unsigned long long *next_ctr, uint32_t n64)
+                       unsigned long long *next_ctr, uint32_t n64, unsigned long long *usage)
 {
   static_assert(NPART == 2 * WAVE, "two waves per workgroup");
   __shared__ unsigned long long half[2];
   const uint32_t i = blockIdx.x, s = threadIdx.x;
+  /* how full the fullest segment of the positives buffer got (the host's margin check) */
+  if (usage && P.pos_ctr && i == 0)
+    for (uint32_t g = s; g < P.pos_segments; g += NPART)
+      atomicMax(usage, P.pos_ctr[(size_t)g * POS_CTR_STRIDE]);
   for (uint32_t k = i * NPART + s; k < n64; k += gridDim.x * NPART)
     next_ctr[k] = 0;
   unsigned long long x = P.part[(size_t)s * P.part_stride + i];
