@@ -438,6 +438,35 @@ def test_work_shards_add_up(name, opt, nt, tun):
         assert e.value.code == 4               # CMPR_EUNSUPPORTED
 
 
+def test_repeated_launches_with_and_without_redo_pass():
+    """Variant 2 drops its redo launch once a finished launch has shown that the
+    positives buffer has room to spare: every launch of a series gives the same matrix,
+    whether the buffer overflows (64 entries), is nearly full, or is ample."""
+    a = synth.make_set(40000, 21, prefix="A", pool_size=8000)
+    b = synth.make_set(40000, 22, prefix="B", pool_size=8000)
+    o = Options(differences=1, **FULL)
+    want, ost = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    with HipOverlap(o) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        assert np.array_equal(h.overlap_matrix(), want)
+        positives = h.stats().bloom_positive
+    for cap in (64, positives + 64 * 64, positives * 2 + 64 * 64 * 4, 0):
+        with HipOverlap(o) as h:
+            h.set_tunable("variant", 2)
+            h.set_tunable("pos_segments", 1)
+            h.set_tunable("pos_capacity", cap)
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            for launch in range(4):
+                assert np.array_equal(h.overlap_matrix(), want), (cap, launch)
+                st = h.stats()
+                assert st.matches == ost.matches, (cap, launch)
+            pairs = h.overlap_pairs()
+            assert len(pairs) == ost.matches
+
+
 def test_debug_switches_absent_from_the_shipped_library():
     """The ablation switches (ProbeParams::debug) are compiled out of
     libcompairr_hip.so: the tunable is refused, and so are values no kernel has."""
