@@ -201,6 +201,8 @@ def roofline(workload, st, probe_ms, kernel_ms):
     a, p, unit = units[best]
     out.update({"bound": best, "achieved": a, "peak": p, "unit": unit, "frac": a / p,
                 "utilisation": {u: v[0] / v[1] for u, v in units.items()},
+                # SQ_ACTIVE_INST_* / SQ_BUSY_CU_CYCLES of the committed profile run (not live)
+                "busy_fraction_from_counters": k.get("busy_fraction_from_counters"),
                 "counters_from": inp.get("source"),
                 "note": "achieved = per-launch work of the binding unit (committed rocprofv3 PMC "
                         "summary of this workload) / live HIP-event time of the probe kernel; peak = "
