@@ -140,6 +140,7 @@ struct cmpr_context {
      pass 0 (~0: padding) and its residue at the class position | position << 8 */
   DevBuf<uint64_t>  cw;
   DevBuf<uint32_t>  cmain, crp;
+  DevBuf<uint32_t>  slice_items;     /* sub2 items: per slice {first item, blocks} (layout.h CHUNK_WITH_ITEMS) */
   DevBuf<cmpr::ResPack> cpk;             /* sub2 items: the query's residues, 2 bits each */
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */

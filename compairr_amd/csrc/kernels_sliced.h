@@ -507,27 +507,47 @@ probe_sliced_kernel(const ProbeParams P)
           slice_lds[i] = src[i];
         /* (an item chunk -- pass >= 3 -- has no tile references: its "tiles" are
            blocks of 64 items from item ck.first_tile on) */
-        for (uint32_t i = threadIdx.x; ck.pass < 3 && i < ck.ntiles; i += NT)
+        for (uint32_t i = threadIdx.x; (ck.pass & 0xffu) < 3 && i < ck.ntiles; i += NT)
           tref_lds[i] = P.tile_refs[ck.first_tile + i];
         __syncthreads();
       }
     }
     const bool staged = block_phase;       /* own-slice probes: LDS or HBM */
-    const uint32_t pass = ck.pass;         /* 0 main, 1 insertions, 2 deletions */
+    /* a main chunk may hand out, behind its tiles, the item blocks of its slice (the
+       slice is staged once for both; idle waves of a chunk with one or two long tiles
+       get work) */
+    uint32_t ride_first = 0, ride_blocks = 0;
+    if (D >= 2 && block_phase && (ck.pass & CHUNK_WITH_ITEMS)) {
+      ride_first = P.slice_items[2 * ck.slice];
+      ride_blocks = P.slice_items[2 * ck.slice + 1];
+    }
+    const uint32_t chunk_pass = ck.pass & 0xffu;      /* 0 main, 1 insertions, 2 deletions, >= 3 items */
 
     bool all_done = false;
     for (;;) {
       uint32_t t;
       TileDesc td;
       uint32_t item0 = 0;                  /* item tile: its first item */
+      uint32_t pass = chunk_pass;          /* (of this tile) */
       if (block_phase) {
         uint32_t tk = 0;
         if (lane == 0)
           tk = atomicAdd(&bcast[1], 1u);
         tk = __builtin_amdgcn_readfirstlane(tk);
-        if (tk >= ck.ntiles)
+        if (tk >= ck.ntiles + ride_blocks)
           break;
-        if (D >= 2 && pass >= 3) {
+        pass = chunk_pass;
+        if (D >= 2 && tk >= ck.ntiles) {                   /* an item block riding along */
+          pass = 3;
+          item0 = ride_first + (tk - ck.ntiles) * WAVE;
+          t = 0;
+          td.len = 0;
+          td.nvalid = WAVE;
+          td.res_base = 0;
+          td.pass = pass;
+          td.slice = ck.slice;
+          td.k = P.geom.k;
+        } else if (D >= 2 && pass >= 3) {
           item0 = ck.first_tile + tk * WAVE;
           t = 0;
           td.len = 0;

@@ -175,6 +175,9 @@ struct Chunk {
                             ntiles = blocks of 64 items)                        */
 };
 
+/* Chunk::pass bit: a main chunk of variant 1 that also hands out the item blocks of its
+   slice (ProbeParams::slice_items), behind its tiles */
+constexpr uint32_t CHUNK_WITH_ITEMS = 0x100u;
 constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
 
@@ -286,6 +289,7 @@ struct ProbeParams {
   unsigned long long *part;
   uint32_t        part_stride;
   uint32_t        sub2_items;  /* variant 1, nt, d = 2: class-position pairs are items (passes >= 3) */
+  const uint32_t *slice_items; /* ... per slice {first item, blocks} riding along with its first main chunk */
   uint32_t        work_first, work_step;   /* variant 0: this launch takes tiles work_first + k work_step */
   /* output */
   unsigned long long *matrix;      /* R1 * R2 integer sums                   */

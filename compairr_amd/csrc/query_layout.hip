@@ -118,6 +118,8 @@ struct QL {
      class position -- one item per (split query, i, k), grouped by that slice
      (kernels_sliced.h, passes >= 3) */
   uint32_t  sub2_items;
+  uint2    *slice_items;                  /* sub2: per slice (first item, blocks of 64) when the slice's first
+                                             main chunk takes them along (pass | CHUNK_WITH_ITEMS) */
   uint32_t  nitem_slices;                 /* counters in all */
   uint32_t  cblocks;                      /* blocks of 64 items per chunk at most */
   uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
@@ -549,6 +551,8 @@ slices_kernel(const QL Q, uint32_t pi)
             ck.first_tile = Q.list0[pi] + at.list + k * Q.chunk_tiles;
             ck.ntiles = min(Q.chunk_tiles, ntiles - k * Q.chunk_tiles);
             ck.pass = pass + rp;
+            if (Q.sub2_items && pi == 0 && k == 0)
+              ck.pass |= CHUNK_WITH_ITEMS;      /* (the slice's item blocks ride along) */
             Q.chunks[Q.chunk0[pi] + at.chunks + k * reps + rp] = ck;
           }
       }
@@ -645,6 +649,8 @@ class_pad_kernel(const QL Q, uint32_t *padded)
     }
     for (uint32_t g = 1; g < Q.ngroups; g++)
       blocks += (Q.ccnt[k + g] + WAVE - 1) / WAVE;
+    if (Q.tot[0][k / Q.ngroups].chunks > 0)
+      blocks = 0;                            /* (ride along with the slice's first main chunk) */
   }
   Q.cnch[k] = (blocks + Q.cblocks - 1) / Q.cblocks;
 }
@@ -666,6 +672,12 @@ class_chunks_kernel(const QL Q)
     for (uint32_t g = 1; g < Q.ngroups; g++)
       blocks += (Q.ccnt[k + g] + WAVE - 1) / WAVE;
     gi = 0;                                  /* (which group a block belongs to is in its items) */
+    const uint32_t sl = (uint32_t)(k / Q.ngroups);
+    if (Q.tot[0][sl].chunks > 0) {           /* the slice's first main chunk takes them along */
+      Q.slice_items[sl] = make_uint2(Q.cbase[k], blocks);
+      return;
+    }
+    Q.slice_items[sl] = make_uint2(0u, 0u);
   }
   const uint32_t nc = (blocks + Q.cblocks - 1) / Q.cblocks;
   for (uint32_t q = 0; q < nc; q++) {
@@ -807,11 +819,14 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   if (k >= nchunks)
     return;
   const Chunk ck = Q.chunks[k];
-  uint64_t w = ck.pass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : 2) : 0;
-  for (uint32_t t = 0; ck.pass < 3 && t < ck.ntiles; t++) {
+  const uint32_t cpass = ck.pass & ~CHUNK_WITH_ITEMS;
+  uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : 2) : 0;
+  for (uint32_t t = 0; cpass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
-    w += (uint64_t)(ck.pass == 0 ? td.len + 1 : ck.pass == 1 ? td.len + 2 : 2) * td.nvalid;
+    w += (uint64_t)(cpass == 0 ? td.len + 1 : cpass == 1 ? td.len + 2 : 2) * td.nvalid;
   }
+  if (ck.pass & CHUNK_WITH_ITEMS)
+    w += (uint64_t)Q.slice_items[ck.slice].y * WAVE * 48;
   work[k] = (uint32_t)min(w, (uint64_t)0xffffffffu);
   idx[k] = k;
 }
@@ -849,7 +864,7 @@ chunk_mine_kernel(const Chunk *chunks, const uint32_t *idx, uint32_t n, uint32_t
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k < n) {
     const Chunk ck = chunks[idx[k]];
-    flag[k] = work_owner(ck.slice, ck.pass, step) == first ? 1 : 0;
+    flag[k] = work_owner(ck.slice, ck.pass & ~CHUNK_WITH_ITEMS, step) == first ? 1 : 0;
   }
 }
 
@@ -1319,7 +1334,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   HIP_TRY(c, hipMemsetAsync(c->qlen.p, 0, std::max<size_t>(slots, 1) * sizeof(uint16_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->qorig.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
   c->qv.release(); c->qj.release(); c->qgh.release(); c->qcnt.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release();
+  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release(); c->slice_items.release();
   if (!c->opt.ignore_genes) {
     if ((rc = dev_alloc(c, c->qv, slots))) return rc;
     if ((rc = dev_alloc(c, c->qj, slots))) return rc;
@@ -1351,6 +1366,10 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     if ((rc = dev_alloc(c, c->cmain, ni))) return rc;
     if ((rc = dev_alloc(c, c->crp, ni))) return rc;
     if (sub2_items && (rc = dev_alloc(c, c->cpk, ni))) return rc;
+    if (sub2_items) {
+      if ((rc = dev_alloc(c, c->slice_items, 2 * (size_t)nslices))) return rc;
+      HIP_TRY(c, hipMemsetAsync(c->slice_items.p, 0, 2 * (size_t)nslices * sizeof(uint32_t), c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, ni * sizeof(uint64_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0xff, ni * sizeof(uint32_t), c->stream));   /* ~0: padding */
     HIP_TRY(c, hipMemsetAsync(c->crp.p, 0, ni * sizeof(uint32_t), c->stream));
@@ -1360,6 +1379,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.tile_refs = c->tile_refs.p;
   Q.small_tiles = c->small_tiles.p;
   Q.cpk = c->cpk.p;
+  Q.slice_items = (uint2 *)c->slice_items.p;
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
   Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
