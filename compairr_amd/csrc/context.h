@@ -75,7 +75,7 @@ struct cmpr_context {
   int64_t waves_per_block = 8;
   bool    sub2_active = false;    /* ... and the query layout in effect lists them */
   int64_t sub2_items = -1;        /* variant 1, nt, d = 2: class-changing double substitutions as items
-                                     (-1: when the filter is larger than the 256 MB last-level cache) */
+                                     (-1 = default = on; 0: probed where the filter lies) */
   int64_t work_shard_index = 0;   /* this context works on every work_shard_count-th work   */
   int64_t work_shard_count = 1;   /* item (chunk / small tile / tile) of the step, from here */
   int64_t small_slice_tiles = 0;  /* slices with <= this many tiles are not staged (wave phase): never pays since round 2 */

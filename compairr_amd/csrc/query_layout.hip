@@ -1042,8 +1042,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   uint32_t goff[MAX_GROUPS] = {0}, gslices[MAX_GROUPS] = {0}, gslice0[MAX_GROUPS] = {0};
   const bool sub2_items = !c->rows && c->sliced && c->geom.k > 0 && c->opt.differences == 2 &&
                           c->opt.alphabet_size == 4 && !c->opt.indels &&
-                          (c->sub2_items == 1 ||
-                           (c->sub2_items < 0 && c->bloom_words * sizeof(uint64_t) > ((size_t)256 << 20)));
+                          c->sub2_items != 0;
   uint64_t ncs = 0;                          /* counters over all groups */
   if (c->rows && c->geom.k > 0 && c->opt.differences >= 1) {
     for (uint32_t g = 0; g < c->geom.k; g++) {

@@ -245,9 +245,8 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              up to the unsharded ones (variants 1, 2).
      "sub2_items"            nucleotides, d = 2, variant 1: the double substitutions
                              that put a new residue on a class position are grouped
-                             by the slice they land in and probed there (1), or
-                             probed where the filter lies (0); -1 (default): 1 when
-                             the filter is larger than the 256 MB last-level cache
+                             by the slice they land in and probed there (1, and
+                             the default -1), or probed where the filter lies (0)
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
      "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip
