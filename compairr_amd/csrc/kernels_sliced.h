@@ -537,18 +537,12 @@ probe_sliced_kernel(const ProbeParams P)
         if (tk >= ck.ntiles + ride_blocks)
           break;
         pass = chunk_pass;
-        if (D >= 2 && tk >= ck.ntiles) {                   /* an item block riding along */
-          pass = 3;
-          item0 = ride_first + (tk - ck.ntiles) * WAVE;
-          t = 0;
-          td.len = 0;
-          td.nvalid = WAVE;
-          td.res_base = 0;
-          td.pass = pass;
-          td.slice = ck.slice;
-          td.k = P.geom.k;
-        } else if (D >= 2 && pass >= 3) {
-          item0 = ck.first_tile + tk * WAVE;
+        /* an item block: one of an item chunk, or one riding along behind the tiles of a
+           main chunk */
+        const bool riding = D >= 2 && tk >= ck.ntiles;
+        if (riding || (D >= 2 && pass >= 3)) {
+          item0 = riding ? ride_first + (tk - ck.ntiles) * WAVE : ck.first_tile + tk * WAVE;
+          pass = riding ? 3u : pass;
           t = 0;
           td.len = 0;
           td.nvalid = WAVE;
