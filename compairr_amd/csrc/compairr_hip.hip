@@ -31,7 +31,11 @@ std::string &cmpr_create_error()
 /* u64s behind the segment counters of the positives buffer: statistics, cursors,
    overflow flag, and the statistics + cursors of the redo pass */
 static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
-namespace { void use_counter_block(cmpr_context *c, int which); }
+namespace {
+void use_counter_block(cmpr_context *c, int which);
+void invalidate_plan(cmpr_context *c);
+int make_plan(cmpr_context *c);
+}
 
 int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
 {
@@ -173,9 +177,12 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->host_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  /* k0 and km only ever feed hipEventElapsedTime: no system-scope fence behind them (a
+     fenced record holds the stream up for ~5 us; k1 is also what the host waits on) */
+  const unsigned tflags = getenv("COMPAIRR_HIP_EVENT_FENCE") ? hipEventDefault : hipEventDisableSystemFence;
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
-    CREATE_TRY(hipEventCreate(&c->ring_k0[i]));
-    CREATE_TRY(hipEventCreate(&c->ring_km[i]));
+    CREATE_TRY(hipEventCreateWithFlags(&c->ring_k0[i], tflags));
+    CREATE_TRY(hipEventCreateWithFlags(&c->ring_km[i], tflags));
     CREATE_TRY(hipEventCreate(&c->ring_k1[i]));
   }
   c->ev_k0 = c->ring_k0[0];
@@ -183,8 +190,16 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   c->ev_k1 = c->ring_k1[0];
   CREATE_TRY(hipEventCreate(&c->ev_stop));
   CREATE_TRY(hipEventCreateWithFlags(&c->ev_usage, hipEventDisableTiming));
-  CREATE_TRY(hipMalloc((void **)&c->d_usage, sizeof(unsigned long long)));
-  CREATE_TRY(hipHostMalloc((void **)&c->h_usage, sizeof(unsigned long long), hipHostMallocDefault));
+  CREATE_TRY(hipMalloc((void **)&c->d_usage, 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(c->d_usage, 0, 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipHostMalloc((void **)&c->h_usage, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  c->h_usage[0] = c->h_usage[1] = 0;
+  CREATE_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
+    CREATE_TRY(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
+
+  CREATE_TRY(hipEventCreate(&c->ev_cap));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
   if (const char *e = getenv("COMPAIRR_HIP_VARIANT")) {
@@ -213,13 +228,14 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   (void)hipSetDevice(c->device);
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
+  invalidate_plan(c);
   c->zob.release();
   c->res2.release(); c->off2.release(); c->cnt2.release(); c->table.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release(); c->slice_items.release(); c->qrec.release();
+  c->qhins.release(); c->qhdel.release(); c->items.release(); c->cpk.release(); c->slice_items.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
@@ -231,6 +247,13 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->ev_usage) (void)hipEventDestroy(c->ev_usage);
   if (c->d_usage) (void)hipFree(c->d_usage);
   if (c->h_usage) (void)hipHostFree(c->h_usage);
+  c->arena_a.release();
+  c->arena_b.release();
+  for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
+    if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->ev_cap) (void)hipEventDestroy(c->ev_cap);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -248,6 +271,10 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
   if (!c || !name)
     return CMPR_EINVAL;
   std::string n(name);
+  /* whatever changes: the cached step (kernels, grid, graphs) is worked out again, and
+     the no-redo shortcut of variant 2 has to be earned again */
+  invalidate_plan(c);
+  c->usage_pending = c->never_overflows = false;
   if (n == "blocks_per_cu") {
     if (value < 1 || value > 16)
       return fail(c, CMPR_EINVAL, "blocks_per_cu must be 1..16");
@@ -308,7 +335,14 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
     c->deferred_resolve = value;
-    c->usage_pending = c->never_overflows = false;
+  } else if (n == "step_graph") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "step_graph must be 0 or 1");
+    c->step_graph = value;
+  } else if (n == "assume_never_overflows") {
+    /* TEST ONLY: the next launch runs without redo pass as if the margin had been
+       shown (tests/test_gpu_parity.py forces an overflow behind it) */
+    c->force_no_redo = value != 0;
   } else if (n == "resolve_blocks_per_cu") {
     if (value < 1 || value > 8)
       return fail(c, CMPR_EINVAL, "resolve_blocks_per_cu must be 1..8");
@@ -385,7 +419,13 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "slice_bytes") *value = !c->sliced ? 0 : c->rows ? (int64_t)c->geom.rw_words * ROW_WORD_BYTES : (int64_t)8 << c->geom.words_log2;
   else if (n == "passes") *value = c->npasses;
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
-  else if (n == "waves_per_block") *value = c->waves_per_block;
+  else if (n == "waves_per_block") *value = c->plan.valid ? (int64_t)c->plan.nw : c->waves_per_block;
+  else if (n == "step_graph") *value = c->step_graph;
+  else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
+  else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
+  else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);
+  else if (n == "graphs") { *value = 0; for (const StepGraph &g : c->graphs) *value += g.exec ? 1 : 0; }
+  else if (n == "never_overflows") *value = c->never_overflows ? 1 : 0;
   else if (n == "debug") *value = c->debug;
   else if (n == "heavy_threshold") *value = c->heavy_threshold;
   else if (n == "class_anchor") *value = c->sliced && c->have_ref ? (int64_t)c->geom.c0 : c->class_anchor;
@@ -549,44 +589,49 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_q = false;
   c->usage_pending = c->never_overflows = false;
+  invalidate_plan(c);
 
   /* upload, validation, grouping by slice, tiles, chunks: all on the device
      (query_layout.hip) */
   if ((rc = cmpr_layout_queries(c, s)))
     return rc;
 
+  /* (kept from call to call when large enough: no hipMalloc / hipFree in the steady state) */
   const size_t cells = (size_t)c->R1 * c->R2;
-  if ((rc = dev_alloc(c, c->matrix, cells))) return rc;
+  if ((rc = dev_reserve(c, c->matrix, cells))) return rc;
   if (is_f64_score(c->opt)) {
-    if ((rc = dev_alloc(c, c->matrix_f64, cells))) return rc;
+    if ((rc = dev_reserve(c, c->matrix_f64, cells))) return rc;
   } else {
     c->matrix_f64.release();
   }
   /* positives buffer of the deferred resolve: a capacity, not a limit -- what
      does not fit is resolved inline by the probe kernel */
   {
+    /* (a work shard queues its share of the positives) */
+    const uint64_t per_query = c->rows && c->opt.differences == 2 ? 32 : 4;
     const uint64_t total = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
-                                               : std::max<uint64_t>(1u << 20, (c->rows && c->opt.differences == 2 ? 32 : 4) * c->n1);
+                                               : (1u << 20) + per_query * c->n1 / (uint64_t)c->work_shard_count;
     const uint64_t S = (uint64_t)c->pos_segments;
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
-    if ((rc = dev_alloc(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
+    if ((rc = dev_reserve(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
     /* one block that is zeroed per launch with ONE memset: the segment counters,
        then the statistics, the two work cursors, the overflow flag, and the
        statistics + cursors of a redo pass (kernels_rows.h) */
     /* (two of them: a launch uses one and clears the other for the next launch --
        reduce_partials_kernel -- so that a step starts without a memset) */
-    if ((rc = dev_alloc(c, c->pos_ctr, 2 * (S * POS_CTR_STRIDE + CTR_TAIL)))) return rc;
+    if ((rc = dev_reserve(c, c->pos_ctr, 2 * (S * POS_CTR_STRIDE + CTR_TAIL)))) return rc;
     c->ctr_clean = false;
     use_counter_block(c, 0);
     /* partial results of the workgroups (ProbeParams::part); cleared here, and by
        reduce_partials_kernel after every launch */
     const size_t cells = (size_t)c->R1 * c->R2;
     c->part_stride = (uint32_t)((cells <= 2048 && !is_f64_score(c->opt) ? cells : 0) + STAT_COUNT);
-    if ((rc = dev_alloc(c, c->part, (size_t)NPART * c->part_stride))) return rc;
+    if ((rc = dev_reserve(c, c->part, (size_t)NPART * c->part_stride))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long),
                               c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = make_plan(c))) return rc;
   c->have_q = true;
   return CMPR_OK;
 }
@@ -610,11 +655,392 @@ void use_counter_block(cmpr_context *c, int which)
   c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
 }
 
-/* enqueue: zero outputs, run the probe kernel over every tile.  `d_out` is the
-   integer matrix to fill (ours or the caller's). */
+/* the cached plan and its graphs are stale (sets or tunables changed) */
+void invalidate_plan(cmpr_context *c)
+{
+  c->plan.valid = false;
+  for (StepGraph &g : c->graphs) {
+    if (g.exec)
+      (void)hipGraphExecDestroy(g.exec);
+    if (g.graph)
+      (void)hipGraphDestroy(g.graph);
+    g = StepGraph();
+  }
+}
+
+/* What a step launches, worked out once per (sets, tunables): kernels, grid, LDS and
+   every kernel argument that does not change from launch to launch. */
+int make_plan(cmpr_context *c)
+{
+  invalidate_plan(c);
+  StepPlan &S = c->plan;
+  S = StepPlan();
+  const size_t cells = (size_t)c->R1 * c->R2;
+  S.cells = cells;
+  S.ctr_blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
+  S.will_launch = c->ntiles > 0 && cells > 0;
+  S.reduce_writes = S.will_launch && cells <= 2048 && !is_f64_score(c->opt);
+  S.deferred = c->sliced && c->deferred_resolve;
+  S.redo_kind = c->rows && S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
+  S.nw = c->sliced ? (uint32_t)c->waves_per_block : WAVES_PER_BLOCK;
+  if (!S.will_launch) {
+    S.valid = true;
+    return CMPR_OK;
+  }
+  const uint32_t A = (uint32_t)c->opt.alphabet_size;
+  ProbeParams &P = S.P;
+  P.zob = c->zob.p;
+  P.zpos = c->zpos;
+  P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+  P.bloom = c->bloom.p;
+  P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
+  P.table = c->table.p;
+  P.slot_mask = c->slots - 1;
+  P.res2 = c->res2.p;
+  P.off2 = c->off2.p;
+  P.v2 = c->v2.p;
+  P.j2 = c->j2.p;
+  P.rep2 = c->rep2.p;
+  P.cnt2 = c->cnt2.p;
+  P.rec2 = c->rec2.p;
+  P.tiles = c->tiles.p;
+  P.qres = c->qres.p;
+  P.qv = c->qv.p;
+  P.qgh = c->qgh.p;
+  P.qj = c->qj.p;
+  P.qrep = c->qrep.p;
+  P.qcnt = c->qcnt.p;
+  P.qlen = c->qlen.p;
+  P.qorig = c->qorig.p;
+  P.qck = c->qck.p;
+  P.qrec = c->qrec.p;
+  P.qhins = c->qhins.p;
+  P.qhdel = c->qhdel.p;
+  P.items = c->items.p;
+  P.cpk = c->cpk.p;
+  P.slice_items = c->slice_items.p;
+  P.ntiles = c->ntiles;
+  P.first_tile = 0;
+  P.sub2_items = c->sub2_active ? 1u : 0u;
+  P.part = c->part.p;
+  P.part_stride = c->part_stride;
+  P.work_first = (uint32_t)c->work_shard_index;
+  P.work_step = (uint32_t)c->work_shard_count;
+  P.matrix_f64 = c->matrix_f64.p;
+  P.R1 = c->R1;
+  P.R2 = c->R2;
+  P.score = c->opt.score;
+  P.ignore_counts = c->opt.ignore_counts;
+  P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
+  P.geom = c->geom;
+  P.chunks = c->chunks.p;
+  P.tile_refs = c->tile_refs.p;
+  P.small_tiles = c->small_tiles.p;
+  P.nsmall = c->nsmall;
+  P.nchunks = c->nchunks;
+  P.debug = (uint32_t)c->debug;
+  if (S.deferred) {
+    P.pos_buf = c->pos_buf.p;
+    P.pos_cap = c->pos_cap;
+    P.pos_segments = (uint32_t)c->pos_segments;
+  }
+
+  /* variant 1: workgroups of 8 waves share one staged slice; when the chunks are
+     short (many slices, few queries each) 4 waves keep more of them busy.
+     variant 2: one workgroup of 16 waves per CU around a ring of slices */
+  int nw = (int)S.nw;
+  if (c->rows && !c->waves_per_block_forced)
+    nw = 16;
+  if (c->sliced && !c->rows && !c->waves_per_block_forced && c->nchunks > 0 &&
+      (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
+    nw = 4;
+  auto lds_for = [&](int waves) -> size_t {
+    const size_t zrow = c->rows ? (c->opt.differences == 2 ? 2 * (size_t)A : (size_t)A)
+                                : c->sliced ? (size_t)(zrow_stride((int)A) + zdelta_entries((int)A))
+                                            : (size_t)A;
+    size_t b = zrow * c->zpos * sizeof(uint64_t) +
+               (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
+               (size_t)waves * sizeof(WaveQueue);
+    if (c->rows)
+      b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
+           (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) +
+           RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef));
+    else if (c->sliced)
+      b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
+           MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
+           (size_t)c->chunk_cap * sizeof(TileRef);
+    return b;
+  };
+  size_t lds = lds_for(nw);
+  while (lds > 160 * 1024 && c->sliced && nw > 4) {
+    nw /= 2;                             /* long sequences: fewer wave queues */
+    lds = lds_for(nw);
+  }
+  if (lds > 160 * 1024)
+    return fail(c, CMPR_EUNSUPPORTED,
+                "sequences too long: Zobrist table does not fit the 160 KiB LDS");
+  P.chunk_cap = c->chunk_cap;
+  /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
+     that resolves inline is deferred_resolve = 0 and the redo pass */
+  ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !S.deferred)
+                       : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
+  if (lds > 48 * 1024)
+    HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
+  uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
+  if (c->rows) {
+    /* variant 2 deals its chunks out statically over the workgroups of the grid:
+       exactly as many as are resident at once (registers count too) */
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, nw * WAVE, lds) ==
+            hipSuccess && occ > 0)
+      per_cu = std::min<uint64_t>(per_cu, (uint64_t)occ);
+  }
+  per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
+  uint64_t grid = (uint64_t)c->cus * per_cu;
+  grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks + ((uint64_t)c->nsmall + nw - 1) / nw
+                                            : ((uint64_t)c->ntiles + WAVES_PER_BLOCK - 1) /
+                                                  WAVES_PER_BLOCK);
+  grid = std::max<uint64_t>(grid, 1);
+  S.fn = fn;
+  S.grid = (uint32_t)grid;
+  S.nw = (uint32_t)nw;
+  S.lds = lds;
+  if (S.deferred) {
+    S.rlds = (BLOCK_THREADS / WAVE) * sizeof(CandQueue) +
+             (P.lds_matrix ? cells * sizeof(unsigned long long) : 0);
+    /* 5 waves/SIMD fit its registers; a multiple of the segment count */
+    uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
+    S.rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
+    S.rfn = select_resolve(!c->opt.ignore_genes);
+  }
+  if (S.redo_kind) {
+    /* the redo pass (issue_step) */
+    S.fn2 = select_rows_kernel(c->opt, nw, true);
+    if (lds > 48 * 1024)
+      HIP_TRY(c, hipFuncSetAttribute((const void *)S.fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  S.valid = true;
+  return CMPR_OK;
+}
+
+/* what changes from launch to launch */
+struct StepArgs {
+  unsigned long long *d_out;
+  bool needs_clear;          /* counter blocks and partial slots are not known to be zero */
+  bool track_usage;          /* measure how full the positives buffer gets */
+  bool with_redo;            /* variant 2: enqueue the redo pass */
+};
+
+/* The memsets, launches and the mid-step event of one step on `st` (directly, or while
+   `st` is being captured into a graph).  The counter block in use was chosen by the
+   caller (use_counter_block). */
+int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev_km)
+{
+  const StepPlan &S = c->plan;
+  const size_t cells = S.cells;
+  /* A step normally starts without a memset: its counter block was cleared by the
+     previous launch's reduce kernel, and with the matrix privatised in LDS the reduce
+     kernel WRITES the cells.  Otherwise (first launch, a launch that failed half-way,
+     matrix too large for LDS, nothing to launch) everything is cleared here. */
+  if (cells && !S.reduce_writes)
+    HIP_TRY(c, hipMemsetAsync(a.d_out, 0, cells * sizeof(unsigned long long), st));
+  if (cells && is_f64_score(c->opt))
+    HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, cells * sizeof(double), st));
+  if (a.needs_clear) {
+    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, 2 * S.ctr_blk * sizeof(unsigned long long), st));
+    HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long), st));
+  }
+  if (!S.will_launch) {                       /* (nobody will clear the other block) */
+    HIP_TRY(c, hipMemsetAsync(c->ctr_other, 0, S.ctr_blk * sizeof(unsigned long long), st));
+    if (ev_km)
+      HIP_TRY(c, hipEventRecord(ev_km, st));
+    c->launches = 0;
+    return CMPR_OK;
+  }
+  ProbeParams P = S.P;
+  P.matrix = a.d_out;
+  P.tile_counter = c->d_tile_counter;
+  P.stats = c->d_stats;
+  P.pair_q = c->pair_q;
+  P.pair_h = c->pair_h;
+  P.pair_count = c->pair_count;
+  P.pair_cap = c->pair_cap;
+  if (S.deferred)
+    P.pos_ctr = c->ctr_cur;
+  if (c->rows && S.deferred)
+    P.overflow = c->d_overflow;
+  hipLaunchKernelGGL(S.fn, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P);
+  HIP_TRY(c, hipGetLastError());
+  c->launches = 1;
+  if (ev_km)                                  /* (a capture gets its event node afterwards: graph_for) */
+    HIP_TRY(c, hipEventRecord(ev_km, st));
+  if (a.track_usage)
+    HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
+  /* a launch of variant 2 without redo pass leaves word of an overflow behind */
+  unsigned long long *sticky = (S.redo_kind && !a.with_redo) ? c->d_usage + 1 : nullptr;
+  auto reduce_partials = [&]() {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
+                       (uint32_t)(P.lds_matrix ? cells : 0), S.reduce_writes ? 1u : 0u, c->ctr_other,
+                       (uint32_t)S.ctr_blk, a.track_usage ? c->d_usage : nullptr, sticky);
+  };
+  const bool resolve_pass = S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
+  if (!resolve_pass) {
+    reduce_partials();
+    HIP_TRY(c, hipGetLastError());
+    return CMPR_OK;
+  }
+  hipLaunchKernelGGL(S.rfn, dim3(S.rgrid), dim3(BLOCK_THREADS), S.rlds, st, P);
+  reduce_partials();
+  HIP_TRY(c, hipGetLastError());
+  c->launches = 2;
+  if (a.track_usage) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_usage, c->d_usage, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_usage, st));
+    c->usage_pending = true;
+    c->usage_grid = S.grid;
+    c->usage_nw = S.nw;
+  }
+  if (a.with_redo) {
+    /* Redo pass: if the positives of the fast launch did not fit their buffer
+       (flag set: resolve_kernel then did nothing), the same step with every
+       positive resolved inline; otherwise its workgroups return at once.
+       Capacity is therefore never a limit, and nothing here waits for the host. */
+    ProbeParams P2 = P;
+    P2.pos_buf = nullptr;
+    P2.part = nullptr;                  /* (straight into matrix and stats2) */
+    P2.redo = 1;
+    P2.stats = c->d_stats2;
+    P2.tile_counter = c->d_tile_counter2;
+    hipLaunchKernelGGL(S.fn2, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P2);
+    HIP_TRY(c, hipGetLastError());
+    c->launches = 3;
+  }
+  return CMPR_OK;
+}
+
+/* the instantiated graph of the steady-state step for (d_out, counter block), captured
+   on first use; nullptr when graphs are off or the capture failed (plain launches then) */
+StepGraph *graph_for(cmpr_context *c, const StepArgs &a, int which)
+{
+  if (!c->step_graph || !c->cap_stream)
+    return nullptr;
+  StepGraph *slot = nullptr;
+  for (StepGraph &g : c->graphs) {
+    if (g.exec && g.d_out == (void *)a.d_out && g.which == which) {
+      g.last_use = c->calls;
+      return &g;
+    }
+    if (!slot || (slot->exec && (!g.exec || g.last_use < slot->last_use)))
+      slot = &g;
+  }
+  if (slot->exec) {                            /* the least recently used one makes room */
+    (void)hipGraphExecDestroy(slot->exec);
+    (void)hipGraphDestroy(slot->graph);
+    *slot = StepGraph();
+  }
+  hipGraph_t graph = nullptr;
+  const char *why = nullptr;
+  hipError_t he = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+  if (he != hipSuccess)
+    why = "hipStreamBeginCapture";
+  hipGraphExec_t exec = nullptr;
+  hipGraphNode_t km = nullptr;
+  if (!why) {
+    const uint32_t launches = c->launches;
+    const int rc = issue_step(c, a, c->cap_stream, nullptr);
+    he = hipStreamEndCapture(c->cap_stream, &graph);
+    c->launches = launches;
+    if (rc != CMPR_OK)
+      why = "a call of the step refused to be captured";
+    else if (he != hipSuccess || !graph)
+      why = "hipStreamEndCapture";
+  }
+  if (!why) {
+    /* the mid-step event (end of the probe kernel) as a node of its own, between the
+       probe kernel's node and whatever the capture put behind it */
+    size_t n = 0;
+    he = hipGraphGetNodes(graph, nullptr, &n);
+    std::vector<hipGraphNode_t> nodes(n ? n : 1);
+    if (he == hipSuccess && n)
+      he = hipGraphGetNodes(graph, nodes.data(), &n);
+    if (he != hipSuccess || !n)
+      why = "hipGraphGetNodes";
+    hipGraphNode_t probe = nullptr;
+    for (size_t k = 0; !why && k < n; k++) {
+      hipGraphNodeType t;
+      hipKernelNodeParams kp;
+      if (hipGraphNodeGetType(nodes[k], &t) == hipSuccess && t == hipGraphNodeTypeKernel &&
+          hipGraphKernelNodeGetParams(nodes[k], &kp) == hipSuccess && kp.func == (void *)c->plan.fn)
+        probe = nodes[k];
+    }
+    if (!why && !probe)
+      why = "probe kernel node not found in the captured graph";
+    std::vector<hipGraphNode_t> next;
+    if (!why) {
+      size_t ne = 0;
+      he = hipGraphGetEdges(graph, nullptr, nullptr, &ne);
+      std::vector<hipGraphNode_t> from(ne ? ne : 1), to(ne ? ne : 1);
+      if (he == hipSuccess && ne)
+        he = hipGraphGetEdges(graph, from.data(), to.data(), &ne);
+      if (he != hipSuccess)
+        why = "hipGraphGetEdges";
+      for (size_t k = 0; !why && k < ne; k++)
+        if (from[k] == probe)
+          next.push_back(to[k]);
+    }
+    if (!why) {
+      he = hipGraphAddEventRecordNode(&km, graph, &probe, 1, c->ev_cap);
+      if (he != hipSuccess)
+        why = "hipGraphAddEventRecordNode";
+    }
+    for (size_t k = 0; !why && k < next.size(); k++) {
+      he = hipGraphRemoveDependencies(graph, &probe, &next[k], 1);
+      if (he == hipSuccess)
+        he = hipGraphAddDependencies(graph, &km, &next[k], 1);
+      if (he != hipSuccess)
+        why = "re-wiring the graph around the event node";
+    }
+  }
+  if (!why) {
+    he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (he != hipSuccess)
+      why = "hipGraphInstantiate";
+  }
+  if (why) {
+    if (getenv("COMPAIRR_HIP_DEBUG"))
+      fprintf(stderr, "compairr_hip: step graph unavailable (%s: %s): plain launches\n", why,
+              he != hipSuccess ? hipGetErrorString(he) : c->err.c_str());
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    c->step_graph = 0;                         /* not on this runtime: plain launches from now on */
+    return nullptr;
+  }
+  slot->d_out = (void *)a.d_out;
+  slot->which = which;
+  slot->graph = graph;
+  slot->exec = exec;
+  slot->km_node = km;
+  slot->last_use = c->calls;
+  return slot;
+}
+
+/* enqueue one step on `st`: `d_out` is the integer matrix to fill (ours or the caller's) */
 int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 {
-  const size_t cells = (size_t)c->R1 * c->R2;
+  int rc;
+  if (!c->plan.valid && (rc = make_plan(c)))
+    return rc;
+  const StepPlan &S = c->plan;
+  /* launches of one context are ordered one after the other, whatever streams the
+     caller hands in: each uses state (counter blocks, positives buffer, partial
+     slots) the previous one leaves behind */
+  if (c->have_last_stream && c->last_stream != st && c->events_valid)
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k1, 0));
+  c->last_stream = st;
+  c->have_last_stream = true;
   /* (three event records per step, not five: each is a packet the stream waits for) */
   {
     const uint32_t slot = (uint32_t)(c->calls % cmpr_context::TIME_RING);
@@ -623,238 +1049,90 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     c->ev_k1 = c->ring_k1[slot];
     c->calls++;
   }
-  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-  /* A step normally starts without a memset: its counter block was cleared by the
-     previous launch's reduce kernel, and with the matrix privatised in LDS the reduce
-     kernel WRITES the cells.  Otherwise (first launch, a launch that failed half-way,
-     matrix too large for LDS, nothing to launch) everything is cleared here. */
-  const size_t ctr_blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
-  const bool will_launch = c->ntiles > 0 && cells > 0;
-  const bool reduce_writes = will_launch && cells <= 2048 && !is_f64_score(c->opt);
-  if (cells && !reduce_writes)
-    HIP_TRY(c, hipMemsetAsync(d_out, 0, cells * sizeof(unsigned long long), st));
-  if (cells && is_f64_score(c->opt))
-    HIP_TRY(c, hipMemsetAsync(c->matrix_f64.p, 0, cells * sizeof(double), st));
-  const bool deferred = c->sliced && c->deferred_resolve;
-  if (!c->ctr_clean) {
-    HIP_TRY(c, hipMemsetAsync(c->pos_ctr.p, 0, 2 * ctr_blk * sizeof(unsigned long long), st));
-    HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long), st));
-    use_counter_block(c, 0);
-  } else {
-    use_counter_block(c, c->ctr_cur == c->pos_ctr.p ? 1 : 0);
-  }
+  StepArgs a;
+  a.d_out = d_out;
+  a.needs_clear = !c->ctr_clean;
+  int which = 0;
+  if (c->ctr_clean)
+    which = c->ctr_cur == c->pos_ctr.p ? 1 : 0;
+  use_counter_block(c, which);
   c->ctr_clean = false;                     /* until this launch is through */
-  if (!will_launch)                         /* (nobody will clear the other block) */
-    HIP_TRY(c, hipMemsetAsync(c->ctr_other, 0, ctr_blk * sizeof(unsigned long long), st));
-  c->launches = 0;
-  bool launched = false;
 
-  if (c->ntiles > 0 && cells > 0) {
-    const uint32_t A = (uint32_t)c->opt.alphabet_size;
-    ProbeParams P{};
-    P.zob = c->zob.p;
-    P.zpos = c->zpos;
-    P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
-    P.bloom = c->bloom.p;
-    P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
-    P.table = c->table.p;
-    P.slot_mask = c->slots - 1;
-    P.res2 = c->res2.p;
-    P.off2 = c->off2.p;
-    P.v2 = c->v2.p;
-    P.j2 = c->j2.p;
-    P.rep2 = c->rep2.p;
-    P.cnt2 = c->cnt2.p;
-    P.rec2 = c->rec2.p;
-    P.tiles = c->tiles.p;
-    P.qres = c->qres.p;
-    P.qv = c->qv.p;
-    P.qgh = c->qgh.p;
-    P.qj = c->qj.p;
-    P.qrep = c->qrep.p;
-    P.qcnt = c->qcnt.p;
-    P.qlen = c->qlen.p;
-    P.qorig = c->qorig.p;
-    P.qck = c->qck.p;
-    P.qrec = c->qrec.p;
-    P.qhins = c->qhins.p;
-    P.qhdel = c->qhdel.p;
-    P.cw = c->cw.p;
-    P.cpk = c->cpk.p;
-    P.slice_items = c->slice_items.p;
-    P.cmain = c->cmain.p;
-    P.crp = c->crp.p;
-    P.pair_q = c->pair_q;
-    P.pair_h = c->pair_h;
-    P.pair_count = c->pair_count;
-    P.pair_cap = c->pair_cap;
-    P.ntiles = c->ntiles;
-    P.first_tile = 0;
-    P.sub2_items = c->sub2_active ? 1u : 0u;
-    P.part = c->part.p;
-    P.part_stride = c->part_stride;
-    P.work_first = (uint32_t)c->work_shard_index;
-    P.work_step = (uint32_t)c->work_shard_count;
-    P.matrix = d_out;
-    P.matrix_f64 = c->matrix_f64.p;
-    P.R1 = c->R1;
-    P.R2 = c->R2;
-    P.score = c->opt.score;
-    P.ignore_counts = c->opt.ignore_counts;
-    P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
-    P.tile_counter = c->d_tile_counter;
-    P.stats = c->d_stats;
-    P.geom = c->geom;
-    P.chunks = c->chunks.p;
-    P.tile_refs = c->tile_refs.p;
-    P.small_tiles = c->small_tiles.p;
-    P.nsmall = c->nsmall;
-    P.nchunks = c->nchunks;
-    P.debug = (uint32_t)c->debug;
-    if (deferred) {
-      P.pos_buf = c->pos_buf.p;
-      P.pos_ctr = c->ctr_cur;
-      P.pos_cap = c->pos_cap;
-      P.pos_segments = (uint32_t)c->pos_segments;
-    }
+  /* The redo launch of variant 2 is needed until a finished launch on these sets, with
+     this grid, has shown the margin.  The argument holds only while the chunks are dealt
+     statically (no unstaged tiles claimed through a global counter: those move whole
+     tiles, not part-filled blocks, between the segments from launch to launch). */
+  const bool static_deal = c->nsmall == 0;
+  if (c->force_no_redo && S.redo_kind) {      /* test only */
+    c->never_overflows = true;
+    c->safe_grid = S.grid;
+    c->safe_nw = S.nw;
+  }
+  c->force_no_redo = false;
+  if (c->never_overflows && (!S.redo_kind || c->safe_grid != S.grid || c->safe_nw != S.nw))
+    c->never_overflows = false;
+  if (c->usage_pending && (c->usage_grid != S.grid || c->usage_nw != S.nw))
+    c->usage_pending = false;                 /* measured with another deal of the chunks */
+  if (S.redo_kind && S.will_launch && c->usage_pending && hipEventQuery(c->ev_usage) == hipSuccess) {
+    c->usage_pending = false;
+    const uint64_t waves_per_segment =
+        (((uint64_t)S.grid + S.P.pos_segments - 1) / S.P.pos_segments) * (uint64_t)S.nw;
+    const uint64_t margin = 2 * WAVE * (waves_per_segment + 1);
+    c->never_overflows = static_deal && *c->h_usage + margin <= c->pos_cap;
+    c->safe_grid = S.grid;
+    c->safe_nw = S.nw;
+  }
+  a.track_usage = S.redo_kind && S.will_launch && static_deal && !c->never_overflows && !c->usage_pending;
+  a.with_redo = S.redo_kind && !c->never_overflows;
+  c->last_without_redo = S.redo_kind && S.will_launch && !a.with_redo;
 
-    /* variant 1: workgroups of 8 waves share one staged slice; when the chunks are
-       short (many slices, few queries each) 4 waves keep more of them busy.
-       variant 2: one workgroup per CU, 15 compute waves + the loader wave around a
-       ring of two slices */
-    int nw = c->sliced ? (int)c->waves_per_block : WAVES_PER_BLOCK;
-    if (c->rows && !c->waves_per_block_forced)
-      nw = 16;
-    if (c->sliced && !c->rows && !c->waves_per_block_forced && c->nchunks > 0 &&
-        (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
-      nw = 4;
-    auto lds_for = [&](int waves) -> size_t {
-      const size_t zrow = c->rows ? (c->opt.differences == 2 ? 2 * (size_t)A : (size_t)A)
-                                  : c->sliced ? (size_t)(zrow_stride((int)A) + zdelta_entries((int)A))
-                                              : (size_t)A;
-      size_t b = zrow * c->zpos * sizeof(uint64_t) +
-                 (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
-                 (size_t)waves * sizeof(WaveQueue);
-      if (c->rows)
-        b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
-             (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) +
-             RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef));
-      else if (c->sliced)
-        b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
-             MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
-             (size_t)c->chunk_cap * sizeof(TileRef);
-      return b;
-    };
-    size_t lds = lds_for(nw);
-    while (lds > 160 * 1024 && c->sliced && nw > 4) {
-      nw /= 2;                             /* long sequences: fewer wave queues */
-      lds = lds_for(nw);
-    }
-    if (lds > 160 * 1024)
-      return fail(c, CMPR_EUNSUPPORTED,
-                  "sequences too long: Zobrist table does not fit the 160 KiB LDS");
-    P.chunk_cap = c->chunk_cap;
-    /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
-       that resolves inline is deferred_resolve = 0 and the redo pass below */
-    ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !deferred)
-                         : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
-    if (c->rows && deferred)
-      P.overflow = c->d_overflow;
-    if (lds > 48 * 1024 && (c->attr_fn != (const void *)fn || c->attr_lds < lds)) {
-      /* once per kernel and size, not once per launch */
-      HIP_TRY(c, hipFuncSetAttribute((const void *)fn,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      c->attr_fn = (const void *)fn;
-      c->attr_lds = lds;
-    }
-    /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
-    uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
-    if (c->rows) {
-      /* variant 2 deals its chunks out statically over the workgroups of the grid:
-         exactly as many as are resident at once (registers count too) */
-      int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, nw * WAVE, lds) ==
-              hipSuccess && occ > 0)
-        per_cu = std::min<uint64_t>(per_cu, (uint64_t)occ);
-    }
-    per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
-    uint64_t grid = (uint64_t)c->cus * per_cu;
-    grid = std::min<uint64_t>(grid, c->sliced ? (uint64_t)c->nchunks + ((uint64_t)c->nsmall + nw - 1) / nw
-                                              : ((uint64_t)c->ntiles + WAVES_PER_BLOCK - 1) /
-                                                    WAVES_PER_BLOCK);
-    grid = std::max<uint64_t>(grid, 1);
-    hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3((uint32_t)nw * WAVE), lds, st, P);
-    HIP_TRY(c, hipGetLastError());
-    c->launches = 1;
-    launched = true;
-    HIP_TRY(c, hipEventRecord(c->ev_km, st));
-    /* the redo launch below: needed until a finished launch has shown the margin */
-    const bool redo_kind = c->rows && deferred && !(c->debug & DBG_SKIP_RESOLVE);
-    if (redo_kind && c->usage_pending && hipEventQuery(c->ev_usage) == hipSuccess) {
-      c->usage_pending = false;
-      const uint64_t waves_per_segment =
-          ((grid + P.pos_segments - 1) / P.pos_segments) * (uint64_t)nw;
-      const uint64_t margin = 2 * WAVE * (waves_per_segment + 1);
-      c->never_overflows = *c->h_usage + margin <= c->pos_cap;
-    }
-    const bool track_usage = redo_kind && !c->never_overflows && !c->usage_pending;
-    if (track_usage)
-      HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
-    auto reduce_partials = [&]() {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
-                         (uint32_t)(P.lds_matrix ? cells : 0), reduce_writes ? 1u : 0u, c->ctr_other,
-                         (uint32_t)ctr_blk, track_usage ? c->d_usage : nullptr);
-    };
-    if (!(deferred && !(c->debug & DBG_SKIP_RESOLVE))) {
-      reduce_partials();
-      HIP_TRY(c, hipGetLastError());
-    }
-    if (deferred && !(c->debug & DBG_SKIP_RESOLVE)) {
-      const size_t rlds = (BLOCK_THREADS / WAVE) * sizeof(CandQueue) +
-                          (P.lds_matrix ? cells * sizeof(unsigned long long) : 0);
-      /* 5 waves/SIMD fit its registers; a multiple of the segment count */
-      uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
-      rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
-      hipLaunchKernelGGL(select_resolve(!c->opt.ignore_genes), dim3(rgrid), dim3(BLOCK_THREADS),
-                         rlds, st, P);
-      reduce_partials();
-      HIP_TRY(c, hipGetLastError());
-      c->launches = 2;
-      if (track_usage) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_usage, c->d_usage, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipEventRecord(c->ev_usage, st));
-        c->usage_pending = true;
-      }
-      if (c->rows && !c->never_overflows) {
-        /* Redo pass: if the positives of the fast launch did not fit their buffer
-           (flag set: resolve_kernel then did nothing), the same step with every
-           positive resolved inline; otherwise its workgroups return at once.
-           Capacity is therefore never a limit, and nothing here waits for the host. */
-        ProbeFn fn2 = select_rows_kernel(c->opt, nw, true);
-        if (lds > 48 * 1024 && (c->attr_fn2 != (const void *)fn2 || c->attr_lds2 < lds)) {
-          HIP_TRY(c, hipFuncSetAttribute((const void *)fn2,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          c->attr_fn2 = (const void *)fn2;
-          c->attr_lds2 = lds;
-        }
-        ProbeParams P2 = P;
-        P2.pos_buf = nullptr;
-        P2.part = nullptr;                  /* (straight into matrix and stats2) */
-        P2.redo = 1;
-        P2.stats = c->d_stats2;
-        P2.tile_counter = c->d_tile_counter2;
-        hipLaunchKernelGGL(fn2, dim3((uint32_t)grid), dim3((uint32_t)nw * WAVE), lds, st, P2);
-        HIP_TRY(c, hipGetLastError());
-        c->launches = 3;
-      }
+  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
+  StepGraph *g = nullptr;
+  if (S.will_launch && !a.needs_clear && !a.track_usage && !a.with_redo && !c->pair_count && !c->debug)
+    g = graph_for(c, a, which);
+  if (g) {
+    const hipError_t he = hipGraphExecEventRecordNodeSetEvent(g->exec, g->km_node, c->ev_km);
+    if (he != hipSuccess) {
+      if (getenv("COMPAIRR_HIP_DEBUG"))
+        fprintf(stderr, "compairr_hip: step graph unavailable (hipGraphExecEventRecordNodeSetEvent: %s): "
+                        "plain launches\n", hipGetErrorString(he));
+      (void)hipGetLastError();
+      c->step_graph = 0;
+      g = nullptr;
     }
   }
-  if (!launched)
-    HIP_TRY(c, hipEventRecord(c->ev_km, st));
+  if (g) {
+    HIP_TRY(c, hipGraphLaunch(g->exec, st));
+    c->launches = S.deferred ? 2 : 1;
+  } else if ((rc = issue_step(c, a, st, c->ev_km))) {
+    return rc;
+  }
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
   c->ctr_clean = true;
   return CMPR_OK;
+}
+
+/* Before the stream is synchronised: fetch the word a launch without redo pass leaves
+   behind when its positives did not fit (reduce_partials_kernel). */
+int fetch_overflow_word(cmpr_context *c, hipStream_t st)
+{
+  c->h_usage[1] = 0;
+  if (c->last_without_redo)
+    HIP_TRY(c, hipMemcpyAsync(c->h_usage + 1, c->d_usage + 1, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, st));
+  return CMPR_OK;
+}
+
+/* After the synchronisation: true = the launch overflowed and had no redo pass; its
+   result is invalid, the shortcut is withdrawn and the caller repeats the step (the
+   repeat carries the redo pass). */
+bool overflowed_without_redo(cmpr_context *c, hipStream_t st)
+{
+  if (!c->last_without_redo || c->h_usage[1] == 0)
+    return false;
+  (void)hipMemsetAsync(c->d_usage + 1, 0, sizeof(unsigned long long), st);
+  c->never_overflows = c->usage_pending = false;
+  return true;
 }
 
 int check_ready(cmpr_context *c)
@@ -898,17 +1176,27 @@ extern "C" int cmpr_overlap_matrix(cmpr_context *c, uint64_t *out)
     return fail(c, CMPR_EINVAL, "matrix_out is NULL");
   if (is_f64_score(c->opt))
     return fail(c, CMPR_EINVAL, "ratio score needs cmpr_overlap_matrix_f64");
-  rc = enqueue_overlap(c, c->matrix.p, c->stream);
-  if (rc)
-    return rc;
   const size_t cells = (size_t)c->R1 * c->R2;
-  if (cells)
-    HIP_TRY(c, hipMemcpyAsync(out, c->matrix.p, cells * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-  c->stop_is_k1 = false;
-  c->events_valid = true;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int attempt = 0;; attempt++) {
+    rc = enqueue_overlap(c, c->matrix.p, c->stream);
+    if (rc)
+      return rc;
+    if (cells)
+      HIP_TRY(c, hipMemcpyAsync(out, c->matrix.p, cells * sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, c->stream));
+    if ((rc = fetch_overflow_word(c, c->stream)))
+      return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->stop_is_k1 = false;
+    c->events_valid = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    /* a launch that relied on the no-redo shortcut and overflowed all the same: once
+       more, now with the redo pass behind it */
+    if (!overflowed_without_redo(c, c->stream))
+      break;
+    if (attempt)
+      return fail(c, CMPR_ESTATE, "positives buffer overflowed twice without redo pass");
+  }
   return CMPR_OK;
 }
 
@@ -919,23 +1207,31 @@ static int cmpr_overlap_matrix_f64_impl(cmpr_context *c, double *out)
     return rc;
   if (!out && (size_t)c->R1 * c->R2 > 0)
     return fail(c, CMPR_EINVAL, "matrix_out is NULL");
-  rc = enqueue_overlap(c, c->matrix.p, c->stream);
-  if (rc)
-    return rc;
   const size_t cells = (size_t)c->R1 * c->R2;
   std::vector<unsigned long long> tmp(cells);
-  if (cells) {
-    if (is_f64_score(c->opt))
-      HIP_TRY(c, hipMemcpyAsync(out, c->matrix_f64.p, cells * sizeof(double),
-                                hipMemcpyDeviceToHost, c->stream));
-    else
-      HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->matrix.p, cells * sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, c->stream));
+  for (int attempt = 0;; attempt++) {
+    rc = enqueue_overlap(c, c->matrix.p, c->stream);
+    if (rc)
+      return rc;
+    if (cells) {
+      if (is_f64_score(c->opt))
+        HIP_TRY(c, hipMemcpyAsync(out, c->matrix_f64.p, cells * sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+      else
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->matrix.p, cells * sizeof(uint64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    if ((rc = fetch_overflow_word(c, c->stream)))
+      return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->stop_is_k1 = false;
+    c->events_valid = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!overflowed_without_redo(c, c->stream))
+      break;
+    if (attempt)
+      return fail(c, CMPR_ESTATE, "positives buffer overflowed twice without redo pass");
   }
-  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-  c->stop_is_k1 = false;
-  c->events_valid = true;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (!is_f64_score(c->opt)) {
     const bool mean = c->opt.score == CMPR_SCORE_MEAN && !c->opt.ignore_counts;
     for (size_t k = 0; k < cells; k++)
@@ -962,20 +1258,28 @@ extern "C" int cmpr_overlap_pairs(cmpr_context *c, uint64_t capacity, uint32_t *
   if ((rc = dev_alloc(c, dq, (size_t)capacity))) return rc;
   if ((rc = dev_alloc(c, dh, (size_t)capacity))) return rc;
   if ((rc = dev_alloc(c, dn, 1))) return rc;
-  HIP_TRY(c, hipMemsetAsync(dn.p, 0, sizeof(unsigned long long), c->stream));
   c->pair_q = dq.p;
   c->pair_h = dh.p;
   c->pair_count = dn.p;
   c->pair_cap = capacity;
-  rc = enqueue_overlap(c, c->matrix.p, c->stream);
-  if (rc)
-    return rc;
   unsigned long long n = 0;
-  HIP_TRY(c, hipMemcpyAsync(&n, dn.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-  c->stop_is_k1 = false;
-  c->events_valid = true;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int attempt = 0;; attempt++) {
+    HIP_TRY(c, hipMemsetAsync(dn.p, 0, sizeof(unsigned long long), c->stream));
+    rc = enqueue_overlap(c, c->matrix.p, c->stream);
+    if (rc)
+      return rc;
+    HIP_TRY(c, hipMemcpyAsync(&n, dn.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = fetch_overflow_word(c, c->stream)))
+      return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->stop_is_k1 = false;
+    c->events_valid = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!overflowed_without_redo(c, c->stream))
+      break;
+    if (attempt)
+      return fail(c, CMPR_ESTATE, "positives buffer overflowed twice without redo pass");
+  }
   const uint64_t have = std::min<uint64_t>(n, capacity);
   if (have) {
     HIP_TRY(c, hipMemcpy(query_out, dq.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1019,12 +1323,17 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipSetDevice(c->device));
   hipEvent_t ev_end = c->stop_is_k1 ? c->ev_k1 : c->ev_stop;
   HIP_TRY(c, hipEventSynchronize(ev_end));
-  unsigned long long st[STAT_COUNT], ovf = 0;
+  unsigned long long st[STAT_COUNT], ovf = 0, sticky = 0;
   HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(&ovf, c->d_overflow, sizeof ovf, hipMemcpyDeviceToHost));
-  if (ovf && c->never_overflows) {
-    /* (cannot happen while the margin argument of enqueue_overlap holds: be loud) */
-    c->never_overflows = false;
+  HIP_TRY(c, hipMemcpy(&sticky, c->d_usage + 1, sizeof sticky, hipMemcpyDeviceToHost));
+  if (sticky) {
+    /* One of the launches since the last check (cmpr_overlap_matrix_device does not
+       synchronise, so it cannot look itself) ran without redo pass and overflowed its
+       positives buffer: the matrix it left is incomplete.  The shortcut is withdrawn;
+       the next launches carry the redo pass again. */
+    HIP_TRY(c, hipMemset(c->d_usage + 1, 0, sizeof sticky));
+    c->never_overflows = c->usage_pending = false;
     return fail(c, CMPR_ESTATE, "positives buffer overflowed in a launch without redo pass: result invalid, "
                                 "repeat the call");
   }
@@ -1056,6 +1365,8 @@ extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
 {
   /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
   try {
+    if (c)
+      invalidate_plan(c);
     return cmpr_set_reference_device(c, s, longest_query);
   } catch (const std::bad_alloc &) {
     return fail(c, CMPR_ENOMEM, "out of host memory");

@@ -10,6 +10,8 @@
 #include "../../include/compairr_hip.h"
 #include "kernels.h"
 
+#include "select.h"
+
 #include <string>
 #include <vector>
 
@@ -31,12 +33,28 @@ template <typename T>
 struct DevBuf {
   T     *p = nullptr;
   size_t n = 0;
+  size_t cap = 0;          /* elements allocated (>= n; dev_reserve keeps an allocation that is large enough) */
   void release()
   {
     if (p)
       (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
+  }
+};
+
+/* device memory for the temporaries of a call, kept from call to call and grown when a
+   call needs more (cmpr_set_queries: no hipMalloc / hipFree in the steady state) */
+struct DevArena {
+  char  *base = nullptr;
+  size_t cap = 0;
+  void release()
+  {
+    if (base)
+      (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
   }
 };
 
@@ -45,6 +63,30 @@ using cmpr::PosEntry;
 using cmpr::SliceGeom;
 using cmpr::Slot;
 using cmpr::TileDesc;
+
+/* Everything about a step that does not change from launch to launch (kernels, grid,
+   LDS, kernel arguments): worked out once after cmpr_set_queries, not per call. */
+struct StepPlan {
+  bool     valid = false;
+  bool     will_launch = false, reduce_writes = false, deferred = false, redo_kind = false;
+  size_t   cells = 0, ctr_blk = 0;
+  cmpr::ProbeParams P{};            /* the per-launch fields are filled in at enqueue */
+  cmpr::ProbeFn fn = nullptr, fn2 = nullptr, rfn = nullptr;
+  uint32_t grid = 0, nw = 0, rgrid = 0;
+  size_t   lds = 0, rlds = 0;
+};
+
+/* One instantiated hipGraph of the steady-state step (probe, resolve, reduce and the
+   event between them) per (output matrix, counter block): one hipGraphLaunch per step
+   instead of three kernel launches and an event record. */
+struct StepGraph {
+  void           *d_out = nullptr;
+  int             which = -1;
+  hipGraph_t      graph = nullptr;
+  hipGraphExec_t  exec = nullptr;
+  hipGraphNode_t  km_node = nullptr;   /* its event-record node (re-pointed at the ring's event per launch) */
+  uint64_t        last_use = 0;
+};
 
 struct cmpr_context {
   cmpr_options opt{};
@@ -138,8 +180,7 @@ struct cmpr_context {
   DevBuf<cmpr::QueryRec> qrec;     /* per slot: what verification reads, 64 bytes */
   /* variant 2, class rows: per item the row's blanked hash, the query's slot in
      pass 0 (~0: padding) and its residue at the class position | position << 8 */
-  DevBuf<uint64_t>  cw;
-  DevBuf<uint32_t>  cmain, crp;
+  DevBuf<cmpr::ItemRec> items;
   DevBuf<uint32_t>  slice_items;     /* sub2 items: per slice {first item, blocks} (layout.h CHUNK_WITH_ITEMS) */
   DevBuf<cmpr::ResPack> cpk;             /* sub2 items: the query's residues, 2 bits each */
   uint64_t          algorithmic_bytes = 0;
@@ -157,10 +198,31 @@ struct cmpr_context {
      these sets has shown that the fullest segment of the positives buffer stays clear
      of its capacity by more than launches can differ (which wave ends up with which
      tile only moves the number of part-filled 64-entry blocks): */
-  unsigned long long        *d_usage = nullptr;        /* fullest segment of a launch (reduce kernel) */
-  unsigned long long        *h_usage = nullptr;        /* pinned copy */
+  unsigned long long        *d_usage = nullptr;        /* [0] fullest segment of a launch (reduce kernel);
+                                                          [1] sticky: a launch WITHOUT redo pass overflowed */
+  unsigned long long        *h_usage = nullptr;        /* pinned copy of both */
   hipEvent_t                 ev_usage = nullptr;
   bool                       usage_pending = false, never_overflows = false;
+  /* the margin argument holds for one static deal of the chunks: the grid and the waves
+     per workgroup the usage was measured with / the shortcut was established for */
+  uint32_t                   usage_grid = 0, usage_nw = 0, safe_grid = 0, safe_nw = 0;
+  bool                       last_without_redo = false;   /* the last launch relied on never_overflows */
+  bool                       force_no_redo = false;       /* test only (tunable "assume_never_overflows") */
+  hipStream_t                last_stream = nullptr;       /* stream of the last enqueue (launches of one */
+  bool                       have_last_stream = false;    /* context are ordered one after the other)   */
+  DevArena                   arena_a, arena_b;            /* temporaries of cmpr_set_queries */
+  hipStream_t                copy_stream = nullptr;       /* uploads of cmpr_set_queries */
+  static const uint32_t      NCOPY_EV = 4;
+  hipEvent_t                 ev_copy[NCOPY_EV] = {};
+  /* of the last cmpr_set_queries: host time inside the copies, from the last copy to the
+     end (the device work the upload did not hide), and in all */
+  double                     layout_upload_ms = 0, layout_tail_ms = 0, layout_total_ms = 0;
+  StepPlan                   plan;
+  static const uint32_t      NGRAPHS = 8;
+  StepGraph                  graphs[NGRAPHS];
+  int64_t                    step_graph = 1;              /* tunable: 0 = plain launches only */
+  hipStream_t                cap_stream = nullptr;        /* the stream the graphs are captured on */
+  hipEvent_t                 ev_cap = nullptr;            /* placeholder event of a captured graph */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */
@@ -208,6 +270,25 @@ int dev_alloc(cmpr_context *c, DevBuf<T> &b, size_t n)
     n = 1;
   HIP_TRY(c, hipMalloc((void **)&b.p, n * sizeof(T)));
   b.n = n;
+  b.cap = n;
+  return CMPR_OK;
+}
+
+/* like dev_alloc, but an allocation that is large enough is kept (contents undefined) */
+template <typename T>
+int dev_reserve(cmpr_context *c, DevBuf<T> &b, size_t n)
+{
+  if (n == 0)
+    n = 1;
+  if (b.p && b.cap >= n) {
+    b.n = n;
+    return CMPR_OK;
+  }
+  b.release();
+  const size_t want = n + n / 16;
+  HIP_TRY(c, hipMalloc((void **)&b.p, want * sizeof(T)));
+  b.n = n;
+  b.cap = want;
   return CMPR_OK;
 }
 

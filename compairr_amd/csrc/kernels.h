@@ -579,14 +579,19 @@ __device__ __forceinline__ unsigned long long *matrix_dst(const ProbeParams &P)
    NPART loads in flight at once -- a thread walking the slots one after the other
    took 36 us, a quarter of a step at 8 GPUs).  `overwrite`: the cells are written,
    not added to (the matrix was not cleared before the launch).  Also clears the
-   counter block of the NEXT launch (`next_ctr`, n64 words). */
+   counter block of the NEXT launch (`next_ctr`, n64 words).  `sticky` (launches that
+   run without a redo pass): set, and left set until the host has seen it, when the
+   positives of this launch did not fit their buffer -- its result is then invalid. */
 static __global__ void __launch_bounds__(NPART)
 reduce_partials_kernel(const ProbeParams P, uint32_t cells, uint32_t overwrite,
-                       unsigned long long *next_ctr, uint32_t n64, unsigned long long *usage)
+                       unsigned long long *next_ctr, uint32_t n64, unsigned long long *usage,
+                       unsigned long long *sticky)
 {
   static_assert(NPART == 2 * WAVE, "two waves per workgroup");
   __shared__ unsigned long long half[2];
   const uint32_t i = blockIdx.x, s = threadIdx.x;
+  if (sticky && P.overflow && i == 0 && s == 0 && *(volatile unsigned long long *)P.overflow != 0ull)
+    *sticky = 1ull;
   /* how full the fullest segment of the positives buffer got (the host's margin check) */
   if (usage && P.pos_ctr && i == 0)
     for (uint32_t g = s; g < P.pos_segments; g += NPART)

@@ -94,11 +94,13 @@ __host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint6
   q[3] = (1ull << (((wh >> 10) + code) & 31u)) | (1ull << (32u + (((wh >> 15) + code) & 31u)));
 }
 
-/* word of W inside a slice of `nwords` 32-byte words (any count, not only
-   powers of two: the filter is sized to the entry count) */
+/* word of W inside a slice of `nwords` 32-byte words (any count up to 2^13, not only
+   powers of two: the filter is sized to the entry count): the top 16 bits of W scaled
+   to the slice -- a 24-bit multiply, which the vector unit issues at full rate
+   (v_mul_hi_u32 takes four issue slots: tools/calib.hip) */
 __host__ __device__ inline uint32_t row_word(uint64_t Wk, uint32_t nwords)
 {
-  return (uint32_t)(((uint64_t)(uint32_t)(Wk >> 32) * nwords) >> 32);
+  return ((uint32_t)(Wk >> 48) * nwords) >> 16;
 }
 
 /* ------------------------------------------------------------------ */
@@ -377,10 +379,10 @@ probe_rows_kernel(const ProbeParams P)
     const bool valid = lane < nvalid;
     if (tpass >= 3) {
       /* a block of 64 class-row items, from item res_base on */
-      const uint32_t cs = res_base + lane;
-      x.a = P.cw[cs];
-      x.b = P.cmain[cs];
-      x.c = P.crp[cs];
+      const ItemRec it = P.items[res_base + lane];
+      x.a = it.w;
+      x.b = it.main;
+      x.c = it.rp;
     } else {
       const uint32_t slot = t * WAVE + lane;
       if (valid) {
@@ -615,7 +617,7 @@ probe_rows_kernel(const ProbeParams P)
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 
       auto woff_of = [&](uint64_t Wk) -> uint32_t {
-        return __umulhi((uint32_t)(Wk >> 32), nwords) << 5;
+        return (__umul24((uint32_t)(Wk >> 48), nwords) >> 16) << 5;      /* row_word() x 32 bytes */
       };
       auto word_lds = [&](uint32_t wo) -> RowWord {
         RowWord w;
@@ -931,10 +933,10 @@ probe_rows_kernel(const ProbeParams P)
             eb[r - 1] = 0xffffffffu;
             ec[r - 1] = 0;
             if (r < nblk) {
-              const uint32_t cs = tres + r * WAVE + lane;
-              ea[r - 1] = P.cw[cs];
-              eb[r - 1] = P.cmain[cs];
-              ec[r - 1] = P.crp[cs];
+              const ItemRec it = P.items[tres + r * WAVE + lane];
+              ea[r - 1] = it.w;
+              eb[r - 1] = it.main;
+              ec[r - 1] = it.rp;
             }
           }
           uint64_t iw = cW;

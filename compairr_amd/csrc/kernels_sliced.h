@@ -578,10 +578,11 @@ probe_sliced_kernel(const ProbeParams P)
       ResPack ipk{};                       /* residues, 2 bits each              */
       uint32_t icrp = 0;
       if (item_tile) {
-        islot = P.cmain[item0 + lane];
-        ihash = P.cw[item0 + lane];
+        const ItemRec it = P.items[item0 + lane];
+        islot = it.main;
+        ihash = it.w;
         ipk = P.cpk[item0 + lane];
-        icrp = P.crp[item0 + lane];
+        icrp = it.rp;
       }
       const uint32_t nvalid = __builtin_amdgcn_readfirstlane(td.nvalid);
       const uint32_t K = __builtin_amdgcn_readfirstlane(td.k);   /* 0: light tile */

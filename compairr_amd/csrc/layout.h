@@ -195,6 +195,15 @@ __host__ __device__ constexpr uint32_t zdelta_entries(int A)
   return A == 4 ? 16u : 0u;
 }
 
+/* One item (kernels_rows.h passes >= 3; kernels_sliced.h sub2 items): the row's blanked
+   hash (sub2: the query's hash), the query's slot (~0: padding behind the items of a
+   slice) and its residue | position << 8 | kind << 24 -- 16 bytes, one load per lane */
+struct alignas(16) ItemRec {
+  uint64_t w;
+  uint32_t main;
+  uint32_t rp;
+};
+
 /* A Bloom-positive variant waiting for its hash-table walk */
 struct PosEntry {
   uint64_t hash;
@@ -230,7 +239,7 @@ struct QueryRec {
   uint32_t rep;       /* matrix row                                         */
   uint32_t len;
   uint32_t res[9];    /* residues 0..35, four to a dword                    */
-  uint32_t pad;
+  uint32_t orig;      /* the query's index in the caller's set 1            */
 };
 
 __host__ __device__ inline uint32_t rec_units(uint32_t len)
@@ -268,11 +277,9 @@ struct ProbeParams {
                                       the query's Zobrist hash                   */
   const uint64_t *qhins, *qhdel;   /* variant 2 with -i: the shifted hashes that seed
                                       the rolling indel enumeration              */
-  const uint64_t *cw;              /* variant 2, class rows, per item: the row's blanked   */
-  const uint32_t *cmain;           /* hash, the query's slot in pass 0 (~0: padding),      */
-  const uint32_t *crp;             /* its residue at the class position | position << 8    */
+  const ItemRec  *items;           /* variant 2 class rows / variant 1 sub2: the flat items       */
   const ResPack  *cpk;             /* variant 1 sub2 items: the query's residues, 2 bits each
-                                      (<= RESPACK_MAX positions); cw then holds the query's hash     */
+                                      (<= RESPACK_MAX positions); ItemRec::w then holds the query's hash */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */

@@ -7,19 +7,25 @@
  * file does that regrouping with kernels, so that from cmpr_set_view to "resident
  * in HBM" the host only copies the caller's arrays:
  *
- *   validate_*_kernel   what scan_view checked on the host: monotone offsets,
- *                       ranges of residue / gene / repertoire numbers, counts >= 1;
- *                       longest sequence; per-repertoire count totals
- *   keys_kernel         per query: class key -> slice -> group (slice, heavy,
- *                       length) of every pass, Zobrist hash (db_hash,
- *                       db.cc:903-916, variant 2), group histogram (atomics)
+ *   (upload)            the caller's arrays in a few query ranges on a copy stream;
+ *                       the keys kernel of a range runs while the next is copied
+ *   keys_kernel         per query: what scan_view checked on the host (monotone
+ *                       offsets, ranges of residue / gene / repertoire numbers,
+ *                       counts >= 1, per-repertoire count totals), then class key ->
+ *                       slice -> group (slice, heavy, length), Zobrist hash (db_hash,
+ *                       db.cc:903-916, variant 2), and its rank in the group -- the
+ *                       return value of the histogram's atomic
  *   slices_kernel<0>    per slice: tiles / chunks / residue words it needs
  *   (scan)              hipCUB exclusive scan over the slices
  *   slices_kernel<1>    per slice: tile descriptors, first slot of every group,
  *                       chunk descriptors
- *   place_kernel        per query: claims a slot of its group (atomic) and writes
- *                       its fields and residues there (position-major tiles)
- *   place_class_kernel  variant 2: the compact class-row passes (kernels_rows.h)
+ *   scatter_kernel      per query: ONE 64-byte record (layout.h QueryRec) + 32 bytes of
+ *                       hashes to slot = group base + rank: whole memory lines, the only
+ *                       scattered writes of the layout
+ *   fill_tiles_kernel   per tile (one wave): reads those records in slot order and
+ *                       writes every per-slot array and the position-major residues
+ *                       coalesced, padding lanes included (no memset of the layout)
+ *   place_items_kernel  variant 2 / sub2: the flat items (kernels_rows.h), 16 bytes each
  *   sibling_*_kernel    -i: tiles regrouped by the slice their insertion /
  *                       deletion variants fall into
  *   chunk order         heaviest chunks first (hipCUB radix sort)
@@ -27,6 +33,15 @@
  * Inside a group the queries land in the order their atomics complete, not in
  * input order: the matrix is a sum of exact integers, the pairs list is
  * unordered (README.md:163), so no result depends on it.
+ *
+ * Work shards (tunables work_shard_index / _count; one context per GPU): a context
+ * lays out only what it works on -- the queries whose slice it owns, the items filed
+ * under slices it owns, and, in tiles of a pseudo-slice that no chunk lists, the
+ * queries those items belong to (their records are what a verification reads).
+ *
+ * Temporaries live in two arenas the context keeps from call to call, the resident
+ * arrays are reallocated only when they have to grow, and the host waits for the
+ * device twice: for the sizes of the layout, and at the end.
  */
 #include "context.h"
 #include "kernels_sliced.h"
@@ -34,6 +49,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace cmpr;
@@ -43,7 +61,7 @@ namespace {
 constexpr uint32_t MAXP = 1 + MAX_CLASS_RES;     /* passes with a layout of their own */
 
 enum : uint32_t { VERR_OFFSETS = 1, VERR_LONG = 2, VERR_REP = 3, VERR_GENE = 4, VERR_COUNT = 5,
-                  VERR_RESIDUE = 6 };
+                  VERR_RESIDUE = 6, VERR_TOO_LONG = 7 };
 
 struct SliceTot {
   uint32_t tiles, chunks, small, list;
@@ -66,15 +84,21 @@ struct SliceTotSum {
 constexpr uint32_t MAX_GROUPS = 32;          /* item groups: >= MAX_CLASS_RES + 1, >= 8 class positions x 3 */
 static_assert(MAX_GROUPS >= MAX_CLASS_RES + 1 && MAX_GROUPS >= 8 * 3, "item groups");
 
+/* per slot, next to its QueryRec: hashes and class key (scatter_kernel -> fill_tiles_kernel) */
+struct QAux {
+  uint64_t h, hins, hdel;
+  uint32_t ck, pad;
+};
+
 struct QL {
   /* the caller's set, uploaded as it is */
   const uint8_t  *res;
   const uint64_t *off;
   const uint32_t *v, *j, *rep;
   const uint64_t *cnt;
-  uint64_t        n;
+  uint64_t        n, total;          /* sequences; residues in all (offsets[n]) */
   uint32_t        n_rep, n_v_max, n_j_max;
-  uint32_t        A, zpos, n_v, longest, per_slice;
+  uint32_t        A, zpos, n_v, longest, per_slice;   /* longest: the longest a query may be (zpos - 3) */
   uint32_t        genes, counts, existence, indels, differences, sliced, rows;
   const uint64_t *zob;
   SliceGeom       geom;
@@ -82,9 +106,13 @@ struct QL {
   uint32_t        min_mixed;         /* lengths >= this share tiles; ~0: none do */
   uint32_t        chunk_tiles, small_max, class_unstaged;
   uint64_t        nbuckets;          /* (slice, heavy) buckets */
-  uint64_t        nslices;
+  uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slice */
+  uint64_t        nslices_real;
+  uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
+  uint32_t        sub2_owner_pass0, pad_q;
   /* per pass */
-  uint32_t *cnt_g[MAXP], *base_g[MAXP], *fill_g[MAXP], *grp[MAXP];
+  uint32_t *cnt_g[MAXP], *base_g[MAXP], *grp[MAXP];
+  uint32_t *rank;                    /* per query: its rank in its group */
   SliceTot *tot[MAXP], *pre[MAXP];
   uint32_t  tile0[MAXP], chunk0[MAXP], list0[MAXP], small0[MAXP];
   unsigned long long res0[MAXP];
@@ -92,6 +120,7 @@ struct QL {
   /* per query */
   uint64_t *h_tmp, *hins_tmp, *hdel_tmp;
   uint32_t *ck_tmp, *slot_of;
+  struct QAux *aux;                  /* per slot: what the record has no room for */
   /* outputs */
   TileDesc *tiles;
   Chunk    *chunks;
@@ -124,15 +153,43 @@ struct QL {
   uint32_t  cblocks;                      /* blocks of 64 items per chunk at most */
   uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
   uint32_t  cchunk0;                      /* first item chunk in the chunk list */
-  uint64_t *cw;
-  uint32_t *cmain;
-  uint32_t *crp;
+  cmpr::ItemRec *items;
   cmpr::ResPack *cpk;
   /* validation / statistics */
   uint32_t           *verr;          /* [0] first error kind, [1] longest */
   double             *rep_total;
   unsigned long long *alg_bytes;
 };
+
+/* Work sharding (tunables work_shard_index / _count): which context of `step` takes
+   the work filed under a slice in a pass.  By slice, not by position in the work
+   list: WHICH queries a slice holds is a property of the input, how they are cut
+   into tiles and chunks is decided by atomics and differs from one layout run (one
+   GPU) to the next. */
+__host__ __device__ inline uint32_t work_owner(uint32_t slice, uint32_t pass, uint32_t step)
+{
+  return (uint32_t)((((uint64_t)slice * 2654435761u + pass * 40503u) >> 7) % step);
+}
+
+/* does this context work on what is filed under `slice` in `pass`? */
+__device__ inline bool owned(const QL &Q, uint32_t slice, uint32_t pass)
+{
+  return Q.wstep <= 1u || work_owner(slice, pass, Q.wstep) == Q.wfirst;
+}
+
+/* ... on the items counted by counter k (see QL: item groups)? */
+__device__ inline bool item_owned(const QL &Q, uint32_t k)
+{
+  if (Q.wstep <= 1u)
+    return true;
+  if (Q.sub2_items)            /* (ride along with the slice's main chunk, or chunks of pass 3: one owner) */
+    return owned(Q, k / Q.ngroups, 0u);
+  uint32_t gi = 0;
+  for (uint32_t x = 1; x < Q.ngroups; x++)
+    if (k >= Q.goff[x])
+      gi = x;
+  return owned(Q, Q.gslice0[gi] + (k - Q.goff[gi]), 3u + gi);
+}
 
 /* ---- validation ---------------------------------------------------------- */
 
@@ -363,62 +420,132 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
   }
 }
 
+/* One thread per query of [q0, q1): first what a host pass over the set would check,
+   then -- for a sound query -- its keys. */
 __global__ void __launch_bounds__(256)
-keys_kernel(const QL Q)
+keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
 {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long alg = 0;
-  if (i < Q.n) {
-    const uint64_t b = Q.off[i];
-    const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-    const uint8_t *s = Q.res + b;
-    const uint32_t vg = Q.genes ? Q.v[i] : 0u, jg = Q.genes ? Q.j[i] : 0u;
-    uint32_t ck = 0;
-    bool heavy = false;
-    if (Q.sliced)
-      ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, vg, jg, &heavy);
-    if (Q.rows) {
-      /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that
-         seed the rolling indel enumeration (:90-104, :122-136) */
-      uint64_t h = 0;
-      if (Q.genes) {
-        const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-        h = gk[vg] ^ gk[Q.n_v + jg];
-      }
-      uint64_t hins = h, hdel = h;
-      for (uint32_t p = 0; p < L; p++) {
-        const uint32_t r = s[p];
-        h ^= Q.zob[Q.A * p + r];
-        if (Q.indels) {
-          hins ^= Q.zob[Q.A * (p + 1) + r];
-          if (p > 0)
-            hdel ^= Q.zob[Q.A * (p - 1) + r];
-        }
-      }
-      Q.h_tmp[i] = h;
-      if (Q.indels) {
-        Q.hins_tmp[i] = hins;
-        Q.hdel_tmp[i] = hdel;
-      }
-      Q.ck_tmp[i] = ck;
-    } else if (Q.sub2_items) {
-      Q.ck_tmp[i] = ck;
-    }
-    const uint64_t gl = Q.longest - L;
-    {
-      const uint64_t bucket = Q.sliced ? 2 * (uint64_t)(ck & Q.geom.smask) + (heavy ? 1 : 0) : 0;
-      const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
-      Q.grp[0][i] = g;
-      atomicAdd(Q.cnt_g[0] + g, 1u);
-    }
-    if (Q.ngroups)
-      for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) { atomicAdd(Q.ccnt + k, 1u); });
-    alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
+  extern __shared__ double tot_lds[];          /* n_rep doubles when they fit */
+  const bool lds_tot = Q.n_rep <= 2048;
+  if (lds_tot) {
+    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
+      tot_lds[r] = 0.0;
+    __syncthreads();
   }
+  const uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long alg = 0;
+  uint32_t err = 0, Lmax = 0;
+  if (i < q1) {
+    const uint64_t b = Q.off[i], e = Q.off[i + 1];
+    uint32_t L = 0;
+    if (e < b || e > Q.total)
+      err = VERR_OFFSETS;
+    else if (e - b > 0xffffu)
+      err = VERR_LONG;
+    else if (e - b > Q.longest)
+      err = VERR_TOO_LONG;
+    else
+      L = (uint32_t)(e - b);
+    const uint32_t rp = Q.rep[i];
+    if (!err && rp >= Q.n_rep)
+      err = VERR_REP;
+    if (!err && Q.genes && (Q.v[i] >= Q.n_v_max || Q.j[i] >= Q.n_j_max))
+      err = VERR_GENE;
+    if (!err && Q.counts && Q.cnt[i] < 1)
+      err = VERR_COUNT;
+    const uint8_t *s = Q.res + b;
+    if (!err) {
+      bool bad = false;
+      for (uint32_t p = 0; p < L; p++)
+        bad = bad || s[p] >= Q.A;
+      if (bad)
+        err = VERR_RESIDUE;
+    }
+    Q.grp[0][i] = 0xffffffffu;
+    if (!err) {
+      Lmax = L;
+      const double x = Q.counts ? (double)Q.cnt[i] : 1.0;
+      if (lds_tot)
+        unsafeAtomicAdd(tot_lds + rp, x);
+      else
+        unsafeAtomicAdd(Q.rep_total + rp, x);
+      const uint32_t vg = Q.genes ? Q.v[i] : 0u, jg = Q.genes ? Q.j[i] : 0u;
+      uint32_t ck = 0;
+      bool heavy = false;
+      if (Q.sliced)
+        ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, vg, jg, &heavy);
+      if (Q.rows) {
+        /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that
+           seed the rolling indel enumeration (:90-104, :122-136) */
+        uint64_t h = 0;
+        if (Q.genes) {
+          const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+          h = gk[vg] ^ gk[Q.n_v + jg];
+        }
+        uint64_t hins = h, hdel = h;
+        for (uint32_t p = 0; p < L; p++) {
+          const uint32_t r = s[p];
+          h ^= Q.zob[Q.A * p + r];
+          if (Q.indels) {
+            hins ^= Q.zob[Q.A * (p + 1) + r];
+            if (p > 0)
+              hdel ^= Q.zob[Q.A * (p - 1) + r];
+          }
+        }
+        Q.h_tmp[i] = h;
+        if (Q.indels) {
+          Q.hins_tmp[i] = hins;
+          Q.hdel_tmp[i] = hdel;
+        }
+        Q.ck_tmp[i] = ck;
+      } else if (Q.sub2_items) {
+        Q.ck_tmp[i] = ck;
+      }
+      /* the items of the query that this context works on */
+      bool any_item = false;
+      if (Q.ngroups)
+        for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+          if (item_owned(Q, k)) {
+            atomicAdd(Q.ccnt + k, 1u);
+            any_item = true;
+          }
+        });
+      /* its place: a tile of its slice if this context works on that slice; else, if
+         one of its items is worked on here, a tile of the foreign pseudo-slice (no
+         chunk lists it: the record is all that is needed); else none */
+      const uint64_t gl = Q.longest - L;
+      const uint32_t slice = Q.sliced ? (ck & Q.geom.smask) : 0u;
+      uint64_t bucket = ~0ull;
+      if (owned(Q, slice, 0u))
+        bucket = Q.sliced ? 2 * (uint64_t)slice + (heavy ? 1 : 0) : 0;
+      else if (any_item)
+        bucket = 2 * Q.nslices_real;
+      if (bucket != ~0ull) {
+        const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
+        Q.grp[0][i] = g;
+        Q.rank[i] = atomicAdd(Q.cnt_g[0] + g, 1u);
+      }
+      alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
+    }
+  }
+  if (err)
+    atomicCAS(Q.verr, 0u, err);
+  /* longest: one atomic per wave */
+  uint32_t m = Lmax;
+  for (int o = 32; o > 0; o >>= 1)
+    m = max(m, (uint32_t)__shfl_down((int)m, o, WAVE));
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicMax(Q.verr + 1, m);
   for (int o = 32; o > 0; o >>= 1)
     alg += __shfl_down(alg, o, WAVE);
   if ((threadIdx.x & 63) == 0 && alg)
     atomicAdd(Q.alg_bytes, alg);
+  if (lds_tot) {
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
+      if (tot_lds[r] != 0.0)
+        unsafeAtomicAdd(Q.rep_total + r, tot_lds[r]);
+  }
 }
 
 /* ---- slices: tiles, chunks ------------------------------------------------ */
@@ -522,7 +649,7 @@ slices_kernel(const QL Q, uint32_t pi)
      tiles is not worth a workgroup + a staged copy: its tiles go to the list
      that single waves work through, probing the slice in HBM / L2. */
   uint32_t nchunks = 0, nsmall = 0, nlist = 0;
-  if (Q.sliced && ntiles) {
+  if (Q.sliced && ntiles && sl < Q.nslices_real) {       /* (the foreign pseudo-slice: tiles, no work) */
     /* (variant 2 with -i: the deletion and insertion rows of a tile follow its
        substitution rows in the same unit, on the same staged slice -- its class keys
        have no length term -- so there is one chunk per slice, not one per pass) */
@@ -572,63 +699,126 @@ slices_kernel(const QL Q, uint32_t pi)
 
 /* ---- placement ------------------------------------------------------------ */
 
+/* One thread per query: its record and its hashes to slot = group base + rank, as two
+   whole pieces of memory (64 + 32 bytes) -- the only scattered writes of the layout. */
 __global__ void __launch_bounds__(256)
-place_kernel(const QL Q)
+scatter_kernel(const QL Q)
 {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= Q.n)
     return;
   const uint32_t g = Q.grp[0][i];
-  const uint32_t slot = Q.base_g[0][g] + atomicAdd(Q.fill_g[0] + g, 1u);
-  const uint32_t tile = slot / WAVE, lane = slot % WAVE;
+  if (g == 0xffffffffu) {                    /* not worked on by this context */
+    Q.slot_of[i] = 0xffffffffu;
+    return;
+  }
+  const uint32_t slot = Q.base_g[0][g] + Q.rank[i];
+  Q.slot_of[i] = slot;
   const uint64_t b = Q.off[i];
   const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-  Q.slot_of[i] = slot;
-  Q.qlen[slot] = (uint16_t)L;
-  Q.qorig[slot] = (uint32_t)i;
-  Q.qrep[slot] = Q.existence ? (uint32_t)i : Q.rep[i];    /* -x: the row is the sequence itself */
-  if (Q.genes) {
-    Q.qv[slot] = Q.v[i];
-    Q.qj[slot] = Q.j[i];
-  }
-  if (Q.counts)
-    Q.qcnt[slot] = Q.cnt[i];
-  if (Q.rows) {
-    Q.qgh[slot] = Q.h_tmp[i];
-    Q.qck[slot] = Q.ck_tmp[i];
-    if (Q.indels) {
-      Q.qhins[slot] = Q.hins_tmp[i];
-      Q.qhdel[slot] = Q.hdel_tmp[i];
-    }
-  } else if (Q.genes) {
-    const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-    Q.qgh[slot] = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
-  }
-  /* residues four to a dword, position-major / lane-minor (layout.h TileDesc), and
-     the first nine dwords once more in the query's record */
-  uint32_t *dst = Q.qres + Q.tiles[tile].res_base + lane;
   const uint8_t *s = Q.res + b;
   QueryRec qr;
   qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
   qr.v = Q.genes ? Q.v[i] : 0u;
   qr.j = Q.genes ? Q.j[i] : 0u;
-  qr.rep = Q.existence ? (uint32_t)i : Q.rep[i];
+  qr.rep = Q.existence ? (uint32_t)i : Q.rep[i];    /* -x: the row is the sequence itself */
   qr.len = L;
-  qr.pad = 0;
+  qr.orig = (uint32_t)i;
 #pragma unroll
-  for (uint32_t w = 0; w < 9; w++)
-    qr.res[w] = 0;
-  for (uint32_t w = 0; 4 * w < L; w++) {
+  for (uint32_t w = 0; w < 9; w++) {
     uint32_t d = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++)
       if (4 * w + k < L)
         d |= (uint32_t)s[4 * w + k] << (8 * k);
-    dst[(size_t)w * WAVE] = d;
-    if (w < 9)
-      qr.res[w] = d;
+    qr.res[w] = d;
   }
   Q.qrec[slot] = qr;
+  QAux a;
+  a.h = a.hins = a.hdel = 0;
+  a.ck = a.pad = 0;
+  if (Q.rows) {
+    a.h = Q.h_tmp[i];
+    a.ck = Q.ck_tmp[i];
+    if (Q.indels) {
+      a.hins = Q.hins_tmp[i];
+      a.hdel = Q.hdel_tmp[i];
+    }
+  } else if (Q.genes) {
+    const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+    a.h = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
+  }
+  Q.aux[slot] = a;
+}
+
+/* One wave per tile, one lane per slot: the records scatter_kernel left, read in slot
+   order, become the per-slot arrays and the tile's position-major residues (layout.h
+   TileDesc) -- every write coalesced, the padding lanes written too (zeros), so that
+   nothing of the layout needs a memset. */
+__global__ void __launch_bounds__(256)
+fill_tiles_kernel(const QL Q, uint32_t ntiles)
+{
+  const uint32_t t = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  if (t >= ntiles)
+    return;
+  const uint32_t lane = threadIdx.x % WAVE;
+  const TileDesc td = Q.tiles[t];
+  const uint32_t slot = t * WAVE + lane;
+  const bool valid = lane < td.nvalid;
+  QueryRec qr;
+  QAux a;
+  if (valid) {
+    qr = Q.qrec[slot];
+    a = Q.aux[slot];
+  } else {
+    qr.cnt = 0;
+    qr.v = qr.j = qr.rep = qr.len = qr.orig = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 9; w++)
+      qr.res[w] = 0;
+    a.h = a.hins = a.hdel = 0;
+    a.ck = a.pad = 0;
+    Q.qrec[slot] = qr;
+  }
+  Q.qlen[slot] = (uint16_t)qr.len;
+  Q.qorig[slot] = qr.orig;
+  Q.qrep[slot] = qr.rep;
+  if (Q.genes) {
+    Q.qv[slot] = qr.v;
+    Q.qj[slot] = qr.j;
+  }
+  if (Q.counts)
+    Q.qcnt[slot] = qr.cnt;
+  if (Q.rows) {
+    Q.qgh[slot] = a.h;
+    Q.qck[slot] = a.ck;
+    if (Q.indels) {
+      Q.qhins[slot] = a.hins;
+      Q.qhdel[slot] = a.hdel;
+    }
+  } else if (Q.genes) {
+    Q.qgh[slot] = a.h;
+  }
+  /* residues four to a dword, position-major / lane-minor; the first nine dwords are in
+     the record, longer sequences fetch the rest where the caller's residues lie */
+  uint32_t *dst = Q.qres + td.res_base + lane;
+  const uint32_t nd = (td.len + 3u) >> 2;
+#pragma unroll
+  for (uint32_t w = 0; w < 9; w++)
+    if (w < nd)
+      dst[(size_t)w * WAVE] = qr.res[w];
+  if (nd > 9) {
+    const uint8_t *s = valid ? Q.res + Q.off[qr.orig] : Q.res;
+    const uint32_t L = qr.len;
+    for (uint32_t w = 9; w < nd; w++) {
+      uint32_t d = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        if (4 * w + k < L)
+          d |= (uint32_t)s[4 * w + k] << (8 * k);
+      dst[(size_t)w * WAVE] = d;
+    }
+  }
 }
 
 /* variant 2, class rows: per (class part, slice) the items padded to whole blocks
@@ -699,6 +889,8 @@ place_items_kernel(const QL Q)
   if (i >= Q.n)
     return;
   const uint32_t slot = Q.slot_of[i];
+  if (slot == 0xffffffffu)                   /* (no item of it is worked on here either) */
+    return;
   const uint32_t ck = Q.ck_tmp[i];
   const bool heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, class_base_of(Q, i));
   uint64_t hq = 0;
@@ -719,14 +911,18 @@ place_items_kernel(const QL Q)
     }
   }
   for_each_item<true>(Q, i, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
+    if (!item_owned(Q, k))
+      return;
     const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
     if (Q.sub2_items) {
       w = hq;                                   /* the query's hash and residues travel with the item */
       Q.cpk[item] = pk;
     }
-    Q.cw[item] = w;
-    Q.cmain[item] = slot;
-    Q.crp[item] = crp;
+    ItemRec it;
+    it.w = w;
+    it.main = slot;
+    it.rp = crp;
+    Q.items[item] = it;
   });
 }
 
@@ -845,16 +1041,6 @@ gather_chunks_kernel(const Chunk *src, const uint32_t *idx, uint32_t n, Chunk *d
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k < n)
     dst[k] = src[idx[k]];
-}
-
-/* Work sharding (tunables work_shard_index / _count): which context of `step` takes
-   the work filed under a slice in a pass.  By slice, not by position in the work
-   list: WHICH queries a slice holds is a property of the input, how they are cut
-   into tiles and chunks is decided by atomics and differs from one layout run (one
-   GPU) to the next. */
-__host__ __device__ inline uint32_t work_owner(uint32_t slice, uint32_t pass, uint32_t step)
-{
-  return (uint32_t)((((uint64_t)slice * 2654435761u + pass * 40503u) >> 7) % step);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1000,42 +1186,72 @@ static int select_mine(cmpr_context *c, const uint32_t *list, uint32_t n, Tmp<ui
   return CMPR_OK;
 }
 
+/* cutting an arena: offsets first (sizes known), pointers once it is large enough */
+struct ArenaCut {
+  size_t used = 0;
+  size_t take(size_t bytes)
+  {
+    const size_t at = used;
+    used += (bytes + 255) & ~(size_t)255;
+    return at;
+  }
+};
+
+static int arena_fit(cmpr_context *c, DevArena &A, size_t bytes)
+{
+  if (A.base && A.cap >= bytes)
+    return CMPR_OK;
+  A.release();
+  const size_t want = bytes + bytes / 16 + 4096;
+  HIP_TRY(c, hipMalloc((void **)&A.base, want));
+  A.cap = want;
+  return CMPR_OK;
+}
+
+struct U32To64 {
+  __host__ __device__ unsigned long long operator()(const uint32_t &x) const { return x; }
+};
+
+/* sum of n uint32 as 64 bits into *out (the 32-bit prefix sums beside it may not wrap
+   unnoticed: ADVICE r2) */
+static hipError_t sum64(void *tmp, size_t &bytes, const uint32_t *in, unsigned long long *out, int n,
+                        hipStream_t st)
+{
+  hipcub::TransformInputIterator<unsigned long long, U32To64, const uint32_t *> it(in, U32To64());
+  return hipcub::DeviceReduce::Sum(tmp, bytes, it, out, n, st);
+}
+
 int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
 {
   int rc;
-  /* ---- the caller's arrays, as they are; validation ---- */
-  Tmp<uint8_t> res;
-  Tmp<uint64_t> off, cnt;
-  Tmp<uint32_t> v, j, rep;
-  uint32_t longest = 0;
-  if ((rc = cmpr_upload_and_validate(c, s, res.b, off.b, v.b, j.b, rep.b, cnt.b, longest, c->tot1)))
-    return rc;
-  if (longest + EXTRA_POSITIONS > c->zpos)
-    return fail(c, CMPR_EINVAL,
-                "query longer than the longest_query given to cmpr_set_reference");
-  c->n1 = s->n;
-  c->R1 = c->opt.existence ? (uint32_t)s->n : s->n_repertoires;
-
-  /* exact integer accumulation needs every cell < 2^64; a cell is at most
-     (sum of counts of its row repertoire) x (sum of counts of its column one) */
-  {
-    double m1 = 0, m2 = 0;
-    for (double x : c->tot1) m1 = std::max(m1, x);
-    for (double x : c->tot2) m2 = std::max(m2, x);
-    c->max_cell_bound = m1 * m2;
-    if (!is_f64_score(c->opt) && c->max_cell_bound >= 18446744073709551616.0 / 2)
-      return fail(c, CMPR_EUNSUPPORTED,
-                  "duplicate counts too large for exact 64-bit accumulation");
-  }
-
+  const auto t_begin = std::chrono::steady_clock::now();
+  const uint64_t n = s->n;
+  const uint64_t total = n ? s->offsets[n] : 0;
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
-  const uint64_t nslices = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
+  const uint32_t Lcap = c->zpos - EXTRA_POSITIONS;        /* the longest a query may be */
+  if (n > 0x7fffffffull)                                  /* (hipCUB item counts are int) */
+    return fail(c, CMPR_EUNSUPPORTED, "more than 2^31-1 sequences in one set");
+  c->n1 = n;
+  c->R1 = c->opt.existence ? (uint32_t)n : s->n_repertoires;
+
+  const uint32_t wstep = (uint32_t)c->work_shard_count;
+  const uint32_t wfirst = (uint32_t)c->work_shard_index;
+  if (wfirst >= wstep)
+    return fail(c, CMPR_EINVAL, "work_shard_index must be below work_shard_count");
+  if (wstep > 1 && !c->sliced)
+    return fail(c, CMPR_EUNSUPPORTED, "work shards need a sliced layout (kernel variant 1 or 2)");
+  /* variant 1 with -i lists every tile under two sibling slices of other owners: there
+     every context lays out everything and takes its share of the chunk list */
+  const bool indel_passes = c->sliced && c->opt.indels && !c->rows;
+  const bool place_mine = wstep > 1 && !indel_passes;
+
+  const uint64_t nslices_real = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
+  const uint64_t nslices = nslices_real + (place_mine ? 1 : 0);     /* + the foreign pseudo-slice */
   const uint64_t nbuckets = c->sliced ? 2 * nslices : 1;
-  const uint64_t per_slice = (uint64_t)longest + 1;
-  if (nbuckets * per_slice >= 0xffffffffull)
+  const uint64_t per_slice = (uint64_t)Lcap + 1;
+  if (nbuckets * per_slice >= 0x7fffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
   const uint64_t G = nbuckets * per_slice;
-  /* class-row passes of variant 2 (flat items, not tiles) */
   /* item groups of variant 2 (flat items, not tiles; see QL) */
   const uint32_t npass = 1;                  /* passes laid out as tiles */
   uint32_t ngroups = 0;
@@ -1086,16 +1302,87 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   /* (variant 2 mixes lengths with -i too: its class keys then carry no length term,
      ref_index.hip, and its indel rows mask every lane by its own length) */
   const bool mixed_ok = c->sliced && (!c->opt.indels || c->rows);
+  const uint64_t n2s = indel_passes ? 2 * nslices : 0;
+
+  /* ---- arena A: everything whose size the host knows now ---- */
+  ArenaCut cut;
+  /* (the counters that start at zero lie side by side: one memset) */
+  const size_t o_gcnt = cut.take(G * npass * sizeof(uint32_t));
+  const size_t o_ccnt = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_cfill = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_sibcnt = cut.take(n2s * sizeof(uint32_t));
+  const size_t o_sibfill = cut.take(n2s * sizeof(uint32_t));
+  const size_t o_alg = cut.take(sizeof(unsigned long long));
+  const size_t o_verr = cut.take(2 * sizeof(uint32_t));
+  const size_t o_reptot = cut.take((size_t)s->n_repertoires * sizeof(double));
+  const size_t o_sums = cut.take(8 * sizeof(unsigned long long));
+  const size_t zero_bytes = cut.used;
+  const size_t o_res = cut.take((size_t)total + 16);
+  const size_t o_off = cut.take((size_t)(n + 1) * sizeof(uint64_t));
+  const size_t o_v = cut.take(c->opt.ignore_genes ? 0 : (size_t)n * sizeof(uint32_t));
+  const size_t o_j = cut.take(c->opt.ignore_genes ? 0 : (size_t)n * sizeof(uint32_t));
+  const size_t o_rep = cut.take((size_t)n * sizeof(uint32_t));
+  const size_t o_cnt = cut.take(c->opt.ignore_counts ? 0 : (size_t)n * sizeof(uint64_t));
+  const size_t o_gbase = cut.take(G * npass * sizeof(uint32_t));
+  const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
+  const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
+  const size_t o_tfirst = cut.take(G * sizeof(uint32_t));
+  const size_t o_slotof = cut.take((size_t)n * sizeof(uint32_t));
+  const size_t o_tot = cut.take(nslices * sizeof(SliceTot));
+  const size_t o_pre = cut.take(nslices * sizeof(SliceTot));
+  const bool need_ck = c->rows || sub2_items;
+  const size_t o_h = cut.take(c->rows ? (size_t)n * sizeof(uint64_t) : 0);
+  const size_t o_ck = cut.take(need_ck ? (size_t)n * sizeof(uint32_t) : 0);
+  const size_t o_hins = cut.take(c->rows && c->opt.indels ? (size_t)n * sizeof(uint64_t) : 0);
+  const size_t o_hdel = cut.take(c->rows && c->opt.indels ? (size_t)n * sizeof(uint64_t) : 0);
+  const size_t o_cbase = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_cnch = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_cchpre = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_cpad = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_sibnch = cut.take(n2s * sizeof(uint32_t));
+  const size_t o_siblpre = cut.take(n2s * sizeof(uint32_t));
+  const size_t o_sibcpre = cut.take(n2s * sizeof(uint32_t));
+  /* hipCUB temporary storage: the largest any of the scans / sums below asks for */
+  size_t cub_bytes = 0;
+  {
+    SliceTot zero;
+    memset(&zero, 0, sizeof zero);
+    size_t b = 0;
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (SliceTot *)nullptr, (SliceTot *)nullptr, SliceTotSum(),
+                                            zero, (int)nslices, c->stream);
+    cub_bytes = std::max(cub_bytes, b);
+    const int big = (int)std::max<uint64_t>(std::max<uint64_t>(ncs, n2s), 1);
+    b = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, big, c->stream);
+    cub_bytes = std::max(cub_bytes, b);
+    b = 0;
+    (void)sum64(nullptr, b, nullptr, nullptr, big, c->stream);
+    cub_bytes = std::max(cub_bytes, b);
+  }
+  const size_t o_cub = cut.take(cub_bytes + 256);
+  if ((rc = arena_fit(c, c->arena_a, cut.used))) return rc;
+  const auto t_arena_a = std::chrono::steady_clock::now();
+  char *const base = c->arena_a.base;
+  auto at = [&](size_t off) -> char * { return base + off; };
+  HIP_TRY(c, hipMemsetAsync(base, 0, zero_bytes, c->stream));
 
   QL Q;
   memset(&Q, 0, sizeof Q);
-  Q.res = res.b.p; Q.off = off.b.p; Q.v = v.b.p; Q.j = j.b.p; Q.rep = rep.b.p; Q.cnt = cnt.b.p;
-  Q.n = s->n;
+  Q.res = (const uint8_t *)at(o_res);
+  Q.off = (const uint64_t *)at(o_off);
+  Q.v = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_v);
+  Q.j = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_j);
+  Q.rep = (const uint32_t *)at(o_rep);
+  Q.cnt = c->opt.ignore_counts ? nullptr : (const uint64_t *)at(o_cnt);
+  Q.n = n;
+  Q.total = total;
   Q.n_rep = s->n_repertoires;
+  Q.n_v_max = c->opt.n_v_genes;
+  Q.n_j_max = c->opt.n_j_genes;
   Q.A = A;
   Q.zpos = c->zpos;
   Q.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
-  Q.longest = longest;
+  Q.longest = Lcap;
   Q.per_slice = (uint32_t)per_slice;
   Q.genes = c->opt.ignore_genes ? 0 : 1;
   Q.counts = c->opt.ignore_counts ? 0 : 1;
@@ -1113,6 +1400,9 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
+  Q.nslices_real = nslices_real;
+  Q.wfirst = place_mine ? wfirst : 0u;
+  Q.wstep = place_mine ? wstep : 1u;
   Q.ngroups = ngroups;
   Q.sub2_items = sub2_items ? 1u : 0u;
   c->sub2_active = sub2_items;
@@ -1123,258 +1413,274 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   }
   Q.nitem_slices = (uint32_t)ncs;
   Q.cblocks = 4096;                          /* (a claim word counts tiles in 16 bits) */
+  Q.cnt_g[0] = (uint32_t *)at(o_gcnt);
+  Q.base_g[0] = (uint32_t *)at(o_gbase);
+  Q.grp[0] = (uint32_t *)at(o_grp);
+  Q.rank = (uint32_t *)at(o_rank);
+  Q.tot[0] = (SliceTot *)at(o_tot);
+  Q.pre[0] = (SliceTot *)at(o_pre);
+  Q.tfirst_g = (uint32_t *)at(o_tfirst);
+  Q.h_tmp = (uint64_t *)at(o_h);
+  Q.hins_tmp = (uint64_t *)at(o_hins);
+  Q.hdel_tmp = (uint64_t *)at(o_hdel);
+  Q.ck_tmp = (uint32_t *)at(o_ck);
+  Q.slot_of = (uint32_t *)at(o_slotof);
+  Q.alg_bytes = (unsigned long long *)at(o_alg);
+  Q.verr = (uint32_t *)at(o_verr);
+  Q.rep_total = (double *)at(o_reptot);
+  Q.ccnt = (uint32_t *)at(o_ccnt);
+  Q.cbase = (uint32_t *)at(o_cbase);
+  Q.cfill = (uint32_t *)at(o_cfill);
+  Q.cnch = (uint32_t *)at(o_cnch);
+  Q.cchpre = (uint32_t *)at(o_cchpre);
+  uint32_t *const cpad = (uint32_t *)at(o_cpad);
+  uint32_t *const sib_cnt = (uint32_t *)at(o_sibcnt), *const sib_fill = (uint32_t *)at(o_sibfill);
+  uint32_t *const sib_nch = (uint32_t *)at(o_sibnch), *const sib_lpre = (uint32_t *)at(o_siblpre);
+  uint32_t *const sib_cpre = (uint32_t *)at(o_sibcpre);
+  unsigned long long *const sums = (unsigned long long *)at(o_sums);
+  void *const cub_tmp = at(o_cub);
 
-  /* ---- scratch: group counters, per-query keys ---- */
-  Tmp<uint32_t> gcnt, gbase, gfill, grp, tfirst, ck_tmp, slot_of;
-  Tmp<uint64_t> h_tmp, hins_tmp, hdel_tmp;
-  Tmp<SliceTot> tot, pre;
-  Tmp<unsigned long long> alg;
-  Tmp<uint32_t> ccnt, cbase, cfill, cnch, cchpre, cpad;
-  if (ngroups) {
-    if ((rc = dev_alloc(c, ccnt.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cbase.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cfill.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cnch.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cchpre.b, (size_t)ncs))) return rc;
-    if ((rc = dev_alloc(c, cpad.b, (size_t)ncs))) return rc;
-    HIP_TRY(c, hipMemsetAsync(ccnt.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(cfill.b.p, 0, (size_t)ncs * sizeof(uint32_t), c->stream));
-    Q.ccnt = ccnt.b.p;
-    Q.cbase = cbase.b.p;
-    Q.cfill = cfill.b.p;
-    Q.cnch = cnch.b.p;
-    Q.cchpre = cchpre.b.p;
-  }
-  if ((rc = dev_alloc(c, gcnt.b, (size_t)G * npass))) return rc;
-  if ((rc = dev_alloc(c, gbase.b, (size_t)G * npass))) return rc;
-  if ((rc = dev_alloc(c, gfill.b, (size_t)G * npass))) return rc;
-  if ((rc = dev_alloc(c, grp.b, (size_t)s->n * npass))) return rc;
-  if ((rc = dev_alloc(c, tfirst.b, (size_t)G))) return rc;
-  if ((rc = dev_alloc(c, slot_of.b, (size_t)s->n))) return rc;
-  if ((rc = dev_alloc(c, tot.b, (size_t)nslices * npass))) return rc;
-  if ((rc = dev_alloc(c, pre.b, (size_t)nslices * npass))) return rc;
-  if ((rc = dev_alloc(c, alg.b, 1))) return rc;
-  if (sub2_items)
-    if ((rc = dev_alloc(c, ck_tmp.b, (size_t)s->n))) return rc;
-  if (c->rows) {
-    if ((rc = dev_alloc(c, h_tmp.b, (size_t)s->n))) return rc;
-    if ((rc = dev_alloc(c, ck_tmp.b, (size_t)s->n))) return rc;
-    if (c->opt.indels) {
-      if ((rc = dev_alloc(c, hins_tmp.b, (size_t)s->n))) return rc;
-      if ((rc = dev_alloc(c, hdel_tmp.b, (size_t)s->n))) return rc;
+  /* ---- the caller's arrays, a range of queries at a time on the copy stream; the keys
+          kernel of a range (validation included) runs while the next is copied ---- */
+  double upload_ms = 0;
+  {
+    /* (few, large ranges: every copy call costs ~20 us of host time, and the keys kernel of
+       the last range is what the upload does not hide) */
+    const uint64_t min_range = 1u << 18;
+    const uint64_t nranges = std::max<uint64_t>(1, std::min<uint64_t>(4, n / min_range));
+    const size_t lds = s->n_repertoires <= 2048 ? s->n_repertoires * sizeof(double) : 0;
+    HIP_TRY(c, hipEventRecord(c->ev_copy[0], c->stream));            /* (the memset above) */
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0));
+    static const uint64_t zero_off[1] = {0};
+    if (n == 0)
+      HIP_TRY(c, hipMemcpyAsync(at(o_off), zero_off, sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+    for (uint64_t r = 0; r < nranges && n; r++) {
+      const uint64_t q0 = n * r / nranges, q1 = n * (r + 1) / nranges;
+      const uint64_t r0 = s->offsets[q0], r1 = s->offsets[q1];
+      if (r1 < r0 || r1 > total)
+        return fail(c, CMPR_EINVAL, verr_message(VERR_OFFSETS));
+      const auto t0 = std::chrono::steady_clock::now();
+      hipStream_t cs = c->copy_stream;
+      if (r1 > r0)
+        HIP_TRY(c, hipMemcpyAsync(at(o_res) + r0, s->residues + r0, (size_t)(r1 - r0), hipMemcpyHostToDevice, cs));
+      HIP_TRY(c, hipMemcpyAsync(at(o_off) + q0 * sizeof(uint64_t), s->offsets + q0,
+                                (size_t)(q1 - q0 + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+      HIP_TRY(c, hipMemcpyAsync(at(o_rep) + q0 * sizeof(uint32_t), s->repertoire + q0,
+                                (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+      if (!c->opt.ignore_genes) {
+        HIP_TRY(c, hipMemcpyAsync(at(o_v) + q0 * sizeof(uint32_t), s->v_gene + q0,
+                                  (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        HIP_TRY(c, hipMemcpyAsync(at(o_j) + q0 * sizeof(uint32_t), s->j_gene + q0,
+                                  (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+      }
+      if (!c->opt.ignore_counts)
+        HIP_TRY(c, hipMemcpyAsync(at(o_cnt) + q0 * sizeof(uint64_t), s->count + q0,
+                                  (size_t)(q1 - q0) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+      hipEvent_t ev = c->ev_copy[r % cmpr_context::NCOPY_EV];
+      HIP_TRY(c, hipEventRecord(ev, cs));
+      upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+      hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(q1 - q0)), dim3(256), lds, c->stream, Q, q0, q1);
+      HIP_TRY(c, hipGetLastError());
+    }
+    if (n == 0) {
+      HIP_TRY(c, hipEventRecord(c->ev_copy[0], c->copy_stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_copy[0], 0));
     }
   }
-  HIP_TRY(c, hipMemsetAsync(gcnt.b.p, 0, (size_t)G * npass * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(gfill.b.p, 0, (size_t)G * npass * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(alg.b.p, 0, sizeof(unsigned long long), c->stream));
-  for (uint32_t pi = 0; pi < npass; pi++) {
-    Q.cnt_g[pi] = gcnt.b.p + (size_t)G * pi;
-    Q.base_g[pi] = gbase.b.p + (size_t)G * pi;
-    Q.fill_g[pi] = gfill.b.p + (size_t)G * pi;
-    Q.grp[pi] = grp.b.p + (size_t)s->n * pi;
-    Q.tot[pi] = tot.b.p + (size_t)nslices * pi;
-    Q.pre[pi] = pre.b.p + (size_t)nslices * pi;
-  }
-  Q.tfirst_g = tfirst.b.p;
-  Q.h_tmp = h_tmp.b.p;
-  Q.hins_tmp = hins_tmp.b.p;
-  Q.hdel_tmp = hdel_tmp.b.p;
-  Q.ck_tmp = ck_tmp.b.p;
-  Q.slot_of = slot_of.b.p;
-  Q.alg_bytes = alg.b.p;
+  const auto t_uploaded = std::chrono::steady_clock::now();
 
-  if (s->n) {
-    hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-  }
-
-  /* ---- per slice: what it needs; exclusive scan; totals ---- */
-  Tmp<char> cub_tmp;
-  size_t cub_bytes = 0;
+  /* ---- per slice: what it needs; exclusive scan; items per (group, slice) padded to
+          blocks of 64; -i (variant 1): the sibling lists; all sizes in ONE round trip ---- */
   {
     SliceTot zero;
     memset(&zero, 0, sizeof zero);
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, cub_bytes, Q.tot[0], Q.pre[0], SliceTotSum(), zero,
-                                      (int)nslices, c->stream);
-    if ((rc = dev_alloc(c, cub_tmp.b, cub_bytes))) return rc;
-    for (uint32_t pi = 0; pi < npass; pi++) {
-      hipLaunchKernelGGL(slices_kernel<0>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, pi);
-      HIP_TRY(c, hipGetLastError());
-      size_t b = cub_bytes;
-      HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(cub_tmp.b.p, b, Q.tot[pi], Q.pre[pi],
-                                                   SliceTotSum(), zero, (int)nslices, c->stream));
-    }
+    hipLaunchKernelGGL(slices_kernel<0>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
+    HIP_TRY(c, hipGetLastError());
+    size_t b = cub_bytes;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(cub_tmp, b, Q.tot[0], Q.pre[0], SliceTotSum(), zero,
+                                                 (int)nslices, c->stream));
   }
-  std::vector<SliceTot> last_tot(npass), last_pre(npass);
-  for (uint32_t pi = 0; pi < npass; pi++) {
-    HIP_TRY(c, hipMemcpyAsync(&last_tot[pi], Q.tot[pi] + (nslices - 1), sizeof(SliceTot),
-                              hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&last_pre[pi], Q.pre[pi] + (nslices - 1), sizeof(SliceTot),
-                              hipMemcpyDeviceToHost, c->stream));
+  if (ngroups) {
+    hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad);
+    HIP_TRY(c, hipGetLastError());
+    size_t b = cub_bytes;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, cpad, Q.cbase, (int)ncs, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, Q.cnch, Q.cchpre, (int)ncs, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, sum64(cub_tmp, b, cpad, sums + 0, (int)ncs, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, sum64(cub_tmp, b, Q.cnch, sums + 1, (int)ncs, c->stream));
   }
-  unsigned long long alg_bytes = 0;
-  HIP_TRY(c, hipMemcpyAsync(&alg_bytes, alg.b.p, sizeof alg_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (indel_passes) {
+    hipLaunchKernelGGL(sibling_count_kernel, dim3(blocks_for(G)), dim3(256), 0, c->stream, Q, G, sib_cnt);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(sibling_chunks_kernel, dim3(blocks_for(n2s)), dim3(256), 0, c->stream,
+                       sib_cnt, n2s, (uint32_t)chunk_tiles, sib_nch);
+    HIP_TRY(c, hipGetLastError());
+    size_t b = cub_bytes;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, sib_cnt, sib_lpre, (int)n2s, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, sib_nch, sib_cpre, (int)n2s, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, sum64(cub_tmp, b, sib_cnt, sums + 2, (int)n2s, c->stream));
+    b = cub_bytes;
+    HIP_TRY(c, sum64(cub_tmp, b, sib_nch, sums + 3, (int)n2s, c->stream));
+  }
+  SliceTot last_tot, last_pre;
+  uint32_t hv[2] = {0, 0};
+  unsigned long long alg_bytes = 0, hsums[4] = {0, 0, 0, 0};
+  c->tot1.assign(s->n_repertoires, 0.0);
+  HIP_TRY(c, hipMemcpyAsync(&last_tot, Q.tot[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&last_pre, Q.pre[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hv, Q.verr, sizeof hv, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&alg_bytes, Q.alg_bytes, sizeof alg_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hsums, sums, sizeof hsums, hipMemcpyDeviceToHost, c->stream));
+  if (s->n_repertoires)
+    HIP_TRY(c, hipMemcpyAsync(c->tot1.data(), Q.rep_total, s->n_repertoires * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto t_sizes = std::chrono::steady_clock::now();
+  if (hv[0] == VERR_TOO_LONG)
+    return fail(c, CMPR_EINVAL, "query longer than the longest_query given to cmpr_set_reference");
+  if (hv[0])
+    return fail(c, hv[0] == VERR_LONG ? CMPR_EUNSUPPORTED : CMPR_EINVAL, verr_message(hv[0]));
   c->algorithmic_bytes = alg_bytes;
 
-  uint64_t ntiles = 0, nchunks = 0, nlist = 0, nsmall = 0, res_words = 0, cslots = 0;
-  for (uint32_t pi = 0; pi < npass; pi++) {
+  /* exact integer accumulation needs every cell < 2^64; a cell is at most
+     (sum of counts of its row repertoire) x (sum of counts of its column one) */
+  {
+    double m1 = 0, m2 = 0;
+    for (double x : c->tot1) m1 = std::max(m1, x);
+    for (double x : c->tot2) m2 = std::max(m2, x);
+    c->max_cell_bound = m1 * m2;
+    if (!is_f64_score(c->opt) && c->max_cell_bound >= 18446744073709551616.0 / 2)
+      return fail(c, CMPR_EUNSUPPORTED,
+                  "duplicate counts too large for exact 64-bit accumulation");
+  }
+
+  uint64_t ntiles = 0, nchunks = 0, nlist = 0, nsmall = 0, res_words = 0;
+  {
     const SliceTotSum add;
-    const SliceTot t = add(last_pre[pi], last_tot[pi]);
-    Q.tile0[pi] = (uint32_t)ntiles;
-    Q.chunk0[pi] = (uint32_t)nchunks;
-    Q.list0[pi] = (uint32_t)nlist;
-    Q.small0[pi] = (uint32_t)nsmall;
-    Q.res0[pi] = pi == 0 ? 0ull : cslots;
-    ntiles += t.tiles;
-    nchunks += t.chunks;
-    nlist += t.list;
-    nsmall += t.small;
-    if (pi == 0)
-      res_words = t.res;
-    else
-      cslots += t.res;
-    if (pi == 0)
-      c->nmain_tiles = t.tiles;
+    const SliceTot t = add(last_pre, last_tot);
+    Q.tile0[0] = Q.chunk0[0] = Q.list0[0] = Q.small0[0] = 0;
+    Q.res0[0] = 0;
+    ntiles = t.tiles;
+    nchunks = t.chunks;
+    nlist = t.list;
+    nsmall = t.small;
+    res_words = t.res;
+    c->nmain_tiles = t.tiles;
   }
-  /* ---- class rows: items per (class part, slice), padded to blocks of 64 ---- */
-  uint64_t class_chunks = 0;
-  if (ngroups) {
-    hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad.b.p);
-    HIP_TRY(c, hipGetLastError());
-    size_t b2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, cpad.b.p, cbase.b.p, (int)ncs, c->stream);
-    Tmp<char> t2;
-    if ((rc = dev_alloc(c, t2.b, b2))) return rc;
-    size_t bb = b2;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, cpad.b.p, cbase.b.p, (int)ncs, c->stream));
-    bb = b2;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, cnch.b.p, cchpre.b.p, (int)ncs, c->stream));
-    uint32_t last[4];
-    HIP_TRY(c, hipMemcpyAsync(&last[0], cpad.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&last[1], cbase.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&last[2], cnch.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&last[3], cchpre.b.p + (ncs - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    cslots = (uint64_t)last[0] + last[1];
-    class_chunks = (uint64_t)last[2] + last[3];
-  }
+  const uint64_t cslots = hsums[0], class_chunks = hsums[1];
   if (ntiles * WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many query tiles");
   if (res_words + 9 * WAVE >= 0xffffffffull || cslots + WAVE >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "query set too large for 32-bit residue positions");
   const uint64_t main_chunks = nchunks, main_list = nlist;
-
-  /* ---- -i: sibling lists of the two indel passes ---- */
-  Tmp<uint32_t> sib_cnt, sib_nch, sib_lpre, sib_cpre, sib_fill;
-  uint64_t sib_chunks = 0, sib_list = 0;
-  /* variant 1: the indel passes list the tiles by sibling slice; variant 2: the same
-     tiles, the same slice, three chunks per chunk (slices_kernel) */
-  const bool indel_passes = c->sliced && c->opt.indels && !c->rows;
-  if (indel_passes) {
-    const uint64_t n2s = 2 * nslices;
-    if ((rc = dev_alloc(c, sib_cnt.b, (size_t)n2s))) return rc;
-    if ((rc = dev_alloc(c, sib_nch.b, (size_t)n2s))) return rc;
-    if ((rc = dev_alloc(c, sib_lpre.b, (size_t)n2s))) return rc;
-    if ((rc = dev_alloc(c, sib_cpre.b, (size_t)n2s))) return rc;
-    if ((rc = dev_alloc(c, sib_fill.b, (size_t)n2s))) return rc;
-    HIP_TRY(c, hipMemsetAsync(sib_cnt.b.p, 0, n2s * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(sib_fill.b.p, 0, n2s * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(sibling_count_kernel, dim3(blocks_for(G)), dim3(256), 0, c->stream, Q, G,
-                       sib_cnt.b.p);
-    HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(sibling_chunks_kernel, dim3(blocks_for(n2s)), dim3(256), 0, c->stream,
-                       sib_cnt.b.p, n2s, (uint32_t)chunk_tiles, sib_nch.b.p);
-    HIP_TRY(c, hipGetLastError());
-    size_t b2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, sib_cnt.b.p, sib_lpre.b.p, (int)n2s, c->stream);
-    Tmp<char> t2;
-    if ((rc = dev_alloc(c, t2.b, b2))) return rc;
-    size_t bb = b2;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, sib_cnt.b.p, sib_lpre.b.p, (int)n2s, c->stream));
-    bb = b2;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.b.p, bb, sib_nch.b.p, sib_cpre.b.p, (int)n2s, c->stream));
-    uint32_t lc[2], lp[2], cc[2];
-    HIP_TRY(c, hipMemcpyAsync(&lc[0], sib_cnt.b.p + (n2s - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&lp[0], sib_lpre.b.p + (n2s - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&cc[0], sib_nch.b.p + (n2s - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&cc[1], sib_cpre.b.p + (n2s - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    sib_list = (uint64_t)lc[0] + lp[0];
-    sib_chunks = (uint64_t)cc[0] + cc[1];
-    nchunks += sib_chunks;
-    nlist += sib_list;
-  }
+  const uint64_t sib_list = hsums[2], sib_chunks = hsums[3];
+  nchunks += sib_chunks;
+  nlist += sib_list;
   Q.cchunk0 = (uint32_t)nchunks;
   nchunks += class_chunks;
-  if (nchunks >= 0xffffffffull || nlist >= 0xffffffffull)
+  if (nchunks >= 0x7fffffffull || nlist >= 0xffffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many chunks");
 
-  /* ---- the resident layout ---- */
-  const size_t slots = (size_t)c->nmain_tiles * WAVE;
+  /* ---- arena B: the temporaries sized by the device ---- */
+  const size_t slots = (size_t)ntiles * WAVE;
+  size_t sort_bytes = 0, small_sort_bytes = 0;
+  if (nchunks)
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                       (uint32_t *)nullptr, (uint32_t *)nullptr, (int)nchunks, 0, 32,
+                                                       c->stream);
+  if (nsmall)
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, small_sort_bytes, (uint32_t *)nullptr,
+                                                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                       (int)nsmall, 0, 17, c->stream);
+  ArenaCut cb;
+  const size_t o_aux = cb.take(std::max<size_t>(slots, 1) * sizeof(QAux));
+  const size_t o_chunks_u = cb.take((size_t)nchunks * sizeof(Chunk));
+  const size_t o_wk = cb.take((size_t)nchunks * sizeof(uint32_t));
+  const size_t o_wk2 = cb.take((size_t)nchunks * sizeof(uint32_t));
+  const size_t o_ix = cb.take((size_t)nchunks * sizeof(uint32_t));
+  const size_t o_ix2 = cb.take((size_t)nchunks * sizeof(uint32_t));
+  const size_t o_sort = cb.take(sort_bytes + 256);
+  const size_t o_ln = cb.take((size_t)nsmall * sizeof(uint32_t));
+  const size_t o_ln2 = cb.take((size_t)nsmall * sizeof(uint32_t));
+  const size_t o_sout = cb.take((size_t)nsmall * sizeof(uint32_t));
+  const size_t o_ssort = cb.take(small_sort_bytes + 256);
+  if ((rc = arena_fit(c, c->arena_b, cb.used))) return rc;
+  char *const bb = c->arena_b.base;
+  Chunk *const chunks_unsorted = (Chunk *)(bb + o_chunks_u);
+  Q.aux = (QAux *)(bb + o_aux);
+
+  /* ---- the resident layout (reallocated only when it has to grow; written in full by
+          fill_tiles_kernel, padding included) ---- */
   c->ntiles = (uint32_t)ntiles;
   c->nchunks = (uint32_t)nchunks;
   c->nsmall = (uint32_t)nsmall;
-  Tmp<Chunk> chunks_unsorted;
-  if ((rc = dev_alloc(c, c->tiles, (size_t)ntiles))) return rc;
-  if ((rc = dev_alloc(c, chunks_unsorted.b, (size_t)nchunks))) return rc;
-  if ((rc = dev_alloc(c, c->chunks, (size_t)nchunks))) return rc;
-  if ((rc = dev_alloc(c, c->tile_refs, (size_t)nlist))) return rc;
-  if ((rc = dev_alloc(c, c->small_tiles, (size_t)nsmall))) return rc;
-  /* + 9 rows: verify_candidate reads nine dwords per query whatever its length */
-  if ((rc = dev_alloc(c, c->qres, (size_t)res_words + 9 * WAVE))) return rc;
-  if ((rc = dev_alloc(c, c->qrep, slots))) return rc;
-  if ((rc = dev_alloc(c, c->qlen, slots))) return rc;
-  if ((rc = dev_alloc(c, c->qorig, slots))) return rc;
-  if ((rc = dev_alloc(c, c->qrec, slots))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->qrec.p, 0, std::max<size_t>(slots, 1) * sizeof(QueryRec), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->qres.p, 0, ((size_t)res_words + 9 * WAVE) * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->qrep.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->qlen.p, 0, std::max<size_t>(slots, 1) * sizeof(uint16_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->qorig.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
-  c->qv.release(); c->qj.release(); c->qgh.release(); c->qcnt.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->cw.release(); c->cmain.release(); c->crp.release(); c->cpk.release(); c->slice_items.release();
+  if ((rc = dev_reserve(c, c->tiles, (size_t)ntiles))) return rc;
+  if ((rc = dev_reserve(c, c->chunks, (size_t)nchunks))) return rc;
+  if ((rc = dev_reserve(c, c->tile_refs, (size_t)nlist))) return rc;
+  if ((rc = dev_reserve(c, c->small_tiles, (size_t)nsmall))) return rc;
+  /* + 9 rows: slack behind the last tile for readers that fetch nine dwords per query */
+  if ((rc = dev_reserve(c, c->qres, (size_t)res_words + 9 * WAVE))) return rc;
+  if ((rc = dev_reserve(c, c->qrep, slots))) return rc;
+  if ((rc = dev_reserve(c, c->qlen, slots))) return rc;
+  if ((rc = dev_reserve(c, c->qorig, slots))) return rc;
+  if ((rc = dev_reserve(c, c->qrec, slots))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->qres.p + res_words, 0, 9 * WAVE * sizeof(uint32_t), c->stream));
   if (!c->opt.ignore_genes) {
-    if ((rc = dev_alloc(c, c->qv, slots))) return rc;
-    if ((rc = dev_alloc(c, c->qj, slots))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->qv.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->qj.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
+    if ((rc = dev_reserve(c, c->qv, slots))) return rc;
+    if ((rc = dev_reserve(c, c->qj, slots))) return rc;
+  } else {
+    c->qv.release();
+    c->qj.release();
   }
   if (!c->opt.ignore_genes || c->rows) {
-    if ((rc = dev_alloc(c, c->qgh, slots))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->qgh.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
+    if ((rc = dev_reserve(c, c->qgh, slots))) return rc;
+  } else {
+    c->qgh.release();
   }
   if (!c->opt.ignore_counts) {
-    if ((rc = dev_alloc(c, c->qcnt, slots))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->qcnt.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
+    if ((rc = dev_reserve(c, c->qcnt, slots))) return rc;
+  } else {
+    c->qcnt.release();
   }
   if (c->rows) {
-    if ((rc = dev_alloc(c, c->qck, slots))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->qck.p, 0, std::max<size_t>(slots, 1) * sizeof(uint32_t), c->stream));
-    if (c->opt.indels) {
-      if ((rc = dev_alloc(c, c->qhins, slots))) return rc;
-      if ((rc = dev_alloc(c, c->qhdel, slots))) return rc;
-      HIP_TRY(c, hipMemsetAsync(c->qhins.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->qhdel.p, 0, std::max<size_t>(slots, 1) * sizeof(uint64_t), c->stream));
-    }
+    if ((rc = dev_reserve(c, c->qck, slots))) return rc;
+  } else {
+    c->qck.release();
+  }
+  if (c->rows && c->opt.indels) {
+    if ((rc = dev_reserve(c, c->qhins, slots))) return rc;
+    if ((rc = dev_reserve(c, c->qhdel, slots))) return rc;
+  } else {
+    c->qhins.release();
+    c->qhdel.release();
   }
   if (ngroups) {
-    /* (+ 64: a block read past the last item stays inside) */
+    /* (+ 64: a block read past the last item stays inside; all ones = padding) */
     const size_t ni = (size_t)cslots + WAVE;
-    if ((rc = dev_alloc(c, c->cw, ni))) return rc;
-    if ((rc = dev_alloc(c, c->cmain, ni))) return rc;
-    if ((rc = dev_alloc(c, c->crp, ni))) return rc;
-    if (sub2_items && (rc = dev_alloc(c, c->cpk, ni))) return rc;
+    if ((rc = dev_reserve(c, c->items, ni))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->items.p, 0xff, ni * sizeof(ItemRec), c->stream));
     if (sub2_items) {
-      if ((rc = dev_alloc(c, c->slice_items, 2 * (size_t)nslices))) return rc;
-      HIP_TRY(c, hipMemsetAsync(c->slice_items.p, 0, 2 * (size_t)nslices * sizeof(uint32_t), c->stream));
+      if ((rc = dev_reserve(c, c->cpk, ni))) return rc;
+      if ((rc = dev_reserve(c, c->slice_items, 2 * (size_t)nslices_real))) return rc;
+      HIP_TRY(c, hipMemsetAsync(c->slice_items.p, 0, 2 * (size_t)nslices_real * sizeof(uint32_t), c->stream));
+    } else {
+      c->cpk.release();
+      c->slice_items.release();
     }
-    HIP_TRY(c, hipMemsetAsync(c->cw.p, 0, ni * sizeof(uint64_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->cmain.p, 0xff, ni * sizeof(uint32_t), c->stream));   /* ~0: padding */
-    HIP_TRY(c, hipMemsetAsync(c->crp.p, 0, ni * sizeof(uint32_t), c->stream));
+  } else {
+    c->items.release();
+    c->cpk.release();
+    c->slice_items.release();
   }
+  const auto t_reserved = std::chrono::steady_clock::now();
   Q.tiles = c->tiles.p;
-  Q.chunks = chunks_unsorted.b.p;
+  Q.chunks = chunks_unsorted;
   Q.tile_refs = c->tile_refs.p;
   Q.small_tiles = c->small_tiles.p;
   Q.cpk = c->cpk.p;
@@ -1382,19 +1688,22 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
   Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
-  Q.cw = c->cw.p; Q.cmain = c->cmain.p; Q.crp = c->crp.p;
+  Q.items = c->items.p;
 
-  for (uint32_t pi = 0; pi < npass; pi++) {
-    hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, pi);
+  hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
+  HIP_TRY(c, hipGetLastError());
+  if (n) {
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
   }
-  if (s->n) {
-    hipLaunchKernelGGL(place_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
+  if (ntiles) {
+    hipLaunchKernelGGL(fill_tiles_kernel, dim3((uint32_t)((ntiles + 3) / 4)), dim3(256), 0, c->stream, Q,
+                       (uint32_t)ntiles);
     HIP_TRY(c, hipGetLastError());
-    if (ngroups) {
-      hipLaunchKernelGGL(place_items_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, Q);
-      HIP_TRY(c, hipGetLastError());
-    }
+  }
+  if (n && ngroups) {
+    hipLaunchKernelGGL(place_items_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
   }
   if (ngroups) {
     hipLaunchKernelGGL(class_chunks_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q);
@@ -1402,80 +1711,63 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   }
   if (indel_passes) {
     hipLaunchKernelGGL(sibling_fill_kernel, dim3(blocks_for(G)), dim3(256), 0, c->stream, Q, G,
-                       sib_lpre.b.p, sib_fill.b.p, (uint32_t)main_list);
+                       sib_lpre, sib_fill, (uint32_t)main_list);
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(sibling_write_chunks_kernel, dim3(blocks_for(2 * nslices)), dim3(256), 0,
-                       c->stream, Q, sib_cnt.b.p, sib_lpre.b.p, sib_cpre.b.p, (uint32_t)main_list,
+                       c->stream, Q, sib_cnt, sib_lpre, sib_cpre, (uint32_t)main_list,
                        (uint32_t)main_chunks);
     HIP_TRY(c, hipGetLastError());
   }
 
-  const uint32_t wstep = (uint32_t)c->work_shard_count;
-  const uint32_t wfirst = (uint32_t)c->work_shard_index;
-  if (wfirst >= wstep)
-    return fail(c, CMPR_EINVAL, "work_shard_index must be below work_shard_count");
-  if (wstep > 1 && !c->sliced)
-    return fail(c, CMPR_EUNSUPPORTED, "work shards need a sliced layout (kernel variant 1 or 2)");
+  /* what is laid out is what this context works on -- except for variant 1 with -i,
+     where it takes its share of the full lists */
+  const bool select_share = wstep > 1 && !place_mine;
   /* ---- heaviest chunks first: the tail of the launch is made of light ones;
           single-wave tiles longest first ---- */
   if (nchunks) {
-    Tmp<uint32_t> wk, wk2, ix, ix2;
-    if ((rc = dev_alloc(c, wk.b, (size_t)nchunks))) return rc;
-    if ((rc = dev_alloc(c, wk2.b, (size_t)nchunks))) return rc;
-    if ((rc = dev_alloc(c, ix.b, (size_t)nchunks))) return rc;
-    if ((rc = dev_alloc(c, ix2.b, (size_t)nchunks))) return rc;
+    uint32_t *wk = (uint32_t *)(bb + o_wk), *wk2 = (uint32_t *)(bb + o_wk2);
+    uint32_t *ix = (uint32_t *)(bb + o_ix), *ix2 = (uint32_t *)(bb + o_ix2);
     hipLaunchKernelGGL(chunk_work_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream, Q,
-                       (uint32_t)nchunks, wk.b.p, ix.b.p);
+                       (uint32_t)nchunks, wk, ix);
     HIP_TRY(c, hipGetLastError());
-    size_t sb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sb, wk.b.p, wk2.b.p, ix.b.p, ix2.b.p,
-                                                 (int)nchunks, 0, 32, c->stream);
-    Tmp<char> st;
-    if ((rc = dev_alloc(c, st.b, sb))) return rc;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(st.b.p, sb, wk.b.p, wk2.b.p, ix.b.p,
-                                                            ix2.b.p, (int)nchunks, 0, 32, c->stream));
+    size_t sb = sort_bytes;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(bb + o_sort, sb, wk, wk2, ix, ix2, (int)nchunks, 0, 32,
+                                                            c->stream));
     uint64_t mine = nchunks;
-    const uint32_t *order = ix2.b.p;
+    const uint32_t *order = ix2;
     Tmp<uint32_t> sel;
-    if (wstep > 1) {
+    if (select_share) {
       /* the context's share of the sorted list */
-      if ((rc = select_mine(c, ix2.b.p, (uint32_t)nchunks, sel, mine, [&](unsigned char *flag) {
+      if ((rc = select_mine(c, ix2, (uint32_t)nchunks, sel, mine, [&](unsigned char *flag) {
             hipLaunchKernelGGL(chunk_mine_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream,
-                               chunks_unsorted.b.p, ix2.b.p, (uint32_t)nchunks, wfirst, wstep, flag);
+                               chunks_unsorted, ix2, (uint32_t)nchunks, wfirst, wstep, flag);
           })))
         return rc;
       order = sel.b.p;
     }
     if (mine)
       hipLaunchKernelGGL(gather_chunks_kernel, dim3(blocks_for(mine)), dim3(256), 0, c->stream,
-                         chunks_unsorted.b.p, order, (uint32_t)mine, c->chunks.p);
+                         chunks_unsorted, order, (uint32_t)mine, c->chunks.p);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (select_share)
+      HIP_TRY(c, hipStreamSynchronize(c->stream));       /* (`sel` is freed on return) */
     c->nchunks = (uint32_t)mine;
   }
   if (nsmall) {
-    Tmp<uint32_t> ln, ln2, out;
-    if ((rc = dev_alloc(c, ln.b, (size_t)nsmall))) return rc;
-    if ((rc = dev_alloc(c, ln2.b, (size_t)nsmall))) return rc;
-    if ((rc = dev_alloc(c, out.b, (size_t)nsmall))) return rc;
+    uint32_t *ln = (uint32_t *)(bb + o_ln), *ln2 = (uint32_t *)(bb + o_ln2), *out = (uint32_t *)(bb + o_sout);
     hipLaunchKernelGGL(small_len_kernel, dim3(blocks_for(nsmall)), dim3(256), 0, c->stream, Q,
-                       (uint32_t)nsmall, ln.b.p);
+                       (uint32_t)nsmall, ln);
     HIP_TRY(c, hipGetLastError());
-    size_t sb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sb, ln.b.p, ln2.b.p, c->small_tiles.p,
-                                                 out.b.p, (int)nsmall, 0, 17, c->stream);
-    Tmp<char> st;
-    if ((rc = dev_alloc(c, st.b, sb))) return rc;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(st.b.p, sb, ln.b.p, ln2.b.p,
-                                                            c->small_tiles.p, out.b.p, (int)nsmall,
-                                                            0, 17, c->stream));
+    size_t sb = small_sort_bytes;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(bb + o_ssort, sb, ln, ln2, c->small_tiles.p, out,
+                                                            (int)nsmall, 0, 17, c->stream));
     uint64_t mine = nsmall;
-    const uint32_t *keep = out.b.p;
+    const uint32_t *keep = out;
     Tmp<uint32_t> sel;
-    if (wstep > 1) {
-      if ((rc = select_mine(c, out.b.p, (uint32_t)nsmall, sel, mine, [&](unsigned char *flag) {
+    if (select_share) {
+      if ((rc = select_mine(c, out, (uint32_t)nsmall, sel, mine, [&](unsigned char *flag) {
             hipLaunchKernelGGL(small_mine_kernel, dim3(blocks_for(nsmall)), dim3(256), 0, c->stream, Q,
-                               out.b.p, (uint32_t)nsmall, wfirst, wstep, flag);
+                               out, (uint32_t)nsmall, wfirst, wstep, flag);
           })))
         return rc;
       keep = sel.b.p;
@@ -1483,9 +1775,23 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     if (mine)
       HIP_TRY(c, hipMemcpyAsync(c->small_tiles.p, keep, (size_t)mine * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (select_share)
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->nsmall = (uint32_t)mine;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto t_end = std::chrono::steady_clock::now();
+  c->layout_upload_ms = upload_ms;
+  c->layout_tail_ms = std::chrono::duration<double, std::milli>(t_end - t_uploaded).count();
+  c->layout_total_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+  if (getenv("COMPAIRR_HIP_DEBUG")) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    fprintf(stderr, "compairr_hip: set_queries %.2f ms = arena A %.2f + upload (keys hidden) %.2f + sizes %.2f + "
+                    "arena B / resident %.2f + placement %.2f  (copy calls %.2f; %zu + %zu MiB of temporaries)\n",
+            c->layout_total_ms, ms(t_begin, t_arena_a), ms(t_arena_a, t_uploaded), ms(t_uploaded, t_sizes),
+            ms(t_sizes, t_reserved), ms(t_reserved, t_end), upload_ms, cut.used >> 20, cb.used >> 20);
+  }
   return CMPR_OK;
 }

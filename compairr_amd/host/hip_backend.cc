@@ -269,15 +269,19 @@ private:
       return false;
     }
     rep.seconds_analysis = since(t0);
+    /* (the pairs pass below sizes its arrays from these counters, and a failing
+       cmpr_get_stats means the matrix itself is not to be trusted: fatal either way) */
     cmpr_stats st;
-    if (api_.get_stats(ctx, &st) == 0) {
-      rep.kernel_ms = st.kernel_ms;
-      rep.variants = st.variants;
-      rep.bloom_positive = st.bloom_positive;
-      rep.hash_equal = st.hash_equal;
-      rep.matches = st.matches;
-      rep.algorithmic_bytes = st.algorithmic_bytes;
+    if (api_.get_stats(ctx, &st)) {
+      error = api_.last_error(ctx);
+      return false;
     }
+    rep.kernel_ms = st.kernel_ms;
+    rep.variants = st.variants;
+    rep.bloom_positive = st.bloom_positive;
+    rep.hash_equal = st.hash_equal;
+    rep.matches = st.matches;
+    rep.algorithmic_bytes = st.algorithmic_bytes;
     rep.device_name = "HIP device";
     if (sh.pairs) {
       /* the matrix pass counted the pairs exactly; list them with a second pass */

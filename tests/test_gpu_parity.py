@@ -467,6 +467,111 @@ def test_repeated_launches_with_and_without_redo_pass():
             assert len(pairs) == ost.matches
 
 
+def test_overflow_without_redo_pass_is_never_silent():
+    """The no-redo shortcut of variant 2 rests on a margin argument; should it ever be
+    wrong, no entry point may hand out the incomplete matrix.  Forced here with the
+    test-only tunable `assume_never_overflows` over a 64-entry positives buffer: the
+    synchronous calls notice, repeat the step with the redo pass and return the right
+    result; after asynchronous launches cmpr_get_stats fails with CMPR_ESTATE."""
+    import torch
+    a = synth.make_set(40000, 21, prefix="A", pool_size=8000)
+    b = synth.make_set(40000, 22, prefix="B", pool_size=8000)
+    o = Options(differences=1, **FULL)
+    want, ost = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    with HipOverlap(o) as h:
+        h.set_tunable("variant", 2)
+        h.set_tunable("pos_segments", 1)
+        h.set_tunable("pos_capacity", 64)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        for launch in range(3):
+            h.set_tunable("assume_never_overflows", 1)
+            assert np.array_equal(h.overlap_matrix(), want), launch
+            assert h.get_tunable("never_overflows") == 0          # withdrawn
+            assert h.stats().matches == ost.matches
+        h.set_tunable("assume_never_overflows", 1)
+        assert np.array_equal(h.overlap_matrix_f64(), want.astype(np.float64))
+        h.set_tunable("assume_never_overflows", 1)
+        assert len(h.overlap_pairs()) == ost.matches
+        # asynchronous entry point: the launch cannot look itself, cmpr_get_stats does
+        t = torch.zeros(want.size, dtype=torch.int64, device="cuda")
+        s = torch.cuda.current_stream()
+        h.set_tunable("assume_never_overflows", 1)
+        h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)
+        h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)      # (carries no redo pass either)
+        s.synchronize()
+        with pytest.raises(hipmod.HipError) as e:
+            h.stats()
+        assert e.value.code == 5                                   # CMPR_ESTATE
+        h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)      # redo pass again: right
+        s.synchronize()
+        assert np.array_equal(t.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
+        assert h.stats().matches == ost.matches
+
+
+def test_shortcut_is_withdrawn_when_the_deal_changes():
+    """the margin was measured for one static deal of the chunks; another grid
+    (blocks_per_cu) or unstaged tiles claimed through a global counter void it."""
+    a = synth.make_set(40000, 21, prefix="A", pool_size=8000)
+    b = synth.make_set(40000, 22, prefix="B", pool_size=8000)
+    o = Options(differences=1, **FULL)
+    want, _ = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    with HipOverlap(o) as h:
+        h.set_tunable("variant", 2)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        for _ in range(4):
+            assert np.array_equal(h.overlap_matrix(), want)
+        assert h.get_tunable("never_overflows") == 1
+        h.set_tunable("blocks_per_cu", 1)
+        assert h.get_tunable("never_overflows") == 0
+        for _ in range(4):
+            assert np.array_equal(h.overlap_matrix(), want)
+    with HipOverlap(o) as h:                                        # tiles claimed one by one
+        h.set_tunable("variant", 2)
+        h.set_tunable("slice_words_log2", 3)
+        h.set_tunable("small_slice_tiles", 64)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        for _ in range(5):
+            assert np.array_equal(h.overlap_matrix(), want)
+        if h.get_tunable("small_tiles") > 0:
+            assert h.get_tunable("never_overflows") == 0
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_step_graph_and_streams(variant):
+    """The steady-state step is one hipGraph per (output matrix, counter block); launches
+    on different streams are ordered by the library.  Same matrix as the plain launches,
+    and the probe kernel's event time still comes with every step."""
+    import torch
+    a = synth.make_set(50000, 1, prefix="A")
+    b = synth.make_set(50000, 2, prefix="B")
+    o = Options(differences=1, **FULL)
+    with HipOverlap(o) as h:
+        h.set_tunable("variant", variant)
+        h.set_tunable("step_graph", 0)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        want = h.overlap_matrix()
+        assert h.get_tunable("graphs") == 0
+        h.set_tunable("step_graph", 1)
+        mats = [torch.zeros(want.size, dtype=torch.int64, device="cuda") for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for k in range(12):
+            h.overlap_matrix_device(mats[k & 1].data_ptr(), streams[(k // 3) & 1].cuda_stream)
+        torch.cuda.synchronize()
+        for m in mats:
+            assert np.array_equal(m.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
+        assert h.stats().matches > 0
+        assert 1 <= h.get_tunable("graphs") <= 4
+        k, p = h.kernel_times(6)
+        assert len(k) == 6 and all(0 < y < x for x, y in zip(k, p)), (k, p)
+        assert np.array_equal(h.overlap_matrix(), want)
+
+
 def test_debug_switches_absent_from_the_shipped_library():
     """The ablation switches (ProbeParams::debug) are compiled out of
     libcompairr_hip.so: the tunable is refused, and so are values no kernel has."""
