@@ -679,8 +679,11 @@ int make_plan(cmpr_context *c)
   S.cells = cells;
   S.ctr_blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
   S.will_launch = c->ntiles > 0 && cells > 0;
-  S.reduce_writes = S.will_launch && cells <= 2048 && !is_f64_score(c->opt);
   S.deferred = c->sliced && c->deferred_resolve;
+  /* (variant 2 resolving inline adds to the matrix where it lies: cleared before, not
+     written by the reduce kernel) */
+  const bool rows_inline = c->rows && !S.deferred;
+  S.reduce_writes = S.will_launch && cells <= 2048 && !is_f64_score(c->opt) && !rows_inline;
   S.redo_kind = c->rows && S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
   S.nw = c->sliced ? (uint32_t)c->waves_per_block : WAVES_PER_BLOCK;
   if (!S.will_launch) {
@@ -731,7 +734,7 @@ int make_plan(cmpr_context *c)
   P.R2 = c->R2;
   P.score = c->opt.score;
   P.ignore_counts = c->opt.ignore_counts;
-  P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt)) ? 1 : 0;
+  P.lds_matrix = (cells <= 2048 && !is_f64_score(c->opt) && !rows_inline) ? 1 : 0;
   P.geom = c->geom;
   P.chunks = c->chunks.p;
   P.tile_refs = c->tile_refs.p;
@@ -759,7 +762,7 @@ int make_plan(cmpr_context *c)
                                 : c->sliced ? (size_t)(zrow_stride((int)A) + zdelta_entries((int)A))
                                             : (size_t)A;
     size_t b = zrow * c->zpos * sizeof(uint64_t) +
-               (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) +
+               (P.lds_matrix && !c->rows ? cells * sizeof(unsigned long long) : 0) +
                (size_t)waves * sizeof(WaveQueue);
     if (c->rows)
       b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +

@@ -220,7 +220,10 @@ struct cmpr_context {
   StepPlan                   plan;
   static const uint32_t      NGRAPHS = 8;
   StepGraph                  graphs[NGRAPHS];
-  int64_t                    step_graph = 1;              /* tunable: 0 = plain launches only */
+  /* tunable; OFF by default: on ROCm 7.2 a replayed 3-kernel graph with its event node
+     starts ~10 us later than the same launches issued one by one (r03d: 0.133 vs 0.124 ms
+     per step at 1/8 of the work) -- the gaps of a step are the event packets, not the host */
+  int64_t                    step_graph = 0;
   hipStream_t                cap_stream = nullptr;        /* the stream the graphs are captured on */
   hipEvent_t                 ev_cap = nullptr;            /* placeholder event of a captured graph */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */

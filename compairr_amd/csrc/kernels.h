@@ -300,6 +300,7 @@ struct WaveQueue {
   uint32_t slot[QCAP];   /* query: tile * 64 + lane                          */
   uint32_t ca[QCAP];     /* kind | p1 << 3 | r1 << 24                        */
   uint32_t cb[QCAP];     /* p2 | r2 << 24                                    */
+  uint32_t m[QCAP];      /* variant 2 (kernels_rows.h q_push): the entry's mask of positive variants */
 };
 
 __device__ __forceinline__ uint32_t pack_a(uint32_t kind, uint32_t p1, uint32_t r1)

@@ -166,6 +166,123 @@ template <int A> struct RowCfg {
   static constexpr uint32_t RBITS = A == 20 ? 5u : 2u;
 };
 
+/* ------------------------------------------------------------------ */
+/* the per-wave queue of this kernel holds ENTRIES, not variants        */
+/* ------------------------------------------------------------------ */
+/*
+ * A lane that finds positives in a block of rows does not turn them into variants on
+ * the spot -- that loop ran for the whole wave whenever ONE lane had a positive bit,
+ * ~45 instructions for one or two busy lanes, on nearly every block.  It queues one
+ * ENTRY: the base hash, where the rows are, and the mask of positive variants.  When
+ * 64 entries are queued, all 64 lanes take one each, pop ONE variant from it (hash,
+ * kind | position | residue), the 64 variants leave as one block (positives buffer /
+ * inline resolve, flush_or_resolve) and the entries that still hold bits are queued
+ * again.  The expansion thus runs at full lane utilisation, once per 64 variants.
+ *
+ *   kind      hash            ca                                  cb, m
+ *   K_ROWS    query hash h    K_ROWS | p0 << 3 | rpack << 19      mask of RB rows x A residues, bit A j + v,
+ *                                                                 low half in cb, high half in m[0..27];
+ *                                                                 rpack (the query's own residues of the RB
+ *                                                                 rows, RBITS each) continues in m[28..31]
+ *   K_SUB,    the row's       kind | p << 3                       m = mask of residues v (one row: an item,
+ *   K_INS     blanked hash                                        or an insertion row)
+ *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant
+ */
+constexpr uint32_t K_ROWS = 5;
+
+template <int A, int D, bool GENES, bool INLINE>
+__device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n, bool last = false)
+{
+  constexpr uint32_t ZS = D == 2 ? 2u * A : (uint32_t)A;
+  constexpr uint32_t RBITS = RowCfg<A>::RBITS, RMASK = (1u << RBITS) - 1u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int first = W.qn - n;
+  const bool act = (int)W.lane < n;
+  const int e = first + (int)W.lane;
+  uint64_t B = 0;
+  uint32_t slot = POS_NULL_SLOT, ca = 0, cb = 0, m = 0;
+  if (act) {
+    B = W.q.hash[e];
+    slot = W.q.slot[e];
+    ca = W.q.ca[e];
+    cb = W.q.cb[e];
+    m = W.q.m[e];
+  }
+  const uint32_t kind = ca & 7u, p0 = (ca >> 3) & 0xffffu;
+  uint64_t hv = B;
+  uint32_t oca = ca, ocb = cb, ncb = cb, nm = m;
+  bool more = false;
+  if (kind == K_ROWS) {
+    uint64_t mk = ((uint64_t)(m & 0x0fffffffu) << 32) | cb;
+    const uint32_t rpack = (ca >> 19) | ((m >> 28) << 13);
+    const uint32_t idx = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
+    const uint32_t j = idx / (uint32_t)A, v = idx - j * (uint32_t)A;
+    const uint32_t p = p0 + j, r = (rpack >> (RBITS * j)) & RMASK;
+    const uint32_t za = zl_addr + ZS * p * 8u;
+    hv = B ^ lds_u64(za + r * 8u) ^ lds_u64(za + v * 8u);
+    oca = pack_a(K_SUB, p, v);
+    ocb = 0;
+    mk &= mk - 1ull;
+    more = mk != 0;
+    ncb = (uint32_t)mk;
+    nm = (m & 0xf0000000u) | (uint32_t)(mk >> 32);
+  } else if (kind == K_SUB || kind == K_INS) {
+    const uint32_t v = (uint32_t)__ffs((int)m) - 1u;
+    hv = B ^ lds_u64(zl_addr + (ZS * p0 + v) * 8u);
+    oca = pack_a(kind, p0, v);
+    ocb = 0;
+    nm = m & (m - 1u);
+    more = nm != 0;
+  }
+  /* the variants take the places of their entries and leave as one block */
+  if (act) {
+    W.q.hash[e] = hv;
+    W.q.ca[e] = oca;
+    W.q.cb[e] = ocb;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  W.qn = first;
+  if (!CMPR_DBG(W.P, DBG_SKIP_RESOLVE))
+    flush_or_resolve<GENES, INLINE>(W, first, n, last);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  /* entries with variants left queue up again */
+  more = more && act;
+  const uint64_t mm = __ballot(more);
+  if (mm) {
+    if (more) {
+      const int x = W.qn + (int)rank_below(mm);
+      W.q.hash[x] = B;
+      W.q.slot[x] = slot;
+      W.q.ca[x] = ca;
+      W.q.cb[x] = ncb;
+      W.q.m[x] = nm;
+    }
+    W.qn += __popcll(mm);
+  }
+}
+
+/* queue one entry per lane with `pos` (nbits = its positive variants, for the counters) */
+template <int A, int D, bool GENES, bool INLINE>
+__device__ __forceinline__ void q_push(SProber &W, uint32_t zl_addr, bool pos, uint64_t B, uint32_t ca,
+                                       uint32_t cb, uint32_t m, uint32_t nbits)
+{
+  const uint64_t mm = __ballot(pos);
+  if (mm) {
+    if (pos) {
+      const int e = W.qn + (int)rank_below(mm);
+      W.q.hash[e] = B;
+      W.q.slot[e] = W.qslot;
+      W.q.ca[e] = ca;
+      W.q.cb[e] = cb;
+      W.q.m[e] = m;
+      W.st.bloom_pos += nbits;
+    }
+    W.qn += __popcll(mm);
+    while (W.qn >= WAVE)
+      drain_round<A, D, GENES, INLINE>(W, zl_addr, WAVE);
+  }
+}
+
 /*
  * Chunk::pass of this kernel:
  *   0      the sequence itself + every substitution row that is not a class
@@ -194,7 +311,7 @@ template <int A> struct RowCfg {
  * works on it.
  *
  * LDS: [RING slices, rw_words x 32 B each][ZS x zpos Zobrist keys]
- *      [R1 x R2 matrix (optional)][NW WaveQueues][CR tables][heavy bitmap (-i)]
+ *      [NW WaveQueues][CR tables][heavy bitmap (-i)]
  *      [RING ring slots][RING x chunk_cap tile refs]
  */
 constexpr uint32_t RING = 4;
@@ -258,9 +375,10 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t zl_addr = RING * slice_bytes;              /* LDS address of zl */
   uint64_t *zl = (uint64_t *)(smem + zl_addr);
   const uint32_t nz = ZS * P.zpos;
-  unsigned long long *mat_all = (unsigned long long *)(zl + nz);
-  const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
-  WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
+  /* (no copy of the matrix in LDS: the fast form scores nothing -- resolve_kernel does --
+     and the form that resolves inline, the rare path, adds to the matrix where it lies;
+     the 16 KiB go to the slices) */
+  WaveQueue *queues = (WaveQueue *)(zl + nz);
   uint32_t *cr_lds = (uint32_t *)(queues + NW);
   uint32_t *hv_lds = cr_lds + MAX_CLASS_RES * A;
   RingSlot *ring = (RingSlot *)(hv_lds + (INDELS ? HEAVY_WORDS : 0u));
@@ -269,9 +387,6 @@ probe_rows_kernel(const ProbeParams P)
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT)
     zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
-  if (P.lds_matrix)
-    for (uint32_t i = threadIdx.x; i < cells; i += NT)
-      mat_all[i] = 0;
   for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += NT)
     cr_lds[i] = P.geom.ctab[P.geom.off_cr + i];
   if (INDELS)
@@ -284,7 +399,7 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t KH = P.geom.k;
   const uint32_t smask = P.geom.smask;
-  SProber W{P, (const uint64_t *)smem, queues[wave], P.lds_matrix ? mat_all : nullptr,
+  SProber W{P, (const uint64_t *)smem, queues[wave], nullptr,
             lane, 0u, 0u, 0u, smask, 0u, 0, {0ull, 0u, 0u, 0u}, 0ull};
   claim_pos_block(W);
   unsigned long long reads = 0;                   /* filter words read by this lane */
@@ -617,7 +732,12 @@ probe_rows_kernel(const ProbeParams P)
       const unsigned char *own_glob = filter + (size_t)tslice * slice_bytes;
 
       auto woff_of = [&](uint64_t Wk) -> uint32_t {
-        return (__umul24((uint32_t)(Wk >> 48), nwords) >> 16) << 5;      /* row_word() x 32 bytes */
+        /* row_word() x 32 bytes.  (The word number is kept opaque: the compiler would turn
+           (x >> 16) << 5 into (x >> 11) & ~31, which cannot merge with the base add that
+           follows -- v_lshl_add_u32 does shift and add in one instruction.) */
+        uint32_t w = __umul24((uint32_t)(Wk >> 48), nwords) >> 16;
+        asm("" : "+v"(w));
+        return w << 5;
       };
       auto word_lds = [&](uint32_t wo) -> RowWord {
         RowWord w;
@@ -664,7 +784,12 @@ probe_rows_kernel(const ProbeParams P)
       uint32_t m[MCR];
 #pragma unroll
       for (uint32_t i = 0; i < MCR; i++)
-        m[i] = class_pos(L, i, P.geom.c0);
+        m[i] = P.geom.c0 + i;                 /* (c0 + i) % L when all of them lie inside: no division */
+      if (L < P.geom.c0 + MCR) {              /* wave-uniform, rare: a tile of very short sequences */
+#pragma unroll
+        for (uint32_t i = 0; i < MCR; i++)    /* (the division runs on the vector unit: back to a scalar) */
+          m[i] = __builtin_amdgcn_readfirstlane(class_pos(L, i, P.geom.c0));
+      }
       uint64_t cpos_lo = 0, cpos_hi = 0;
       bool cpos_far = false;
 #pragma unroll
@@ -705,27 +830,16 @@ probe_rows_kernel(const ProbeParams P)
       /* queue the positives of a block of substitution rows: bit A * j + v of
          (m0, m1) <-> residue v at row j of the block; rpack holds the lanes' own
          residues of those rows */
-      auto emit_sub_rows = [&](uint64_t m0, uint64_t m1, uint32_t p0, uint32_t rpack) {
+      /* queue the positives of a block of substitution rows: bit A * j + v of m0 <->
+         residue v at row j of the block; rpack holds the lanes' own residues of those
+         rows (one entry per lane with a positive: q_push) */
+      static_assert(RB <= RPW && RB * A <= 60 && RB * RBITS <= 17, "a block of rows is one entry");
+      auto emit_sub_rows = [&](uint64_t m0, uint32_t p0, uint32_t rpack) {
         if (CMPR_DBG(P, DBG_SKIP_EMIT))
-          m0 = m1 = 0;
-        while (__ballot((m0 | m1) != 0)) {
-          const bool pos = (m0 | m1) != 0;
-          const bool first = m0 != 0;
-          const uint64_t mm = first ? m0 : m1;
-          const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
-          uint32_t j = idx / (uint32_t)A;
-          const uint32_t v = idx - j * (uint32_t)A;
-          j += (pos && !first) ? (uint32_t)RPW : 0u;
-          const uint32_t p = p0 + j;
-          const uint32_t r = (rpack >> (RBITS * j)) & RMASK;
-          const uint32_t za = zl_addr + ZS * p * 8u;
-          const uint64_t hv = h ^ lds_u64(za + r * 8u) ^ lds_u64(za + v * 8u);
-          s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB, p, v), 0);
-          if (first)
-            m0 &= m0 - 1ull;
-          else
-            m1 &= m1 - 1ull;
-        }
+          m0 = 0;
+        q_push<A, D, GENES, INLINE>(W, zl_addr, m0 != 0, h, K_ROWS | (p0 << 3) | (rpack << 19), (uint32_t)m0,
+                                    (uint32_t)(m0 >> 32) | ((rpack >> 13) << 28),
+                                    (uint32_t)__popcll((unsigned long long)m0));
       };
 
       if (tpass == 0) {
@@ -733,7 +847,7 @@ probe_rows_kernel(const ProbeParams P)
         {
           const RowWord w = fetch_own(h);
           const bool hit = ((row_bits(w, h) >> A) & 1u) != 0;
-          s_push<GENES, INLINE>(W, valid && hit, h, pack_a(K_SAME, 0, 0), 0);
+          q_push<A, D, GENES, INLINE>(W, zl_addr, valid && hit, h, pack_a(K_SAME, 0, 0), 0, 1u, 1u);
           nvar += 1;
         }
 
@@ -786,6 +900,9 @@ probe_rows_kernel(const ProbeParams P)
                 for (uint32_t j = 0; j < (uint32_t)RB; j++)
                   cbits |= is_class_pos(p0 + j) ? (1u << j) : 0u;
             }
+            /* (wave-uniform, but the bit set may live in vector registers: the rows test it
+               with scalar instructions) */
+            cbits = __builtin_amdgcn_readfirstlane(cbits);
             uint64_t m0 = 0, m1 = 0;
             uint32_t rpack = 0;
             uint64_t Wk[RB];
@@ -795,7 +912,10 @@ probe_rows_kernel(const ProbeParams P)
             for (int j = 0; j < RB; j++) {
               rj[j] = (uint32_t)(rr >> (8 * j)) & 31u;
               rpack |= (rj[j] & RMASK) << (RBITS * j);
-              Wk[j] = lds_u64(zl_addr + (ZS * (p0 + (uint32_t)j) + rj[j]) * 8u);
+              /* (the row's base address as ONE scalar: residue << 3 + base is one instruction) */
+              uint32_t zrow = zl_addr + ZS * 8u * (p0 + (uint32_t)j);
+              asm("" : "+s"(zrow));
+              Wk[j] = lds_u64(zrow + rj[j] * 8u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -812,10 +932,13 @@ probe_rows_kernel(const ProbeParams P)
               if (j + 1 < RB)
                 wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
               __builtin_amdgcn_sched_barrier(0);
-              uint32_t x = row_bits(wc, Wk[j]) & AMASK & ~(1u << rj[j]);
-              const bool live = (p < Ll) & !((cbits >> j) & 1u);
+              /* (a class position of a heavy tile: no residue of the row counts -- a scalar
+                 select, so that the lane's own length is the only vector test of the row) */
+              const uint32_t am = ((cbits >> j) & 1u) ? 0u : AMASK;
+              uint32_t x = row_bits(wc, Wk[j]) & am & ~(1u << rj[j]);
+              const bool live = p < Ll;
               x = live ? x : 0u;
-              nlive += live ? 1u : 0u;
+              nlive += (live && am) ? 1u : 0u;
               if (j < RPW)
                 m0 |= (uint64_t)x << (A * j);
               else
@@ -824,7 +947,7 @@ probe_rows_kernel(const ProbeParams P)
             }
             nrows += (uint32_t)RB;
             PT_MARK(PT_ROWS);
-            emit_sub_rows(m0, m1, p0, rpack);
+            emit_sub_rows(m0 | m1, p0, rpack);
             PT_MARK(PT_EMIT);
           }
           };
@@ -904,7 +1027,7 @@ probe_rows_kernel(const ProbeParams P)
                   /* (position, residue) pairs in increasing position order */
                   const uint32_t p1 = swap ? e : b, r1 = swap ? wres : v;
                   const uint32_t p2 = swap ? b : e, r2 = swap ? v : wres;
-                  s_push<GENES, INLINE>(W, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24));
+                  q_push<A, D, GENES, INLINE>(W, zl_addr, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24), 1u, 1u);
                   if (first)
                     m0 &= m0 - 1ull;
                   else
@@ -952,14 +1075,12 @@ probe_rows_kernel(const ProbeParams P)
             const uint32_t bits = row_bits(w, iw);
             uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << icr)) & (ival ? ~0u : 0u);
             nvar += !ival ? 0u : kind == K_DEL ? 1u : (icr == 31u ? (uint32_t)A : (uint32_t)(A - 1));
-            const uint32_t za = zl_addr + ZS * p * 8u;
-            while (__ballot(x != 0)) {
-              const bool pos = x != 0;
-              const uint32_t v = (pos && kind != K_DEL) ? (uint32_t)__ffs((int)x) - 1u : 0u;
-              const uint64_t hv = kind == K_DEL ? iw : iw ^ lds_u64(za + v * 8u);
-              s_push<GENES, INLINE>(W, pos, hv, pack_a(kind, p, v), 0);
-              x &= x - 1u;
-            }
+            /* one entry per item with positives: a row (K_SUB, K_INS: blanked hash + mask of
+               residues) or the deletion variant itself */
+            if (CMPR_DBG(P, DBG_SKIP_EMIT))
+              x = 0;
+            q_push<A, D, GENES, INLINE>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
+                                        (uint32_t)__popc(x));
             /* next block's data moves up */
             iw = ea[0];
             im = eb[0];
@@ -1033,7 +1154,7 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t md[MCR], lo[MCR], hi[MCR];
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++) {
-            md[i] = class_pos(L - 1, i, P.geom.c0);
+            md[i] = __builtin_amdgcn_readfirstlane(class_pos(L - 1, i, P.geom.c0));
             lo[i] = hi[i] = 0;
             if (i < KH) {
               lo[i] = cr_lds[i * A + res_reg(md[i])] & hvy;        /* t[md] = q[md],     md < p  */
@@ -1120,7 +1241,7 @@ probe_rows_kernel(const ProbeParams P)
                 const uint32_t r = res_reg(pp);
                 if (pp > 0 && r != g)
                   hr ^= zl[ZS * (pp - 1) + g] ^ zl[ZS * (pp - 1) + r];
-                s_push<GENES, INLINE>(W, (mask >> (pp - p0)) & 1u, hr, pack_a(K_DEL, pp, 0), 0);
+                q_push<A, D, GENES, INLINE>(W, zl_addr, (mask >> (pp - p0)) & 1u, hr, pack_a(K_DEL, pp, 0), 0, 1u, 1u);
                 g = r;
               }
             }
@@ -1139,7 +1260,7 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t mi[MCR], lo[MCR], hi[MCR];
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++) {
-            mi[i] = class_pos(L + 1, i, P.geom.c0);
+            mi[i] = __builtin_amdgcn_readfirstlane(class_pos(L + 1, i, P.geom.c0));
             lo[i] = hi[i] = 0;
             if (i < KH) {
               if (mi[i] < L)
@@ -1244,25 +1365,14 @@ probe_rows_kernel(const ProbeParams P)
               }
               wc = wn;
             }
-            while (__ballot((m0 | m1) != 0)) {
-              const bool pos = (m0 | m1) != 0;
-              const bool first = m0 != 0;
-              const uint64_t mm = first ? m0 : m1;
-              const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
-              uint32_t j = idx / (uint32_t)A;
-              const uint32_t v = idx - j * (uint32_t)A;
-              j += (pos && !first) ? (uint32_t)RPW : 0u;
-              uint64_t hw = hrow[0];
+            /* one entry per row with positives: the gap hash + the mask of residues */
+            if (__ballot((m0 | m1) != 0)) {
 #pragma unroll
-              for (int jj = 1; jj < RB; jj++)
-                hw = j == (uint32_t)jj ? hrow[jj] : hw;
-              const uint32_t ip = ip0 + j;
-              const uint64_t hv = hw ^ lds_u64(zl_addr + (ZS * ip + v) * 8u);
-              s_push<GENES, INLINE>(W, pos, hv, pack_a(K_INS, ip, v), 0);
-              if (first)
-                m0 &= m0 - 1ull;
-              else
-                m1 &= m1 - 1ull;
+              for (int j = 0; j < RB; j++) {
+                const uint32_t xj = (uint32_t)((j < RPW ? m0 >> (A * j) : m1 >> (A * (j - RPW)))) & AMASK;
+                q_push<A, D, GENES, INLINE>(W, zl_addr, xj != 0, hrow[j], pack_a(K_INS, ip0 + (uint32_t)j, 0), 0,
+                                            xj, (uint32_t)__popc(xj));
+              }
             }
           }
         }
@@ -1290,9 +1400,12 @@ probe_rows_kernel(const ProbeParams P)
     PT_MARK(PT_CLAIM);
   }
 
-  /* leftovers: fewer than 64 entries */
+  /* leftovers: fewer than 64 entries at a time, until every entry is empty; then the
+     block of the positives buffer that was claimed ahead goes back as a block of nulls */
+  while (W.qn > 0)
+    drain_round<A, D, GENES, INLINE>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_or_resolve<GENES, INLINE>(W, 0, W.qn, true);
+  flush_or_resolve<GENES, INLINE>(W, 0, 0, true);
   PT_MARK(PT_TAIL);
   PT_FLUSH;
 
@@ -1309,14 +1422,6 @@ probe_rows_kernel(const ProbeParams P)
     }
   }
 
-  if (P.lds_matrix) {
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cells; i += NT) {
-      const unsigned long long x = mat_all[i];
-      if (x)
-        atomicAdd(matrix_dst(P) + i, x);
-    }
-  }
 }
 
 }  // namespace cmpr

@@ -162,7 +162,7 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n, b
     } else {
       if (W.lane == 0) {
         atomicMax(ctr + 1, ~base);
-        if (!FALLBACK)
+        if (!FALLBACK && n > 0)               /* (an empty block that does not fit loses nothing) */
           atomicOr(P.overflow, 1ull);
       }
       inline_resolve = FALLBACK;

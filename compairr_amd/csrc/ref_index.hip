@@ -190,8 +190,9 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
   if (c->sliced) {
     const size_t zrow = c->rows ? 2 * (size_t)A : (size_t)(zrow_stride((int)A) + zdelta_entries((int)A));
     /* everything but the slice(s), with the fewest waves a workgroup may have */
+    /* (variant 2 keeps no copy of the matrix in LDS) */
     const size_t fixed = zrow * c->zpos * sizeof(uint64_t) +
-                         4 * sizeof(WaveQueue) + 2048 * sizeof(unsigned long long) +
+                         4 * sizeof(WaveQueue) + (c->rows ? 0 : 2048 * sizeof(unsigned long long)) +
                          MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
                          64 * sizeof(TileRef) + (c->rows ? RING * (sizeof(RingSlot) + 64 * sizeof(TileRef)) : 0);
     if (c->rows && c->slice_words_log2 < 0) {

@@ -552,7 +552,6 @@ def test_step_graph_and_streams(variant):
     o = Options(differences=1, **FULL)
     with HipOverlap(o) as h:
         h.set_tunable("variant", variant)
-        h.set_tunable("step_graph", 0)
         h.set_reference(b, a.longest)
         h.set_queries(a)
         want = h.overlap_matrix()

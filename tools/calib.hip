@@ -56,12 +56,15 @@ __global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *cyc,
    waves per SIMD) and the grid holds 8 x as many workgroups as fit at once, so that
    an uneven first placement evens out. */
 enum { C_XOR = 0, C_AND_OR, C_ALIGNBIT, C_FMA, C_PK_FMA, C_MUL_HI, C_MUL_U24, C_LSHL64, C_CNDMASK,
-       C_MAD_U24, C_BFE, C_MIX_XOR_ANDOR, C_MIX_ROWBITS, C_ADD3, C_COUNT };
+       C_MAD_U24, C_BFE, C_MIX_XOR_ANDOR, C_MIX_ROWBITS, C_ADD3, C_LSHR, C_MOV, C_CMP_CNDMASK, C_BITOP3,
+       C_LSHL_ADD, C_MUL_U24_SDWA, C_COUNT };
 static const char *const class_names[C_COUNT] = {
     "v_xor_b32 (VOP2)", "v_and_or_b32 (VOP3)", "v_alignbit_b32 (VOP3)", "v_fma_f32 (VOP3)", "v_pk_fma_f32",
     "v_mul_hi_u32", "v_mul_u32_u24 (VOP2)", "v_lshlrev_b64", "v_cndmask_b32 (VOP2, vcc)", "v_mad_u32_u24 (VOP3)",
     "v_bfe_u32 (VOP3)", "mix: v_xor_b32 + v_and_or_b32", "mix: 8 v_alignbit_b32 + 7 v_and_b32 + v_xor_b32 (row_bits)",
-    "v_add3_u32 (VOP3)"};
+    "v_add3_u32 (VOP3)", "v_lshrrev_b32 (VOP2)", "v_mov_b32 (VOP1)",
+    "pair: v_cmp_lt_u32_e64 + v_cndmask_b32_e64 (SGPR mask)", "v_bitop3_b32 (VOP3)", "v_lshl_add_u32 (VOP3)",
+    "v_mul_u32_u24_sdwa (WORD_1)"};
 
 template <int CLS>
 __global__ void __launch_bounds__(256) valu_class_kernel(uint32_t *out, uint64_t *cyc, int iters)
@@ -114,6 +117,25 @@ __global__ void __launch_bounds__(256) valu_class_kernel(uint32_t *out, uint64_t
           asm volatile("v_bfe_u32 %0, %1, %2, %3" : "=v"(a[k]) : "v"(a[k]), "v"(sh), "v"(c));
         else if (CLS == C_ADD3)
           asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a[k]) : "v"(a[k]), "v"(m), "v"(c));
+        else if (CLS == C_LSHR)
+          asm volatile("v_lshrrev_b32_e32 %0, 1, %1" : "=v"(a[k]) : "v"(a[k]));
+        else if (CLS == C_MOV)
+          asm volatile("v_mov_b32_e32 %0, %1" : "=v"(a[k]) : "v"(a[(k + 1) & 15]));
+        else if (CLS == C_CMP_CNDMASK) {
+          unsigned long long sm;
+          if (k & 1)
+            asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(sm) : "v"(a[k]), "v"(m));
+          else
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[k]) : "v"(a[k]), "v"(m), "s"((unsigned long long)c));
+          if (k & 1)
+            asm volatile("" :: "s"(sm));
+        } else if (CLS == C_BITOP3)
+          asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80" : "=v"(a[k]) : "v"(a[k]), "v"(m), "v"(c));
+        else if (CLS == C_LSHL_ADD)
+          asm volatile("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(a[k]) : "v"(a[k]), "v"(m));
+        else if (CLS == C_MUL_U24_SDWA)
+          asm volatile("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
+                       "src1_sel:WORD_1" : "=v"(a[k]) : "v"(m), "v"(a[k]));
         else if (CLS == C_MIX_XOR_ANDOR) {
           if (k & 1)
             asm volatile("v_xor_b32_e32 %0, %1, %2" : "=v"(a[k]) : "v"(m), "v"(a[k]));
@@ -285,7 +307,7 @@ int main()
 #define CASE(C) case C: launch_class<C>(grid, lds, d_out, d_cyc, iters); break;
           CASE(C_XOR) CASE(C_AND_OR) CASE(C_ALIGNBIT) CASE(C_FMA) CASE(C_PK_FMA) CASE(C_MUL_HI) CASE(C_MUL_U24)
           CASE(C_LSHL64) CASE(C_CNDMASK) CASE(C_MAD_U24) CASE(C_BFE) CASE(C_MIX_XOR_ANDOR) CASE(C_MIX_ROWBITS)
-          CASE(C_ADD3)
+          CASE(C_ADD3) CASE(C_LSHR) CASE(C_MOV) CASE(C_CMP_CNDMASK) CASE(C_BITOP3) CASE(C_LSHL_ADD) CASE(C_MUL_U24_SDWA)
 #undef CASE
           }
         };
