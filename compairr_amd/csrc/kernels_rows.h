@@ -1402,10 +1402,34 @@ probe_rows_kernel(const ProbeParams P)
 
   /* leftovers: fewer than 64 entries at a time, until every entry is empty; then the
      block of the positives buffer that was claimed ahead goes back as a block of nulls */
-  while (W.qn > 0)
-    drain_round<A, D, GENES, INLINE>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_or_resolve<GENES, INLINE>(W, 0, 0, true);
+  /* (the rounds this takes = the most variants any entry still holds; their blocks of the
+     positives buffer are claimed with ONE atomic now, not one per round, each waiting
+     for the answer of the one before: at the end of the kernel every wave is here) */
+  {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t bits = 0;
+    if ((int)lane < W.qn) {
+      const uint32_t ca = W.q.ca[lane], kind = ca & 7u, m = W.q.m[lane];
+      bits = kind == K_ROWS ? (uint32_t)__popc(W.q.cb[lane]) + (uint32_t)__popc(m & 0x0fffffffu)
+                            : (kind == K_SUB || kind == K_INS) ? (uint32_t)__popc(m) : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+      bits = max(bits, (uint32_t)__shfl_xor((int)bits, off, WAVE));
+    const uint32_t rounds = __builtin_amdgcn_readfirstlane(bits);
+    unsigned long long extra = 0;
+    if (P.pos_buf != nullptr && rounds > 1u && lane == 0)
+      extra = atomicAdd(P.pos_ctr + (size_t)(blockIdx.x & (P.pos_segments - 1)) * POS_CTR_STRIDE,
+                        (unsigned long long)(rounds - 1u) * WAVE);
+    for (uint32_t r = 0; r < rounds; r++) {
+      if (r >= 1u)
+        W.held = extra + (unsigned long long)(r - 1u) * WAVE;      /* (lane 0's is the one read) */
+      drain_round<A, D, GENES, INLINE>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE, true);
+    }
+    if (rounds == 0u) {               /* the block claimed ahead goes back as a block of nulls */
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      flush_or_resolve<GENES, INLINE>(W, 0, 0, true);
+    }
+  }
   PT_MARK(PT_TAIL);
   PT_FLUSH;
 

@@ -8,8 +8,9 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
+python3 $R/tools/csrc_hash.py > $O/csrc_sha256.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err
+timeout 900 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o p --output-format csv -- \
     python3 $R/bench.py --cpu-sample -1 "$@" > $O/stats_bench.json 2> $O/stats.err
 i=0
