@@ -72,6 +72,9 @@ def parse_args():
     p.add_argument("--ignore-genes", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=0,
                    help="queries in the CPU-baseline sample (0 = auto, -1 = skip)")
+    p.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto",
+                   help="CPU baseline: the reference binary (oracle/_ref, fed TSV files) or the oracle "
+                        "port (oracle/liboracle.so, sets in memory); auto = the binary when present")
     p.add_argument("--self", dest="self_cmp", action="store_true",
                    help="one-file mode: the queries are the reference set itself")
     p.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE")
@@ -106,7 +109,7 @@ def cpu_baseline(ref, queries, opt, sample, args):
     threads = max(1, min(cores, 256))           # the reference caps -t at 256
     q = queries.subset(slice(0, sample))
     exe = os.path.join(ROOT, "oracle", "_ref", "compairr")
-    if os.path.exists(exe):
+    if os.path.exists(exe) and args.cpu_kind != "port":
         import re
         import subprocess
         import tempfile
@@ -146,29 +149,34 @@ def cpu_baseline(ref, queries, opt, sample, args):
             _oracle.integer_cells(m, opt).astype(np.float64), q, None)
 
 
-def roofline(workload, st, probe_ms, kernel_ms):
-    """The dominant kernel (the probe kernel) against the unit that binds it.
+def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
+    """The probe kernel (the step's dominant kernel) against the unit that binds it.
 
-    Per-launch work of each unit comes from the committed rocprofv3 counter summary
-    of this workload (profiles/roofline_inputs.json, written by tools/pmc_summary.py:
-    wave-level VALU / SALU instructions, LDS-array cycles, HBM bytes per the guide's
-    FETCH_SIZE / WRITE_SIZE recipe); the unit rates are the calibrated ones of
-    profiles/*/calibration.json (tools/calib.hip, same chip); the time is the live
-    HIP-event time of the kernel.  `bound` is the unit with the highest utilisation,
-    `frac` that utilisation (<= 1).  `algorithmic_equiv` keeps SURVEY 8d's figure
-    (8 bytes per variant, as the reference reads its filter) for comparison with
-    round 1: it is not a physical rate -- this kernel answers a row of variants
-    with one LDS read."""
+    Per-launch work of each unit at N = 1 comes from the committed rocprofv3 counter
+    summary of THIS workload (profiles/roofline_inputs.json, one entry per workload,
+    written by tools/pmc_summary.py: wave-level VALU instructions, LDS-array cycles, HBM
+    bytes per the guide's FETCH_SIZE / WRITE_SIZE recipe), scaled by this rank's share
+    of the step (live filter reads / the profile's: 1 at N = 1, ~1/N for a shard);
+    the time is the live HIP-event time of the kernel.  Peaks: HBM 8 TB/s; LDS one array
+    cycle per CU and clock; VALU = SIMDs x nominal clock / the calibrated issue cost of the
+    kernel's own instruction mix (tools/calib.hip per instruction class -- plain VOP1/VOP2
+    and v_bitop3 issue every ~2.2 cycles per wave64 at >= 4 waves per SIMD, v_alignbit,
+    multiplies, 64-bit shifts and most three-operand VOP3 every ~4.1 -- weighted by
+    tools/isa_mix.py over the kernel's ISA).  `bound` is the unit with the highest
+    utilisation, `frac` that utilisation.  `counters_stale` says the library sources
+    have changed since the counters were taken.  `algorithmic_equiv` keeps SURVEY 8d's
+    figure (8 bytes per variant, as the reference reads its filter): not a physical
+    rate -- this kernel answers a row of variants with one LDS read."""
     t = probe_ms * 1e-3
     out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-           "traffic": None, "kernel": "probe_rows_kernel",
+           "traffic": None, "kernel": kernel_name,
            "kernel_ms": probe_ms, "step_kernels_ms": kernel_ms,
            "resolve_kernel_ms": kernel_ms - probe_ms,
            "algorithmic_bytes_per_launch": st.algorithmic_bytes,
            "algorithmic_equiv": {"GB/s": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,
                                  "of_hbm_peak": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "note": "SURVEY 8d bytes (8 B per variant) / probe + resolve time; "
-                                         "exceeds 1 because variants are not answered by HBM reads"},
+                                         "exceeds 1 where variants are not answered by HBM reads"},
            "variants_per_launch": st.variants, "filter_reads_per_launch": st.filter_reads,
            "bloom_positive_per_launch": st.bloom_positive, "pairs_per_launch": st.matches}
     path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
@@ -177,36 +185,43 @@ def roofline(workload, st, probe_ms, kernel_ms):
             inp = json.load(fh)
     except Exception:
         inp = None
-    if not inp or inp.get("workload") != workload:
+    k = (inp or {}).get("workloads", {}).get(workload)
+    if not k:
         out["note"] = "no committed counter summary for this workload: utilisation not priced"
         return out
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+    out["counters_stale"] = bool(inp.get("csrc_sha256") != csrc_hash(ROOT))
     cal = inp["calibration"]
-    k = inp["probe_kernel"]
+    share = 1.0
+    if k.get("filter_reads") and st.filter_reads:
+        share = st.filter_reads / k["filter_reads"]
     units = {}
     if k.get("valu_insts"):
-        peak = cal["valu_wave_insts_per_s"]
-        units["valu"] = (k["valu_insts"] / t, peak, "wave-instructions/s")
+        cyc = k.get("mix_cycles_per_valu_inst") or cal["valu_cycles_slow"]
+        peak = cal["simds"] * cal["nominal_clock_hz"] / cyc
+        units["valu"] = (k["valu_insts"] * share / t, peak, "wave-instructions/s")
     if k.get("lds_active_cycles"):
-        peak = cal["lds_cycles_per_s"]
-        units["lds"] = (k["lds_active_cycles"] / t, peak, "LDS-array cycles/s")
-    if k.get("salu_insts"):
-        peak = cal["salu_insts_per_s"]
-        units["salu"] = (k["salu_insts"] / t, peak, "scalar instructions/s")
+        peak = cal["cus"] * (k.get("effective_clock_hz") or cal["nominal_clock_hz"])
+        units["lds"] = (k["lds_active_cycles"] * share / t, peak, "LDS-array cycles/s")
     if k.get("hbm_bytes"):
-        units["hbm"] = (k["hbm_bytes"] / t / 1e9, HBM_PEAK_GBS, "GB/s")
-        out["traffic"] = k["hbm_bytes"]
+        units["hbm"] = (k["hbm_bytes"] * share / t / 1e9, HBM_PEAK_GBS, "GB/s")
+        out["traffic"] = k["hbm_bytes"] * share
     if not units:
         return out
     best = max(units, key=lambda u: units[u][0] / units[u][1])
     a, p, unit = units[best]
     out.update({"bound": best, "achieved": a, "peak": p, "unit": unit, "frac": a / p,
                 "utilisation": {u: v[0] / v[1] for u, v in units.items()},
-                # SQ_ACTIVE_INST_* / SQ_BUSY_CU_CYCLES of the committed profile run (not live)
+                "share_of_the_profiled_launch": share,
+                "valu_issue_cycles_per_instruction": k.get("mix_cycles_per_valu_inst"),
+                # SQ_ACTIVE_INST_* / SQ_BUSY_CU_CYCLES of the committed profile run (not live):
+                # vector instructions per CU cycle -- 1.0 = one per SIMD every 4 cycles
                 "busy_fraction_from_counters": k.get("busy_fraction_from_counters"),
-                "counters_from": inp.get("source"),
-                "note": "achieved = per-launch work of the binding unit (committed rocprofv3 PMC "
-                        "summary of this workload) / live HIP-event time of the probe kernel; peak = "
-                        "the calibrated rate of that unit (tools/calib.hip)"})
+                "counters_from": k.get("source"),
+                "note": "achieved = per-launch work of the binding unit (committed rocprofv3 PMC summary "
+                        "of this workload x this rank's share) / live HIP-event time of the probe kernel; "
+                        "peak: see bench.py roofline()"})
     return out
 
 
@@ -407,7 +422,8 @@ def main():
             # of the queries (once per query set) + one step
             "value_incl_layout": total_queries / (t_layout + elapsed / args.steps),
             "parity_vs_n1": parity_vs_n1,
-            "roofline": roofline(wl, st, p_avg_ms, k_avg_ms),
+            "roofline": roofline(wl, st, p_avg_ms, k_avg_ms,
+                                 {0: "probe_kernel", 1: "probe_sliced_kernel", 2: "probe_rows_kernel"}[layout["variant"]]),
             "cpu_baseline": baseline,
             "parity_on_cpu_sample": parity,
         }

@@ -140,7 +140,8 @@ struct BuildParams {
   uint64_t       *bloom;           /* NULL: build the table only            */
   uint32_t        bloom_byte_mask;
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
-  uint32_t        pad[2];
+  uint32_t        indels;          /* row filter: also the gap entries (kernels_rows.h) */
+  uint32_t        pad;
   SliceGeom       geom;
 };
 

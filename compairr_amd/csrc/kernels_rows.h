@@ -26,8 +26,12 @@
  * The same entries serve the other variant kinds: an insertion variant of q
  * (v put in front of position ip) blanked at ip IS q with a gap at ip, so the
  * row of all A insertions at ip is one read under the rolling gap hash
- * (variants.cc:329-353); a deletion variant is a whole sequence, looked up by its
- * code-A entry (variants.cc:301-325); a double substitution (p, q) is read as
+ * (variants.cc:329-353).  A deletion variant (variants.cc:301-325) costs no read at
+ * all: with -i every set-2 sequence t is also entered once per GAP position ip, under
+ * the hash of "t with a blank put in front of position ip" and code A + 1 -- and q
+ * with position p blanked IS (q without p) with a blank in front of p, so the word
+ * already read for the substitution row of p answers "q without p" in bit A + 1
+ * (round 3; before, one word read per deletion variant).  A double substitution (p, q) is read as
  * row p of "q already substituted at q" (variants.cc:370-399): A-1 reads instead
  * of (A-1)^2 probes.  Bloom positives are queued with their full variant hash
  * exactly as in the other kernels, so everything behind the filter
@@ -152,6 +156,40 @@ build_rows_kernel(const BuildParams B)
         }
     enter(h ^ B.zob[B.A * p + s[p]], s[p], row_slice(g, key, ci));
   }
+  if (!B.indels)
+    return;
+  /* the gap entries: u = t with a blank in front of position ip (length L + 1), for
+     ip = 0 .. L, filed like any blanked row of a sequence of length L + 1 -- class
+     residues at the positions of that length, taken around the gap (with -i the class
+     keys carry no length term: the base key, and with it "heavy", is t's own) */
+  uint64_t hg = 0;                               /* hash of u: blank at 0 = everything shifted by one */
+  if (B.use_genes) {
+    const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+    hg = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+  }
+  for (uint32_t p = 0; p < L; p++)
+    hg ^= B.zob[B.A * (p + 1) + s[p]];
+  uint32_t base = ck;                            /* class key without the class residues */
+  if (heavy)
+    for (uint32_t k = 0; k < g.k; k++)
+      base ^= g.ctab[g.off_cr + k * B.A + s[class_pos(L, k, g.c0)]];
+  for (uint32_t ip = 0; ip <= L; ip++) {
+    if (ip > 0)                                  /* t[ip - 1] moves from position ip to ip - 1 */
+      hg ^= B.zob[B.A * ip + s[ip - 1]] ^ B.zob[B.A * (ip - 1) + s[ip - 1]];
+    uint32_t key = base;
+    int ci = -1;
+    if (heavy)
+      for (uint32_t k = 0; k < g.k; k++) {
+        const uint32_t mk = class_pos(L + 1, k, g.c0);
+        if (mk == ip) {
+          if (ci < 0)
+            ci = (int)k;
+        } else {
+          key ^= g.ctab[g.off_cr + k * B.A + s[mk < ip ? mk : mk - 1]];
+        }
+      }
+    enter(hg, B.A + 1u, row_slice(g, key, ci));
+  }
 }
 
 /* ------------------------------------------------------------------ */
@@ -184,11 +222,16 @@ template <int A> struct RowCfg {
  *                                                                 low half in cb, high half in m[0..27];
  *                                                                 rpack (the query's own residues of the RB
  *                                                                 rows, RBITS each) continues in m[28..31]
+ *   K_INSROWS gap hash of     K_INSROWS | ip0 << 3 | rroll << 19  the same layout; rroll = the residues
+ *             the first row                                       q[ip0] .. q[ip0 + RB - 2] that roll the gap hash
  *   K_SUB,    the row's       kind | p << 3                       m = mask of residues v (one row: an item,
  *   K_INS     blanked hash                                        or an insertion row)
- *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant
+ *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant (K_DEL with
+ *                                                                 m = DEL_LAZY: hash worked out in the drain)
  */
 constexpr uint32_t K_ROWS = 5;
+constexpr uint32_t K_INSROWS = 6;        /* a block of insertion rows of one query (-i) */
+constexpr uint32_t DEL_LAZY = 2;         /* m of a K_DEL entry whose hash is worked out when it is drained */
 
 template <int A, int D, bool GENES, bool INLINE>
 __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n, bool last = false)
@@ -226,6 +269,26 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     more = mk != 0;
     ncb = (uint32_t)mk;
     nm = (m & 0xf0000000u) | (uint32_t)(mk >> 32);
+  } else if (kind == K_INSROWS) {
+    /* RB insertion rows from ip0 on: the gap hash of row j is that of row j - 1 with
+       q[ip0 + j - 1] moved one position down (variants.cc:329-353) */
+    uint64_t mk = ((uint64_t)(m & 0x0fffffffu) << 32) | cb;
+    const uint32_t rroll = (ca >> 19) | ((m >> 28) << 13);
+    const uint32_t idx = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
+    const uint32_t j = idx / (uint32_t)A, v = idx - j * (uint32_t)A;
+    uint64_t hg = B;
+#pragma unroll 1
+    for (uint32_t i = 1; i <= j; i++) {
+      const uint32_t r = (rroll >> (RBITS * (i - 1u))) & RMASK;
+      hg ^= lds_u64(zl_addr + (ZS * (p0 + i - 1u) + r) * 8u) ^ lds_u64(zl_addr + (ZS * (p0 + i) + r) * 8u);
+    }
+    hv = hg ^ lds_u64(zl_addr + (ZS * (p0 + j) + v) * 8u);
+    oca = pack_a(K_INS, p0 + j, v);
+    ocb = 0;
+    mk &= mk - 1ull;
+    more = mk != 0;
+    ncb = (uint32_t)mk;
+    nm = (m & 0xf0000000u) | (uint32_t)(mk >> 32);
   } else if (kind == K_SUB || kind == K_INS) {
     const uint32_t v = (uint32_t)__ffs((int)m) - 1u;
     hv = B ^ lds_u64(zl_addr + (ZS * p0 + v) * 8u);
@@ -233,6 +296,26 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     ocb = 0;
     nm = m & (m - 1u);
     more = nm != 0;
+  } else if (kind == K_DEL && m == DEL_LAZY && act) {
+    /* "the query without position p0", from its first-deleted hash and its residues
+       (zobrist_hash_delete_first + the rolling update, variants.cc:301-325) */
+    const ProbeParams &P = W.P;
+    uint64_t hd = P.qhdel[slot];
+    const QueryRec *qr = P.qrec + slot;
+    const uint32_t *far = P.qres + P.tiles[slot >> 6].res_base + (slot & 63u);
+    auto res_of = [&](uint32_t y) -> uint32_t {
+      const uint32_t w = y < 36u ? qr->res[y >> 2] : far[(size_t)(y >> 2) * WAVE];
+      return (w >> ((y & 3u) * 8u)) & 0xffu;
+    };
+    uint32_t prev = res_of(0);
+#pragma unroll 1
+    for (uint32_t y = 1; y <= p0; y++) {
+      const uint32_t r = res_of(y);
+      if (r != prev)
+        hd ^= lds_u64(zl_addr + (ZS * (y - 1u) + prev) * 8u) ^ lds_u64(zl_addr + (ZS * (y - 1u) + r) * 8u);
+      prev = r;
+    }
+    hv = hd;
   }
   /* the variants take the places of their entries and leave as one block */
   if (act) {
@@ -867,6 +950,15 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
           uint32_t nlive = 0;                     /* rows of this lane that count (x A - 1 variants) */
           uint32_t nrows = 0;                     /* rows read (wave-uniform) */
+          /* -i: the word of row p also answers "q without p" (bit A + 1: the gap entries of
+             build_rows_kernel).  Rolling with the rows: hd = hash of q without the position at
+             hand (zobrist_hash_delete_first and the update of variants.cc:301-325), zprev = key
+             of the previous position's own residue, rprev that residue (a deletion variant
+             exists once per run of equal residues: at its first position). */
+          uint64_t hd = 0, zprev = 0;
+          uint32_t rprev = 31u, ndel = 0;
+          if (INDELS && valid)
+            hd = P.qhdel[W.qslot];
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += RB) {
@@ -905,8 +997,9 @@ probe_rows_kernel(const ProbeParams P)
             cbits = __builtin_amdgcn_readfirstlane(cbits);
             uint64_t m0 = 0, m1 = 0;
             uint32_t rpack = 0;
-            uint64_t Wk[RB];
+            uint64_t Wk[RB], zm[RB], hdj[RB];
             uint32_t rj[RB], wo[RB];
+            uint32_t dm = 0;                      /* -i: rows whose deletion variant is Bloom-positive */
             /* the rows' own keys, all RB reads in flight together ... */
 #pragma unroll
             for (int j = 0; j < RB; j++) {
@@ -916,10 +1009,24 @@ probe_rows_kernel(const ProbeParams P)
               uint32_t zrow = zl_addr + ZS * 8u * (p0 + (uint32_t)j);
               asm("" : "+s"(zrow));
               Wk[j] = lds_u64(zrow + rj[j] * 8u);
+              if (INDELS) {                       /* key of this row's residue one position down */
+                zm[j] = 0;
+                if (p0 + (uint32_t)j > 0u) {
+                  uint32_t zdown = zl_addr + ZS * 8u * (p0 + (uint32_t)j - 1u);
+                  asm("" : "+s"(zdown));
+                  zm[j] = lds_u64(zdown + rj[j] * 8u);
+                }
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
+              if (INDELS) {
+                if (p0 + (uint32_t)j > 0u)        /* q[p] moves one down, q[p - 1] comes back */
+                  hd ^= zprev ^ zm[j];
+                zprev = Wk[j];
+                hdj[j] = hd;
+              }
               Wk[j] ^= h;
               wo[j] = woff_of(Wk[j]);
             }
@@ -935,10 +1042,17 @@ probe_rows_kernel(const ProbeParams P)
               /* (a class position of a heavy tile: no residue of the row counts -- a scalar
                  select, so that the lane's own length is the only vector test of the row) */
               const uint32_t am = ((cbits >> j) & 1u) ? 0u : AMASK;
-              uint32_t x = row_bits(wc, Wk[j]) & am & ~(1u << rj[j]);
+              const uint32_t bits = row_bits(wc, Wk[j]);
+              uint32_t x = bits & am & ~(1u << rj[j]);
               const bool live = p < Ll;
               x = live ? x : 0u;
               nlive += (live && am) ? 1u : 0u;
+              if (INDELS) {
+                const bool del = live && am && rj[j] != rprev && Ll > 1u;
+                rprev = rj[j];
+                ndel += del ? 1u : 0u;
+                dm |= (del && ((bits >> (A + 1)) & 1u)) ? (1u << j) : 0u;
+              }
               if (j < RPW)
                 m0 |= (uint64_t)x << (A * j);
               else
@@ -948,6 +1062,20 @@ probe_rows_kernel(const ProbeParams P)
             nrows += (uint32_t)RB;
             PT_MARK(PT_ROWS);
             emit_sub_rows(m0 | m1, p0, rpack);
+            if (INDELS) {
+              if (CMPR_DBG(P, DBG_SKIP_EMIT) || CMPR_DBG(P, DBG_SKIP_DEL_ROWS))
+                dm = 0;
+              /* (one push per round: a lane rarely has two positive deletions in a block) */
+              while (__ballot(dm != 0)) {
+                const uint32_t jd = dm ? (uint32_t)__ffs((int)dm) - 1u : 0u;
+                uint64_t hsel = hdj[0];
+#pragma unroll
+                for (int j = 1; j < RB; j++)
+                  hsel = jd == (uint32_t)j ? hdj[j] : hsel;
+                q_push<A, D, GENES, INLINE>(W, zl_addr, dm != 0, hsel, pack_a(K_DEL, p0 + jd, 0), 0, 1u, 1u);
+                dm &= dm - 1u;
+              }
+            }
             PT_MARK(PT_EMIT);
           }
           };
@@ -955,7 +1083,7 @@ probe_rows_kernel(const ProbeParams P)
             sub_rows(std::true_type{});
           else
             sub_rows(std::false_type{});
-          nvar += nlive * (uint32_t)(A - 1);
+          nvar += nlive * (uint32_t)(A - 1) + ndel;
           treads += valid ? nrows : 0u;
         }
 
@@ -1067,7 +1195,7 @@ probe_rows_kernel(const ProbeParams P)
           for (uint32_t r = 0; r < nblk; r++) {
             const bool ival = im != 0xffffffffu;          /* (~0: padding behind the items of a slice) */
             const uint32_t icr = ic & 0xffu;
-            const uint32_t kind = ic >> 24, p = (ic >> 8) & 0xffffu;
+            const uint32_t kind = (ic >> 24) & 7u, p = (ic >> 8) & 0xffffu;
             W.qslot = im;
             treads += ival ? 1u : 0u;
             const uint32_t wo = woff_of(iw);
@@ -1081,6 +1209,14 @@ probe_rows_kernel(const ProbeParams P)
               x = 0;
             q_push<A, D, GENES, INLINE>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
                                         (uint32_t)__popc(x));
+            if (INDELS) {
+              /* the row of a class position answers "q without p" too; its hash is worked out
+                 when the entry is drained (m = DEL_LAZY: rare, and the item carries no residues) */
+              const bool delc = ival && (ic & ITEM_DEL_COUNTS) != 0;
+              nvar += delc ? 1u : 0u;
+              const bool dpos = delc && ((bits >> (A + 1)) & 1u) != 0 && !CMPR_DBG(P, DBG_SKIP_EMIT);
+              q_push<A, D, GENES, INLINE>(W, zl_addr, dpos, 0ull, pack_a(K_DEL, p, 0), 0, DEL_LAZY, 1u);
+            }
             /* next block's data moves up */
             iw = ea[0];
             im = eb[0];
@@ -1096,13 +1232,11 @@ probe_rows_kernel(const ProbeParams P)
       }
 
       if (INDELS && tpass == 0) {
-        /* the two shifted hashes of the rolling enumeration (requested together: the
-           insertion one arrives while the deletions are worked on) */
-        uint64_t h_ins = 0, h_del = 0;
-        if (valid) {
-          h_del = P.qhdel[W.qslot];
+        /* the shifted hash that seeds the rolling gap hashes of the insertion rows (the
+           deletion variants were answered with the substitution rows, above) */
+        uint64_t h_ins = 0;
+        if (valid)
           h_ins = P.qhins[W.qslot];
-        }
         /* Indel variants change the length, hence the class.  t = the variant:
              base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
            and its rows are filed under base(t) ^ (class residues of t other than
@@ -1144,110 +1278,6 @@ probe_rows_kernel(const ProbeParams P)
         uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
         const uint32_t nd = (L + 3u) >> 2;
 
-        /* ---- deletions (variants.cc:301-325): t = q without position p, one
-                per run of equal residues; t is looked up as a whole sequence
-                (code A).  Four positions (a residue dword) at a time: their rolling
-                keys are read together, the filter words one position ahead. ---- */
-        if (L > 1 && !CMPR_DBG(P, DBG_SKIP_DEL_ROWS)) {
-          const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L - 1];
-          const uint32_t hvy = heavy_of(base_t);
-          uint32_t md[MCR], lo[MCR], hi[MCR];
-#pragma unroll
-          for (uint32_t i = 0; i < MCR; i++) {
-            md[i] = __builtin_amdgcn_readfirstlane(class_pos(L - 1, i, P.geom.c0));
-            lo[i] = hi[i] = 0;
-            if (i < KH) {
-              lo[i] = cr_lds[i * A + res_reg(md[i])] & hvy;        /* t[md] = q[md],     md < p  */
-              hi[i] = cr_lds[i * A + res_reg(md[i] + 1)] & hvy;    /* t[md] = q[md + 1], md >= p */
-            }
-          }
-          uint64_t hd = h_del;                    /* zobrist_hash_delete_first */
-          uint32_t gone = 0;
-          for (uint32_t p0 = 0; p0 < L; p0 += 32) {
-            const uint32_t pe = p0 + 32 < L ? p0 + 32 : L;
-            const uint64_t hd0 = hd;
-            const uint32_t gone0 = gone;
-            uint32_t mask = 0;
-            for (uint32_t pq = p0; pq < pe; pq += 4) {
-              uint32_t wd;
-              if (pq < 4u * TDW) {
-                wd = s0;
-                s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
-              } else {
-                wd = qr[(pq >> 2) * WAVE];
-              }
-              uint32_t r4[4];
-              uint64_t ka[4], kb[4];
-#pragma unroll
-              for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t pp = pq + k;
-                r4[k] = (wd >> (8u * k)) & 31u;
-                const uint32_t g = k == 0 ? gone : r4[k - 1];
-                ka[k] = kb[k] = 0;
-                if (pp > 0 && pp < pe) {                       /* wave-uniform */
-                  ka[k] = lds_u64(zl_addr + (ZS * (pp - 1u) + g) * 8u);
-                  kb[k] = lds_u64(zl_addr + (ZS * (pp - 1u) + r4[k]) * 8u);
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
-              uint64_t hp[4];
-              uint32_t woq[4];
-              bool fr[4];
-#pragma unroll
-              for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t pp = pq + k;
-                const uint32_t g = k == 0 ? gone : r4[k - 1];
-                fr[k] = (pp == 0) || (r4[k] != g);
-                if (pp > 0 && pp < pe && fr[k])
-                  hd ^= ka[k] ^ kb[k];
-                hp[k] = hd;
-                woq[k] = woff_of(hd);
-              }
-              if (pq + 4u <= pe)
-                gone = r4[3];
-              else
-                gone = pe - pq == 1u ? r4[0] : pe - pq == 2u ? r4[1] : r4[2];
-              RowWord wc = word_lds(woq[0]);
-#pragma unroll
-              for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t pp = pq + k;
-                RowWord wn = wc;
-                if (k + 1 < 4)
-                  wn = word_lds(woq[k + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pp < pe) {                                 /* wave-uniform */
-                  uint32_t key = base_t;
-#pragma unroll
-                  for (uint32_t i = 0; i < MCR; i++)
-                    key ^= md[i] < pp ? lo[i] : hi[i];
-                  /* a variant filed under another slice is an item of the deletion-item
-                     pass (query_layout.hip), not looked up here */
-                  const bool here = (key & smask) == cslice;
-                  const bool hit = ((row_bits(wc, hp[k]) >> A) & 1u) != 0;
-                  const bool lives = fr[k] && here && pp < Ll && Ll > 1u;   /* (the lane's own length) */
-                  treads += valid ? 1u : 0u;
-                  nvar += lives ? 1u : 0u;
-                  mask |= (lives && hit) ? (1u << (pp - p0)) : 0u;
-                }
-                wc = wn;
-              }
-            }
-            mask &= vmask;
-            if (__ballot(mask != 0)) {
-              uint64_t hr = hd0;
-              uint32_t g = gone0;
-#pragma unroll 1
-              for (uint32_t pp = p0; pp < pe; pp++) {
-                const uint32_t r = res_reg(pp);
-                if (pp > 0 && r != g)
-                  hr ^= zl[ZS * (pp - 1) + g] ^ zl[ZS * (pp - 1) + r];
-                q_push<A, D, GENES, INLINE>(W, zl_addr, (mask >> (pp - p0)) & 1u, hr, pack_a(K_DEL, pp, 0), 0, 1u, 1u);
-                g = r;
-              }
-            }
-          }
-        }
-
         /* ---- insertions (variants.cc:329-353): t = q with v in front of
                 position ip; blanked at ip it is q with a gap there, whose rolling
                 hash addresses the row of all A residues.  RB rows per block: the
@@ -1269,6 +1299,14 @@ probe_rows_kernel(const ProbeParams P)
                 hi[i] = cr_lds[i * A + res_reg(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
             }
           }
+          /* behind the last class position of the variants nothing moves a class residue: the
+             rows of such a block lie in the staged slice, lane for lane (and in a light tile
+             all rows do) -- no key arithmetic there */
+          uint32_t mi_max = 0;
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++)
+            if (i < KH)
+              mi_max = mi[i] > mi_max ? mi[i] : mi_max;
           uint64_t hg = h_ins;                    /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
           uint32_t carry = 31u;                   /* q[ip0 - 1]: the residue behind which block ip0 starts */
           for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
@@ -1321,6 +1359,10 @@ probe_rows_kernel(const ProbeParams P)
                 hg ^= ka[j] ^ kb[j];
               hrow[j] = hg;
               wor[j] = woff_of(hg);
+              itr[j] = false;
+              slr[j] = cslice;
+              if (K == 0u || ip0 > mi_max)             /* wave-uniform: see mi_max */
+                continue;
               uint32_t key = base_t;
               int ci_u = -1;                           /* first class residue of t at the blanked position */
 #pragma unroll
@@ -1365,14 +1407,19 @@ probe_rows_kernel(const ProbeParams P)
               }
               wc = wn;
             }
-            /* one entry per row with positives: the gap hash + the mask of residues */
-            if (__ballot((m0 | m1) != 0)) {
+            /* one entry per lane with positives in the block: the gap hash of its first row, the
+               residues that roll it to the others (q[ip0] .. q[ip0 + RB - 2]) and the mask */
+            {
+              uint64_t mi0 = m0 | m1;
+              if (CMPR_DBG(P, DBG_SKIP_EMIT))
+                mi0 = 0;
+              uint32_t rroll = 0;
 #pragma unroll
-              for (int j = 0; j < RB; j++) {
-                const uint32_t xj = (uint32_t)((j < RPW ? m0 >> (A * j) : m1 >> (A * (j - RPW)))) & AMASK;
-                q_push<A, D, GENES, INLINE>(W, zl_addr, xj != 0, hrow[j], pack_a(K_INS, ip0 + (uint32_t)j, 0), 0,
-                                            xj, (uint32_t)__popc(xj));
-              }
+              for (int j = 1; j < RB; j++)
+                rroll |= (rprev[j] & RMASK) << (RBITS * (j - 1));
+              q_push<A, D, GENES, INLINE>(W, zl_addr, mi0 != 0, hrow[0], K_INSROWS | (ip0 << 3) | (rroll << 19),
+                                          (uint32_t)mi0, (uint32_t)(mi0 >> 32) | ((rroll >> 13) << 28),
+                                          (uint32_t)__popcll((unsigned long long)mi0));
             }
           }
         }
@@ -1410,7 +1457,7 @@ probe_rows_kernel(const ProbeParams P)
     uint32_t bits = 0;
     if ((int)lane < W.qn) {
       const uint32_t ca = W.q.ca[lane], kind = ca & 7u, m = W.q.m[lane];
-      bits = kind == K_ROWS ? (uint32_t)__popc(W.q.cb[lane]) + (uint32_t)__popc(m & 0x0fffffffu)
+      bits = (kind == K_ROWS || kind == K_INSROWS) ? (uint32_t)__popc(W.q.cb[lane]) + (uint32_t)__popc(m & 0x0fffffffu)
                             : (kind == K_SUB || kind == K_INS) ? (uint32_t)__popc(m) : 1u;
     }
     for (int off = 32; off > 0; off >>= 1)

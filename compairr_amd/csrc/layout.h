@@ -198,6 +198,9 @@ __host__ __device__ constexpr uint32_t zdelta_entries(int A)
 /* One item (kernels_rows.h passes >= 3; kernels_sliced.h sub2 items): the row's blanked
    hash (sub2: the query's hash), the query's slot (~0: padding behind the items of a
    slice) and its residue | position << 8 | kind << 24 -- 16 bytes, one load per lane */
+constexpr uint32_t ITEM_DEL_COUNTS = 1u << 27;   /* ItemRec::rp of a K_SUB item with -i: "q without this
+                                                    position" is a variant (first of a run), answered by
+                                                    bit A + 1 of the same row (kernels_rows.h) */
 struct alignas(16) ItemRec {
   uint64_t w;
   uint32_t main;

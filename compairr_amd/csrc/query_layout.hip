@@ -294,7 +294,8 @@ __device__ inline uint64_t variants_of(const QL &Q, const uint8_t *s, uint32_t L
 }
 
 /* item kinds = the variant kinds of layout.h */
-enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_DEL = K_DEL, ITEM_SUB2 = K_SUB2 };
+enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_SUB2 = K_SUB2 };
+/* flag of an ITEM_SUB item, above its kind: the row's deletion answer counts (layout.h ITEM_DEL_COUNTS) */
 
 __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
 {
@@ -349,9 +350,12 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
             first = false;
           key ^= g.ctab[g.off_cr + k * A + s[pos]];
         }
+      /* (with -i the row also answers "q without pos": ITEM_DEL_COUNTS = that deletion
+         variant exists -- the first position of a run of equal residues, variants.cc:301-325) */
       if (first)
         f(Q.goff[ci] + (key & g.cmask), HASH ? h ^ Q.zob[A * pos + s[pos]] : 0ull,
-          (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24));
+          (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24) |
+              (Q.indels && L > 1 && (pos == 0 || s[pos] != s[pos - 1]) ? ITEM_DEL_COUNTS : 0u));
     }
   }
   if (!Q.indels)
@@ -363,15 +367,11 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
       base ^= g.ctab[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
   const uint32_t base_i = base ^ g.ctab[L] ^ g.ctab[L + 1];          /* insertion variants */
   const bool heavy_i = class_is_heavy(g.ctab, g, base_i);
-  const uint32_t dlen = L > 1 ? g.ctab[L] ^ g.ctab[L - 1] : 0u;
-  const uint32_t base_d = base ^ dlen;                               /* deletion variants */
-  const bool heavy_d = L > 1 && class_is_heavy(g.ctab, g, base_d);
-  const uint32_t sibling = (ck ^ dlen) & g.smask;
-  /* One walk over the positions.  With P(x) = XOR_{y<x} Z[y][q[y]], P+(x) and P-(x)
-     the same over Z[y+1] / Z[y-1], and the query's two shifted hashes from the keys
-     kernel:   gap at ip:  P(ip) ^ hins ^ P+(ip);   q without p:  P(p) ^ hdel ^ P-(p+1). */
-  const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull, hdel = HASH ? Q.hdel_tmp[i] : 0ull;
-  uint64_t P0 = 0, Pp = 0, Pm = 0;
+  /* One walk over the positions.  With P(x) = XOR_{y<x} Z[y][q[y]], P+(x) the same
+     over Z[y+1], and the query's shifted hash from the keys kernel:
+       gap at ip:  P(ip) ^ hins ^ P+(ip). */
+  const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull;
+  uint64_t P0 = 0, Pp = 0;
   for (uint32_t x = 0; x <= L; x++) {
     /* ---- insertion row blanked at x, if x is a class position of the variant t
             (length L + 1, t[y] = y < x ? q[y] : q[y - 1] around the gap) and t's
@@ -394,28 +394,9 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
     }
     if (x == L)
       break;
-    /* ---- deletion variant t = q without x (one per run of equal residues) whose
-            slice of the main part is not the sibling staged for the tile's
-            deletion pass ---- */
-    if (L > 1 && (x == 0 || s[x] != s[x - 1])) {
-      uint32_t key = base_d;
-      if (heavy_d)
-        for (uint32_t k = 0; k < K; k++) {
-          const uint32_t mk = class_pos(L - 1, k, g.c0);
-          key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk + 1]];
-        }
-      if ((key & g.smask) != sibling) {
-        uint64_t w = 0;
-        if (HASH)
-          w = P0 ^ hdel ^ (x > 0 ? Pm ^ Q.zob[A * (x - 1) + s[x]] : 0ull);
-        f(Q.goff[K] + (key & g.smask), w, 31u | (x << 8) | (ITEM_DEL << 24));
-      }
-    }
     if (HASH) {
       P0 ^= Q.zob[A * x + s[x]];
       Pp ^= Q.zob[A * (x + 1) + s[x]];
-      if (x > 0)
-        Pm ^= Q.zob[A * (x - 1) + s[x]];
     }
   }
 }
@@ -1268,13 +1249,6 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       ncs += gslices[g];
     }
     ngroups = c->geom.k;
-    if (c->opt.indels) {
-      goff[ngroups] = (uint32_t)ncs;
-      gslices[ngroups] = c->geom.smask + 1;
-      gslice0[ngroups] = 0;
-      ncs += gslices[ngroups];
-      ngroups++;
-    }
   }
   if (sub2_items) {
     ngroups = c->geom.k * 3;

@@ -210,7 +210,8 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
       c->rows = false;
     }
   }
-  const uint64_t entries = (s->n ? s->offsets[s->n] : 0) + s->n;   /* row filter: L + 1 per sequence */
+  /* row filter: L + 1 entries per sequence, and with -i its L + 1 gap entries (kernels_rows.h) */
+  const uint64_t entries = ((s->n ? s->offsets[s->n] : 0) + s->n) * (c->rows && c->opt.indels ? 2 : 1);
   if (c->rows) {
     /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a
        word then has ~40 % of its bits set and a test of eight of them passes by
@@ -239,8 +240,9 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     c->geom.smask = (uint32_t)(S - 1);
     /* class parts (layout.h row_slice): each holds one entry per split sequence,
        the main part L + 1 - K per sequence: S n / entries slices, a power of two */
+    /* (with -i a class part holds two entries per split sequence: blank row and gap row) */
     uint64_t Sc = 1;
-    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1))
+    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1) * (c->opt.indels ? 2 : 1))
       Sc <<= 1;
     c->geom.cmask = (uint32_t)(Sc - 1);
   } else {
@@ -486,6 +488,7 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     B.bloom = c->rows ? nullptr : c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.sliced = c->sliced ? 1u : 0u;
+    B.indels = c->rows && c->opt.indels ? 1u : 0u;
     B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,

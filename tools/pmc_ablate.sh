@@ -11,7 +11,7 @@ i=0
 for t in "$@"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU -d $O/ab_$i -o p --output-format csv -- \
-      python3 $R/bench.py --cpu-sample -1 --steps 3 --warmup 1 --tunable $t > $O/ab_$i.log 2>&1
+      python3 $R/bench.py --cpu-sample -1 --steps 3 --warmup 1 $EXTRA --tunable $t > $O/ab_$i.log 2>&1
   python3 - $O/ab_$i "$t" <<'PY'
 import csv,glob,sys,collections
 acc=collections.defaultdict(list); dur=[]

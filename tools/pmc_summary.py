@@ -3,7 +3,7 @@
 passes) into profiles/<round>/<tag>_pmc_summary.json, profiles/traffic.json and
 profiles/roofline_inputs.json (what bench.py prices its `roofline` object on).
 
-usage: tools/pmc_summary.py <gpurun_out/tag dir> <profiles/rNN dir> <tag> "<workload name>"
+usage: tools/pmc_summary.py <gpurun_out/tag dir> <profiles/rNN dir> <tag> "<workload name>" [<kernel.s> <mangled kernel name>]
 
 Kernels are kept apart by their full name (the fast and the redo form of the probe
 kernel are different instantiations); "probe" below is the probe kernel with the
@@ -23,6 +23,7 @@ import sys
 
 src, dst, tag, workload = sys.argv[1:5]
 os.makedirs(dst, exist_ok=True)
+root = os.path.dirname(dst.rstrip("/"))
 
 per = collections.defaultdict(lambda: {"dur": [], "ctr": collections.defaultdict(list), "dispatch": None})
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -106,43 +107,67 @@ if "hbm_bytes_per_step" in out:
                    "source": os.path.join(dst, "%s_pmc_summary.json" % tag),
                    "note": out["hbm_bytes_note"]}, fh, indent=1)
 
-# ---- what bench.py's roofline object is priced on ----
+# ---- what bench.py's roofline object is priced on: one entry per workload ----
+# (optional 5th / 6th argument: the kernel's ISA file and mangled name, for the issue
+#  cost of its instruction mix -- tools/isa_mix.py)
 cal_path = os.path.join(dst, "calibration.json")
 if "probe" in out["kernels"] and os.path.exists(cal_path):
     cal = json.load(open(cal_path))
     c = out["kernels"]["probe"]["counters"]
     g = lambda n: c[n]["per_launch_mean"] if n in c else None
-    valu4 = [v for v in cal["valu"] if v["waves_per_simd"] == 4][0]
-    simds = cal["cus"] * 4
-    nominal = cal["clock_mhz"] * 1e6
-    # effective shader clock of this kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    cost = {x["class"].split(" ")[0].rstrip(":"): x["waves_per_simd"]["4"]["cycles_per_instr_at_nominal_clock"]
+            for x in cal["valu_classes"]}
     f_eff = None
     if g("GRBM_GUI_ACTIVE"):
+        # effective shader clock of this kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs
         f_eff = g("GRBM_GUI_ACTIVE") / 8 / (out["kernels"]["probe"]["pmc_pass_mean_duration_us"] * 1e-6)
-    inputs = {
-        "workload": workload,
-        "source": os.path.join(dst, "%s_pmc_summary.json" % tag),
-        "probe_kernel": {
-            "name": out["kernels"]["probe"]["name"],
-            "valu_insts": g("SQ_INSTS_VALU"), "salu_insts": None,
-            "salu_insts_reported": g("SQ_INSTS_SALU"),
-            "lds_active_cycles": g("SQ_LDS_IDX_ACTIVE"),
-            "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
-            "hbm_bytes": out["kernels"]["probe"].get("hbm_bytes_per_launch"),
-            "effective_clock_hz": f_eff,
-            "busy_fraction_from_counters": out["kernels"]["probe"].get("busy_fraction"),
-        },
-        "calibration": {
-            "from": cal_path,
-            # wave64 VALU instructions per second, all SIMDs, 4 waves per SIMD: the wall
-            # time of tools/calib.hip's stream at the nominal clock (folds in the clock
-            # the chip holds under a dense VALU stream)
-            "valu_wave_insts_per_s": simds * nominal / valu4["cycles_per_instr_per_simd_at_nominal_clock"],
-            # one LDS array per CU, cycles at the effective clock of this kernel
-            "lds_cycles_per_s": cal["cus"] * (f_eff or nominal),
-            "salu_insts_per_s": None,
-        },
+    mix = None
+    if len(sys.argv) > 6:
+        import subprocess
+        mix = json.loads(subprocess.check_output([sys.executable, os.path.join(os.path.dirname(__file__), "isa_mix.py"),
+                                                  sys.argv[5], sys.argv[6], cal_path]).decode())
+    bench = {}
+    bp = os.path.join(src, "bench.json")
+    if os.path.exists(bp) and os.path.getsize(bp):
+        lines = [l for l in open(bp).read().splitlines() if l.startswith("{")]
+        if lines:
+            bench = json.loads(lines[-1])
+    inp_path = os.path.join(root, "roofline_inputs.json")
+    try:
+        inputs = json.load(open(inp_path))
+        assert "workloads" in inputs
+    except Exception:
+        inputs = {"workloads": {}}
+    sha = None
+    sp = os.path.join(src, "csrc_sha256.txt")
+    if os.path.exists(sp):
+        sha = open(sp).read().strip()
+    if inputs.get("csrc_sha256") not in (None, sha):
+        # counters of another state of the sources: they are not mixed
+        inputs["workloads"] = {}
+    inputs["csrc_sha256"] = sha
+    inputs["calibration"] = {
+        "from": cal_path, "cus": cal["cus"], "simds": cal["cus"] * 4, "nominal_clock_hz": cal["clock_mhz"] * 1e6,
+        # cycles per wave64 instruction per SIMD at >= 4 waves per SIMD, wall time x nominal clock
+        "valu_cycles_fast": cost.get("v_xor_b32"), "valu_cycles_slow": cost.get("v_alignbit_b32"),
+        "valu_cycles_by_class": cost,
     }
-    with open(os.path.join(root, "roofline_inputs.json"), "w") as fh:
+    inputs["workloads"][workload] = {
+        "source": os.path.join(dst, "%s_pmc_summary.json" % tag),
+        "kernel": out["kernels"]["probe"]["name"],
+        "kernel_us_in_profile": out["kernels"]["probe"]["pmc_pass_mean_duration_us"],
+        "valu_insts": g("SQ_INSTS_VALU"), "salu_insts": g("SQ_INSTS_SALU"),
+        "lds_active_cycles": g("SQ_LDS_IDX_ACTIVE"),
+        "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
+        "hbm_bytes": out["kernels"]["probe"].get("hbm_bytes_per_launch"),
+        "effective_clock_hz": f_eff,
+        "busy_fraction_from_counters": out["kernels"]["probe"].get("busy_fraction"),
+        "mix_cycles_per_valu_inst": mix["mean_cycles_per_instruction"] if mix else None,
+        "mix": mix,
+        # work of the profiled (N = 1) launch: a shard's share is priced against these
+        "filter_reads": (bench.get("roofline") or {}).get("filter_reads_per_launch"),
+        "variants": (bench.get("roofline") or {}).get("variants_per_launch"),
+    }
+    with open(inp_path, "w") as fh:
         json.dump(inputs, fh, indent=1)
 print(json.dumps(out, indent=1)[:3000])
