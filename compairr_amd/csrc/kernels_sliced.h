@@ -387,6 +387,34 @@ __device__ __forceinline__ const uint64_t *hbm_word(const SProber &W, uint64_t h
   return (const uint64_t *)((const char *)W.P.bloom + ((uint64_t)vslice << W.slice_shift) + woff);
 }
 
+/* nucleotides: the three OTHER residues of a position, all three filter words in flight
+   together (one wait per position, not one per probe: with a wait behind every read the
+   wave stood still for an LDS round trip three times per position -- the vector unit of
+   the d = 2 kernels ran at a third of its issue rate).  `eaddr` = LDS address of the
+   lane's entry of the delta table (ze: key k at + 8 k); bit k - 1 of the result <->
+   residue (r + k) & 3. */
+__device__ __forceinline__ uint32_t probe3_lds(const SProber &W, uint64_t hbase, uint32_t eaddr)
+{
+  uint64_t hv[3], word[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    hv[k] = hbase ^ lds_u64(eaddr, k + 1);
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    word[k] = lds_u64(bloom_off(hv[k]) & W.wmask_bytes);
+  __builtin_amdgcn_sched_barrier(0);
+  BloomPat pat[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    pat[k] = pattern_fields(hv[k]);
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t b3 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    b3 |= bloom_hit(word[k], pat[k]) ? (1u << k) : 0u;
+  return b3;
+}
+
 /* The residues of a tile, streamed one dword (4 positions x 64 lanes) ahead of
    use so that the HBM/L2 latency of the next dword hides behind the rows of
    the current one. */
@@ -709,12 +737,7 @@ probe_sliced_kernel(const ProbeParams P)
               uint32_t b3 = 0;
               if (staged && !((cbits >> jj) & 1u)) {
                 const uint32_t eaddr = ze_addr + (16u * p + 4u * r) * 8u;
-#pragma unroll
-                for (uint32_t k = 1; k <= 3; k++) {
-                  const uint64_t hv = h ^ lds_u64(eaddr, (int)k);
-                  const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
-                  b3 |= bloom_hit(word, pattern_fields(hv)) ? (1u << (k - 1)) : 0u;
-                }
+                b3 = probe3_lds(W, h, eaddr);
               } else if (!((cbits >> jj) & 1u)) {
                 const uint64_t *zp = zl + 4 * p;
                 const uint64_t h1 = h ^ zp[r];
@@ -996,12 +1019,7 @@ probe_sliced_kernel(const ProbeParams P)
                   if (fast && !cq) {
                     const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
                     if (!CMPR_DBG(P, DBG_SKIP_LDS_ROWS))
-#pragma unroll
-                    for (uint32_t k = 1; k <= 3; k++) {
-                      const uint64_t hv = hpv ^ lds_u64(eaddr, (int)k);
-                      const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
-                      b3 |= bloom_hit(word, pattern_fields(hv)) ? (1u << (k - 1)) : 0u;
-                    }
+                      b3 = probe3_lds(W, hpv, eaddr);
                   } else if (!cp && !cq) {
                     const uint64_t *zq = zl + 4 * qq;
                     const uint64_t hq = hpv ^ zq[rq];
@@ -1123,12 +1141,7 @@ probe_sliced_kernel(const ProbeParams P)
               uint32_t b3 = 0;
               if (!cq) {
                 const uint32_t eaddr = ze_addr + (16u * qq + 4u * rq) * 8u;
-#pragma unroll
-                for (uint32_t k = 1; k <= 3; k++) {
-                  const uint64_t hv = hpv ^ lds_u64(eaddr, (int)k);
-                  const uint64_t word = lds_u64(bloom_off(hv) & W.wmask_bytes);
-                  b3 |= bloom_hit(word, pattern_fields(hv)) ? (1u << (k - 1)) : 0u;
-                }
+                b3 = probe3_lds(W, hpv, eaddr);
               } else if (qq > p) {
                 /* (W.tile_slice is the staged slice = the query's own ^ the change at p) */
                 const uint64_t *zq = zl + 4 * qq;

@@ -144,7 +144,10 @@ int cmpr_set_reference(cmpr_context *ctx, const cmpr_set_view *set2,
  * Upload set 1 (the queries) and lay it out for the kernel.  After this call
  * the queries are resident in HBM; cmpr_overlap_* may be called repeatedly.
  * Passing the same view as set 2 gives the reference's one-file mode
- * (overlap.cc:799-825).
+ * (overlap.cc:799-825).  The context keeps its device allocations from call to
+ * call (a second set of similar size costs no allocation).  With the work-shard
+ * tunables set, only what this context works on is laid out (the queries are still
+ * uploaded and keyed in full).
  */
 int cmpr_set_queries(cmpr_context *ctx, const cmpr_set_view *set1);
 
@@ -172,6 +175,21 @@ int cmpr_overlap_matrix_f64(cmpr_context *ctx, double *matrix_out);
  * will reduce across GPUs).  The kernels are enqueued on `stream`
  * (a hipStream_t, NULL = the context's own stream) and the call returns
  * without synchronising when `stream` is not NULL.
+ *
+ * Launches of one context are ordered one after the other whatever streams they are
+ * given (each uses state the previous one leaves behind; the library inserts the
+ * event wait when the stream changes).
+ *
+ * Because this entry point does not wait, it cannot look at the one condition that
+ * can invalidate a launch after the fact: amino acids with d >= 1 drop their redo
+ * pass once a finished launch on the same sets has shown that the positives buffer
+ * has room to spare; should a later launch overflow all the same, its matrix is
+ * incomplete.  The device records that; the next cmpr_get_stats() then fails with
+ * CMPR_ESTATE ("... overflowed in a launch without redo pass"), withdraws the
+ * shortcut, and later launches carry the redo pass again.  Callers of this entry
+ * point must therefore call cmpr_get_stats() before trusting a series of launches.
+ * The synchronous entry points (cmpr_overlap_matrix, _f64, _pairs) check by
+ * themselves and repeat the step with the redo pass: they never return such a result.
  */
 int cmpr_overlap_matrix_device(cmpr_context *ctx, void *d_matrix, void *stream);
 
@@ -247,9 +265,14 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              that put a new residue on a class position are grouped
                              by the slice they land in and probed there (1, and
                              the default -1), or probed where the filter lies (0)
+     "step_graph"            1: the steady-state step is replayed as one hipGraph per
+                             (output matrix, counter block) instead of three launches;
+                             default 0 (measured slower on ROCm 7.2)
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
      "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip
+     "assume_never_overflows" TEST ONLY: the next launch runs without redo pass as if
+                             the margin had been shown
    "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
    must be set before cmpr_set_reference(); "chunk_tiles", "waves_per_block",
    "small_slice_tiles" and the work shard before cmpr_set_queries().  ("debug" exists
@@ -258,7 +281,11 @@ int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 
 /* Current value of a tunable (for the data-dependent ones, the value in effect
    after cmpr_set_reference / cmpr_set_queries), plus the read-only names
-   "slices", "tiles", "chunks" and "query_slots" (tiles x 64, padding included). */
+   "slices", "tiles", "chunks", "query_slots" (tiles x 64, padding included),
+   "never_overflows" (1: the redo pass is currently dropped), "graphs" (instantiated
+   step graphs) and, of the last cmpr_set_queries in microseconds, "layout_total_us",
+   "layout_upload_us" (host time inside the copy calls) and "layout_tail_us" (from the
+   last copy to the end: the device work the upload did not hide). */
 int cmpr_get_tunable(cmpr_context *ctx, const char *name, int64_t *value);
 
 #ifdef __cplusplus
