@@ -1040,16 +1040,25 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   /* launches of one context are ordered one after the other, whatever streams the
      caller hands in: each uses state (counter blocks, positives buffer, partial
      slots) the previous one leaves behind */
+  const bool same_stream = c->have_last_stream && c->last_stream == st;
   if (c->have_last_stream && c->last_stream != st && c->events_valid)
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_k1, 0));
   c->last_stream = st;
   c->have_last_stream = true;
-  /* (three event records per step, not five: each is a packet the stream waits for) */
+  /* (event records are packets the stream waits for, ~4.5 us each: three per step, and
+     only two when the previous launch of this context is still running on the same
+     stream -- this one then starts where that one ends, and its end event IS this
+     launch's start) */
+  const bool back_to_back = c->events_valid && c->stop_is_k1 && same_stream &&
+                            hipEventQuery(c->ev_k1) == hipErrorNotReady;
+  (void)hipGetLastError();
   {
+    hipEvent_t prev_end = c->ev_k1;
     const uint32_t slot = (uint32_t)(c->calls % cmpr_context::TIME_RING);
-    c->ev_k0 = c->ring_k0[slot];
+    c->ev_k0 = back_to_back ? prev_end : c->ring_k0[slot];
     c->ev_km = c->ring_km[slot];
     c->ev_k1 = c->ring_k1[slot];
+    c->ring_start[slot] = c->ev_k0;
     c->calls++;
   }
   StepArgs a;
@@ -1089,7 +1098,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   a.with_redo = S.redo_kind && !c->never_overflows;
   c->last_without_redo = S.redo_kind && S.will_launch && !a.with_redo;
 
-  HIP_TRY(c, hipEventRecord(c->ev_k0, st));
+  if (!back_to_back)
+    HIP_TRY(c, hipEventRecord(c->ev_k0, st));
   StepGraph *g = nullptr;
   if (S.will_launch && !a.needs_clear && !a.track_usage && !a.with_redo && !c->pair_count && !c->debug)
     g = graph_for(c, a, which);
@@ -1302,12 +1312,14 @@ extern "C" int cmpr_get_kernel_times(cmpr_context *c, uint32_t max, double *kern
     return fail(c, CMPR_ESTATE, "no overlap call has been made");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventSynchronize(c->ev_k1));
-  uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max, c->calls), cmpr_context::TIME_RING);
+  /* (one less than the ring holds: the start of the oldest call may be the end event of the
+     call before it, whose ring entry the newest call has just taken) */
+  uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max, c->calls), cmpr_context::TIME_RING - 1);
   for (uint64_t k = 0; k < n; k++) {
     const uint32_t slot = (uint32_t)((c->calls - n + k) % cmpr_context::TIME_RING);
     float a = 0, b = 0;
-    HIP_TRY(c, hipEventElapsedTime(&a, c->ring_k0[slot], c->ring_k1[slot]));
-    HIP_TRY(c, hipEventElapsedTime(&b, c->ring_k0[slot], c->ring_km[slot]));
+    HIP_TRY(c, hipEventElapsedTime(&a, c->ring_start[slot], c->ring_k1[slot]));
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ring_start[slot], c->ring_km[slot]));
     if (kernel_ms)
       kernel_ms[k] = a;
     if (probe_ms)

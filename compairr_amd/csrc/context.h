@@ -98,6 +98,8 @@ struct cmpr_context {
      that a caller can time many launches without synchronising after each */
   static const uint32_t TIME_RING = 64;
   hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
+  hipEvent_t   ring_start[TIME_RING] = {};   /* start event of the call in this slot: its own k0, or the
+                                                previous call's k1 when the two ran back to back */
   uint64_t     calls = 0;            /* overlap launches so far */
   hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
   bool         events_valid = false;

@@ -265,7 +265,7 @@ class HipOverlap:
 
     def kernel_times(self, max_calls: int = 64):
         """(kernel_ms[], probe_ms[]) of the last calls, oldest first (HIP events)."""
-        n = min(max_calls, 64)
+        n = min(max_calls, 63)
         k = (C.c_double * n)()
         p = (C.c_double * n)()
         got = C.c_uint32(0)

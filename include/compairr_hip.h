@@ -223,7 +223,7 @@ int cmpr_count_duplicates(cmpr_context *ctx, const cmpr_set_view *set, uint64_t 
 int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);
 
 /*
- * HIP-event kernel times of the last `max` (at most 64) cmpr_overlap_* calls,
+ * HIP-event kernel times of the last `max` (at most 63) cmpr_overlap_* calls,
  * oldest first: kernel_ms[k] = probe + resolve kernels, probe_ms[k] = the probe
  * kernel alone (either may be NULL).  Lets a caller queue many launches on a
  * stream without synchronising after each (the reference has one timed region,

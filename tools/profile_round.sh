@@ -15,16 +15,16 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o p --output-form
     python3 $R/bench.py --cpu-sample -1 "$@" > $O/stats_bench.json 2> $O/stats.err
 i=0
 # PMC_GROUPS=essential: the six groups the roofline needs (long workloads)
-GROUPS=("FETCH_SIZE" "WRITE_SIZE"
+CTR_GROUPS=("FETCH_SIZE" "WRITE_SIZE"
         "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"
         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES")
 if [ "$PMC_GROUPS" != "essential" ]; then
-  GROUPS+=("TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
+  CTR_GROUPS+=("TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
            "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_LDS_ADDR_CONFLICT SQ_THREAD_CYCLES_VALU")
 fi
-for ctrs in "${GROUPS[@]}"; do
+for ctrs in "${CTR_GROUPS[@]}"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $ctrs -d $O/pmc_$i -o p --output-format csv -- \
       python3 $R/bench.py --cpu-sample -1 --steps 3 --warmup 1 "$@" > $O/pmc_$i.log 2>&1
