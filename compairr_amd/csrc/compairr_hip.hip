@@ -249,6 +249,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->h_usage) (void)hipHostFree(c->h_usage);
   c->arena_a.release();
   c->arena_b.release();
+  if (c->stage_host) (void)hipHostFree(c->stage_host);
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -339,6 +340,10 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "step_graph must be 0 or 1");
     c->step_graph = value;
+  } else if (n == "narrow_upload") {
+    if (value < -1 || value > 1)
+      return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
+    c->narrow_upload = value;
   } else if (n == "assume_never_overflows") {
     /* TEST ONLY: the next launch runs without redo pass as if the margin had been
        shown (tests/test_gpu_parity.py forces an overflow behind it) */
@@ -421,6 +426,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->plan.valid ? (int64_t)c->plan.nw : c->waves_per_block;
   else if (n == "step_graph") *value = c->step_graph;
+  else if (n == "narrow_upload") *value = c->narrow_upload;
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
   else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);

@@ -213,6 +213,9 @@ struct cmpr_context {
   hipStream_t                last_stream = nullptr;       /* stream of the last enqueue (launches of one */
   bool                       have_last_stream = false;    /* context are ordered one after the other)   */
   DevArena                   arena_a, arena_b;            /* temporaries of cmpr_set_queries */
+  void                      *stage_host = nullptr;        /* pinned staging of the narrowed upload */
+  size_t                     stage_host_bytes = 0;
+  int64_t                    narrow_upload = -1;          /* tunable: -1 auto, 0 off, 1 on */
   hipStream_t                copy_stream = nullptr;       /* uploads of cmpr_set_queries */
   static const uint32_t      NCOPY_EV = 4;
   hipEvent_t                 ev_copy[NCOPY_EV] = {};

@@ -49,10 +49,12 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 using namespace cmpr;
 
@@ -527,6 +529,33 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       if (tot_lds[r] != 0.0)
         unsafeAtomicAdd(Q.rep_total + r, tot_lds[r]);
   }
+}
+
+/* ---- narrowed upload: back to the caller's types -------------------------- */
+
+/* The host narrowed what it could before the copy (lengths instead of 64-bit offsets,
+   16-bit gene / repertoire numbers, 32-bit counts: 12 bytes per query instead of 28,
+   cmpr_layout_queries); a range of them becomes the caller's arrays again here.  The
+   offsets are an exclusive scan of the lengths (hipCUB, started at the range's first
+   offset). */
+struct Len16To64 {
+  __host__ __device__ unsigned long long operator()(const uint16_t &x) const { return x; }
+};
+
+__global__ void __launch_bounds__(256)
+widen_kernel(const uint16_t *v16, const uint16_t *j16, const uint16_t *rep16, const uint32_t *cnt32,
+             uint32_t *v, uint32_t *j, uint32_t *rep, uint64_t *cnt, uint64_t q0, uint64_t q1)
+{
+  const uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= q1)
+    return;
+  rep[i] = rep16[i];
+  if (v) {
+    v[i] = v16[i];
+    j[i] = j16[i];
+  }
+  if (cnt)
+    cnt[i] = cnt32[i];
 }
 
 /* ---- slices: tiles, chunks ------------------------------------------------ */
@@ -1297,6 +1326,16 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   const size_t o_j = cut.take(c->opt.ignore_genes ? 0 : (size_t)n * sizeof(uint32_t));
   const size_t o_rep = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_cnt = cut.take(c->opt.ignore_counts ? 0 : (size_t)n * sizeof(uint64_t));
+  /* narrowed upload (below): lengths, 16-bit ids, 32-bit counts as they arrive */
+  const unsigned hw = std::thread::hardware_concurrency();
+  const bool narrow_fits = s->n_repertoires <= 65536 &&
+                           (c->opt.ignore_genes || (c->opt.n_v_genes <= 65536 && c->opt.n_j_genes <= 65536));
+  bool narrow = narrow_fits && (c->narrow_upload == 1 || (c->narrow_upload < 0 && n >= (1u << 20) && hw >= 8));
+  const size_t o_len16 = cut.take(narrow ? (size_t)(n + 1) * sizeof(uint16_t) : 0);
+  const size_t o_rep16 = cut.take(narrow ? (size_t)n * sizeof(uint16_t) : 0);
+  const size_t o_v16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
+  const size_t o_j16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
+  const size_t o_cnt32 = cut.take(narrow && !c->opt.ignore_counts ? (size_t)n * sizeof(uint32_t) : 0);
   const size_t o_gbase = cut.take(G * npass * sizeof(uint32_t));
   const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
@@ -1332,6 +1371,13 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     b = 0;
     (void)sum64(nullptr, b, nullptr, nullptr, big, c->stream);
     cub_bytes = std::max(cub_bytes, b);
+    if (narrow) {
+      hipcub::TransformInputIterator<unsigned long long, Len16To64, const uint16_t *> it(nullptr, Len16To64());
+      b = 0;
+      (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, it, (unsigned long long *)nullptr, hipcub::Sum(),
+                                              0ull, (int)(n + 1), c->stream);
+      cub_bytes = std::max(cub_bytes, b);
+    }
   }
   const size_t o_cub = cut.take(cub_bytes + 256);
   if ((rc = arena_fit(c, c->arena_a, cut.used))) return rc;
@@ -1415,9 +1461,17 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   void *const cub_tmp = at(o_cub);
 
   /* ---- the caller's arrays, a range of queries at a time on the copy stream; the keys
-          kernel of a range (validation included) runs while the next is copied ---- */
+          kernel of a range (validation included) runs while the next is copied.
+
+          NARROWED (large sets, >= 8 host threads): the link carries 43 bytes per query of
+          this ABI -- 7.9 ms per 10M at the ~54 GB/s it gives pageable memory -- of which 28
+          are 64-bit offsets and counts and 32-bit ids that fit 2 + 2 + 2 + 2 + 4.  Host
+          threads narrow range r + 1 into pinned memory while range r is on the link; a scan
+          and a small kernel restore the caller's types on the device.  A value that does
+          not fit (a count >= 2^32, an id >= 2^16, offsets that are no CDR3 lengths) sends
+          the whole set the wide way, where the keys kernel names the error if it is one. ---- */
   double upload_ms = 0;
-  {
+  for (int attempt = 0;; attempt++) {
     /* (few, large ranges: every copy call costs ~20 us of host time, and the keys kernel of
        the last range is what the upload does not hide) */
     const uint64_t min_range = 1u << 18;
@@ -1430,33 +1484,138 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       HIP_TRY(c, hipMemcpyAsync(at(o_off), zero_off, sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
     /* (the last range is the smallest: its keys kernel is what the upload does not hide) */
     static const uint32_t cut4[5] = {0, 30, 60, 86, 100};
+    uint64_t rq[5] = {0, 0, 0, 0, 0};
+    for (uint64_t r = 0; r <= nranges; r++)
+      rq[r] = nranges == 4 ? n * cut4[r] / 100 : n * r / nranges;
+
+    /* the narrowing threads: thread t takes the t-th part of every range, range by range */
+    const unsigned T = narrow ? std::max(1u, std::min(32u, hw)) : 0u;
+    uint16_t *h_len16 = nullptr, *h_rep16 = nullptr, *h_v16 = nullptr, *h_j16 = nullptr;
+    uint32_t *h_cnt32 = nullptr;
+    std::atomic<uint32_t> done[4];
+    std::atomic<uint32_t> misfit(0);
+    for (auto &d : done)
+      d.store(0);
+    std::vector<std::thread> workers;
+    struct Join {
+      std::vector<std::thread> &w;
+      ~Join() { for (auto &t : w) if (t.joinable()) t.join(); }
+    } join{workers};
+    if (narrow) {
+      const size_t need = (size_t)(n + 1) * 2 + (size_t)n * (2 + 2 + 2 + 4) + 64;
+      if (c->stage_host_bytes < need) {
+        if (c->stage_host)
+          (void)hipHostFree(c->stage_host);
+        c->stage_host = nullptr;
+        c->stage_host_bytes = 0;
+        HIP_TRY(c, hipHostMalloc(&c->stage_host, need + need / 16, hipHostMallocDefault));
+        c->stage_host_bytes = need + need / 16;
+      }
+      char *hp = (char *)c->stage_host;
+      h_len16 = (uint16_t *)hp; hp += (((size_t)(n + 1) * 2) + 15) & ~(size_t)15;
+      h_rep16 = (uint16_t *)hp; hp += ((size_t)n * 2 + 15) & ~(size_t)15;
+      h_v16 = (uint16_t *)hp;   hp += ((size_t)n * 2 + 15) & ~(size_t)15;
+      h_j16 = (uint16_t *)hp;   hp += ((size_t)n * 2 + 15) & ~(size_t)15;
+      h_cnt32 = (uint32_t *)hp;
+      h_len16[n] = 0;
+      const bool genes = !c->opt.ignore_genes, counts = !c->opt.ignore_counts;
+      for (unsigned t = 0; t < T; t++)
+        workers.emplace_back([=, &done, &misfit]() {
+          for (uint64_t r = 0; r < nranges; r++) {
+            const uint64_t a = rq[r] + (rq[r + 1] - rq[r]) * t / T, b = rq[r] + (rq[r + 1] - rq[r]) * (t + 1) / T;
+            uint32_t bad = 0;
+            for (uint64_t i = a; i < b; i++) {
+              const uint64_t o0 = s->offsets[i], o1 = s->offsets[i + 1];
+              const uint64_t len = o1 - o0;
+              bad |= (o1 < o0) | (len > 0xffffu);
+              h_len16[i] = (uint16_t)len;
+              const uint32_t rp = s->repertoire[i];
+              bad |= rp > 0xffffu;
+              h_rep16[i] = (uint16_t)rp;
+            }
+            if (genes)
+              for (uint64_t i = a; i < b; i++) {
+                const uint32_t vv = s->v_gene[i], jj = s->j_gene[i];
+                bad |= (vv > 0xffffu) | (jj > 0xffffu);
+                h_v16[i] = (uint16_t)vv;
+                h_j16[i] = (uint16_t)jj;
+              }
+            if (counts)
+              for (uint64_t i = a; i < b; i++) {
+                const uint64_t x = s->count[i];
+                bad |= x > 0xffffffffull;
+                h_cnt32[i] = (uint32_t)x;
+              }
+            if (bad)
+              misfit.store(1);
+            done[r].fetch_add(1, std::memory_order_release);
+          }
+        });
+    }
+
+    bool redo_wide = false;
     for (uint64_t r = 0; r < nranges && n; r++) {
-      const uint64_t q0 = nranges == 4 ? n * cut4[r] / 100 : n * r / nranges;
-      const uint64_t q1 = nranges == 4 ? n * cut4[r + 1] / 100 : n * (r + 1) / nranges;
+      const uint64_t q0 = rq[r], q1 = rq[r + 1];
       const uint64_t r0 = s->offsets[q0], r1 = s->offsets[q1];
       if (r1 < r0 || r1 > total)
         return fail(c, CMPR_EINVAL, verr_message(VERR_OFFSETS));
-      const auto t0 = std::chrono::steady_clock::now();
+      auto t0 = std::chrono::steady_clock::now();
       hipStream_t cs = c->copy_stream;
       if (r1 > r0)
         HIP_TRY(c, hipMemcpyAsync(at(o_res) + r0, s->residues + r0, (size_t)(r1 - r0), hipMemcpyHostToDevice, cs));
-      HIP_TRY(c, hipMemcpyAsync(at(o_off) + q0 * sizeof(uint64_t), s->offsets + q0,
-                                (size_t)(q1 - q0 + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
-      HIP_TRY(c, hipMemcpyAsync(at(o_rep) + q0 * sizeof(uint32_t), s->repertoire + q0,
-                                (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
-      if (!c->opt.ignore_genes) {
-        HIP_TRY(c, hipMemcpyAsync(at(o_v) + q0 * sizeof(uint32_t), s->v_gene + q0,
+      if (narrow) {
+        upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        while (done[r].load(std::memory_order_acquire) < T)
+          std::this_thread::yield();
+        if (misfit.load()) {
+          redo_wide = true;
+          break;
+        }
+        t0 = std::chrono::steady_clock::now();
+        HIP_TRY(c, hipMemcpyAsync(at(o_len16) + q0 * 2, h_len16 + q0, (size_t)(q1 - q0 + 1) * 2, hipMemcpyHostToDevice, cs));
+        HIP_TRY(c, hipMemcpyAsync(at(o_rep16) + q0 * 2, h_rep16 + q0, (size_t)(q1 - q0) * 2, hipMemcpyHostToDevice, cs));
+        if (!c->opt.ignore_genes) {
+          HIP_TRY(c, hipMemcpyAsync(at(o_v16) + q0 * 2, h_v16 + q0, (size_t)(q1 - q0) * 2, hipMemcpyHostToDevice, cs));
+          HIP_TRY(c, hipMemcpyAsync(at(o_j16) + q0 * 2, h_j16 + q0, (size_t)(q1 - q0) * 2, hipMemcpyHostToDevice, cs));
+        }
+        if (!c->opt.ignore_counts)
+          HIP_TRY(c, hipMemcpyAsync(at(o_cnt32) + q0 * 4, h_cnt32 + q0, (size_t)(q1 - q0) * 4, hipMemcpyHostToDevice, cs));
+      } else {
+        HIP_TRY(c, hipMemcpyAsync(at(o_off) + q0 * sizeof(uint64_t), s->offsets + q0,
+                                  (size_t)(q1 - q0 + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+        HIP_TRY(c, hipMemcpyAsync(at(o_rep) + q0 * sizeof(uint32_t), s->repertoire + q0,
                                   (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
-        HIP_TRY(c, hipMemcpyAsync(at(o_j) + q0 * sizeof(uint32_t), s->j_gene + q0,
-                                  (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        if (!c->opt.ignore_genes) {
+          HIP_TRY(c, hipMemcpyAsync(at(o_v) + q0 * sizeof(uint32_t), s->v_gene + q0,
+                                    (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+          HIP_TRY(c, hipMemcpyAsync(at(o_j) + q0 * sizeof(uint32_t), s->j_gene + q0,
+                                    (size_t)(q1 - q0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        }
+        if (!c->opt.ignore_counts)
+          HIP_TRY(c, hipMemcpyAsync(at(o_cnt) + q0 * sizeof(uint64_t), s->count + q0,
+                                    (size_t)(q1 - q0) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
       }
-      if (!c->opt.ignore_counts)
-        HIP_TRY(c, hipMemcpyAsync(at(o_cnt) + q0 * sizeof(uint64_t), s->count + q0,
-                                  (size_t)(q1 - q0) * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
       hipEvent_t ev = c->ev_copy[r % cmpr_context::NCOPY_EV];
       HIP_TRY(c, hipEventRecord(ev, cs));
       upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+      if (narrow) {
+        /* back to offsets (scan of the lengths from the range's first offset: its last
+           output is the next range's first offset) and to the caller's widths */
+        hipcub::TransformInputIterator<unsigned long long, Len16To64, const uint16_t *> it(
+            (const uint16_t *)at(o_len16) + q0, Len16To64());
+        size_t b = cub_bytes;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(cub_tmp, b, it, (unsigned long long *)at(o_off) + q0,
+                                                     hipcub::Sum(), (unsigned long long)r0, (int)(q1 - q0 + 1),
+                                                     c->stream));
+        hipLaunchKernelGGL(widen_kernel, dim3(blocks_for(q1 - q0)), dim3(256), 0, c->stream,
+                           (const uint16_t *)at(o_v16), (const uint16_t *)at(o_j16), (const uint16_t *)at(o_rep16),
+                           (const uint32_t *)at(o_cnt32),
+                           c->opt.ignore_genes ? nullptr : (uint32_t *)at(o_v),
+                           c->opt.ignore_genes ? nullptr : (uint32_t *)at(o_j), (uint32_t *)at(o_rep),
+                           c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), q0, q1);
+        HIP_TRY(c, hipGetLastError());
+      }
       hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(q1 - q0)), dim3(256), lds, c->stream, Q, q0, q1);
       HIP_TRY(c, hipGetLastError());
     }
@@ -1464,6 +1623,18 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       HIP_TRY(c, hipEventRecord(c->ev_copy[0], c->copy_stream));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_copy[0], 0));
     }
+    if (!redo_wide)
+      break;
+    /* something does not fit the narrow types: once more, the caller's arrays as they are */
+    for (auto &t : workers)
+      t.join();
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemsetAsync(base, 0, zero_bytes, c->stream));
+    narrow = false;
+    upload_ms = 0;
+    if (attempt)
+      return fail(c, CMPR_ESTATE, "upload did not settle");
   }
   const auto t_uploaded = std::chrono::steady_clock::now();
 

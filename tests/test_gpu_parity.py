@@ -76,6 +76,10 @@ LAYOUTS = {
     "rows_overflow": {"variant": 2, "slice_words_log2": 4, "pos_capacity": 64},
     # a filter 8 x denser than the default: mostly false positives behind it
     "rows_dense": {"variant": 2, "bloom_bits_log2_delta": -3, "slice_words_log2": 6},
+    # the queries uploaded narrowed (lengths, 16-bit ids, 32-bit counts; by default only
+    # for sets of a million and more) and widened again on the device
+    "rows_narrow": {"variant": 2, "narrow_upload": 1},
+    "lds_narrow": {"variant": 1, "narrow_upload": 1, "slice_words_log2": 5},
 }
 
 
@@ -383,6 +387,35 @@ def test_errors_through_the_abi():
         h.set_queries(a)
         with pytest.raises(hipmod.HipError):
             h.overlap_matrix()         # ratio needs the f64 entry point
+
+
+def test_narrowed_upload_falls_back_when_a_value_does_not_fit():
+    """cmpr_set_queries narrows offsets / ids / counts on the host before the copy; a count
+    of 2^32 or more, or input errors, send the set the wide way with the same result / the
+    same error as without narrowing."""
+    a = synth.make_set(30000, 31, prefix="A", pool_size=5000)
+    b = synth.make_set(30000, 32, prefix="B", pool_size=5000)
+    a.count = a.count.copy()
+    a.count[::1000] = (1 << 33) + 5                  # does not fit 32 bits
+    o = Options(differences=1, indels=True, **FULL)
+    want, ost = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    for narrow in (0, 1):
+        got, st = gpu_cells(a, b, o, {"narrow_upload": narrow})
+        assert np.array_equal(got, want), narrow
+        assert st.matches == ost.matches
+    bad = synth.make_set(5000, 33, prefix="A")
+    bad.v_gene = bad.v_gene.copy()
+    bad.v_gene[777] = synth.N_V + 3                  # out of range: the same error either way
+    msgs = []
+    for narrow in (0, 1):
+        with HipOverlap(o) as h:
+            h.set_tunable("narrow_upload", narrow)
+            h.set_reference(b, bad.longest)
+            with pytest.raises(hipmod.HipError) as e:
+                h.set_queries(bad)
+            msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "gene" in msgs[0]
 
 
 @pytest.mark.parametrize("name,opt,nt,tun", [
