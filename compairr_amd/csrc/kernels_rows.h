@@ -1309,16 +1309,12 @@ probe_rows_kernel(const ProbeParams P)
               mi_max = mi[i] > mi_max ? mi[i] : mi_max;
           uint64_t hg = h_ins;                    /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
           uint32_t carry = 31u;                   /* q[ip0 - 1]: the residue behind which block ip0 starts */
-          for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
-            if (ip0 && ip0 % (4u * TDW) == 0) {
-              const uint32_t w0 = ip0 >> 2;
-              s0 = w0 < nd ? qr[w0 * WAVE] : 0u;
-              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
-              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
-              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
-              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
-              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
-            }
+          /* One block of RB rows.  INNER (wave-uniform, the blocks between the first and the
+             last of an ordinary tile): every row has 0 < ip <= L and lies behind the last class
+             position -- no test per row, no class-key arithmetic, nothing read where it lies;
+             the generic form keeps all of that for the first and the last block. */
+          auto ins_block = [&](uint32_t ip0, auto inner_c) {
+            constexpr bool INNER = decltype(inner_c)::value;
             /* residues of positions ip0 .. ip0 + RB - 1 in the low bytes of s0 (s1) */
             const uint64_t rr = ((uint64_t)s1 << 32) | s0;
             if constexpr (RB == 4) {
@@ -1340,9 +1336,12 @@ probe_rows_kernel(const ProbeParams P)
               const uint32_t ip = ip0 + (uint32_t)j;
               rprev[j] = j == 0 ? carry : (uint32_t)(rr >> (8 * (j - 1))) & 31u;
               ka[j] = kb[j] = 0;
-              if (ip > 0 && ip <= L) {                         /* wave-uniform */
-                ka[j] = lds_u64(zl_addr + (ZS * (ip - 1u) + rprev[j]) * 8u);
-                kb[j] = lds_u64(zl_addr + (ZS * ip + rprev[j]) * 8u);
+              if (INNER || (ip > 0 && ip <= L)) {              /* wave-uniform */
+                uint32_t zdn = zl_addr + ZS * 8u * (ip - 1u), zup = zl_addr + ZS * 8u * ip;
+                asm("" : "+s"(zdn));
+                asm("" : "+s"(zup));
+                ka[j] = lds_u64(zdn + rprev[j] * 8u);
+                kb[j] = lds_u64(zup + rprev[j] * 8u);
               }
             }
             carry = (uint32_t)(rr >> (8 * (RB - 1))) & 31u;
@@ -1355,29 +1354,31 @@ probe_rows_kernel(const ProbeParams P)
 #pragma unroll
             for (int j = 0; j < RB; j++) {
               const uint32_t ip = ip0 + (uint32_t)j;
-              if (ip > 0 && ip <= L)
+              if (INNER || (ip > 0 && ip <= L))
                 hg ^= ka[j] ^ kb[j];
               hrow[j] = hg;
               wor[j] = woff_of(hg);
               itr[j] = false;
               slr[j] = cslice;
-              if (K == 0u || ip0 > mi_max)             /* wave-uniform: see mi_max */
-                continue;
-              uint32_t key = base_t;
-              int ci_u = -1;                           /* first class residue of t at the blanked position */
+              if constexpr (!INNER) {
+                if (K != 0u && ip0 <= mi_max) {            /* wave-uniform: see mi_max */
+                  uint32_t key = base_t;
+                  int ci_u = -1;                           /* first class residue of t at the blanked position */
 #pragma unroll
-              for (uint32_t i = 0; i < MCR; i++)
-                if (i < KH) {
-                  if (mi[i] != ip)
-                    key ^= mi[i] < ip ? lo[i] : hi[i];
-                  else if (ci_u < 0)
-                    ci_u = (int)i;
+                  for (uint32_t i = 0; i < MCR; i++)
+                    if (i < KH) {
+                      if (mi[i] != ip)
+                        key ^= mi[i] < ip ? lo[i] : hi[i];
+                      else if (ci_u < 0)
+                        ci_u = (int)i;
+                    }
+                  /* a row blanked at a class position of a split variant class is an
+                     item of that position's class part (query_layout.hip) */
+                  itr[j] = hvy && ci_u >= 0;
+                  slr[j] = row_slice(P.geom, key, -1);
+                  any_glob = any_glob || (ip <= L && __ballot(valid && !itr[j] && slr[j] != cslice) != 0);
                 }
-              /* a row blanked at a class position of a split variant class is an
-                 item of that position's class part (query_layout.hip) */
-              itr[j] = hvy && ci_u >= 0;
-              slr[j] = row_slice(P.geom, key, -1);
-              any_glob = any_glob || (ip <= L && __ballot(valid && !itr[j] && slr[j] != cslice) != 0);
+              }
             }
             RowWord wc = word_lds(wor[0]);
 #pragma unroll
@@ -1387,19 +1388,21 @@ probe_rows_kernel(const ProbeParams P)
               if (j + 1 < RB)
                 wn = word_lds(wor[j + 1]);
               __builtin_amdgcn_sched_barrier(0);
-              if (ip <= L) {                                   /* wave-uniform */
+              if (INNER || ip <= L) {                          /* wave-uniform */
                 RowWord w = wc;
-                if (any_glob) {                                /* rare: a lane's row lies in another slice */
-                  if (valid && !itr[j] && slr[j] != cslice)
-                    w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
+                if constexpr (!INNER) {
+                  if (any_glob) {                              /* rare: a lane's row lies in another slice */
+                    if (valid && !itr[j] && slr[j] != cslice)
+                      w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
+                  }
                 }
                 treads += valid ? 1u : 0u;
                 uint32_t x = row_bits(w, hrow[j]) & AMASK & vmask;
-                if (ip > 0)
+                if (INNER || ip > 0)
                   x &= ~(1u << rprev[j]);                       /* v != q[ip - 1] */
-                const bool lives = !itr[j] && ip <= Ll;               /* (the lane's own length) */
+                const bool lives = (INNER || !itr[j]) && ip <= Ll;    /* (the lane's own length) */
                 x = lives ? x : 0u;
-                nvar += lives ? (ip > 0 ? (uint32_t)(A - 1) : (uint32_t)A) : 0u;
+                nvar += lives ? ((INNER || ip > 0) ? (uint32_t)(A - 1) : (uint32_t)A) : 0u;
                 if (j < RPW)
                   m0 |= (uint64_t)x << (A * j);
                 else
@@ -1421,6 +1424,21 @@ probe_rows_kernel(const ProbeParams P)
                                           (uint32_t)mi0, (uint32_t)(mi0 >> 32) | ((rroll >> 13) << 28),
                                           (uint32_t)__popcll((unsigned long long)mi0));
             }
+          };
+          for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
+            if (ip0 && ip0 % (4u * TDW) == 0) {
+              const uint32_t w0 = ip0 >> 2;
+              s0 = w0 < nd ? qr[w0 * WAVE] : 0u;
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+            }
+            if (ip0 >= 1u && ip0 + (uint32_t)RB - 1u <= L && (K == 0u || ip0 > mi_max))
+              ins_block(ip0, std::true_type{});
+            else
+              ins_block(ip0, std::false_type{});
           }
         }
       }
