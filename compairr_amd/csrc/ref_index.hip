@@ -121,6 +121,10 @@ record_positions_kernel(const uint32_t *piece_pre, uint64_t n, uint32_t *voff)
     voff[i] = piece_pre[i] * 4u;              /* in 16-byte units */
 }
 
+struct WidenU32 {
+  __host__ __device__ unsigned long long operator()(const uint32_t &x) const { return x; }
+};
+
 }  // namespace
 
 int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query)
@@ -134,6 +138,8 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_ref = false;
   c->have_q = false;
+  if (s->n > 0x7fffffffull)                               /* (hipCUB item counts are int) */
+    return fail(c, CMPR_EUNSUPPORTED, "more than 2^31-1 sequences in one set");
 
   /* ---- the set as the caller has it, validated on the device ---- */
   uint32_t longest = 0;
@@ -459,11 +465,19 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
       hipLaunchKernelGGL(record_positions_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
                          pre.b.p, s->n, c->voff2.p);
       HIP_TRY(c, hipGetLastError());
-      uint32_t lastp = 0, lastn = 0;
-      HIP_TRY(c, hipMemcpyAsync(&lastp, pre.b.p + (s->n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(&lastn, pieces.b.p + (s->n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      /* the total in 64 bits, beside the 32-bit prefix sums: those may not wrap unnoticed */
+      Tmp<unsigned long long> total;
+      Tmp<char> tmp2;
+      if ((rc = dev_alloc(c, total.b, 1))) return rc;
+      hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> it(pieces.b.p, WidenU32());
+      size_t tb2 = 0;
+      (void)hipcub::DeviceReduce::Sum(nullptr, tb2, it, total.b.p, (int)s->n, c->stream);
+      if ((rc = dev_alloc(c, tmp2.b, tb2))) return rc;
+      HIP_TRY(c, hipcub::DeviceReduce::Sum(tmp2.b.p, tb2, it, total.b.p, (int)s->n, c->stream));
+      unsigned long long npieces = 0;
+      HIP_TRY(c, hipMemcpyAsync(&npieces, total.b.p, sizeof npieces, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      units = ((uint64_t)lastp + lastn) * 4;
+      units = (uint64_t)npieces * 4;
     }
     units += 8;                 /* verify_candidate reads 64 bytes whatever the length */
     if (units >> 32)

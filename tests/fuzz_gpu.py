@@ -85,6 +85,10 @@ def random_case(rng):
         tun["sub2_items"] = 1                             # (takes effect for nucleotides, d = 2, variant 1)
     if rng.random() < 0.3:
         tun["host_threads"] = int(rng.integers(1, 9))
+    if rng.random() < 0.3:
+        tun["narrow_upload"] = 1                          # (by default only for sets of a million and more)
+    if rng.random() < 0.15:
+        tun["step_graph"] = 1
     same = rng.random() < 0.2
     return a, (a if same else b), o, tun
 
@@ -101,21 +105,44 @@ def main():
         a, b, o, tun = random_case(rng)
         want, ost = _oracle.overlap(a, b, o, threads=8)
         want = _oracle.integer_cells(want, o)
-        with HipOverlap(o) as h:
-            order = ["variant"] + [k for k in tun if k != "variant"]
-            for k in order:
-                if k in tun:
-                    h.set_tunable(k, tun[k])
-            h.set_reference(b, a.longest)
-            h.set_queries(a)
-            got = h.overlap_matrix()
-            st = h.stats()
-            pairs = h.overlap_pairs() if n % 4 == 0 else None
-        ok = np.array_equal(got, want) and st.matches == ost.matches and st.variants == ost.variants
-        if ok and pairs is not None:
-            ok = len(pairs) == ost.matches
+        # sometimes as work shards (each context lays out only what it works on): the
+        # matrices, counters and pair lists of the shards add up to the whole
+        shards = int(rng.integers(2, 6)) if (tun.get("variant", -1) != 0 and rng.random() < 0.2) else 1
+        got, nmatch, nvar, npairs = None, 0, 0, 0
+        ok = True
+        for index in range(shards):
+            with HipOverlap(o) as h:
+                order = ["variant"] + [k for k in tun if k != "variant"]
+                for k in order:
+                    if k in tun:
+                        h.set_tunable(k, tun[k])
+                if shards > 1:
+                    h.set_tunable("work_shard_count", shards)
+                    h.set_tunable("work_shard_index", index)
+                h.set_reference(b, a.longest)
+                if h.get_tunable("variant") == 0 and shards > 1:
+                    shards = 1                            # (long sequences fell back to the unsliced kernel)
+                    h.set_tunable("work_shard_count", 1)
+                    h.set_tunable("work_shard_index", 0)
+                h.set_queries(a)
+                m = h.overlap_matrix()
+                st = h.stats()
+                # repeated launches (the third may run without its redo pass) give the same
+                for _ in range(2 if n % 3 == 0 else 0):
+                    ok = ok and np.array_equal(h.overlap_matrix(), m)
+                if n % 4 == 0:
+                    npairs += len(h.overlap_pairs())
+            got = m if got is None else got + m
+            nmatch += st.matches
+            nvar += st.variants
+            if shards == 1:
+                break
+        ok = ok and np.array_equal(got, want) and nmatch == ost.matches and nvar == ost.variants
+        if ok and n % 4 == 0:
+            ok = npairs == ost.matches
+        st = None
         if not ok:
-            print("MISMATCH after %d cases: n1=%d n2=%d opt=%s tun=%s" % (n, a.n, b.n, o, tun))
+            print("MISMATCH after %d cases: n1=%d n2=%d opt=%s tun=%s shards=%d" % (n, a.n, b.n, o, tun, shards))
             sys.exit(1)
         n += 1
     print("%d random cases, all bit-exact (%.0f s)" % (n, time.time() - t0))
