@@ -1149,6 +1149,10 @@ bool overflowed_without_redo(cmpr_context *c, hipStream_t st)
 {
   if (!c->last_without_redo || c->h_usage[1] == 0)
     return false;
+  /* (the word may also stem from an asynchronous launch before this one that nobody has
+     asked about yet: cmpr_get_stats still has to report that one) */
+  if (c->async_unchecked)
+    c->async_overflowed = true;
   (void)hipMemsetAsync(c->d_usage + 1, 0, sizeof(unsigned long long), st);
   c->never_overflows = c->usage_pending = false;
   return true;
@@ -1181,6 +1185,8 @@ extern "C" int cmpr_overlap_matrix_device(cmpr_context *c, void *d_matrix, void 
     return rc;
   c->stop_is_k1 = true;                     /* (nothing follows the kernels on this path) */
   c->events_valid = true;
+  if (c->last_without_redo)
+    c->async_unchecked = true;              /* until cmpr_get_stats has looked */
   if (!stream)
     HIP_TRY(c, hipStreamSynchronize(st));
   return CMPR_OK;
@@ -1348,12 +1354,15 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipMemcpy(st, c->d_stats, sizeof st, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(&ovf, c->d_overflow, sizeof ovf, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(&sticky, c->d_usage + 1, sizeof sticky, hipMemcpyDeviceToHost));
-  if (sticky) {
+  const bool async_overflowed = c->async_overflowed;
+  c->async_unchecked = c->async_overflowed = false;
+  if (sticky || async_overflowed) {
     /* One of the launches since the last check (cmpr_overlap_matrix_device does not
        synchronise, so it cannot look itself) ran without redo pass and overflowed its
        positives buffer: the matrix it left is incomplete.  The shortcut is withdrawn;
        the next launches carry the redo pass again. */
-    HIP_TRY(c, hipMemset(c->d_usage + 1, 0, sizeof sticky));
+    if (sticky)
+      HIP_TRY(c, hipMemset(c->d_usage + 1, 0, sizeof sticky));
     c->never_overflows = c->usage_pending = false;
     return fail(c, CMPR_ESTATE, "positives buffer overflowed in a launch without redo pass: result invalid, "
                                 "repeat the call");

@@ -210,6 +210,9 @@ struct cmpr_context {
   uint32_t                   usage_grid = 0, usage_nw = 0, safe_grid = 0, safe_nw = 0;
   bool                       last_without_redo = false;   /* the last launch relied on never_overflows */
   bool                       force_no_redo = false;       /* test only (tunable "assume_never_overflows") */
+  /* a cmpr_overlap_matrix_device launch without redo pass that cmpr_get_stats has not
+     looked at yet / one such was found overflowed by a synchronous call's own check */
+  bool                       async_unchecked = false, async_overflowed = false;
   hipStream_t                last_stream = nullptr;       /* stream of the last enqueue (launches of one */
   bool                       have_last_stream = false;    /* context are ordered one after the other)   */
   DevArena                   arena_a, arena_b;            /* temporaries of cmpr_set_queries */

@@ -189,7 +189,9 @@ int cmpr_overlap_matrix_f64(cmpr_context *ctx, double *matrix_out);
  * shortcut, and later launches carry the redo pass again.  Callers of this entry
  * point must therefore call cmpr_get_stats() before trusting a series of launches.
  * The synchronous entry points (cmpr_overlap_matrix, _f64, _pairs) check by
- * themselves and repeat the step with the redo pass: they never return such a result.
+ * themselves and repeat the step with the redo pass: they never return such a result
+ * (and a synchronous call that comes between such a launch and the question does not
+ * take the answer away: cmpr_get_stats() still fails once).
  */
 int cmpr_overlap_matrix_device(cmpr_context *ctx, void *d_matrix, void *stream);
 

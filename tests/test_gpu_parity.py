@@ -541,6 +541,17 @@ def test_overflow_without_redo_pass_is_never_silent():
         s.synchronize()
         assert np.array_equal(t.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
         assert h.stats().matches == ost.matches
+        # a synchronous call between the asynchronous launch and the question: its own
+        # check finds the word, repeats ITS step -- and the question still gets the answer
+        h.set_tunable("assume_never_overflows", 1)
+        h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)
+        h.set_tunable("assume_never_overflows", 1)
+        assert np.array_equal(h.overlap_matrix(), want)
+        with pytest.raises(hipmod.HipError) as e:
+            h.stats()
+        assert e.value.code == 5
+        assert np.array_equal(h.overlap_matrix(), want)
+        assert h.stats().matches == ost.matches
 
 
 def test_shortcut_is_withdrawn_when_the_deal_changes():
