@@ -337,4 +337,10 @@ int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uin
 /* ref_index.hip: cmpr_set_reference */
 int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query);
 
+/* variant 2 with single substitutions only: the filter holds pair rows (kernels_rows.h) */
+inline bool pair_rows(const cmpr_context *c)
+{
+  return c->rows && c->opt.differences == 1 && !c->opt.indels;
+}
+
 #endif

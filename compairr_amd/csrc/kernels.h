@@ -141,6 +141,7 @@ struct BuildParams {
   uint32_t        bloom_byte_mask;
   uint32_t        sliced;          /* 1: class-keyed slices (layout.h)      */
   uint32_t        indels;          /* row filter: also the gap entries (kernels_rows.h) */
+  uint32_t        pairs;           /* row filter: pair rows (d = 1 without -i, kernels_rows.h) */
   uint32_t        pad;
   SliceGeom       geom;
 };

@@ -98,6 +98,58 @@ __host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint6
   q[3] = (1ull << (((wh >> 10) + code) & 31u)) | (1ull << (32u + (((wh >> 15) + code) & 31u)));
 }
 
+/* ---- pair rows (d = 1 without -i): TWO positions blanked per entry ----
+ *
+ * With single substitutions only, a set-2 sequence t is entered once per PAIR of positions
+ * (p, p + 1), p even, under the hash with BOTH blanked,
+ *   W = H(t) ^ Z[p][a] ^ Z[p+1][b],   a = t[p], b = t[p+1] (b = A: t ends at p),
+ * and sets bit (a_k + a + b) mod 32 of dwords 0..3 and bit (a_k + a - b) mod 32 of dwords
+ * 4..7 -- sum and difference of the two codes.  A query q with (ra, rb) at the pair reads
+ * the word of its own pair-blanked hash ONCE, rotates and ANDs each half (xs, xd: bit i <->
+ * "an entry with a + b = i" / "a - b = i" may be present) and gets from it
+ *   "q with v at p"      (b = rb):  xs[v + rb] & xd[v - rb]   = (xs ror rb) & (xd rol rb),
+ *   "q with w at p + 1"  (a = ra):  xs[ra + w] & xd[ra - w]   = (xs ror ra) & (rev(xd) ror (31 - ra)),
+ * all 2 (A - 1) substitution variants of the two positions out of one 32-byte read, each
+ * still a test of eight filter bits.  (Sum and difference: a test that asked for "a = v"
+ * and "b = rb" separately would pass for every v that ANY neighbour of q carries, q itself
+ * included -- half the test would be true for every query that is in set 2.)
+ */
+__host__ __device__ inline void pair_entry_bits(uint64_t Wk, uint32_t a, uint32_t b, uint64_t q[4])
+{
+  const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
+  const uint32_t s = a + b, d = a - b;
+  q[0] = (1ull << ((wl + s) & 31u)) | (1ull << (32u + (((wl >> 8) + s) & 31u)));
+  q[1] = (1ull << (((wl >> 16) + s) & 31u)) | (1ull << (32u + (((wl >> 24) + s) & 31u)));
+  q[2] = (1ull << ((wh + d) & 31u)) | (1ull << (32u + (((wh >> 5) + d) & 31u)));
+  q[3] = (1ull << (((wh >> 10) + d) & 31u)) | (1ull << (32u + (((wh >> 15) + d) & 31u)));
+}
+
+/* the two halves of a pair word, rotated and ANDed (xs: sums, xd: differences) */
+__device__ __forceinline__ void pair_bits(const RowWord &w, uint64_t Wk, uint32_t &xs, uint32_t &xd)
+{
+  const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
+  const uint32_t x0 = __builtin_amdgcn_alignbit(w.a.x, w.a.x, wl);
+  const uint32_t x1 = __builtin_amdgcn_alignbit(w.a.y, w.a.y, wl >> 8);
+  const uint32_t x2 = __builtin_amdgcn_alignbit(w.a.z, w.a.z, wl >> 16);
+  const uint32_t x3 = __builtin_amdgcn_alignbit(w.a.w, w.a.w, wl >> 24);
+  const uint32_t x4 = __builtin_amdgcn_alignbit(w.b.x, w.b.x, wh);
+  const uint32_t x5 = __builtin_amdgcn_alignbit(w.b.y, w.b.y, wh >> 5);
+  const uint32_t x6 = __builtin_amdgcn_alignbit(w.b.z, w.b.z, wh >> 10);
+  const uint32_t x7 = __builtin_amdgcn_alignbit(w.b.w, w.b.w, wh >> 15);
+  xs = x0 & x1 & x2 & x3;
+  xd = x4 & x5 & x6 & x7;
+}
+
+/* the answers of a pair: bit v of ansA <-> "v at the first position", bit w of ansB <->
+   "w at the second" (own residues and everything above A still in: the caller masks) */
+__device__ __forceinline__ void pair_answers(uint32_t xs, uint32_t xd, uint32_t ra, uint32_t rb,
+                                             uint32_t &ansA, uint32_t &ansB)
+{
+  ansA = __builtin_amdgcn_alignbit(xs, xs, rb) & __builtin_amdgcn_alignbit(xd, xd, 0u - rb);
+  const uint32_t rev = __builtin_bitreverse32(xd);
+  ansB = __builtin_amdgcn_alignbit(xs, xs, ra) & __builtin_amdgcn_alignbit(rev, rev, 31u - ra);
+}
+
 /* word of W inside a slice of `nwords` 32-byte words (any count up to 2^13, not only
    powers of two: the filter is sized to the entry count): the top 16 bits of W scaled
    to the slice -- a 24-bit multiply, which the vector unit issues at full rate
@@ -144,6 +196,34 @@ build_rows_kernel(const BuildParams B)
       atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
   };
   enter(h, B.A, row_slice(g, ck, -1));
+  if (B.pairs) {
+    /* pair rows: one entry per pair of positions, filed under the class key without the
+       terms of the class positions inside the pair, in the class part of the first of them */
+    for (uint32_t p = 0; p < L; p += 2) {
+      const uint32_t a = s[p], b2 = p + 1 < L ? s[p + 1] : B.A;
+      uint32_t key = ck;
+      int ci = -1;
+      if (heavy)
+        for (uint32_t k = 0; k < g.k; k++) {
+          const uint32_t mk = class_pos(L, k, g.c0);
+          if ((mk & ~1u) == p) {
+            key ^= g.ctab[g.off_cr + k * B.A + s[mk]];
+            if (ci < 0)
+              ci = (int)k;
+          }
+        }
+      uint64_t Wk = h ^ B.zob[B.A * p + a];
+      if (p + 1 < L)
+        Wk ^= B.zob[B.A * (p + 1) + b2];
+      const uint64_t w = (uint64_t)row_slice(g, key, ci) * nwords + row_word(Wk, nwords);
+      uint64_t q[4];
+      pair_entry_bits(Wk, a, b2, q);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
+    }
+    return;
+  }
   for (uint32_t p = 0; p < L; p++) {
     uint32_t key = ck;
     int ci = -1;                               /* first class residue at p, if any */
@@ -224,6 +304,8 @@ template <int A> struct RowCfg {
  *                                                                 rows, RBITS each) continues in m[28..31]
  *   K_INSROWS gap hash of     K_INSROWS | ip0 << 3 | rroll << 19  the same layout; rroll = the residues
  *             the first row                                       q[ip0] .. q[ip0 + RB - 2] that roll the gap hash
+ *   K_PAIR    query hash h    K_PAIR | p << 3 | ra << 19          cb = mask of residues v at p, m = mask of
+ *                             | rb << 24                          residues w at p + 1; ra, rb = the query's own
  *   K_SUB,    the row's       kind | p << 3                       m = mask of residues v (one row: an item,
  *   K_INS     blanked hash                                        or an insertion row)
  *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant (K_DEL with
@@ -231,6 +313,7 @@ template <int A> struct RowCfg {
  */
 constexpr uint32_t K_ROWS = 5;
 constexpr uint32_t K_INSROWS = 6;        /* a block of insertion rows of one query (-i) */
+constexpr uint32_t K_PAIR = 7;           /* a pair of substitution rows (pair rows: d = 1 without -i) */
 constexpr uint32_t DEL_LAZY = 2;         /* m of a K_DEL entry whose hash is worked out when it is drained */
 
 template <int A, int D, bool GENES, bool INLINE>
@@ -269,6 +352,18 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     more = mk != 0;
     ncb = (uint32_t)mk;
     nm = (m & 0xf0000000u) | (uint32_t)(mk >> 32);
+  } else if (kind == K_PAIR) {
+    const uint32_t second = cb == 0u ? 1u : 0u;
+    const uint32_t bitsv = second ? m : cb;
+    const uint32_t v = (uint32_t)__ffs((int)bitsv) - 1u;
+    const uint32_t p = p0 + second, r = second ? (ca >> 24) & 31u : (ca >> 19) & 31u;
+    const uint32_t za = zl_addr + ZS * p * 8u;
+    hv = B ^ lds_u64(za + r * 8u) ^ lds_u64(za + v * 8u);
+    oca = pack_a(K_SUB, p, v);
+    ocb = 0;
+    ncb = second ? 0u : cb & (cb - 1u);
+    nm = second ? m & (m - 1u) : m;
+    more = (ncb | nm) != 0u;
   } else if (kind == K_INSROWS) {
     /* RB insertion rows from ip0 on: the gap hash of row j is that of row j - 1 with
        q[ip0 + j - 1] moved one position down (variants.cc:329-353) */
@@ -448,6 +543,7 @@ probe_rows_kernel(const ProbeParams P)
   constexpr uint32_t RBITS = RowCfg<A>::RBITS;
   constexpr uint32_t RMASK = (1u << RBITS) - 1u;
   constexpr uint32_t AMASK = (1u << A) - 1u;
+  constexpr bool PAIRS = D == 1 && !INDELS;       /* the filter holds pair rows (build_rows_kernel) */
 
   extern __shared__ __align__(16) unsigned char smem[];
   if ((uint32_t)(uintptr_t)smem != 0u)
@@ -934,7 +1030,142 @@ probe_rows_kernel(const ProbeParams P)
           nvar += 1;
         }
 
-        if (D >= 1) {
+        if constexpr (PAIRS) {
+          /* ---- single substitutions (variants.cc:280-293), pair rows: one word read per
+                  PAIR of positions answers the 2 (A - 1) variants of both (pair_bits), PB
+                  pairs per block.  A block is branch-free -- pairs past the end of the
+                  tile, past the end of a shorter query of it and the class pairs of a heavy
+                  tile (left to their items) are computed and masked. ---- */
+          constexpr int PB = A == 20 ? 3 : 2;            /* pairs per block */
+          constexpr uint32_t PP = 2u * PB;               /* positions per block: 6 or 4, both divide 24 */
+          const uint32_t nd = (L + 3u) >> 2;
+          uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
+          uint32_t nrows = 0;                     /* words read (wave-uniform) */
+          const uint32_t zlast = P.zpos - 1u;
+          auto pair_rows = [&](auto staged_c) {
+          constexpr bool STAGED = decltype(staged_c)::value;
+          for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += PP) {
+            if (p0 && p0 % (4u * TDW) == 0) {
+              const uint32_t w0 = p0 >> 2;
+              s0 = qr[w0 * WAVE];
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+            }
+            const uint64_t rr = ((uint64_t)s1 << 32) | s0;
+            if constexpr (PP == 4) {
+              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+            } else {
+              static_assert(PP == 4 || PP == 6, "six bytes of the shift register per block");
+              s0 = __builtin_amdgcn_alignbit(s2, s1, 16);
+              s1 = __builtin_amdgcn_alignbit(s3, s2, 16);
+              s2 = __builtin_amdgcn_alignbit(s4, s3, 16);
+              s3 = __builtin_amdgcn_alignbit(s5, s4, 16);
+              s4 = s5 >> 16;
+              s5 = 0;
+            }
+            /* class positions among the positions of the block (wave-uniform bits) */
+            uint32_t cbits = 0;
+            if (K) {
+              if (p0 + PP <= 64u)
+                cbits = (uint32_t)(cpos_lo >> p0);
+              else
+                for (uint32_t j = 0; j < PP; j++)
+                  cbits |= is_class_pos(p0 + j) ? (1u << j) : 0u;
+            }
+            cbits = __builtin_amdgcn_readfirstlane(cbits);
+            uint64_t Wk[PB];
+            uint32_t ra[PB], rb[PB], wo[PB];
+            /* the pairs' own keys, all 2 PB reads in flight together ... */
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+              const uint32_t p = p0 + 2u * (uint32_t)j;
+              ra[j] = (uint32_t)(rr >> (16 * j)) & 31u;
+              const uint32_t rq = (uint32_t)(rr >> (16 * j + 8)) & 31u;
+              const bool second = p + 1u < Ll;      /* (the lane's own length: tiles may mix lengths) */
+              rb[j] = second ? rq : (uint32_t)A;
+              uint32_t zrow = zl_addr + ZS * 8u * min(p, zlast);
+              asm("" : "+s"(zrow));
+              uint32_t zrow2 = zl_addr + ZS * 8u * min(p + 1u, zlast);
+              asm("" : "+s"(zrow2));
+              const uint64_t za = lds_u64(zrow + ra[j] * 8u);
+              const uint64_t zb = lds_u64(zrow2 + rq * 8u);
+              Wk[j] = za ^ (second ? zb : 0ull);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+              Wk[j] ^= h;
+              wo[j] = woff_of(Wk[j]);
+            }
+            /* ... then the filter words, one pair ahead of the pair being tested */
+            RowWord wc = STAGED ? word_lds(wo[0]) : word_glob(own_glob, wo[0]);
+            uint32_t xa[PB], xb[PB];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+              const uint32_t p = p0 + 2u * (uint32_t)j;
+              RowWord wn = wc;
+              if (j + 1 < PB)
+                wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              /* (a class pair of a heavy tile: nothing of it counts here -- a scalar select) */
+              const uint32_t am = ((cbits >> (2 * j)) & 3u) ? 0u : AMASK;
+              uint32_t xs, xd;
+              pair_bits(wc, Wk[j], xs, xd);
+              uint32_t a1, a2;
+              pair_answers(xs, xd, ra[j], rb[j], a1, a2);
+              a1 &= am & ~(1u << ra[j]);
+              a2 &= am & ~(1u << rb[j]);
+              xa[j] = p < Ll ? a1 : 0u;
+              xb[j] = p + 1u < Ll ? a2 : 0u;
+              wc = wn;
+            }
+            nrows += (uint32_t)PB;
+            PT_MARK(PT_ROWS);
+            {
+              uint32_t any = 0;
+#pragma unroll
+              for (int j = 0; j < PB; j++)
+                any |= xa[j] | xb[j];
+              if (CMPR_DBG(P, DBG_SKIP_EMIT))
+                any = 0;
+              if (__ballot(any != 0u)) {
+#pragma unroll
+                for (int j = 0; j < PB; j++)
+                  q_push<A, D, GENES, INLINE>(W, zl_addr, (xa[j] | xb[j]) != 0u && any != 0u, h,
+                                              K_PAIR | ((p0 + 2u * (uint32_t)j) << 3) | (ra[j] << 19) | (rb[j] << 24),
+                                              xa[j], xb[j], (uint32_t)__popc(xa[j]) + (uint32_t)__popc(xb[j]));
+              }
+            }
+            PT_MARK(PT_EMIT);
+          }
+          };
+          if (staged)
+            pair_rows(std::true_type{});
+          else
+            pair_rows(std::false_type{});
+          /* the variants these rows stand for: A - 1 per position of the lane's query that is
+             not in a class pair (wave-uniform positions: mixed tiles hold no wrapped ones) */
+          uint32_t ncls = 0;
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++)
+            if (i < K) {
+              const uint32_t pp = m[i] & ~1u;
+              bool fresh = true;
+#pragma unroll
+              for (uint32_t k = 0; k < MCR; k++)
+                if (k < i && (m[k] & ~1u) == pp)
+                  fresh = false;
+              if (fresh)
+                ncls += (pp < Ll ? 1u : 0u) + (pp + 1u < Ll ? 1u : 0u);
+            }
+          nvar += (Ll - ncls) * (uint32_t)(A - 1);
+          treads += valid ? nrows : 0u;
+        }
+
+        if (D >= 1 && !PAIRS) {
           /* ---- single substitutions (variants.cc:280-293), a row per position, RB
                   rows per block.  A block is branch-free, so that its 2 RB LDS
                   reads (own key, filter word) are in flight together: rows past
@@ -1194,12 +1425,48 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t im = cur.b, ic = cur.c;
           for (uint32_t r = 0; r < nblk; r++) {
             const bool ival = im != 0xffffffffu;          /* (~0: padding behind the items of a slice) */
-            const uint32_t icr = ic & 0xffu;
-            const uint32_t kind = (ic >> 24) & 7u, p = (ic >> 8) & 0xffffu;
             W.qslot = im;
             treads += ival ? 1u : 0u;
             const uint32_t wo = woff_of(iw);
             const RowWord w = staged ? word_lds(wo) : word_glob(own_glob, wo);
+            if constexpr (PAIRS) {
+              /* a class pair (query_layout.hip for_each_item): pair-blanked hash, own residues
+                 (second = A: the query ends with the first), first position */
+              const uint32_t ira = ic & 31u, irb = (ic >> 5) & 31u, p = (ic >> 10) & 0x3fffu;
+              uint32_t xs, xd, a1, a2;
+              pair_bits(w, iw, xs, xd);
+              pair_answers(xs, xd, ira, irb, a1, a2);
+              const uint32_t vm = ival ? AMASK : 0u;
+              a1 &= vm & ~(1u << ira);
+              a2 &= (irb < (uint32_t)A ? vm : 0u) & ~(1u << irb);
+              nvar += !ival ? 0u : (uint32_t)(A - 1) * (irb < (uint32_t)A ? 2u : 1u);
+              if (CMPR_DBG(P, DBG_SKIP_EMIT))
+                a1 = a2 = 0;
+              const bool pos = (a1 | a2) != 0u;
+              if (__ballot(pos)) {
+                /* (the entry carries the query's hash, like the pairs of a tile) */
+                uint64_t hq = 0;
+                if (pos) {
+                  hq = iw ^ lds_u64(zl_addr + (ZS * p + ira) * 8u);
+                  if (irb < (uint32_t)A)
+                    hq ^= lds_u64(zl_addr + (ZS * (p + 1u) + irb) * 8u);
+                }
+                q_push<A, D, GENES, INLINE>(W, zl_addr, pos, hq, K_PAIR | (p << 3) | (ira << 19) | (irb << 24),
+                                            a1, a2, (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
+              }
+              iw = ea[0];
+              im = eb[0];
+              ic = ec[0];
+#pragma unroll
+              for (uint32_t q = 0; q + 2 < ITEM_BLOCKS; q++) {
+                ea[q] = ea[q + 1];
+                eb[q] = eb[q + 1];
+                ec[q] = ec[q + 1];
+              }
+              continue;
+            }
+            const uint32_t icr = ic & 0xffu;
+            const uint32_t kind = (ic >> 24) & 7u, p = (ic >> 8) & 0xffffu;
             const uint32_t bits = row_bits(w, iw);
             uint32_t x = (kind == K_DEL ? (bits >> A) & 1u : bits & AMASK & ~(1u << icr)) & (ival ? ~0u : 0u);
             nvar += !ival ? 0u : kind == K_DEL ? 1u : (icr == 31u ? (uint32_t)A : (uint32_t)(A - 1));
@@ -1476,6 +1743,7 @@ probe_rows_kernel(const ProbeParams P)
     if ((int)lane < W.qn) {
       const uint32_t ca = W.q.ca[lane], kind = ca & 7u, m = W.q.m[lane];
       bits = (kind == K_ROWS || kind == K_INSROWS) ? (uint32_t)__popc(W.q.cb[lane]) + (uint32_t)__popc(m & 0x0fffffffu)
+             : kind == K_PAIR ? (uint32_t)__popc(W.q.cb[lane]) + (uint32_t)__popc(m)
                             : (kind == K_SUB || kind == K_INS) ? (uint32_t)__popc(m) : 1u;
     }
     for (int off = 32; off > 0; off >>= 1)

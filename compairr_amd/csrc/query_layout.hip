@@ -102,6 +102,7 @@ struct QL {
   uint32_t        n_rep, n_v_max, n_j_max;
   uint32_t        A, zpos, n_v, longest, per_slice;   /* longest: the longest a query may be (zpos - 3) */
   uint32_t        genes, counts, existence, indels, differences, sliced, rows;
+  uint32_t        pairs;             /* variant 2: pair rows (kernels_rows.h) */
   const uint64_t *zob;
   SliceGeom       geom;
   uint32_t        npass;             /* 1 + class-row passes (variant 2) */
@@ -296,7 +297,7 @@ __device__ inline uint64_t variants_of(const QL &Q, const uint8_t *s, uint32_t L
 }
 
 /* item kinds = the variant kinds of layout.h */
-enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_SUB2 = K_SUB2 };
+enum : uint32_t { ITEM_SUB = K_SUB, ITEM_INS = K_INS, ITEM_SUB2 = K_SUB2, ITEM_PAIR = 7 /* kernels_rows.h K_PAIR */ };
 /* flag of an ITEM_SUB item, above its kind: the row's deletion answer counts (layout.h ITEM_DEL_COUNTS) */
 
 __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
@@ -340,6 +341,36 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
   /* ---- substitution rows at class positions: class part ci, key without the terms
           of that position; a position that carries several class residues is
           handled by the first of them ---- */
+  if (heavy && Q.pairs) {
+    /* pair rows (kernels_rows.h): one item per PAIR of positions (p, p + 1), p even, that
+       holds a class position -- class part of the first class residue inside, key without
+       the terms of every class residue inside, the hash with both positions blanked */
+    const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
+    for (uint32_t ci = 0; ci < K; ci++) {
+      const uint32_t p = class_pos(L, ci, g.c0) & ~1u;
+      bool first = true;
+      uint32_t key = ck;
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t mk = class_pos(L, k, g.c0);
+        if ((mk & ~1u) == p) {
+          if (k < ci)
+            first = false;
+          key ^= g.ctab[g.off_cr + k * A + s[mk]];
+        }
+      }
+      if (first) {
+        const uint32_t ra = s[p], rb = p + 1 < L ? (uint32_t)s[p + 1] : A;
+        uint64_t w = 0;
+        if (HASH) {
+          w = h ^ Q.zob[A * p + ra];
+          if (p + 1 < L)
+            w ^= Q.zob[A * (p + 1) + rb];
+        }
+        f(Q.goff[ci] + (key & g.cmask), w, ra | (rb << 5) | (p << 10) | (ITEM_PAIR << 24));
+      }
+    }
+    return;
+  }
   if (heavy) {
     const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
     for (uint32_t ci = 0; ci < K; ci++) {
@@ -1408,6 +1439,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.counts = c->opt.ignore_counts ? 0 : 1;
   Q.existence = c->opt.existence ? 1 : 0;
   Q.indels = c->opt.indels ? 1 : 0;
+  Q.pairs = pair_rows(c) ? 1 : 0;
   Q.differences = (uint32_t)c->opt.differences;
   Q.sliced = c->sliced ? 1 : 0;
   Q.rows = c->rows ? 1 : 0;

@@ -503,6 +503,7 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.sliced = c->sliced ? 1u : 0u;
     B.indels = c->rows && c->opt.indels ? 1u : 0u;
+    B.pairs = pair_rows(c) ? 1u : 0u;
     B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
