@@ -764,7 +764,7 @@ int make_plan(cmpr_context *c)
       (uint64_t)(c->ntiles - c->nsmall) < 6ull * c->nchunks)
     nw = 4;
   auto lds_for = [&](int waves) -> size_t {
-    const size_t zrow = c->rows ? (c->opt.differences == 2 ? 2 * (size_t)A : (size_t)A)
+    const size_t zrow = c->rows ? (size_t)zs_of((int)A, c->opt.differences == 2 ? 2 : 1, pair_rows(c))
                                 : c->sliced ? (size_t)(zrow_stride((int)A) + zdelta_entries((int)A))
                                             : (size_t)A;
     size_t b = zrow * c->zpos * sizeof(uint64_t) +

@@ -116,28 +116,44 @@ __host__ __device__ inline void row_entry_bits(uint64_t Wk, uint32_t code, uint6
  */
 __host__ __device__ inline void pair_entry_bits(uint64_t Wk, uint32_t a, uint32_t b, uint64_t q[4])
 {
+  /* rotation amounts: the low five bits of wl, wh, wl >> 8, wh >> 8 -- the same four for
+     the sum dwords 0..3 and the difference dwords 4..7 (two shifts per test instead of
+     six; the halves are different dwords, their contents independent all the same) */
   const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
   const uint32_t s = a + b, d = a - b;
-  q[0] = (1ull << ((wl + s) & 31u)) | (1ull << (32u + (((wl >> 8) + s) & 31u)));
-  q[1] = (1ull << (((wl >> 16) + s) & 31u)) | (1ull << (32u + (((wl >> 24) + s) & 31u)));
-  q[2] = (1ull << ((wh + d) & 31u)) | (1ull << (32u + (((wh >> 5) + d) & 31u)));
-  q[3] = (1ull << (((wh >> 10) + d) & 31u)) | (1ull << (32u + (((wh >> 15) + d) & 31u)));
+  q[0] = (1ull << ((wl + s) & 31u)) | (1ull << (32u + ((wh + s) & 31u)));
+  q[1] = (1ull << (((wl >> 8) + s) & 31u)) | (1ull << (32u + (((wh >> 8) + s) & 31u)));
+  q[2] = (1ull << ((wl + d) & 31u)) | (1ull << (32u + ((wh + d) & 31u)));
+  q[3] = (1ull << (((wl >> 8) + d) & 31u)) | (1ull << (32u + (((wh >> 8) + d) & 31u)));
 }
 
 /* the two halves of a pair word, rotated and ANDed (xs: sums, xd: differences) */
 __device__ __forceinline__ void pair_bits(const RowWord &w, uint64_t Wk, uint32_t &xs, uint32_t &xd)
 {
   const uint32_t wl = (uint32_t)Wk, wh = (uint32_t)(Wk >> 32);
+  const uint32_t wl8 = wl >> 8, wh8 = wh >> 8;
   const uint32_t x0 = __builtin_amdgcn_alignbit(w.a.x, w.a.x, wl);
-  const uint32_t x1 = __builtin_amdgcn_alignbit(w.a.y, w.a.y, wl >> 8);
-  const uint32_t x2 = __builtin_amdgcn_alignbit(w.a.z, w.a.z, wl >> 16);
-  const uint32_t x3 = __builtin_amdgcn_alignbit(w.a.w, w.a.w, wl >> 24);
-  const uint32_t x4 = __builtin_amdgcn_alignbit(w.b.x, w.b.x, wh);
-  const uint32_t x5 = __builtin_amdgcn_alignbit(w.b.y, w.b.y, wh >> 5);
-  const uint32_t x6 = __builtin_amdgcn_alignbit(w.b.z, w.b.z, wh >> 10);
-  const uint32_t x7 = __builtin_amdgcn_alignbit(w.b.w, w.b.w, wh >> 15);
+  const uint32_t x1 = __builtin_amdgcn_alignbit(w.a.y, w.a.y, wh);
+  const uint32_t x2 = __builtin_amdgcn_alignbit(w.a.z, w.a.z, wl8);
+  const uint32_t x3 = __builtin_amdgcn_alignbit(w.a.w, w.a.w, wh8);
+  const uint32_t x4 = __builtin_amdgcn_alignbit(w.b.x, w.b.x, wl);
+  const uint32_t x5 = __builtin_amdgcn_alignbit(w.b.y, w.b.y, wh);
+  const uint32_t x6 = __builtin_amdgcn_alignbit(w.b.z, w.b.z, wl8);
+  const uint32_t x7 = __builtin_amdgcn_alignbit(w.b.w, w.b.w, wh8);
   xs = x0 & x1 & x2 & x3;
   xd = x4 & x5 & x6 & x7;
+}
+
+/* (1 << n) - 1, n <= 31, and a sign-extended bit field: one instruction each */
+__device__ __forceinline__ uint32_t bfm_u32(uint32_t n)
+{
+  uint32_t r;
+  asm("v_bfm_b32 %0, %1, 0" : "=v"(r) : "v"(n));
+  return r;
+}
+__device__ __forceinline__ int bfe_i32(uint32_t x, int off, int width)
+{
+  return __builtin_amdgcn_sbfe((int)x, (uint32_t)off, (uint32_t)width);
 }
 
 /* the answers of a pair: bit v of ansA <-> "v at the first position", bit w of ansB <->
@@ -284,6 +300,15 @@ template <int A> struct RowCfg {
   static constexpr uint32_t RBITS = A == 20 ? 5u : 2u;
 };
 
+/* keys per position of the kernel's LDS copy of the Zobrist table: d = 2 stores a row twice
+   (rotated reads); pair rows add a ZERO key for code A -- the residue code the layout pads
+   a query with behind its end (query_layout.hip fill_tiles_kernel), so that a pair that
+   hangs over the end hashes, and reads, without a test */
+__host__ __device__ constexpr uint32_t zs_of(int A, int D, bool pairs)
+{
+  return D == 2 ? 2u * (uint32_t)A : (pairs ? (uint32_t)A + 1u : (uint32_t)A);
+}
+
 /* ------------------------------------------------------------------ */
 /* the per-wave queue of this kernel holds ENTRIES, not variants        */
 /* ------------------------------------------------------------------ */
@@ -316,10 +341,10 @@ constexpr uint32_t K_INSROWS = 6;        /* a block of insertion rows of one que
 constexpr uint32_t K_PAIR = 7;           /* a pair of substitution rows (pair rows: d = 1 without -i) */
 constexpr uint32_t DEL_LAZY = 2;         /* m of a K_DEL entry whose hash is worked out when it is drained */
 
-template <int A, int D, bool GENES, bool INLINE>
+template <int A, int D, bool GENES, bool INLINE, bool PAIRS>
 __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n, bool last = false)
 {
-  constexpr uint32_t ZS = D == 2 ? 2u * A : (uint32_t)A;
+  constexpr uint32_t ZS = zs_of(A, D, PAIRS);
   constexpr uint32_t RBITS = RowCfg<A>::RBITS, RMASK = (1u << RBITS) - 1u;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int first = W.qn - n;
@@ -440,7 +465,7 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
 }
 
 /* queue one entry per lane with `pos` (nbits = its positive variants, for the counters) */
-template <int A, int D, bool GENES, bool INLINE>
+template <int A, int D, bool GENES, bool INLINE, bool PAIRS>
 __device__ __forceinline__ void q_push(SProber &W, uint32_t zl_addr, bool pos, uint64_t B, uint32_t ca,
                                        uint32_t cb, uint32_t m, uint32_t nbits)
 {
@@ -457,7 +482,7 @@ __device__ __forceinline__ void q_push(SProber &W, uint32_t zl_addr, bool pos, u
     }
     W.qn += __popcll(mm);
     while (W.qn >= WAVE)
-      drain_round<A, D, GENES, INLINE>(W, zl_addr, WAVE);
+      drain_round<A, D, GENES, INLINE, PAIRS>(W, zl_addr, WAVE);
   }
 }
 
@@ -537,13 +562,13 @@ probe_rows_kernel(const ProbeParams P)
     return;
   constexpr uint32_t NT = NW * WAVE;
   constexpr uint32_t MCR = max_class_res(A);
-  constexpr uint32_t ZS = D == 2 ? 2u * A : (uint32_t)A;   /* d = 2: rows stored twice (rotated reads) */
+  constexpr bool PAIRS = D == 1 && !INDELS;       /* the filter holds pair rows (build_rows_kernel) */
+  constexpr uint32_t ZS = zs_of(A, D, PAIRS);
   constexpr int RPW = RowCfg<A>::RPW;
   constexpr int RB = RowCfg<A>::RB;
   constexpr uint32_t RBITS = RowCfg<A>::RBITS;
   constexpr uint32_t RMASK = (1u << RBITS) - 1u;
   constexpr uint32_t AMASK = (1u << A) - 1u;
-  constexpr bool PAIRS = D == 1 && !INDELS;       /* the filter holds pair rows (build_rows_kernel) */
 
   extern __shared__ __align__(16) unsigned char smem[];
   if ((uint32_t)(uintptr_t)smem != 0u)
@@ -564,8 +589,10 @@ probe_rows_kernel(const ProbeParams P)
   TileRef *tref_lds = (TileRef *)(ring + RING);             /* RING x chunk_cap */
   const uint32_t chunk_cap = P.chunk_cap;
 
-  for (uint32_t i = threadIdx.x; i < nz; i += NT)
-    zl[i] = P.zob[(i / ZS) * A + (i % ZS) % A];
+  for (uint32_t i = threadIdx.x; i < nz; i += NT) {
+    const uint32_t r = i % ZS;
+    zl[i] = (PAIRS && r == (uint32_t)A) ? 0ull : P.zob[(i / ZS) * A + r % A];
+  }
   for (uint32_t i = threadIdx.x; i < MAX_CLASS_RES * (uint32_t)A; i += NT)
     cr_lds[i] = P.geom.ctab[P.geom.off_cr + i];
   if (INDELS)
@@ -1016,7 +1043,7 @@ probe_rows_kernel(const ProbeParams P)
       auto emit_sub_rows = [&](uint64_t m0, uint32_t p0, uint32_t rpack) {
         if (CMPR_DBG(P, DBG_SKIP_EMIT))
           m0 = 0;
-        q_push<A, D, GENES, INLINE>(W, zl_addr, m0 != 0, h, K_ROWS | (p0 << 3) | (rpack << 19), (uint32_t)m0,
+        q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, m0 != 0, h, K_ROWS | (p0 << 3) | (rpack << 19), (uint32_t)m0,
                                     (uint32_t)(m0 >> 32) | ((rpack >> 13) << 28),
                                     (uint32_t)__popcll((unsigned long long)m0));
       };
@@ -1026,7 +1053,7 @@ probe_rows_kernel(const ProbeParams P)
         {
           const RowWord w = fetch_own(h);
           const bool hit = ((row_bits(w, h) >> A) & 1u) != 0;
-          q_push<A, D, GENES, INLINE>(W, zl_addr, valid && hit, h, pack_a(K_SAME, 0, 0), 0, 1u, 1u);
+          q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, valid && hit, h, pack_a(K_SAME, 0, 0), 0, 1u, 1u);
           nvar += 1;
         }
 
@@ -1078,34 +1105,32 @@ probe_rows_kernel(const ProbeParams P)
             cbits = __builtin_amdgcn_readfirstlane(cbits);
             uint64_t Wk[PB];
             uint32_t ra[PB], rb[PB], wo[PB];
-            /* the pairs' own keys, all 2 PB reads in flight together ... */
+            /* which positions of the block the lane's own query still has (tiles may mix
+               lengths): bit i <-> p0 + i < Ll */
+            const int left = (int)Ll - (int)p0;
+            const uint32_t lv = bfm_u32((uint32_t)(left < 0 ? 0 : left > 31 ? 31 : left));
+            /* the pairs' own keys, all 2 PB reads in flight together (a query that ends inside
+               or in front of the pair carries code A there, whose key is zero) ... */
 #pragma unroll
             for (int j = 0; j < PB; j++) {
               const uint32_t p = p0 + 2u * (uint32_t)j;
               ra[j] = (uint32_t)(rr >> (16 * j)) & 31u;
-              const uint32_t rq = (uint32_t)(rr >> (16 * j + 8)) & 31u;
-              const bool second = p + 1u < Ll;      /* (the lane's own length: tiles may mix lengths) */
-              rb[j] = second ? rq : (uint32_t)A;
+              rb[j] = (uint32_t)(rr >> (16 * j + 8)) & 31u;
               uint32_t zrow = zl_addr + ZS * 8u * min(p, zlast);
               asm("" : "+s"(zrow));
               uint32_t zrow2 = zl_addr + ZS * 8u * min(p + 1u, zlast);
               asm("" : "+s"(zrow2));
-              const uint64_t za = lds_u64(zrow + ra[j] * 8u);
-              const uint64_t zb = lds_u64(zrow2 + rq * 8u);
-              Wk[j] = za ^ (second ? zb : 0ull);
+              Wk[j] = h ^ lds_u64(zrow + ra[j] * 8u) ^ lds_u64(zrow2 + rb[j] * 8u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < PB; j++) {
-              Wk[j] ^= h;
+            for (int j = 0; j < PB; j++)
               wo[j] = woff_of(Wk[j]);
-            }
             /* ... then the filter words, one pair ahead of the pair being tested */
             RowWord wc = STAGED ? word_lds(wo[0]) : word_glob(own_glob, wo[0]);
             uint32_t xa[PB], xb[PB];
 #pragma unroll
             for (int j = 0; j < PB; j++) {
-              const uint32_t p = p0 + 2u * (uint32_t)j;
               RowWord wn = wc;
               if (j + 1 < PB)
                 wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
@@ -1116,10 +1141,11 @@ probe_rows_kernel(const ProbeParams P)
               pair_bits(wc, Wk[j], xs, xd);
               uint32_t a1, a2;
               pair_answers(xs, xd, ra[j], rb[j], a1, a2);
-              a1 &= am & ~(1u << ra[j]);
-              a2 &= am & ~(1u << rb[j]);
-              xa[j] = p < Ll ? a1 : 0u;
-              xb[j] = p + 1u < Ll ? a2 : 0u;
+              /* own residue out; the lane's own length as a mask of all ones or none */
+              a1 &= ~(1u << ra[j]);
+              a2 &= ~(1u << rb[j]);
+              xa[j] = a1 & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
+              xb[j] = a2 & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
               wc = wn;
             }
             nrows += (uint32_t)PB;
@@ -1134,7 +1160,7 @@ probe_rows_kernel(const ProbeParams P)
               if (__ballot(any != 0u)) {
 #pragma unroll
                 for (int j = 0; j < PB; j++)
-                  q_push<A, D, GENES, INLINE>(W, zl_addr, (xa[j] | xb[j]) != 0u && any != 0u, h,
+                  q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, (xa[j] | xb[j]) != 0u && any != 0u, h,
                                               K_PAIR | ((p0 + 2u * (uint32_t)j) << 3) | (ra[j] << 19) | (rb[j] << 24),
                                               xa[j], xb[j], (uint32_t)__popc(xa[j]) + (uint32_t)__popc(xb[j]));
               }
@@ -1303,7 +1329,7 @@ probe_rows_kernel(const ProbeParams P)
 #pragma unroll
                 for (int j = 1; j < RB; j++)
                   hsel = jd == (uint32_t)j ? hdj[j] : hsel;
-                q_push<A, D, GENES, INLINE>(W, zl_addr, dm != 0, hsel, pack_a(K_DEL, p0 + jd, 0), 0, 1u, 1u);
+                q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, dm != 0, hsel, pack_a(K_DEL, p0 + jd, 0), 0, 1u, 1u);
                 dm &= dm - 1u;
               }
             }
@@ -1386,7 +1412,7 @@ probe_rows_kernel(const ProbeParams P)
                   /* (position, residue) pairs in increasing position order */
                   const uint32_t p1 = swap ? e : b, r1 = swap ? wres : v;
                   const uint32_t p2 = swap ? b : e, r2 = swap ? v : wres;
-                  q_push<A, D, GENES, INLINE>(W, zl_addr, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24), 1u, 1u);
+                  q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24), 1u, 1u);
                   if (first)
                     m0 &= m0 - 1ull;
                   else
@@ -1451,7 +1477,7 @@ probe_rows_kernel(const ProbeParams P)
                   if (irb < (uint32_t)A)
                     hq ^= lds_u64(zl_addr + (ZS * (p + 1u) + irb) * 8u);
                 }
-                q_push<A, D, GENES, INLINE>(W, zl_addr, pos, hq, K_PAIR | (p << 3) | (ira << 19) | (irb << 24),
+                q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, pos, hq, K_PAIR | (p << 3) | (ira << 19) | (irb << 24),
                                             a1, a2, (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
               }
               iw = ea[0];
@@ -1474,7 +1500,7 @@ probe_rows_kernel(const ProbeParams P)
                residues) or the deletion variant itself */
             if (CMPR_DBG(P, DBG_SKIP_EMIT))
               x = 0;
-            q_push<A, D, GENES, INLINE>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
+            q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
                                         (uint32_t)__popc(x));
             if (INDELS) {
               /* the row of a class position answers "q without p" too; its hash is worked out
@@ -1482,7 +1508,7 @@ probe_rows_kernel(const ProbeParams P)
               const bool delc = ival && (ic & ITEM_DEL_COUNTS) != 0;
               nvar += delc ? 1u : 0u;
               const bool dpos = delc && ((bits >> (A + 1)) & 1u) != 0 && !CMPR_DBG(P, DBG_SKIP_EMIT);
-              q_push<A, D, GENES, INLINE>(W, zl_addr, dpos, 0ull, pack_a(K_DEL, p, 0), 0, DEL_LAZY, 1u);
+              q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, dpos, 0ull, pack_a(K_DEL, p, 0), 0, DEL_LAZY, 1u);
             }
             /* next block's data moves up */
             iw = ea[0];
@@ -1687,7 +1713,7 @@ probe_rows_kernel(const ProbeParams P)
 #pragma unroll
               for (int j = 1; j < RB; j++)
                 rroll |= (rprev[j] & RMASK) << (RBITS * (j - 1));
-              q_push<A, D, GENES, INLINE>(W, zl_addr, mi0 != 0, hrow[0], K_INSROWS | (ip0 << 3) | (rroll << 19),
+              q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, mi0 != 0, hrow[0], K_INSROWS | (ip0 << 3) | (rroll << 19),
                                           (uint32_t)mi0, (uint32_t)(mi0 >> 32) | ((rroll >> 13) << 28),
                                           (uint32_t)__popcll((unsigned long long)mi0));
             }
@@ -1756,7 +1782,7 @@ probe_rows_kernel(const ProbeParams P)
     for (uint32_t r = 0; r < rounds; r++) {
       if (r >= 1u)
         W.held = extra + (unsigned long long)(r - 1u) * WAVE;      /* (lane 0's is the one read) */
-      drain_round<A, D, GENES, INLINE>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE, true);
+      drain_round<A, D, GENES, INLINE, PAIRS>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE, true);
     }
     if (rounds == 0u) {               /* the block claimed ahead goes back as a block of nulls */
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -844,10 +844,18 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
      the record, longer sequences fetch the rest where the caller's residues lie */
   uint32_t *dst = Q.qres + td.res_base + lane;
   const uint32_t nd = (td.len + 3u) >> 2;
+  /* (pair rows: behind its end a query carries code A, whose key in the kernel's table is
+     zero -- kernels_rows.h zs_of; lanes without a query are all padding) */
+  const uint32_t padw = Q.pairs ? Q.A * 0x01010101u : 0u;
+  auto padded = [&](uint32_t d, uint32_t w) -> uint32_t {
+    const int n = (int)qr.len - (int)(4u * w);            /* residues of the query in this dword */
+    const uint32_t m = n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
+    return (d & m) | (padw & ~m);
+  };
 #pragma unroll
   for (uint32_t w = 0; w < 9; w++)
     if (w < nd)
-      dst[(size_t)w * WAVE] = qr.res[w];
+      dst[(size_t)w * WAVE] = padded(qr.res[w], w);
   if (nd > 9) {
     const uint8_t *s = valid ? Q.res + Q.off[qr.orig] : Q.res;
     const uint32_t L = qr.len;
@@ -857,7 +865,7 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
       for (uint32_t k = 0; k < 4; k++)
         if (4 * w + k < L)
           d |= (uint32_t)s[4 * w + k] << (8 * k);
-      dst[(size_t)w * WAVE] = d;
+      dst[(size_t)w * WAVE] = padded(d, w);
     }
   }
 }
