@@ -23,6 +23,11 @@
  *   filter bits per entry a false-positive rate of ~6e-4).  All A answers of the
  *   row come out of one 32-byte LDS read and ~20 instructions.
  *
+ * With single substitutions only (d = 1 without -i) the filter holds PAIR rows instead:
+ * one entry per pair of positions, both blanked, the two residues coded as their sum and
+ * their difference -- one word read answers the 2 (A - 1) variants of two positions
+ * (pair_entry_bits / pair_bits / pair_answers below; round 3).
+ *
  * The same entries serve the other variant kinds: an insertion variant of q
  * (v put in front of position ip) blanked at ip IS q with a gap at ip, so the
  * row of all A insertions at ip is one read under the rolling gap hash
@@ -1748,6 +1753,9 @@ probe_rows_kernel(const ProbeParams P)
     }
     PT_MARK(PT_OTHER);
     /* hand-over: the tile claimed ahead, else a fresh claim */
+#ifdef CMPR_PHASE_TIMING
+    pt_acc[PT_LOADER_WAIT] += nxt_c.ok ? 1u : 0u;      /* (diagnostic: units whose data was requested ahead) */
+#endif
     if (nxt_c.ok) {
       cur_c = nxt_c;
       cur = nxt;

@@ -27,5 +27,11 @@ names = ["claim", "tile_data", "rows", "emit", "other", "loader_wait", "loader_d
 vals = [h.get_tunable("pt%d" % k) for k in range(8)]
 tot = sum(vals) or 1
 print("probe %.3f ms kernel %.3f ms tiles %d chunks %d" % (st.probe_ms, st.kernel_ms, h.get_tunable("tiles"), h.get_tunable("chunks")))
+# (slot 5 is no phase: it counts the units whose data was requested one unit ahead)
+ahead = vals[5]
+vals[5] = 0
+tot = sum(vals) or 1
 for nme, v in zip(names, vals):
-    print("  %-12s %12d cycles  %5.1f %%" % (nme, v, 100.0 * v / tot))
+    if nme != "loader_wait":
+        print("  %-12s %12d cycles  %5.1f %%" % (nme, v, 100.0 * v / tot))
+print("  units whose data was requested ahead: %d" % ahead)
