@@ -337,10 +337,10 @@ int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uin
 /* ref_index.hip: cmpr_set_reference */
 int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query);
 
-/* variant 2 with single substitutions only: the filter holds pair rows (kernels_rows.h) */
+/* variant 2, d = 1 (with or without -i): the filter holds pair rows (kernels_rows.h) */
 inline bool pair_rows(const cmpr_context *c)
 {
-  return c->rows && c->opt.differences == 1 && !c->opt.indels;
+  return c->rows && c->opt.differences == 1;
 }
 
 #endif

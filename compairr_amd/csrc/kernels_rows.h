@@ -220,6 +220,14 @@ build_rows_kernel(const BuildParams B)
   if (B.pairs) {
     /* pair rows: one entry per pair of positions, filed under the class key without the
        terms of the class positions inside the pair, in the class part of the first of them */
+    auto enter_pair = [&](uint64_t Wk, uint32_t a, uint32_t b2, uint32_t slice) {
+      const uint64_t w = (uint64_t)slice * nwords + row_word(Wk, nwords);
+      uint64_t q[4];
+      pair_entry_bits(Wk, a, b2, q);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
+    };
     for (uint32_t p = 0; p < L; p += 2) {
       const uint32_t a = s[p], b2 = p + 1 < L ? s[p + 1] : B.A;
       uint32_t key = ck;
@@ -233,15 +241,64 @@ build_rows_kernel(const BuildParams B)
               ci = (int)k;
           }
         }
+      if (ci >= 0)
+        key ^= pair_part_terms(g.ctab, g, B.A, L, p, [&](uint32_t pos) -> uint32_t { return s[pos]; });
       uint64_t Wk = h ^ B.zob[B.A * p + a];
       if (p + 1 < L)
         Wk ^= B.zob[B.A * (p + 1) + b2];
-      const uint64_t w = (uint64_t)row_slice(g, key, ci) * nwords + row_word(Wk, nwords);
-      uint64_t q[4];
-      pair_entry_bits(Wk, a, b2, q);
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        atomicOr(words + 4 * w + k, (unsigned long long)q[k]);
+      enter_pair(Wk, a, b2, row_slice(g, key, ci));
+    }
+    if (!B.indels)
+      return;
+    /* -i: the gap pairs.  u = t with a blank in front of position ip (length L + 1), ip =
+       0 .. L; the pair of u that holds the blank, with the blank coded as A + 1 ("gap") and
+       BOTH positions blanked in the hash -- what a query one residue longer finds under the
+       hash of its own pair when the residue it has there is the one t lacks (kernels_rows.h
+       probe: deletion answers).  Filed like a pair of a sequence of length L + 1: class
+       residues at the positions of that length, taken around the gap. */
+    uint64_t hg = 0;                               /* hash of u: blank at 0 = everything shifted by one */
+    if (B.use_genes) {
+      const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+      hg = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+    }
+    for (uint32_t p = 0; p < L; p++)
+      hg ^= B.zob[B.A * (p + 1) + s[p]];
+    uint32_t base = ck;                            /* class key without the class residues */
+    if (heavy)
+      for (uint32_t k = 0; k < g.k; k++)
+        base ^= g.ctab[g.off_cr + k * B.A + s[class_pos(L, k, g.c0)]];
+    for (uint32_t ip = 0; ip <= L; ip++) {
+      if (ip > 0)                                  /* t[ip - 1] moves from position ip to ip - 1 */
+        hg ^= B.zob[B.A * ip + s[ip - 1]] ^ B.zob[B.A * (ip - 1) + s[ip - 1]];
+      const uint32_t p0 = ip & ~1u;
+      uint32_t a, b2;
+      uint64_t Wk = hg;
+      if (ip == p0) {                              /* (gap, u[ip + 1] = t[ip]) */
+        a = B.A + 1u;
+        b2 = ip < L ? (uint32_t)s[ip] : B.A;
+        if (ip < L)
+          Wk ^= B.zob[B.A * (ip + 1) + s[ip]];
+      } else {                                     /* (u[ip - 1] = t[ip - 1], gap) */
+        a = s[ip - 1];
+        b2 = B.A + 1u;
+        Wk ^= B.zob[B.A * (ip - 1) + s[ip - 1]];
+      }
+      uint32_t key = base;
+      int ci = -1;
+      if (heavy)
+        for (uint32_t k = 0; k < g.k; k++) {
+          const uint32_t mk = class_pos(L + 1, k, g.c0);
+          if ((mk & ~1u) == p0) {
+            if (ci < 0)
+              ci = (int)k;
+          } else {
+            key ^= g.ctab[g.off_cr + k * B.A + s[mk < ip ? mk : mk - 1]];
+          }
+        }
+      if (ci >= 0)
+        key ^= pair_part_terms(g.ctab, g, B.A, L + 1, p0,
+                               [&](uint32_t pos) -> uint32_t { return s[pos < ip ? pos : pos - 1]; });
+      enter_pair(Wk, a, b2, row_slice(g, key, ci));
     }
     return;
   }
@@ -332,8 +389,9 @@ __host__ __device__ constexpr uint32_t zs_of(int A, int D, bool pairs)
  *                                                                 low half in cb, high half in m[0..27];
  *                                                                 rpack (the query's own residues of the RB
  *                                                                 rows, RBITS each) continues in m[28..31]
- *   K_INSROWS gap hash of     K_INSROWS | ip0 << 3 | rroll << 19  the same layout; rroll = the residues
- *             the first row                                       q[ip0] .. q[ip0 + RB - 2] that roll the gap hash
+ *   K_INSROWS hash of q with  K_INSROWS | g << 3 | q[g] << 19     cb = residues v in front of g, m = residues w
+ *             a gap at g and                                      in front of g + 1 (-i, pair rows)
+ *             q[g] blanked
  *   K_PAIR    query hash h    K_PAIR | p << 3 | ra << 19          cb = mask of residues v at p, m = mask of
  *                             | rb << 24                          residues w at p + 1; ra, rb = the query's own
  *   K_SUB,    the row's       kind | p << 3                       m = mask of residues v (one row: an item,
@@ -368,6 +426,8 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
   uint64_t hv = B;
   uint32_t oca = ca, ocb = cb, ncb = cb, nm = m;
   bool more = false;
+  bool lazy_del = false;                  /* a deletion variant whose hash is worked out here */
+  uint32_t lazy_p = 0;
   if (kind == K_ROWS) {
     uint64_t mk = ((uint64_t)(m & 0x0fffffffu) << 32) | cb;
     const uint32_t rpack = (ca >> 19) | ((m >> 28) << 13);
@@ -394,26 +454,26 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     ncb = second ? 0u : cb & (cb - 1u);
     nm = second ? m & (m - 1u) : m;
     more = (ncb | nm) != 0u;
-  } else if (kind == K_INSROWS) {
-    /* RB insertion rows from ip0 on: the gap hash of row j is that of row j - 1 with
-       q[ip0 + j - 1] moved one position down (variants.cc:329-353) */
-    uint64_t mk = ((uint64_t)(m & 0x0fffffffu) << 32) | cb;
-    const uint32_t rroll = (ca >> 19) | ((m >> 28) << 13);
-    const uint32_t idx = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
-    const uint32_t j = idx / (uint32_t)A, v = idx - j * (uint32_t)A;
-    uint64_t hg = B;
-#pragma unroll 1
-    for (uint32_t i = 1; i <= j; i++) {
-      const uint32_t r = (rroll >> (RBITS * (i - 1u))) & RMASK;
-      hg ^= lds_u64(zl_addr + (ZS * (p0 + i - 1u) + r) * 8u) ^ lds_u64(zl_addr + (ZS * (p0 + i) + r) * 8u);
+    if (v == (uint32_t)A + 1u) {          /* -i: "q without p" */
+      oca = pack_a(K_DEL, p, 0);
+      lazy_del = act;
+      lazy_p = p;
     }
-    hv = hg ^ lds_u64(zl_addr + (ZS * (p0 + j) + v) * 8u);
-    oca = pack_a(K_INS, p0 + j, v);
+  } else if (kind == K_INSROWS) {
+    /* a pair of insertion rows: B = the hash of q with a gap at g and q[g] blanked; cb = the
+       residues v that may stand in front of g (then q[g] follows at g + 1), m = the residues
+       w in front of g + 1 (q[g] stays at g) */
+    const uint32_t second = cb == 0u ? 1u : 0u;
+    const uint32_t bitsv = second ? m : cb;
+    const uint32_t v = (uint32_t)__ffs((int)bitsv) - 1u;
+    const uint32_t rg = (ca >> 19) & 31u;
+    const uint32_t z0 = zl_addr + ZS * p0 * 8u, z1 = z0 + ZS * 8u;
+    hv = B ^ lds_u64(z0 + (second ? rg : v) * 8u) ^ lds_u64(z1 + (second ? v : rg) * 8u);
+    oca = pack_a(K_INS, p0 + second, v);
     ocb = 0;
-    mk &= mk - 1ull;
-    more = mk != 0;
-    ncb = (uint32_t)mk;
-    nm = (m & 0xf0000000u) | (uint32_t)(mk >> 32);
+    ncb = second ? 0u : cb & (cb - 1u);
+    nm = second ? m & (m - 1u) : m;
+    more = (ncb | nm) != 0u;
   } else if (kind == K_SUB || kind == K_INS) {
     const uint32_t v = (uint32_t)__ffs((int)m) - 1u;
     hv = B ^ lds_u64(zl_addr + (ZS * p0 + v) * 8u);
@@ -422,7 +482,11 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     nm = m & (m - 1u);
     more = nm != 0;
   } else if (kind == K_DEL && m == DEL_LAZY && act) {
-    /* "the query without position p0", from its first-deleted hash and its residues
+    lazy_del = true;
+    lazy_p = p0;
+  }
+  if (lazy_del) {
+    /* "the query without position lazy_p", from its first-deleted hash and its residues
        (zobrist_hash_delete_first + the rolling update, variants.cc:301-325) */
     const ProbeParams &P = W.P;
     uint64_t hd = P.qhdel[slot];
@@ -434,7 +498,7 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     };
     uint32_t prev = res_of(0);
 #pragma unroll 1
-    for (uint32_t y = 1; y <= p0; y++) {
+    for (uint32_t y = 1; y <= lazy_p; y++) {
       const uint32_t r = res_of(y);
       if (r != prev)
         hd ^= lds_u64(zl_addr + (ZS * (y - 1u) + prev) * 8u) ^ lds_u64(zl_addr + (ZS * (y - 1u) + r) * 8u);
@@ -567,8 +631,11 @@ probe_rows_kernel(const ProbeParams P)
     return;
   constexpr uint32_t NT = NW * WAVE;
   constexpr uint32_t MCR = max_class_res(A);
-  constexpr bool PAIRS = D == 1 && !INDELS;       /* the filter holds pair rows (build_rows_kernel) */
+  constexpr bool PAIRS = D == 1;                  /* the filter holds pair rows (build_rows_kernel) */
   constexpr uint32_t ZS = zs_of(A, D, PAIRS);
+  /* pair rows: what stands behind the end of a query, also in residue dwords that were never
+     loaded (query_layout.hip pads the loaded ones) */
+  constexpr uint32_t PADW = PAIRS ? (uint32_t)A * 0x01010101u : 0u;
   constexpr int RPW = RowCfg<A>::RPW;
   constexpr int RB = RowCfg<A>::RB;
   constexpr uint32_t RBITS = RowCfg<A>::RBITS;
@@ -701,7 +768,7 @@ probe_rows_kernel(const ProbeParams P)
     TileData x;
     x.a = 0;
     x.b = x.c = 0;
-    x.r0 = x.r1 = x.r2 = x.r3 = x.r4 = x.r5 = 0;
+    x.r0 = x.r1 = x.r2 = x.r3 = x.r4 = x.r5 = PADW;
     const bool valid = lane < nvalid;
     if (tpass >= 3) {
       /* a block of 64 class-row items, from item res_base on */
@@ -936,7 +1003,7 @@ probe_rows_kernel(const ProbeParams P)
          (~0: padding behind the items of a slice) and its residue | position << 8
          (query_layout.hip) */
       const bool valid = class_tile ? cur.b != 0xffffffffu : lane < nvalid;
-      const uint32_t vmask = valid ? ~0u : 0u;
+      [[maybe_unused]] const uint32_t vmask = valid ? ~0u : 0u;
       W.qslot = class_tile ? cur.b : t * WAVE + lane;
       const uint64_t cW = cur.a;
       const uint32_t Ll = (valid && !class_tile) ? cur.b : 0u;
@@ -1074,29 +1141,33 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
           uint32_t nrows = 0;                     /* words read (wave-uniform) */
           const uint32_t zlast = P.zpos - 1u;
+          constexpr uint32_t GAPBIT = 1u << (A + 1);
+          const uint32_t delmask = Ll > 1u ? AMASK | GAPBIT : AMASK;     /* (-i) */
+          uint32_t carry = 31u;                   /* (-i) the residue in front of the block: none yet */
+          uint32_t ndel = 0;                      /* (-i) deletion variants these rows stand for */
           auto pair_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += PP) {
             if (p0 && p0 % (4u * TDW) == 0) {
               const uint32_t w0 = p0 >> 2;
               s0 = qr[w0 * WAVE];
-              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
-              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
-              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
-              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
-              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : PADW;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : PADW;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : PADW;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : PADW;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : PADW;
             }
             const uint64_t rr = ((uint64_t)s1 << 32) | s0;
             if constexpr (PP == 4) {
-              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = PADW;
             } else {
               static_assert(PP == 4 || PP == 6, "six bytes of the shift register per block");
               s0 = __builtin_amdgcn_alignbit(s2, s1, 16);
               s1 = __builtin_amdgcn_alignbit(s3, s2, 16);
               s2 = __builtin_amdgcn_alignbit(s4, s3, 16);
               s3 = __builtin_amdgcn_alignbit(s5, s4, 16);
-              s4 = s5 >> 16;
-              s5 = 0;
+              s4 = __builtin_amdgcn_alignbit(PADW, s5, 16);
+              s5 = PADW;
             }
             /* class positions among the positions of the block (wave-uniform bits) */
             uint32_t cbits = 0;
@@ -1141,7 +1212,7 @@ probe_rows_kernel(const ProbeParams P)
                 wn = STAGED ? word_lds(wo[j + 1]) : word_glob(own_glob, wo[j + 1]);
               __builtin_amdgcn_sched_barrier(0);
               /* (a class pair of a heavy tile: nothing of it counts here -- a scalar select) */
-              const uint32_t am = ((cbits >> (2 * j)) & 3u) ? 0u : AMASK;
+              const uint32_t am = ((cbits >> (2 * j)) & 3u) ? 0u : (INDELS ? AMASK | GAPBIT : AMASK);
               uint32_t xs, xd;
               pair_bits(wc, Wk[j], xs, xd);
               uint32_t a1, a2;
@@ -1149,10 +1220,24 @@ probe_rows_kernel(const ProbeParams P)
               /* own residue out; the lane's own length as a mask of all ones or none */
               a1 &= ~(1u << ra[j]);
               a2 &= ~(1u << rb[j]);
-              xa[j] = a1 & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
-              xb[j] = a2 & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
+              if constexpr (INDELS) {
+                /* -i: bit A + 1 ("gap") of either side answers "q without that position" (the
+                   gap pairs of build_rows_kernel); the variant exists once per run of equal
+                   residues, at its first position (variants.cc:301-325), and not for a query
+                   of one residue */
+                const uint32_t before = j == 0 ? carry : rb[j - 1];
+                const uint32_t ta = (ra[j] != before ? delmask : AMASK) & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
+                const uint32_t tb = (rb[j] != ra[j] ? delmask : AMASK) & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
+                xa[j] = a1 & ta;
+                xb[j] = a2 & tb;
+                ndel += (ta >> (A + 1)) + (tb >> (A + 1));
+              } else {
+                xa[j] = a1 & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
+                xb[j] = a2 & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
+              }
               wc = wn;
             }
+            carry = rb[PB - 1];
             nrows += (uint32_t)PB;
             PT_MARK(PT_ROWS);
             {
@@ -1192,7 +1277,7 @@ probe_rows_kernel(const ProbeParams P)
               if (fresh)
                 ncls += (pp < Ll ? 1u : 0u) + (pp + 1u < Ll ? 1u : 0u);
             }
-          nvar += (Ll - ncls) * (uint32_t)(A - 1);
+          nvar += (Ll - ncls) * (uint32_t)(A - 1) + ndel;
           treads += valid ? nrows : 0u;
         }
 
@@ -1462,28 +1547,49 @@ probe_rows_kernel(const ProbeParams P)
             const RowWord w = staged ? word_lds(wo) : word_glob(own_glob, wo);
             if constexpr (PAIRS) {
               /* a class pair (query_layout.hip for_each_item): pair-blanked hash, own residues
-                 (second = A: the query ends with the first), first position */
-              const uint32_t ira = ic & 31u, irb = (ic >> 5) & 31u, p = (ic >> 10) & 0x3fffu;
+                 (second = A: the query ends with the first), first position; with -i its two
+                 deletion answers, and the insertion pairs (K_INS): hash of q with a gap at g
+                 and q[g] blanked, q[g] (A: the gap is at the end), q[g - 1] (31: none), g */
+              const uint32_t ira = ic & 31u, f2 = (ic >> 5) & 31u, p = (ic >> 10) & 0x3fffu;
+              const bool is_ins = INDELS && ((ic >> 24) & 7u) == K_INS;
+              const uint32_t irb = is_ins ? ira : f2;
               uint32_t xs, xd, a1, a2;
               pair_bits(w, iw, xs, xd);
               pair_answers(xs, xd, ira, irb, a1, a2);
+              constexpr uint32_t GAPBIT = 1u << (A + 1);
               const uint32_t vm = ival ? AMASK : 0u;
-              a1 &= vm & ~(1u << ira);
-              a2 &= (irb < (uint32_t)A ? vm : 0u) & ~(1u << irb);
-              nvar += !ival ? 0u : (uint32_t)(A - 1) * (irb < (uint32_t)A ? 2u : 1u);
+              uint32_t m1 = vm & ~(1u << ira), m2 = (irb < (uint32_t)A ? vm : 0u) & ~(1u << irb);
+              uint32_t nv = (uint32_t)(A - 1) * (irb < (uint32_t)A ? 2u : 1u);
+              if constexpr (INDELS) {
+                if (is_ins) {
+                  /* in front of g: v != q[g - 1]; in front of g + 1 (if q has a position g): w != q[g] */
+                  m1 = vm & ~(1u << f2);
+                  nv = (p == 0u ? (uint32_t)A : (uint32_t)(A - 1)) + (ira < (uint32_t)A ? (uint32_t)(A - 1) : 0u);
+                } else {
+                  const uint32_t d1 = (ic & ITEM_DEL_COUNTS) ? 1u : 0u, d2 = (ic & ITEM_DEL2_COUNTS) ? 1u : 0u;
+                  m1 |= ival && d1 ? GAPBIT : 0u;
+                  m2 |= ival && d2 ? GAPBIT : 0u;
+                  nv += d1 + d2;
+                }
+              }
+              a1 &= m1;
+              a2 &= m2;
+              nvar += ival ? nv : 0u;
               if (CMPR_DBG(P, DBG_SKIP_EMIT))
                 a1 = a2 = 0;
               const bool pos = (a1 | a2) != 0u;
               if (__ballot(pos)) {
-                /* (the entry carries the query's hash, like the pairs of a tile) */
-                uint64_t hq = 0;
-                if (pos) {
+                /* (a substitution pair's entry carries the query's hash, like the pairs of a tile) */
+                uint64_t hq = iw;
+                if (pos && !is_ins) {
                   hq = iw ^ lds_u64(zl_addr + (ZS * p + ira) * 8u);
                   if (irb < (uint32_t)A)
                     hq ^= lds_u64(zl_addr + (ZS * (p + 1u) + irb) * 8u);
                 }
-                q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, pos, hq, K_PAIR | (p << 3) | (ira << 19) | (irb << 24),
-                                            a1, a2, (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
+                const uint32_t eca = is_ins ? K_INSROWS | (p << 3) | (ira << 19)
+                                            : K_PAIR | (p << 3) | (ira << 19) | (irb << 24);
+                q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, pos, hq, eca, a1, a2,
+                                                   (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
               }
               iw = ea[0];
               im = eb[0];
@@ -1576,12 +1682,18 @@ probe_rows_kernel(const ProbeParams P)
         uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
         const uint32_t nd = (L + 3u) >> 2;
 
-        /* ---- insertions (variants.cc:329-353): t = q with v in front of
-                position ip; blanked at ip it is q with a gap there, whose rolling
-                hash addresses the row of all A residues.  RB rows per block: the
-                rolling keys are read together, the filter words one row ahead. ---- */
+        /* ---- insertions (variants.cc:329-353), pair rows: t = q with v in front of
+                position g has the pair (v, q[g]) at (g, g + 1), t' = q with w in front of
+                g + 1 the pair (q[g], w) there, and with both positions blanked the two are
+                the same string -- q with a gap at g and q[g] blanked -- so ONE word, under
+                W2(g) = gap hash of g ^ Z[g+1][q[g]], answers the insertions in front of g
+                (first residue varies) and in front of g + 1 (second varies).  PB pairs per
+                block: the rolling keys are read together, the filter words one pair ahead.
+                (Behind its end a query carries code A, whose keys are zero: the gap hash
+                rolls on unchanged, and q[g] = A is "the sequence ends here".) ---- */
         if (!CMPR_DBG(P, DBG_SKIP_INS_ROWS)) {
-          /* (the residue shift register starts over) */
+          constexpr int PB = A == 20 ? 3 : 2;
+          constexpr uint32_t PP = 2u * PB;
           s0 = cur.r0; s1 = cur.r1; s2 = cur.r2; s3 = cur.r3; s4 = cur.r4; s5 = cur.r5;
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L + 1];
           const uint32_t hvy = heavy_of(base_t);
@@ -1592,152 +1704,167 @@ probe_rows_kernel(const ProbeParams P)
             lo[i] = hi[i] = 0;
             if (i < KH) {
               if (mi[i] < L)
-                lo[i] = cr_lds[i * A + res_reg(mi[i])] & hvy;      /* t[mi] = q[mi],     mi < ip */
+                lo[i] = cr_lds[i * A + res_reg(mi[i])] & hvy;      /* t[mi] = q[mi],     mi in front of the pair */
               if (mi[i] >= 1)
-                hi[i] = cr_lds[i * A + res_reg(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi > ip */
+                hi[i] = cr_lds[i * A + res_reg(mi[i] - 1)] & hvy;  /* t[mi] = q[mi - 1], mi behind the pair */
             }
           }
           /* behind the last class position of the variants nothing moves a class residue: the
-             rows of such a block lie in the staged slice, lane for lane (and in a light tile
-             all rows do) -- no key arithmetic there */
+             pairs of such a block lie in the staged slice, lane for lane (and in a light tile
+             all pairs do) -- no key arithmetic there */
           uint32_t mi_max = 0;
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++)
             if (i < KH)
               mi_max = mi[i] > mi_max ? mi[i] : mi_max;
+          const uint32_t zlast = P.zpos - 1u;
           uint64_t hg = h_ins;                    /* hash of q with a gap at 0 (zobrist_hash_insert_first) */
-          uint32_t carry = 31u;                   /* q[ip0 - 1]: the residue behind which block ip0 starts */
-          /* One block of RB rows.  INNER (wave-uniform, the blocks between the first and the
-             last of an ordinary tile): every row has 0 < ip <= L and lies behind the last class
-             position -- no test per row, no class-key arithmetic, nothing read where it lies;
-             the generic form keeps all of that for the first and the last block. */
-          auto ins_block = [&](uint32_t ip0, auto inner_c) {
+          uint32_t carry = 31u;                   /* q[g0 - 1]: none in front of the first block */
+          auto ins_block = [&](uint32_t g0, auto inner_c) {
             constexpr bool INNER = decltype(inner_c)::value;
-            /* residues of positions ip0 .. ip0 + RB - 1 in the low bytes of s0 (s1) */
-            const uint64_t rr = ((uint64_t)s1 << 32) | s0;
-            if constexpr (RB == 4) {
-              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0;
+            const uint64_t rr = ((uint64_t)s1 << 32) | s0;   /* residues of positions g0 .. g0 + 7 */
+            if constexpr (PP == 4) {
+              s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = PADW;
             } else {
-              constexpr uint32_t SH = 8u * (RB & 3);
-              s0 = __builtin_amdgcn_alignbit(s1, s0, SH);
-              s1 = __builtin_amdgcn_alignbit(s2, s1, SH);
-              s2 = __builtin_amdgcn_alignbit(s3, s2, SH);
-              s3 = __builtin_amdgcn_alignbit(s4, s3, SH);
-              s4 = __builtin_amdgcn_alignbit(s5, s4, SH);
-              s5 >>= SH;
+              s0 = __builtin_amdgcn_alignbit(s2, s1, 16);
+              s1 = __builtin_amdgcn_alignbit(s3, s2, 16);
+              s2 = __builtin_amdgcn_alignbit(s4, s3, 16);
+              s3 = __builtin_amdgcn_alignbit(s5, s4, 16);
+              s4 = __builtin_amdgcn_alignbit(PADW, s5, 16);
+              s5 = PADW;
             }
-            /* row ip moves q[ip - 1] from position ip to ip - 1 */
-            uint32_t rprev[RB];
-            uint64_t ka[RB], kb[RB];
+            /* which gap positions of the block the lane's query has: bit i <-> g0 + i <= Ll */
+            const int left = (int)Ll + 1 - (int)g0;
+            const uint32_t lv = valid ? bfm_u32((uint32_t)(left < 0 ? 0 : left > 31 ? 31 : left)) : 0u;
+            uint32_t rg[PB], rbefore[PB];
+            uint64_t k1[PB], k2[PB], k3[PB], k4[PB];
 #pragma unroll
-            for (int j = 0; j < RB; j++) {
-              const uint32_t ip = ip0 + (uint32_t)j;
-              rprev[j] = j == 0 ? carry : (uint32_t)(rr >> (8 * (j - 1))) & 31u;
-              ka[j] = kb[j] = 0;
-              if (INNER || (ip > 0 && ip <= L)) {              /* wave-uniform */
-                uint32_t zdn = zl_addr + ZS * 8u * (ip - 1u), zup = zl_addr + ZS * 8u * ip;
-                asm("" : "+s"(zdn));
-                asm("" : "+s"(zup));
-                ka[j] = lds_u64(zdn + rprev[j] * 8u);
-                kb[j] = lds_u64(zup + rprev[j] * 8u);
-              }
+            for (int j = 0; j < PB; j++) {
+              const uint32_t g = g0 + 2u * (uint32_t)j;
+              rg[j] = (uint32_t)(rr >> (16 * j)) & 31u;                    /* q[g] */
+              const uint32_t rn = (uint32_t)(rr >> (16 * j + 8)) & 31u;     /* q[g + 1] */
+              rbefore[j] = j == 0 ? carry : (uint32_t)(rr >> (16 * j - 8)) & 31u;
+              const uint32_t gs = __builtin_amdgcn_readfirstlane(g);
+              uint32_t z0 = zl_addr + ZS * 8u * min(gs, zlast), z1 = zl_addr + ZS * 8u * min(gs + 1u, zlast),
+                       z2 = zl_addr + ZS * 8u * min(gs + 2u, zlast);
+              asm("" : "+s"(z0));
+              asm("" : "+s"(z1));
+              asm("" : "+s"(z2));
+              k1[j] = lds_u64(z1 + rg[j] * 8u);        /* q[g] one position up: blanked for the pair */
+              k2[j] = lds_u64(z0 + rg[j] * 8u);        /* ... and where it comes back to, two gaps on */
+              k3[j] = lds_u64(z2 + rn * 8u);
+              k4[j] = lds_u64(z1 + rn * 8u);
             }
-            carry = (uint32_t)(rr >> (8 * (RB - 1))) & 31u;
+            carry = (uint32_t)(rr >> (8 * (PP - 1))) & 31u;
             __builtin_amdgcn_sched_barrier(0);
-            uint64_t m0 = 0, m1 = 0;
-            uint64_t hrow[RB];
-            uint32_t wor[RB], slr[RB];
-            bool itr[RB];
+            uint64_t hrow[PB];
+            uint32_t wor[PB], slr[PB];
+            bool itp[PB];
             bool any_glob = false;
 #pragma unroll
-            for (int j = 0; j < RB; j++) {
-              const uint32_t ip = ip0 + (uint32_t)j;
-              if (INNER || (ip > 0 && ip <= L))
-                hg ^= ka[j] ^ kb[j];
-              hrow[j] = hg;
-              wor[j] = woff_of(hg);
-              itr[j] = false;
+            for (int j = 0; j < PB; j++) {
+              const uint32_t g = g0 + 2u * (uint32_t)j;
+              hrow[j] = hg ^ k1[j];
+              hg ^= k1[j] ^ k2[j] ^ k3[j] ^ k4[j];     /* the gap hash of g + 2 */
+              wor[j] = woff_of(hrow[j]);
+              itp[j] = false;
               slr[j] = cslice;
               if constexpr (!INNER) {
-                if (K != 0u && ip0 <= mi_max) {            /* wave-uniform: see mi_max */
+                if (K != 0u && g0 <= mi_max) {          /* wave-uniform: see mi_max */
                   uint32_t key = base_t;
-                  int ci_u = -1;                           /* first class residue of t at the blanked position */
+                  bool inside = false;                  /* a class residue of the variants inside the pair */
 #pragma unroll
                   for (uint32_t i = 0; i < MCR; i++)
                     if (i < KH) {
-                      if (mi[i] != ip)
-                        key ^= mi[i] < ip ? lo[i] : hi[i];
-                      else if (ci_u < 0)
-                        ci_u = (int)i;
+                      if ((mi[i] & ~1u) == g)
+                        inside = true;
+                      else
+                        key ^= mi[i] < g ? lo[i] : hi[i];
                     }
-                  /* a row blanked at a class position of a split variant class is an
-                     item of that position's class part (query_layout.hip) */
-                  itr[j] = hvy && ci_u >= 0;
+                  /* a pair that holds a class position of a split variant class is an item of
+                     that position's class part (query_layout.hip) */
+                  itp[j] = hvy && inside;
                   slr[j] = row_slice(P.geom, key, -1);
-                  any_glob = any_glob || (ip <= L && __ballot(valid && !itr[j] && slr[j] != cslice) != 0);
+                  any_glob = any_glob || (g <= L && __ballot(valid && !itp[j] && slr[j] != cslice) != 0);
                 }
               }
             }
             RowWord wc = word_lds(wor[0]);
+            uint32_t xa[PB], xb[PB];
 #pragma unroll
-            for (int j = 0; j < RB; j++) {
-              const uint32_t ip = ip0 + (uint32_t)j;
+            for (int j = 0; j < PB; j++) {
               RowWord wn = wc;
-              if (j + 1 < RB)
+              if (j + 1 < PB)
                 wn = word_lds(wor[j + 1]);
               __builtin_amdgcn_sched_barrier(0);
-              if (INNER || ip <= L) {                          /* wave-uniform */
-                RowWord w = wc;
-                if constexpr (!INNER) {
-                  if (any_glob) {                              /* rare: a lane's row lies in another slice */
-                    if (valid && !itr[j] && slr[j] != cslice)
-                      w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
-                  }
+              RowWord w = wc;
+              if constexpr (!INNER) {
+                if (any_glob) {                                /* rare: a lane's pair lies in another slice */
+                  if (valid && !itp[j] && slr[j] != cslice)
+                    w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
                 }
-                treads += valid ? 1u : 0u;
-                uint32_t x = row_bits(w, hrow[j]) & AMASK & vmask;
-                if (INNER || ip > 0)
-                  x &= ~(1u << rprev[j]);                       /* v != q[ip - 1] */
-                const bool lives = (INNER || !itr[j]) && ip <= Ll;    /* (the lane's own length) */
-                x = lives ? x : 0u;
-                nvar += lives ? ((INNER || ip > 0) ? (uint32_t)(A - 1) : (uint32_t)A) : 0u;
-                if (j < RPW)
-                  m0 |= (uint64_t)x << (A * j);
-                else
-                  m1 |= (uint64_t)x << (A * (j - RPW));
               }
+              uint32_t xs, xd, a1, a2;
+              pair_bits(w, hrow[j], xs, xd);
+              pair_answers(xs, xd, rg[j], rg[j], a1, a2);
+              /* in front of g: v != q[g - 1]; in front of g + 1: w != q[g] */
+              a1 &= AMASK & ~(1u << rbefore[j]) & (uint32_t)bfe_i32(lv, 2 * j, 1);
+              a2 &= AMASK & ~(1u << rg[j]) & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
+              const bool here = INNER || !itp[j];
+              xa[j] = here ? a1 : 0u;
+              xb[j] = here ? a2 : 0u;
               wc = wn;
             }
-            /* one entry per lane with positives in the block: the gap hash of its first row, the
-               residues that roll it to the others (q[ip0] .. q[ip0 + RB - 2]) and the mask */
+            treads += valid ? (uint32_t)PB : 0u;
             {
-              uint64_t mi0 = m0 | m1;
-              if (CMPR_DBG(P, DBG_SKIP_EMIT))
-                mi0 = 0;
-              uint32_t rroll = 0;
+              uint32_t any = 0;
 #pragma unroll
-              for (int j = 1; j < RB; j++)
-                rroll |= (rprev[j] & RMASK) << (RBITS * (j - 1));
-              q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, mi0 != 0, hrow[0], K_INSROWS | (ip0 << 3) | (rroll << 19),
-                                          (uint32_t)mi0, (uint32_t)(mi0 >> 32) | ((rroll >> 13) << 28),
-                                          (uint32_t)__popcll((unsigned long long)mi0));
+              for (int j = 0; j < PB; j++)
+                any |= xa[j] | xb[j];
+              if (CMPR_DBG(P, DBG_SKIP_EMIT))
+                any = 0;
+              if (__ballot(any != 0u)) {
+#pragma unroll
+                for (int j = 0; j < PB; j++)
+                  q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, (xa[j] | xb[j]) != 0u && any != 0u, hrow[j],
+                                              K_INSROWS | ((g0 + 2u * (uint32_t)j) << 3) | (rg[j] << 19),
+                                              xa[j], xb[j], (uint32_t)__popc(xa[j]) + (uint32_t)__popc(xb[j]));
+              }
             }
           };
-          for (uint32_t ip0 = 0; ip0 <= L; ip0 += RB) {
-            if (ip0 && ip0 % (4u * TDW) == 0) {
-              const uint32_t w0 = ip0 >> 2;
-              s0 = w0 < nd ? qr[w0 * WAVE] : 0u;
-              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : 0u;
-              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : 0u;
-              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : 0u;
-              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : 0u;
-              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : 0u;
+          for (uint32_t g0 = 0; g0 <= L; g0 += PP) {
+            if (g0 && g0 % (4u * TDW) == 0) {
+              const uint32_t w0 = g0 >> 2;
+              s0 = w0 < nd ? qr[w0 * WAVE] : PADW;
+              s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : PADW;
+              s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : PADW;
+              s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : PADW;
+              s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : PADW;
+              s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : PADW;
             }
-            if (ip0 >= 1u && ip0 + (uint32_t)RB - 1u <= L && (K == 0u || ip0 > mi_max))
-              ins_block(ip0, std::true_type{});
+            if (K == 0u || g0 > mi_max)
+              ins_block(g0, std::true_type{});
             else
-              ins_block(ip0, std::false_type{});
+              ins_block(g0, std::false_type{});
           }
+          /* the variants these pairs stand for: A in front of position 0, A - 1 in front of
+             every other up to the lane's own length -- but for the class pairs of a split
+             variant class (items) */
+          uint32_t nins = valid ? (uint32_t)A + Ll * (uint32_t)(A - 1) : 0u;
+#pragma unroll
+          for (uint32_t i = 0; i < MCR; i++)
+            if (i < KH && K != 0u) {
+              const uint32_t gq = mi[i] & ~1u;
+              bool fresh = true;
+#pragma unroll
+              for (uint32_t k = 0; k < MCR; k++)
+                if (k < i && (mi[k] & ~1u) == gq)
+                  fresh = false;
+              if (fresh && hvy && valid)
+                nins -= (gq <= Ll ? (gq == 0u ? (uint32_t)A : (uint32_t)(A - 1)) : 0u) +
+                        (gq + 1u <= Ll ? (uint32_t)(A - 1) : 0u);
+            }
+          nvar += nins;
         }
       }
 

@@ -124,6 +124,29 @@ __host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i, uint32_t
   return len ? (c0 + i) % len : 0;
 }
 
+/* Pair rows: the class PART of a pair that holds class positions is keyed by what is left of
+   the class residues -- one of three when a pair swallows two -- and that is too coarse for
+   the big (V, J) classes of -i (no length term): 3 x 10^5 sequences twenty ways overfill
+   their slices.  So the slices of the class parts (only they) are keyed by PAIR_EXTRA more
+   residues, at the positions behind the class positions, those inside the pair left out
+   like the class positions inside it.  `res_at(pos)` = the residue the sequence at hand
+   (a set-2 sequence, a query, or an indel variant of either) has at pos. */
+constexpr uint32_t PAIR_EXTRA = 3;
+template <typename F>
+__host__ __device__ inline uint32_t pair_part_terms(const uint32_t *t, const SliceGeom &g, uint32_t A,
+                                                    uint32_t len, uint32_t pair_pos, F res_at)
+{
+  uint32_t x = 0;
+  if (g.k + PAIR_EXTRA > MAX_CLASS_RES || len == 0)
+    return 0;
+  for (uint32_t e = 0; e < PAIR_EXTRA; e++) {
+    const uint32_t pos = class_pos(len, g.k + e, g.c0);
+    if ((pos & ~1u) != pair_pos)
+      x ^= t[g.off_cr + (g.k + e) * A + res_at(pos)];
+  }
+  return x;
+}
+
 /* `t` = the class tables (host vector or device pointer, same layout) */
 __host__ __device__ inline uint32_t class_base(const uint32_t *t, const SliceGeom &g,
                                                bool genes, uint32_t L, uint32_t v, uint32_t j)
@@ -201,6 +224,7 @@ __host__ __device__ constexpr uint32_t zdelta_entries(int A)
 constexpr uint32_t ITEM_DEL_COUNTS = 1u << 27;   /* ItemRec::rp of a K_SUB item with -i: "q without this
                                                     position" is a variant (first of a run), answered by
                                                     bit A + 1 of the same row (kernels_rows.h) */
+constexpr uint32_t ITEM_DEL2_COUNTS = 1u << 28;  /* a pair item (pair rows): the same for its second position */
 struct alignas(16) ItemRec {
   uint64_t w;
   uint32_t main;

@@ -341,32 +341,91 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
   /* ---- substitution rows at class positions: class part ci, key without the terms
           of that position; a position that carries several class residues is
           handled by the first of them ---- */
-  if (heavy && Q.pairs) {
+  if (Q.pairs) {
     /* pair rows (kernels_rows.h): one item per PAIR of positions (p, p + 1), p even, that
        holds a class position -- class part of the first class residue inside, key without
-       the terms of every class residue inside, the hash with both positions blanked */
-    const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
-    for (uint32_t ci = 0; ci < K; ci++) {
-      const uint32_t p = class_pos(L, ci, g.c0) & ~1u;
-      bool first = true;
-      uint32_t key = ck;
-      for (uint32_t k = 0; k < K; k++) {
-        const uint32_t mk = class_pos(L, k, g.c0);
-        if ((mk & ~1u) == p) {
-          if (k < ci)
-            first = false;
-          key ^= g.ctab[g.off_cr + k * A + s[mk]];
+       the terms of every class residue inside, the hash with both positions blanked.  With
+       -i the pair also answers "q without p" / "q without p + 1": the flags say which of the
+       two deletion variants exist (the first position of a run of equal residues,
+       variants.cc:301-325; none for a query of one residue). */
+    if (heavy) {
+      const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
+      for (uint32_t ci = 0; ci < K; ci++) {
+        const uint32_t p = class_pos(L, ci, g.c0) & ~1u;
+        bool first = true;
+        uint32_t key = ck;
+        for (uint32_t k = 0; k < K; k++) {
+          const uint32_t mk = class_pos(L, k, g.c0);
+          if ((mk & ~1u) == p) {
+            if (k < ci)
+              first = false;
+            key ^= g.ctab[g.off_cr + k * A + s[mk]];
+          }
+        }
+        if (first) {
+          const uint32_t ra = s[p], rb = p + 1 < L ? (uint32_t)s[p + 1] : A;
+          uint64_t w = 0;
+          if (HASH) {
+            w = h ^ Q.zob[A * p + ra];
+            if (p + 1 < L)
+              w ^= Q.zob[A * (p + 1) + rb];
+          }
+          uint32_t fl = 0;
+          if (Q.indels && L > 1) {
+            if (p == 0 || s[p] != s[p - 1])
+              fl |= ITEM_DEL_COUNTS;
+            if (p + 1 < L && s[p + 1] != s[p])
+              fl |= ITEM_DEL2_COUNTS;
+          }
+          key ^= pair_part_terms(g.ctab, g, A, L, p, [&](uint32_t pos) -> uint32_t { return s[pos]; });
+          f(Q.goff[ci] + (key & g.cmask), w, ra | (rb << 5) | (p << 10) | (ITEM_PAIR << 24) | fl);
         }
       }
-      if (first) {
-        const uint32_t ra = s[p], rb = p + 1 < L ? (uint32_t)s[p + 1] : A;
-        uint64_t w = 0;
-        if (HASH) {
-          w = h ^ Q.zob[A * p + ra];
-          if (p + 1 < L)
-            w ^= Q.zob[A * (p + 1) + rb];
+    }
+    if (!Q.indels)
+      return;
+    /* -i, insertion pairs: the variants t = q with v in front of g (pair (v, q[g]) at (g,
+       g + 1)) and t' = q with w in front of g + 1 (pair (q[g], w)) share the word under the
+       hash of "q with a gap at g and q[g] blanked"; the pair is an item when it holds a class
+       position of the variants (length L + 1) and their class is split -- filed under the
+       class residues of the variants outside the pair, taken around the gap */
+    uint32_t base = ck;
+    if (heavy)
+      for (uint32_t k = 0; k < K; k++)
+        base ^= g.ctab[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
+    const uint32_t base_i = base ^ g.ctab[L] ^ g.ctab[L + 1];
+    if (!class_is_heavy(g.ctab, g, base_i))
+      return;
+    const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull;
+    uint64_t P0 = 0, Pp = 0;                     /* XOR_{y<x} Z[y][q[y]],  XOR_{y<x} Z[y+1][q[y]] */
+    for (uint32_t x = 0; x <= L; x++) {
+      if ((x & 1u) == 0) {
+        int ci = -1;
+        uint32_t key = base_i;
+        for (uint32_t k = 0; k < K; k++) {
+          const uint32_t mk = class_pos(L + 1, k, g.c0);
+          if ((mk & ~1u) == x) {
+            if (ci < 0)
+              ci = (int)k;
+          } else {
+            key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk - 1]];
+          }
         }
-        f(Q.goff[ci] + (key & g.cmask), w, ra | (rb << 5) | (p << 10) | (ITEM_PAIR << 24));
+        if (ci >= 0) {
+          key ^= pair_part_terms(g.ctab, g, A, L + 1, x,
+                                 [&](uint32_t pos) -> uint32_t { return s[pos < x ? pos : pos - 1]; });
+          uint64_t w = P0 ^ hins ^ Pp;           /* gap at x */
+          if (HASH && x < L)
+            w ^= Q.zob[A * (x + 1) + s[x]];      /* ... and q[x], one position up, blanked */
+          f(Q.goff[ci] + (key & g.cmask), w,
+            (x < L ? (uint32_t)s[x] : A) | ((x > 0 ? (uint32_t)s[x - 1] : 31u) << 5) | (x << 10) | (ITEM_INS << 24));
+        }
+      }
+      if (x == L)
+        break;
+      if (HASH) {
+        P0 ^= Q.zob[A * x + s[x]];
+        Pp ^= Q.zob[A * (x + 1) + s[x]];
       }
     }
     return;
