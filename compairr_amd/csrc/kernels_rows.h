@@ -1692,7 +1692,9 @@ probe_rows_kernel(const ProbeParams P)
                 (Behind its end a query carries code A, whose keys are zero: the gap hash
                 rolls on unchanged, and q[g] = A is "the sequence ends here".) ---- */
         if (!CMPR_DBG(P, DBG_SKIP_INS_ROWS)) {
-          constexpr int PB = A == 20 ? 3 : 2;
+          /* (two pairs per block, also for amino acids: four keys per pair are in flight here,
+             and with three pairs the tile's registers no longer fit) */
+          constexpr int PB = 2;
           constexpr uint32_t PP = 2u * PB;
           s0 = cur.r0; s1 = cur.r1; s2 = cur.r2; s3 = cur.r3; s4 = cur.r4; s5 = cur.r5;
           const uint32_t base_t = base_q ^ cl_L ^ P.geom.ctab[L + 1];
