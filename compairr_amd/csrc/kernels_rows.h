@@ -23,20 +23,24 @@
  *   filter bits per entry a false-positive rate of ~6e-4).  All A answers of the
  *   row come out of one 32-byte LDS read and ~20 instructions.
  *
- * With single substitutions only (d = 1 without -i) the filter holds PAIR rows instead:
- * one entry per pair of positions, both blanked, the two residues coded as their sum and
- * their difference -- one word read answers the 2 (A - 1) variants of two positions
- * (pair_entry_bits / pair_bits / pair_answers below; round 3).
+ * With d = 1 (with or without -i) the filter holds PAIR rows instead: one entry per pair
+ * of positions, both blanked, the two residues coded as their sum and their difference --
+ * one word read answers the 2 (A - 1) substitution variants of two positions
+ * (pair_entry_bits / pair_bits / pair_answers below; round 3).  With -i the same words
+ * answer the indel variants:
+ *   - every set-2 sequence t is also entered once per GAP position ip: u = t with a blank
+ *     in front of ip, the pair of u that holds the blank, the blank coded as A + 1 ("gap").
+ *     A query's pair (p, p + 1) with both blanked IS (q without p) with a blank at p and
+ *     q[p + 1] blanked, and (q without p + 1) with a blank at p + 1 and q[p] blanked: the
+ *     word read for the substitution pair answers both deletion variants
+ *     (variants.cc:301-325) in bit A + 1 of its two sides -- no read of their own;
+ *   - t = q with v in front of g has the pair (v, q[g]) at (g, g + 1), t' = q with w in
+ *     front of g + 1 the pair (q[g], w), and blanked they are the same string: ONE word
+ *     under the rolling hash of "q with a gap at g and q[g] blanked" answers the insertions
+ *     in front of g and in front of g + 1 (variants.cc:329-353).
+ * L + 1 reads per query of length L for all its d = 1 variants with -i, L / 2 without.
  *
- * The same entries serve the other variant kinds: an insertion variant of q
- * (v put in front of position ip) blanked at ip IS q with a gap at ip, so the
- * row of all A insertions at ip is one read under the rolling gap hash
- * (variants.cc:329-353).  A deletion variant (variants.cc:301-325) costs no read at
- * all: with -i every set-2 sequence t is also entered once per GAP position ip, under
- * the hash of "t with a blank put in front of position ip" and code A + 1 -- and q
- * with position p blanked IS (q without p) with a blank in front of p, so the word
- * already read for the substitution row of p answers "q without p" in bit A + 1
- * (round 3; before, one word read per deletion variant).  A double substitution (p, q) is read as
+ * A double substitution (p, q) (d = 2: single rows) is read as
  * row p of "q already substituted at q" (variants.cc:370-399): A-1 reads instead
  * of (A-1)^2 probes.  Bloom positives are queued with their full variant hash
  * exactly as in the other kernels, so everything behind the filter
@@ -314,40 +318,6 @@ build_rows_kernel(const BuildParams B)
         }
     enter(h ^ B.zob[B.A * p + s[p]], s[p], row_slice(g, key, ci));
   }
-  if (!B.indels)
-    return;
-  /* the gap entries: u = t with a blank in front of position ip (length L + 1), for
-     ip = 0 .. L, filed like any blanked row of a sequence of length L + 1 -- class
-     residues at the positions of that length, taken around the gap (with -i the class
-     keys carry no length term: the base key, and with it "heavy", is t's own) */
-  uint64_t hg = 0;                               /* hash of u: blank at 0 = everything shifted by one */
-  if (B.use_genes) {
-    const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
-    hg = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
-  }
-  for (uint32_t p = 0; p < L; p++)
-    hg ^= B.zob[B.A * (p + 1) + s[p]];
-  uint32_t base = ck;                            /* class key without the class residues */
-  if (heavy)
-    for (uint32_t k = 0; k < g.k; k++)
-      base ^= g.ctab[g.off_cr + k * B.A + s[class_pos(L, k, g.c0)]];
-  for (uint32_t ip = 0; ip <= L; ip++) {
-    if (ip > 0)                                  /* t[ip - 1] moves from position ip to ip - 1 */
-      hg ^= B.zob[B.A * ip + s[ip - 1]] ^ B.zob[B.A * (ip - 1) + s[ip - 1]];
-    uint32_t key = base;
-    int ci = -1;
-    if (heavy)
-      for (uint32_t k = 0; k < g.k; k++) {
-        const uint32_t mk = class_pos(L + 1, k, g.c0);
-        if (mk == ip) {
-          if (ci < 0)
-            ci = (int)k;
-        } else {
-          key ^= g.ctab[g.off_cr + k * B.A + s[mk < ip ? mk : mk - 1]];
-        }
-      }
-    enter(hg, B.A + 1u, row_slice(g, key, ci));
-  }
 }
 
 /* ------------------------------------------------------------------ */
@@ -396,13 +366,13 @@ __host__ __device__ constexpr uint32_t zs_of(int A, int D, bool pairs)
  *                             | rb << 24                          residues w at p + 1; ra, rb = the query's own
  *   K_SUB,    the row's       kind | p << 3                       m = mask of residues v (one row: an item,
  *   K_INS     blanked hash                                        or an insertion row)
- *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant (K_DEL with
- *                                                                 m = DEL_LAZY: hash worked out in the drain)
+ *   others    variant hash    as it leaves (pack_a)               cb as it leaves; one variant
+ * (a deletion answer -- bit A + 1 of a K_PAIR mask -- leaves as K_DEL, its hash worked out in the drain
+ * from the query's first-deleted hash and its residues)
  */
 constexpr uint32_t K_ROWS = 5;
-constexpr uint32_t K_INSROWS = 6;        /* a block of insertion rows of one query (-i) */
-constexpr uint32_t K_PAIR = 7;           /* a pair of substitution rows (pair rows: d = 1 without -i) */
-constexpr uint32_t DEL_LAZY = 2;         /* m of a K_DEL entry whose hash is worked out when it is drained */
+constexpr uint32_t K_INSROWS = 6;        /* a pair of insertion rows of one query (-i) */
+constexpr uint32_t K_PAIR = 7;           /* a pair of substitution rows (pair rows: d = 1); with -i also its deletion answers */
 
 template <int A, int D, bool GENES, bool INLINE, bool PAIRS>
 __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n, bool last = false)
@@ -481,9 +451,6 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     ocb = 0;
     nm = m & (m - 1u);
     more = nm != 0;
-  } else if (kind == K_DEL && m == DEL_LAZY && act) {
-    lazy_del = true;
-    lazy_p = p0;
   }
   if (lazy_del) {
     /* "the query without position lazy_p", from its first-deleted hash and its residues
@@ -557,16 +524,17 @@ __device__ __forceinline__ void q_push(SProber &W, uint32_t zl_addr, bool pos, u
 
 /*
  * Chunk::pass of this kernel:
- *   0      the sequence itself + every substitution row that is not a class
+ *   0      the sequence itself + every substitution row (pair) that holds no class
  *          position of a split ("heavy") tile (+ the double substitutions); with -i
- *          also the tile's deletion variants and insertion rows, on the same staged
- *          slice (the class keys of variant 2 have no length term with -i, so an
- *          indel variant stays in its query's slice unless it touches a class
- *          position -- those are items)
- *   3 + i  items: the substitution row of class position i of the heavy queries
- *          (with -i also insertion rows blanked there; group K: deletion variants
- *          that leave their query's slice), blocks of 64 grouped by the slice the
- *          row is filed under (class part i of the filter), ITEM_BLOCKS per claim
+ *          the pairs also answer the tile's deletion variants, and its insertion pairs
+ *          run on the same staged slice (the class keys of variant 2 have no length term
+ *          with -i, so an indel variant stays in its query's slice unless it moves or
+ *          touches a class residue -- pairs that hold one are items, pairs in front of
+ *          one are read where they lie)
+ *   3 + i  items: the substitution row of class position i of the heavy queries (pair
+ *          rows: the pair that holds it, with -i also the insertion pair that does),
+ *          blocks of 64 grouped by the slice the row is filed under (class part i of
+ *          the filter), ITEM_BLOCKS per claim
  * TileDesc::slice is the slice the tile's rows of this pass are filed under;
  * for a staged chunk it is the slice in LDS.
  *
@@ -1297,15 +1265,6 @@ probe_rows_kernel(const ProbeParams P)
           uint32_t s0 = cur.r0, s1 = cur.r1, s2 = cur.r2, s3 = cur.r3, s4 = cur.r4, s5 = cur.r5;
           uint32_t nlive = 0;                     /* rows of this lane that count (x A - 1 variants) */
           uint32_t nrows = 0;                     /* rows read (wave-uniform) */
-          /* -i: the word of row p also answers "q without p" (bit A + 1: the gap entries of
-             build_rows_kernel).  Rolling with the rows: hd = hash of q without the position at
-             hand (zobrist_hash_delete_first and the update of variants.cc:301-325), zprev = key
-             of the previous position's own residue, rprev that residue (a deletion variant
-             exists once per run of equal residues: at its first position). */
-          uint64_t hd = 0, zprev = 0;
-          uint32_t rprev = 31u, ndel = 0;
-          if (INDELS && valid)
-            hd = P.qhdel[W.qslot];
           auto sub_rows = [&](auto staged_c) {
           constexpr bool STAGED = decltype(staged_c)::value;
           for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += RB) {
@@ -1344,9 +1303,8 @@ probe_rows_kernel(const ProbeParams P)
             cbits = __builtin_amdgcn_readfirstlane(cbits);
             uint64_t m0 = 0, m1 = 0;
             uint32_t rpack = 0;
-            uint64_t Wk[RB], zm[RB], hdj[RB];
+            uint64_t Wk[RB];
             uint32_t rj[RB], wo[RB];
-            uint32_t dm = 0;                      /* -i: rows whose deletion variant is Bloom-positive */
             /* the rows' own keys, all RB reads in flight together ... */
 #pragma unroll
             for (int j = 0; j < RB; j++) {
@@ -1356,24 +1314,10 @@ probe_rows_kernel(const ProbeParams P)
               uint32_t zrow = zl_addr + ZS * 8u * (p0 + (uint32_t)j);
               asm("" : "+s"(zrow));
               Wk[j] = lds_u64(zrow + rj[j] * 8u);
-              if (INDELS) {                       /* key of this row's residue one position down */
-                zm[j] = 0;
-                if (p0 + (uint32_t)j > 0u) {
-                  uint32_t zdown = zl_addr + ZS * 8u * (p0 + (uint32_t)j - 1u);
-                  asm("" : "+s"(zdown));
-                  zm[j] = lds_u64(zdown + rj[j] * 8u);
-                }
-              }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
-              if (INDELS) {
-                if (p0 + (uint32_t)j > 0u)        /* q[p] moves one down, q[p - 1] comes back */
-                  hd ^= zprev ^ zm[j];
-                zprev = Wk[j];
-                hdj[j] = hd;
-              }
               Wk[j] ^= h;
               wo[j] = woff_of(Wk[j]);
             }
@@ -1394,12 +1338,6 @@ probe_rows_kernel(const ProbeParams P)
               const bool live = p < Ll;
               x = live ? x : 0u;
               nlive += (live && am) ? 1u : 0u;
-              if (INDELS) {
-                const bool del = live && am && rj[j] != rprev && Ll > 1u;
-                rprev = rj[j];
-                ndel += del ? 1u : 0u;
-                dm |= (del && ((bits >> (A + 1)) & 1u)) ? (1u << j) : 0u;
-              }
               if (j < RPW)
                 m0 |= (uint64_t)x << (A * j);
               else
@@ -1409,20 +1347,6 @@ probe_rows_kernel(const ProbeParams P)
             nrows += (uint32_t)RB;
             PT_MARK(PT_ROWS);
             emit_sub_rows(m0 | m1, p0, rpack);
-            if (INDELS) {
-              if (CMPR_DBG(P, DBG_SKIP_EMIT) || CMPR_DBG(P, DBG_SKIP_DEL_ROWS))
-                dm = 0;
-              /* (one push per round: a lane rarely has two positive deletions in a block) */
-              while (__ballot(dm != 0)) {
-                const uint32_t jd = dm ? (uint32_t)__ffs((int)dm) - 1u : 0u;
-                uint64_t hsel = hdj[0];
-#pragma unroll
-                for (int j = 1; j < RB; j++)
-                  hsel = jd == (uint32_t)j ? hdj[j] : hsel;
-                q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, dm != 0, hsel, pack_a(K_DEL, p0 + jd, 0), 0, 1u, 1u);
-                dm &= dm - 1u;
-              }
-            }
             PT_MARK(PT_EMIT);
           }
           };
@@ -1430,7 +1354,7 @@ probe_rows_kernel(const ProbeParams P)
             sub_rows(std::true_type{});
           else
             sub_rows(std::false_type{});
-          nvar += nlive * (uint32_t)(A - 1) + ndel;
+          nvar += nlive * (uint32_t)(A - 1);
           treads += valid ? nrows : 0u;
         }
 
@@ -1613,14 +1537,6 @@ probe_rows_kernel(const ProbeParams P)
               x = 0;
             q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
                                         (uint32_t)__popc(x));
-            if (INDELS) {
-              /* the row of a class position answers "q without p" too; its hash is worked out
-                 when the entry is drained (m = DEL_LAZY: rare, and the item carries no residues) */
-              const bool delc = ival && (ic & ITEM_DEL_COUNTS) != 0;
-              nvar += delc ? 1u : 0u;
-              const bool dpos = delc && ((bits >> (A + 1)) & 1u) != 0 && !CMPR_DBG(P, DBG_SKIP_EMIT);
-              q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, dpos, 0ull, pack_a(K_DEL, p, 0), 0, DEL_LAZY, 1u);
-            }
             /* next block's data moves up */
             iw = ea[0];
             im = eb[0];

@@ -221,9 +221,10 @@ __host__ __device__ constexpr uint32_t zdelta_entries(int A)
 /* One item (kernels_rows.h passes >= 3; kernels_sliced.h sub2 items): the row's blanked
    hash (sub2: the query's hash), the query's slot (~0: padding behind the items of a
    slice) and its residue | position << 8 | kind << 24 -- 16 bytes, one load per lane */
-constexpr uint32_t ITEM_DEL_COUNTS = 1u << 27;   /* ItemRec::rp of a K_SUB item with -i: "q without this
-                                                    position" is a variant (first of a run), answered by
-                                                    bit A + 1 of the same row (kernels_rows.h) */
+constexpr uint32_t ITEM_DEL_COUNTS = 1u << 27;   /* ItemRec::rp of a pair item with -i: "q without its first
+                                                    position" is a variant (first of a run of equal
+                                                    residues), answered by bit A + 1 of the same word
+                                                    (kernels_rows.h) */
 constexpr uint32_t ITEM_DEL2_COUNTS = 1u << 28;  /* a pair item (pair rows): the same for its second position */
 struct alignas(16) ItemRec {
   uint64_t w;

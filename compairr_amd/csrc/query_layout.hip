@@ -442,53 +442,10 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool 
             first = false;
           key ^= g.ctab[g.off_cr + k * A + s[pos]];
         }
-      /* (with -i the row also answers "q without pos": ITEM_DEL_COUNTS = that deletion
-         variant exists -- the first position of a run of equal residues, variants.cc:301-325) */
+      /* (single rows: d = 2 -- with -i, which goes with d = 1 only, the filter holds pair rows) */
       if (first)
         f(Q.goff[ci] + (key & g.cmask), HASH ? h ^ Q.zob[A * pos + s[pos]] : 0ull,
-          (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24) |
-              (Q.indels && L > 1 && (pos == 0 || s[pos] != s[pos - 1]) ? ITEM_DEL_COUNTS : 0u));
-    }
-  }
-  if (!Q.indels)
-    return;
-  /* (length, V, J) key of the query: its class key without the class residues */
-  uint32_t base = ck;
-  if (heavy)
-    for (uint32_t k = 0; k < K; k++)
-      base ^= g.ctab[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
-  const uint32_t base_i = base ^ g.ctab[L] ^ g.ctab[L + 1];          /* insertion variants */
-  const bool heavy_i = class_is_heavy(g.ctab, g, base_i);
-  /* One walk over the positions.  With P(x) = XOR_{y<x} Z[y][q[y]], P+(x) the same
-     over Z[y+1], and the query's shifted hash from the keys kernel:
-       gap at ip:  P(ip) ^ hins ^ P+(ip). */
-  const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull;
-  uint64_t P0 = 0, Pp = 0;
-  for (uint32_t x = 0; x <= L; x++) {
-    /* ---- insertion row blanked at x, if x is a class position of the variant t
-            (length L + 1, t[y] = y < x ? q[y] : q[y - 1] around the gap) and t's
-            class is split: class part of that position ---- */
-    if (heavy_i) {
-      int ci = -1;
-      uint32_t key = base_i;
-      for (uint32_t k = 0; k < K; k++) {
-        const uint32_t mk = class_pos(L + 1, k, g.c0);
-        if (mk == x) {
-          if (ci < 0)
-            ci = (int)k;
-        } else {
-          key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk - 1]];
-        }
-      }
-      if (ci >= 0)
-        f(Q.goff[ci] + (key & g.cmask), P0 ^ hins ^ Pp,
-          (x > 0 ? (uint32_t)s[x - 1] : 31u) | (x << 8) | (ITEM_INS << 24));
-    }
-    if (x == L)
-      break;
-    if (HASH) {
-      P0 ^= Q.zob[A * x + s[x]];
-      Pp ^= Q.zob[A * (x + 1) + s[x]];
+          (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24));
     }
   }
 }
