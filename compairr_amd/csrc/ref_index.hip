@@ -217,7 +217,10 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     }
   }
   /* row filter: L + 1 entries per sequence, and with -i its L + 1 gap entries (kernels_rows.h) */
-  const uint64_t entries = ((s->n ? s->offsets[s->n] : 0) + s->n) * (c->rows && c->opt.indels ? 2 : 1);
+  /* (what the filter is SIZED for, also with pair rows, which enter fewer -- entries_filed:
+     their eight-bit tests then see next to no false positive, and a slice holds more sequences) */
+  const uint64_t residues2 = s->n ? s->offsets[s->n] : 0;
+  const uint64_t entries = (residues2 + s->n) * (c->rows && c->opt.indels ? 2 : 1);
   if (c->rows) {
     /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a
        word then has ~40 % of its bits set and a test of eight of them passes by
@@ -304,8 +307,10 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
     /* at least 12 filter bits per key in the fullest slice: fill <= 0.28 with 4
        bits per key, false-positive rate <= 6e-3 there and far less elsewhere.
        Row filter: sequences per slice at 24 entries per word (1.5 x the average). */
+    const uint64_t entries_filed = !pair_rows(c) ? entries
+                                   : (residues2 + 1) / 2 + s->n + (c->opt.indels ? residues2 + s->n : 0);
     const double slice_cap = c->rows
-        ? (double)g.rw_words * 24.0 / std::max(1.0, (double)entries / (double)std::max<uint64_t>(s->n, 1))
+        ? (double)g.rw_words * 24.0 / std::max(1.0, (double)entries_filed / (double)std::max<uint64_t>(s->n, 1))
         : slice_bits / 12.0;
     g.k = 0;
     /* Class positions c0 .. c0+K-1.  They must exist in almost every sequence
@@ -365,15 +370,23 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
         }
         const double need = 0.7 * std::log2((double)A);
         uint32_t best = (l5 - mcr) / 2;
-        for (uint32_t c0 = 0; c0 + mcr <= npos; c0++) {
-          bool ok = true;
-          for (uint32_t i = 0; i < mcr; i++)
-            ok = ok && ent[c0 + i] >= need;
-          if (ok) {
-            best = c0;
-            break;
+        /* (pair rows: an even anchor first -- two class positions then share one pair, one item
+           per heavy query instead of two) */
+        const uint32_t step = pair_rows(c) ? 2u : 1u;
+        bool found = false;
+        for (uint32_t first = 0; first < step && !found; first++)
+          for (uint32_t c0 = first; c0 + mcr <= npos; c0 += step) {
+            bool ok = true;
+            for (uint32_t i = 0; i < mcr; i++)
+              ok = ok && ent[c0 + i] >= need;
+            if (ok) {
+              best = c0;
+              found = true;
+              break;
+            }
           }
-        }
+        if (!found && pair_rows(c))
+          best &= ~1u;
         g.c0 = best;
       }
     }
