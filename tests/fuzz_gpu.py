@@ -58,6 +58,10 @@ def random_case(rng):
         tun["class_residues"] = int(rng.integers(0, 9 if nt else 4))
     if rng.random() < 0.3:
         tun["heavy_threshold"] = int(rng.integers(0, 50))
+    if rng.random() < 0.4:
+        # odd and even anchors, also behind the start: pairs that hold one or two class
+        # positions, and with -i the pairs in front of them (read where they lie)
+        tun["class_anchor"] = int(rng.integers(0, 12))
     if rng.random() < 0.3:
         tun["chunk_tiles"] = int(rng.integers(1, 65))
     if rng.random() < 0.3:
