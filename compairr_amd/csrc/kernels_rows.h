@@ -1629,7 +1629,10 @@ probe_rows_kernel(const ProbeParams P)
           }
           /* behind the last class position of the variants nothing moves a class residue: the
              pairs of such a block lie in the staged slice, lane for lane (and in a light tile
-             all pairs do) -- no key arithmetic there */
+             all pairs do) -- no key arithmetic there.  Unless the class positions WRAP (a tile
+             of sequences shorter than c0 + K: (c0 + i) mod L and mod L + 1 are different
+             positions): then every pair of the variants is keyed on its own. */
+          const bool unwrapped = L >= P.geom.c0 + KH;
           uint32_t mi_max = 0;
 #pragma unroll
           for (uint32_t i = 0; i < MCR; i++)
@@ -1688,7 +1691,7 @@ probe_rows_kernel(const ProbeParams P)
               itp[j] = false;
               slr[j] = cslice;
               if constexpr (!INNER) {
-                if (K != 0u && g0 <= mi_max) {          /* wave-uniform: see mi_max */
+                if (K != 0u && (!unwrapped || g0 <= mi_max)) {          /* wave-uniform: see mi_max */
                   uint32_t key = base_t;
                   bool inside = false;                  /* a class residue of the variants inside the pair */
 #pragma unroll
@@ -1760,7 +1763,7 @@ probe_rows_kernel(const ProbeParams P)
               s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : PADW;
               s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : PADW;
             }
-            if (K == 0u || g0 > mi_max)
+            if (K == 0u || (unwrapped && g0 > mi_max))
               ins_block(g0, std::true_type{});
             else
               ins_block(g0, std::false_type{});
