@@ -554,6 +554,30 @@ def test_overflow_without_redo_pass_is_never_silent():
         assert h.stats().matches == ost.matches
 
 
+@pytest.mark.parametrize("nt", [False, True])
+def test_class_positions_that_wrap(nt):
+    """Sequences shorter than class_anchor + K: the class positions are (c0 + i) mod length, and
+    an indel variant of length L +- 1 has them elsewhere than its query -- no row of the
+    variants may be assumed to lie in the query's own slice (round 3: the insertion rows of
+    variant 2 behind the last class position were; found by tests/fuzz_gpu.py once it varied
+    class_anchor)."""
+    A = 4 if nt else 20
+    a = synth.tiny_set(1200, 31, alphabet_size=A, letters=4, max_len=7, prefix="A")
+    b = synth.tiny_set(1500, 32, alphabet_size=A, letters=4, max_len=7, prefix="B")
+    for indels in (True, False):
+        o = Options(differences=1, indels=indels, nucleotides=nt, n_v_genes=2, n_j_genes=2)
+        want, ost = _oracle.overlap(a, b, o, threads=8)
+        want = _oracle.integer_cells(want, o)
+        for variant in (1, 2):
+            for k in (1, 2, 3):
+                for c0 in (1, 4, 5, 6, 7, 10, 11):
+                    tun = {"variant": variant, "class_residues": k, "class_anchor": c0,
+                           "heavy_threshold": 0, "slice_words_log2": 3}
+                    got, st = gpu_cells(a, b, o, tun)
+                    assert np.array_equal(got, want), (nt, indels, tun)
+                    assert st.matches == ost.matches and st.variants == ost.variants, (nt, indels, tun)
+
+
 def test_shortcut_is_withdrawn_when_the_deal_changes():
     """the margin was measured for one static deal of the chunks; another grid
     (blocks_per_cu) or unstaged tiles claimed through a global counter void it."""
