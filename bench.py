@@ -24,8 +24,8 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
 The only collective is one all-reduce (sum, int64) of the R1 x R2 matrix per
 step; it runs on a second stream, ordered by events, so that the all-reduce of a
 step overlaps the kernels of the next (two matrices).  In strong mode the reduced matrix is
-the N = 1 matrix; its checksum is compared with the recorded N = 1 checksum at
-every N ("parity_vs_n1").
+the N = 1 matrix; it is compared, at every N, with the matrix the reference binary printed
+for the same workload (tests/golden/full_size.json, "parity_vs_reference_full_size").
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), with
 `roofline` (the dominant kernel against its binding unit, from the committed
@@ -46,13 +46,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# N = 1 matrix checksums of the recorded workloads (synth.checksum), the parity
-# anchor of the strong-scaling runs; each was confirmed digit for digit against the
-# reference binary by this script's cpu_baseline leg
-KNOWN_CHECKSUMS = {
-    "synthetic 10M-vs-10M CDR3aa, d=1 substitutions only, V/J matched":
-        "fc9769626ca2bcf2c84e8473864b8853",
-}
+
+
+def recorded_workload(args):
+    """The reference binary's own matrix for this workload, if tests/golden/full_size.json
+    (written in the build container by tests/golden/make_full_size.py) holds it: the parity
+    anchor of every run at every N."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _full_size
+    if args.scaling != "strong":
+        return None
+    return _full_size.by_bench_args(args.refs, args.queries, args.differences, args.indels,
+                                    args.nucleotides, args.ignore_genes, args.self_cmp)
 
 
 def parse_args():
@@ -193,16 +198,19 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
     from csrc_hash import csrc_hash
     out["counters_stale"] = bool(inp.get("csrc_sha256") != csrc_hash(ROOT))
     cal = inp["calibration"]
+    # this rank's share of the profiled (N = 1) launch: by filter reads, else by variant tests
     share = 1.0
     if k.get("filter_reads") and st.filter_reads:
         share = st.filter_reads / k["filter_reads"]
+    elif k.get("variants") and st.variants:
+        share = st.variants / k["variants"]
     units = {}
     if k.get("valu_insts"):
         cyc = k.get("mix_cycles_per_valu_inst") or cal["valu_cycles_slow"]
         peak = cal["simds"] * cal["nominal_clock_hz"] / cyc
         units["valu"] = (k["valu_insts"] * share / t, peak, "wave-instructions/s")
     if k.get("lds_active_cycles"):
-        peak = cal["cus"] * (k.get("effective_clock_hz") or cal["nominal_clock_hz"])
+        peak = cal["cus"] * cal["nominal_clock_hz"]        # (both units at the nominal clock)
         units["lds"] = (k["lds_active_cycles"] * share / t, peak, "LDS-array cycles/s")
     if k.get("hbm_bytes"):
         units["hbm"] = (k["hbm_bytes"] * share / t / 1e9, HBM_PEAK_GBS, "GB/s")
@@ -378,11 +386,15 @@ def main():
             if not parity:
                 print("PARITY FAILURE: HIP matrix differs from the CPU %s on the sample"
                       % baseline["kind"], file=sys.stderr)
-        known = KNOWN_CHECKSUMS.get(wl) if strong else None
-        parity_vs_n1 = None if known is None else bool(checksum == known)
-        if parity_vs_n1 is False:
-            print("PARITY FAILURE: reduced matrix checksum %s != recorded N=1 checksum %s"
-                  % (checksum, known), file=sys.stderr)
+        rec = recorded_workload(args)
+        parity_full = None
+        if rec is not None:
+            import _full_size
+            why = _full_size.mismatch(rec, result_matrix)
+            parity_full = why is None
+            if why:
+                print("PARITY FAILURE: the (reduced) matrix differs from the reference's "
+                      "(tests/golden/full_size.json %s): %s" % (rec["name"], why), file=sys.stderr)
         out = {
             "metric": "query sequences/sec for --matrix d=%d%s, %s-vs-%s %s" % (
                 args.differences, " --indels" if args.indels else "",
@@ -420,8 +432,14 @@ def main():
                        "query_layout_ms": layout_ms},
             # from cmpr_set_view in host memory to the matrix: upload + device-side layout
             # of the queries (once per query set) + one step
+            # (warm: a context that has laid out a set of this size before and keeps its
+            #  allocations; cold: the first call of a context, allocations included -- the
+            #  definition BENCH_r01 / r02 used for "value_incl_layout")
             "value_incl_layout": total_queries / (t_layout + elapsed / args.steps),
-            "parity_vs_n1": parity_vs_n1,
+            "value_incl_layout_cold": total_queries / (t_layout_first + elapsed / args.steps),
+            # the whole result of the timed steps against the matrix the reference binary
+            # printed for this very workload (tests/golden/full_size.json), at every N
+            "parity_vs_reference_full_size": parity_full,
             "roofline": roofline(wl, st, p_avg_ms, k_avg_ms,
                                  {0: "probe_kernel", 1: "probe_sliced_kernel", 2: "probe_rows_kernel"}[layout["variant"]]),
             "cpu_baseline": baseline,

@@ -194,12 +194,10 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipMemset(c->d_usage, 0, 2 * sizeof(unsigned long long)));
   CREATE_TRY(hipHostMalloc((void **)&c->h_usage, 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->h_usage[0] = c->h_usage[1] = 0;
-  CREATE_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
   CREATE_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     CREATE_TRY(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
 
-  CREATE_TRY(hipEventCreate(&c->ev_cap));
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
   if (const char *e = getenv("COMPAIRR_HIP_VARIANT")) {
@@ -253,8 +251,6 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  if (c->ev_cap) (void)hipEventDestroy(c->ev_cap);
-  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -267,15 +263,28 @@ extern "C" const char *cmpr_last_error(const cmpr_context *c)
 extern "C" uint32_t cmpr_rows(const cmpr_context *c) { return c ? c->R1 : 0; }
 extern "C" uint32_t cmpr_cols(const cmpr_context *c) { return c ? c->R2 : 0; }
 
+static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t value, bool &affects_plan);
+
 extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value)
 {
   if (!c || !name)
     return CMPR_EINVAL;
   std::string n(name);
-  /* whatever changes: the cached step (kernels, grid, graphs) is worked out again, and
-     the no-redo shortcut of variant 2 has to be earned again */
-  invalidate_plan(c);
-  c->usage_pending = c->never_overflows = false;
+  /* A tunable that was set: the cached step (kernels, grid) is worked out again and the
+     no-redo shortcut of variant 2 has to be earned again -- only behind a successful change
+     (a refused name or value leaves the context as it was), and not for the knobs no
+     launch depends on. */
+  bool plan = true;
+  const int rc = set_tunable_value(c, n, value, plan);
+  if (rc == CMPR_OK && plan) {
+    invalidate_plan(c);
+    c->usage_pending = c->never_overflows = false;
+  }
+  return rc;
+}
+
+static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t value, bool &affects_plan)
+{
   if (n == "blocks_per_cu") {
     if (value < 1 || value > 16)
       return fail(c, CMPR_EINVAL, "blocks_per_cu must be 1..16");
@@ -326,6 +335,7 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (value < 1 || value > 256)
       return fail(c, CMPR_EINVAL, "host_threads must be 1..256");
     c->host_threads = value;
+    affects_plan = false;
   } else if (n == "table_log2_delta") {
     if (value < 0 || value > 3)
       return fail(c, CMPR_EINVAL, "table_log2_delta must be 0..3");
@@ -336,18 +346,16 @@ extern "C" int cmpr_set_tunable(cmpr_context *c, const char *name, int64_t value
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
     c->deferred_resolve = value;
-  } else if (n == "step_graph") {
-    if (value < 0 || value > 1)
-      return fail(c, CMPR_EINVAL, "step_graph must be 0 or 1");
-    c->step_graph = value;
   } else if (n == "narrow_upload") {
     if (value < -1 || value > 1)
       return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
     c->narrow_upload = value;
+    affects_plan = false;
   } else if (n == "assume_never_overflows") {
     /* TEST ONLY: the next launch runs without redo pass as if the margin had been
        shown (tests/test_gpu_parity.py forces an overflow behind it) */
     c->force_no_redo = value != 0;
+    affects_plan = false;
   } else if (n == "resolve_blocks_per_cu") {
     if (value < 1 || value > 8)
       return fail(c, CMPR_EINVAL, "resolve_blocks_per_cu must be 1..8");
@@ -425,12 +433,10 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "passes") *value = c->npasses;
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->plan.valid ? (int64_t)c->plan.nw : c->waves_per_block;
-  else if (n == "step_graph") *value = c->step_graph;
   else if (n == "narrow_upload") *value = c->narrow_upload;
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
   else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);
-  else if (n == "graphs") { *value = 0; for (const StepGraph &g : c->graphs) *value += g.exec ? 1 : 0; }
   else if (n == "never_overflows") *value = c->never_overflows ? 1 : 0;
   else if (n == "debug") *value = c->debug;
   else if (n == "heavy_threshold") *value = c->heavy_threshold;
@@ -593,8 +599,29 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
   if (rc)
     return fail(c, rc, why);
   HIP_TRY(c, hipSetDevice(c->device));
+  /* launches on the old set that may still be running on a caller's stream read what the
+     layout is about to overwrite */
+  if (c->events_valid)
+    HIP_TRY(c, hipEventSynchronize(c->ev_k1));
   c->have_q = false;
   c->usage_pending = c->never_overflows = false;
+  /* asynchronous launches on the OLD set that nobody has asked about (cmpr_get_stats): the
+     question is answered here, loudly, rather than carried over to the new set -- a sticky
+     overflow word must not fail the first cmpr_get_stats on the new one, nor be lost */
+  if (c->async_unchecked || c->async_overflowed) {
+    unsigned long long sticky = 0;
+    HIP_TRY(c, hipMemcpy(&sticky, c->d_usage + 1, sizeof sticky, hipMemcpyDeviceToHost));
+    const bool bad = sticky != 0 || c->async_overflowed;
+    if (sticky)
+      HIP_TRY(c, hipMemset(c->d_usage + 1, 0, sizeof sticky));
+    c->async_unchecked = c->async_overflowed = false;
+    if (bad)
+      return fail(c, CMPR_ESTATE, "positives buffer overflowed in a launch without redo pass on the previous "
+                                  "query set: its result was invalid (cmpr_get_stats was not asked); repeat "
+                                  "the call to set the new queries");
+  }
+  c->last_without_redo = false;
+  c->events_valid = false;
   invalidate_plan(c);
 
   /* upload, validation, grouping by slice, tiles, chunks: all on the device
@@ -661,17 +688,10 @@ void use_counter_block(cmpr_context *c, int which)
   c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
 }
 
-/* the cached plan and its graphs are stale (sets or tunables changed) */
+/* the cached plan is stale (sets or tunables changed) */
 void invalidate_plan(cmpr_context *c)
 {
   c->plan.valid = false;
-  for (StepGraph &g : c->graphs) {
-    if (g.exec)
-      (void)hipGraphExecDestroy(g.exec);
-    if (g.graph)
-      (void)hipGraphDestroy(g.graph);
-    g = StepGraph();
-  }
 }
 
 /* What a step launches, worked out once per (sets, tunables): kernels, grid, LDS and
@@ -841,9 +861,8 @@ struct StepArgs {
   bool with_redo;            /* variant 2: enqueue the redo pass */
 };
 
-/* The memsets, launches and the mid-step event of one step on `st` (directly, or while
-   `st` is being captured into a graph).  The counter block in use was chosen by the
-   caller (use_counter_block). */
+/* The memsets, launches and the mid-step event of one step on `st`.  The counter block in
+   use was chosen by the caller (use_counter_block). */
 int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev_km)
 {
   const StepPlan &S = c->plan;
@@ -882,7 +901,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
   hipLaunchKernelGGL(S.fn, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P);
   HIP_TRY(c, hipGetLastError());
   c->launches = 1;
-  if (ev_km)                                  /* (a capture gets its event node afterwards: graph_for) */
+  if (ev_km)
     HIP_TRY(c, hipEventRecord(ev_km, st));
   if (a.track_usage)
     HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
@@ -927,113 +946,6 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     c->launches = 3;
   }
   return CMPR_OK;
-}
-
-/* the instantiated graph of the steady-state step for (d_out, counter block), captured
-   on first use; nullptr when graphs are off or the capture failed (plain launches then) */
-StepGraph *graph_for(cmpr_context *c, const StepArgs &a, int which)
-{
-  if (!c->step_graph || !c->cap_stream)
-    return nullptr;
-  StepGraph *slot = nullptr;
-  for (StepGraph &g : c->graphs) {
-    if (g.exec && g.d_out == (void *)a.d_out && g.which == which) {
-      g.last_use = c->calls;
-      return &g;
-    }
-    if (!slot || (slot->exec && (!g.exec || g.last_use < slot->last_use)))
-      slot = &g;
-  }
-  if (slot->exec) {                            /* the least recently used one makes room */
-    (void)hipGraphExecDestroy(slot->exec);
-    (void)hipGraphDestroy(slot->graph);
-    *slot = StepGraph();
-  }
-  hipGraph_t graph = nullptr;
-  const char *why = nullptr;
-  hipError_t he = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
-  if (he != hipSuccess)
-    why = "hipStreamBeginCapture";
-  hipGraphExec_t exec = nullptr;
-  hipGraphNode_t km = nullptr;
-  if (!why) {
-    const uint32_t launches = c->launches;
-    const int rc = issue_step(c, a, c->cap_stream, nullptr);
-    he = hipStreamEndCapture(c->cap_stream, &graph);
-    c->launches = launches;
-    if (rc != CMPR_OK)
-      why = "a call of the step refused to be captured";
-    else if (he != hipSuccess || !graph)
-      why = "hipStreamEndCapture";
-  }
-  if (!why) {
-    /* the mid-step event (end of the probe kernel) as a node of its own, between the
-       probe kernel's node and whatever the capture put behind it */
-    size_t n = 0;
-    he = hipGraphGetNodes(graph, nullptr, &n);
-    std::vector<hipGraphNode_t> nodes(n ? n : 1);
-    if (he == hipSuccess && n)
-      he = hipGraphGetNodes(graph, nodes.data(), &n);
-    if (he != hipSuccess || !n)
-      why = "hipGraphGetNodes";
-    hipGraphNode_t probe = nullptr;
-    for (size_t k = 0; !why && k < n; k++) {
-      hipGraphNodeType t;
-      hipKernelNodeParams kp;
-      if (hipGraphNodeGetType(nodes[k], &t) == hipSuccess && t == hipGraphNodeTypeKernel &&
-          hipGraphKernelNodeGetParams(nodes[k], &kp) == hipSuccess && kp.func == (void *)c->plan.fn)
-        probe = nodes[k];
-    }
-    if (!why && !probe)
-      why = "probe kernel node not found in the captured graph";
-    std::vector<hipGraphNode_t> next;
-    if (!why) {
-      size_t ne = 0;
-      he = hipGraphGetEdges(graph, nullptr, nullptr, &ne);
-      std::vector<hipGraphNode_t> from(ne ? ne : 1), to(ne ? ne : 1);
-      if (he == hipSuccess && ne)
-        he = hipGraphGetEdges(graph, from.data(), to.data(), &ne);
-      if (he != hipSuccess)
-        why = "hipGraphGetEdges";
-      for (size_t k = 0; !why && k < ne; k++)
-        if (from[k] == probe)
-          next.push_back(to[k]);
-    }
-    if (!why) {
-      he = hipGraphAddEventRecordNode(&km, graph, &probe, 1, c->ev_cap);
-      if (he != hipSuccess)
-        why = "hipGraphAddEventRecordNode";
-    }
-    for (size_t k = 0; !why && k < next.size(); k++) {
-      he = hipGraphRemoveDependencies(graph, &probe, &next[k], 1);
-      if (he == hipSuccess)
-        he = hipGraphAddDependencies(graph, &km, &next[k], 1);
-      if (he != hipSuccess)
-        why = "re-wiring the graph around the event node";
-    }
-  }
-  if (!why) {
-    he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (he != hipSuccess)
-      why = "hipGraphInstantiate";
-  }
-  if (why) {
-    if (getenv("COMPAIRR_HIP_DEBUG"))
-      fprintf(stderr, "compairr_hip: step graph unavailable (%s: %s): plain launches\n", why,
-              he != hipSuccess ? hipGetErrorString(he) : c->err.c_str());
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    c->step_graph = 0;                         /* not on this runtime: plain launches from now on */
-    return nullptr;
-  }
-  slot->d_out = (void *)a.d_out;
-  slot->which = which;
-  slot->graph = graph;
-  slot->exec = exec;
-  slot->km_node = km;
-  slot->last_use = c->calls;
-  return slot;
 }
 
 /* enqueue one step on `st`: `d_out` is the integer matrix to fill (ours or the caller's) */
@@ -1106,26 +1018,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 
   if (!back_to_back)
     HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-  StepGraph *g = nullptr;
-  if (S.will_launch && !a.needs_clear && !a.track_usage && !a.with_redo && !c->pair_count && !c->debug)
-    g = graph_for(c, a, which);
-  if (g) {
-    const hipError_t he = hipGraphExecEventRecordNodeSetEvent(g->exec, g->km_node, c->ev_km);
-    if (he != hipSuccess) {
-      if (getenv("COMPAIRR_HIP_DEBUG"))
-        fprintf(stderr, "compairr_hip: step graph unavailable (hipGraphExecEventRecordNodeSetEvent: %s): "
-                        "plain launches\n", hipGetErrorString(he));
-      (void)hipGetLastError();
-      c->step_graph = 0;
-      g = nullptr;
-    }
-  }
-  if (g) {
-    HIP_TRY(c, hipGraphLaunch(g->exec, st));
-    c->launches = S.deferred ? 2 : 1;
-  } else if ((rc = issue_step(c, a, st, c->ev_km))) {
+  if ((rc = issue_step(c, a, st, c->ev_km)))
     return rc;
-  }
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
   c->ctr_clean = true;
   return CMPR_OK;
@@ -1179,7 +1073,26 @@ extern "C" int cmpr_overlap_matrix_device(cmpr_context *c, void *d_matrix, void 
     return fail(c, CMPR_EINVAL, "d_matrix is NULL");
   if (is_f64_score(c->opt))
     return fail(c, CMPR_EINVAL, "ratio score needs cmpr_overlap_matrix_f64");
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (!stream) {
+    /* synchronous use: checked like the other synchronous entry points -- a launch that
+       relied on the no-redo shortcut and overflowed is repeated with the redo pass */
+    for (int attempt = 0;; attempt++) {
+      rc = enqueue_overlap(c, (unsigned long long *)d_matrix, c->stream);
+      if (rc)
+        return rc;
+      if ((rc = fetch_overflow_word(c, c->stream)))
+        return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+      c->stop_is_k1 = false;
+      c->events_valid = true;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (!overflowed_without_redo(c, c->stream))
+        return CMPR_OK;
+      if (attempt)
+        return fail(c, CMPR_ESTATE, "positives buffer overflowed twice without redo pass");
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
   rc = enqueue_overlap(c, (unsigned long long *)d_matrix, st);
   if (rc)
     return rc;
@@ -1187,8 +1100,6 @@ extern "C" int cmpr_overlap_matrix_device(cmpr_context *c, void *d_matrix, void 
   c->events_valid = true;
   if (c->last_without_redo)
     c->async_unchecked = true;              /* until cmpr_get_stats has looked */
-  if (!stream)
-    HIP_TRY(c, hipStreamSynchronize(st));
   return CMPR_OK;
 }
 

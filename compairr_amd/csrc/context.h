@@ -76,18 +76,6 @@ struct StepPlan {
   size_t   lds = 0, rlds = 0;
 };
 
-/* One instantiated hipGraph of the steady-state step (probe, resolve, reduce and the
-   event between them) per (output matrix, counter block): one hipGraphLaunch per step
-   instead of three kernel launches and an event record. */
-struct StepGraph {
-  void           *d_out = nullptr;
-  int             which = -1;
-  hipGraph_t      graph = nullptr;
-  hipGraphExec_t  exec = nullptr;
-  hipGraphNode_t  km_node = nullptr;   /* its event-record node (re-pointed at the ring's event per launch) */
-  uint64_t        last_use = 0;
-};
-
 struct cmpr_context {
   cmpr_options opt{};
   int          device = 0;
@@ -226,14 +214,6 @@ struct cmpr_context {
      end (the device work the upload did not hide), and in all */
   double                     layout_upload_ms = 0, layout_tail_ms = 0, layout_total_ms = 0;
   StepPlan                   plan;
-  static const uint32_t      NGRAPHS = 8;
-  StepGraph                  graphs[NGRAPHS];
-  /* tunable; OFF by default: on ROCm 7.2 a replayed 3-kernel graph with its event node
-     starts ~10 us later than the same launches issued one by one (r03d: 0.133 vs 0.124 ms
-     per step at 1/8 of the work) -- the gaps of a step are the event packets, not the host */
-  int64_t                    step_graph = 0;
-  hipStream_t                cap_stream = nullptr;        /* the stream the graphs are captured on */
-  hipEvent_t                 ev_cap = nullptr;            /* placeholder event of a captured graph */
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */

@@ -61,6 +61,9 @@ using namespace cmpr;
 namespace {
 
 constexpr uint32_t MAXP = 1 + MAX_CLASS_RES;     /* passes with a layout of their own */
+/* work shards: queries laid out only because an item of theirs is worked on here live in
+   tiles of 2^FOREIGN_SLICES_LOG2 pseudo-slices behind the real ones (no chunk lists them) */
+constexpr uint32_t FOREIGN_SLICES_LOG2 = 12;
 
 enum : uint32_t { VERR_OFFSETS = 1, VERR_LONG = 2, VERR_REP = 3, VERR_GENE = 4, VERR_COUNT = 5,
                   VERR_RESIDUE = 6, VERR_TOO_LONG = 7 };
@@ -109,7 +112,7 @@ struct QL {
   uint32_t        min_mixed;         /* lengths >= this share tiles; ~0: none do */
   uint32_t        chunk_tiles, small_max, class_unstaged;
   uint64_t        nbuckets;          /* (slice, heavy) buckets */
-  uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slice */
+  uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slices */
   uint64_t        nslices_real;
   uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
   uint32_t        sub2_owner_pass0, pad_q;
@@ -548,8 +551,9 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       uint64_t bucket = ~0ull;
       if (owned(Q, slice, 0u))
         bucket = Q.sliced ? 2 * (uint64_t)slice + (heavy ? 1 : 0) : 0;
-      else if (any_item)
-        bucket = 2 * Q.nslices_real;
+      else if (any_item)        /* (spread by query number: one counter per length would serialise
+                                   millions of atomics -- 27 ms per 10M queries at two shards, round 3) */
+        bucket = 2 * (Q.nslices_real + (((uint32_t)i * 2654435761u) >> (32 - FOREIGN_SLICES_LOG2)));
       if (bucket != ~0ull) {
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
@@ -706,7 +710,7 @@ slices_kernel(const QL Q, uint32_t pi)
      tiles is not worth a workgroup + a staged copy: its tiles go to the list
      that single waves work through, probing the slice in HBM / L2. */
   uint32_t nchunks = 0, nsmall = 0, nlist = 0;
-  if (Q.sliced && ntiles && sl < Q.nslices_real) {       /* (the foreign pseudo-slice: tiles, no work) */
+  if (Q.sliced && ntiles && sl < Q.nslices_real) {       /* (the foreign pseudo-slices: tiles, no work) */
     /* (variant 2 with -i: the deletion and insertion rows of a tile follow its
        substitution rows in the same unit, on the same staged slice -- its class keys
        have no length term -- so there is one chunk per slice, not one per pass) */
@@ -1290,6 +1294,20 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
 {
   int rc;
   const auto t_begin = std::chrono::steady_clock::now();
+  /* whatever way this function is left early: no copy from the caller's arrays (which may be
+     freed on return) or from the pinned staging area (which the next call may reallocate) is
+     still in flight, and no kernel still reads the arenas */
+  struct Quiesce {
+    cmpr_context *c;
+    bool ok = false;
+    ~Quiesce()
+    {
+      if (!ok) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+      }
+    }
+  } quiesce{c};
   const uint64_t n = s->n;
   const uint64_t total = n ? s->offsets[n] : 0;
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
@@ -1311,7 +1329,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   const bool place_mine = wstep > 1 && !indel_passes;
 
   const uint64_t nslices_real = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
-  const uint64_t nslices = nslices_real + (place_mine ? 1 : 0);     /* + the foreign pseudo-slice */
+  const uint64_t nslices = nslices_real + (place_mine ? (1ull << FOREIGN_SLICES_LOG2) : 0);   /* + the foreign pseudo-slices */
   const uint64_t nbuckets = c->sliced ? 2 * nslices : 1;
   const uint64_t per_slice = (uint64_t)Lcap + 1;
   if (nbuckets * per_slice >= 0x7fffffffull)
@@ -1997,5 +2015,6 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
             c->layout_total_ms, ms(t_begin, t_arena_a), ms(t_arena_a, t_uploaded), ms(t_uploaded, t_sizes),
             ms(t_sizes, t_reserved), ms(t_reserved, t_end), upload_ms, cut.used >> 20, cb.used >> 20);
   }
+  quiesce.ok = true;
   return CMPR_OK;
 }

@@ -91,8 +91,6 @@ def random_case(rng):
         tun["host_threads"] = int(rng.integers(1, 9))
     if rng.random() < 0.3:
         tun["narrow_upload"] = 1                          # (by default only for sets of a million and more)
-    if rng.random() < 0.15:
-        tun["step_graph"] = 1
     same = rng.random() < 0.2
     return a, (a if same else b), o, tun
 

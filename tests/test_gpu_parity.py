@@ -7,6 +7,7 @@ properties."""
 import numpy as np
 import pytest
 
+import _full_size
 import _oracle
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
@@ -610,10 +611,10 @@ def test_shortcut_is_withdrawn_when_the_deal_changes():
 
 
 @pytest.mark.parametrize("variant", [1, 2])
-def test_step_graph_and_streams(variant):
-    """The steady-state step is one hipGraph per (output matrix, counter block); launches
-    on different streams are ordered by the library.  Same matrix as the plain launches,
-    and the probe kernel's event time still comes with every step."""
+def test_launches_on_two_streams(variant):
+    """Asynchronous launches of one context on different streams are ordered by the library
+    (two output matrices, two streams); same matrix as the synchronous call, and the probe
+    kernel's event time still comes with every step."""
     import torch
     a = synth.make_set(50000, 1, prefix="A")
     b = synth.make_set(50000, 2, prefix="B")
@@ -623,8 +624,6 @@ def test_step_graph_and_streams(variant):
         h.set_reference(b, a.longest)
         h.set_queries(a)
         want = h.overlap_matrix()
-        assert h.get_tunable("graphs") == 0
-        h.set_tunable("step_graph", 1)
         mats = [torch.zeros(want.size, dtype=torch.int64, device="cuda") for _ in range(2)]
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         for k in range(12):
@@ -633,7 +632,6 @@ def test_step_graph_and_streams(variant):
         for m in mats:
             assert np.array_equal(m.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
         assert h.stats().matches > 0
-        assert 1 <= h.get_tunable("graphs") <= 4
         k, p = h.kernel_times(6)
         assert len(k) == 6 and all(0 < y < x for x, y in zip(k, p)), (k, p)
         assert np.array_equal(h.overlap_matrix(), want)
@@ -675,7 +673,35 @@ def test_repeatable_and_device_output():
         assert np.array_equal(t.cpu().numpy().astype(np.uint64).reshape(m1.shape), m1)
 
 
-# ---- full-size properties (BASELINE configs; no oracle at this size) ----
+# ---- full sizes (BASELINE configs): the reference's own matrices, recorded in
+#      tests/golden/full_size.json by tests/golden/make_full_size.py, and size-independent
+#      properties ----
+
+FULL_SIZE = _full_size.load()
+
+
+def dup_warnings(w):
+    """{set number: duplicates} of the reference's log"""
+    return {int(l.split()[-1]): int(l.split()[1]) for l in w["warnings"]}
+
+
+@pytest.mark.parametrize("name", ["cfg2", "self10m", "cfg5_sub"])
+def test_full_size_matches_reference(name):
+    """cfg2 (1M x 1M aa, d = 0), the 10M self-comparison (d = 1: the reference's published
+    benchmark is self-vs-self) and a sub-shape of cfg5 (200k x 10M nucleotides, d = 2, -g):
+    the matrix the reference binary printed, digit for digit, and its duplicate warnings."""
+    w = FULL_SIZE[name]
+    a, b = _full_size.sets_of(w)
+    with HipOverlap(Options(**_full_size.options_of(w))) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        got = h.overlap_matrix()
+        assert h.stats().matches > 0
+        assert _full_size.mismatch(w, got) is None, _full_size.mismatch(w, got)
+        assert h.count_duplicates() == dup_warnings(w)[2]
+        if not w["one_file_mode"]:
+            assert h.count_duplicates(a) == dup_warnings(w)[1]
+
 
 def test_full_size_properties_1m():
     """config 2/3 shape at 1M: symmetry (swap the sets -> transposed matrix),
@@ -704,13 +730,17 @@ def test_full_size_properties_1m():
 @pytest.mark.parametrize("indels", [False, True])
 def test_full_size_properties_10m(indels):
     """BASELINE configs 3 / 4 at their full size (10M x 10M CDR3aa, d = 1, with and
-    without indels): symmetry under swapping the sets, query-shard linearity, the
-    closed-form variant count, and with -f the matrix total = number of pairs."""
+    without indels): the matrix the reference binary printed for these very inputs; then
+    symmetry under swapping the sets, query-shard linearity, the closed-form variant count,
+    and with -f the matrix total = number of pairs."""
     n = 10_000_000
     a = synth.make_set(n, 1, prefix="A", pool_size=n // 4)
     b = synth.make_set(n, 2, prefix="B", pool_size=n // 4)
     o = Options(differences=1, indels=indels, **FULL)
     mab, st = gpu_cells(a, b, o)
+    w = FULL_SIZE["cfg4" if indels else "cfg3"]
+    assert (w["set1"]["n"], w["set1"]["seed"], w["set2"]["seed"]) == (n, 1, 2)
+    assert _full_size.mismatch(w, mab) is None, _full_size.mismatch(w, mab)     # the reference's matrix
     mba, st2 = gpu_cells(b, a, o)
     assert np.array_equal(mab, mba.T)
     assert st.matches == st2.matches > 0
