@@ -10,12 +10,16 @@ configs[2]: synthetic 10M-vs-10M CDR3aa, d = 1, substitutions only.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
 (hash table + filter) is replicated on every GPU and the step is sharded:
   --scaling strong (default)  the SAME seeded 10M queries, total work fixed
-                              (BASELINE configs[3]).  --shard-by work (default):
-                              every rank holds all queries and takes every N-th
-                              work item of the step (a filter slice with the tiles
-                              of queries that probe it; library tunables
-                              work_shard_index / _count) -- the per-step cost of
-                              streaming the filter through LDS divides by N too.
+                              (BASELINE configs[3]).  --shard-by work (default): a
+                              rank takes the work filed under its share of the filter
+                              slices (library tunables work_shard_index / _count) --
+                              the per-step cost of streaming the filter through LDS
+                              divides by N too -- and the queries go where their work
+                              is: every rank uploads and keys a contiguous N-th of
+                              them, one all-to-all over xGMI moves the records, every
+                              rank lays out what it received
+                              (compairr_amd.dist.exchange_queries; --layout
+                              replicated: every rank uploads and keys all of them).
                               --shard-by queries: N contiguous query shards, the
                               way overlap.cc:421-433 hands out query chunks; every
                               rank then streams the whole filter for 1/N of the
@@ -71,6 +75,10 @@ def parse_args():
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     p.add_argument("--shard-by", choices=["work", "queries"], default="work",
                    help="strong scaling at N > 1: what the ranks divide (see the module docstring)")
+    p.add_argument("--layout", choices=["routed", "replicated"], default="routed",
+                   help="--shard-by work under torch.distributed.run: every rank uploads and keys its N-th of "
+                        "the queries and the records move to the ranks that work on them (default), or every "
+                        "rank uploads and keys all queries (round 3)")
     p.add_argument("--differences", "-d", type=int, default=1)
     p.add_argument("--indels", action="store_true")
     p.add_argument("--nucleotides", action="store_true")
@@ -242,7 +250,7 @@ def main():
     import torch
     import torch.distributed as dist
     from compairr_amd import HipOverlap, Options, synth
-    from compairr_amd.dist import shard_bounds
+    from compairr_amd.dist import exchange_queries, shard_bounds
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -271,7 +279,8 @@ def main():
     else:
         full = synth.make_set(args.queries, 1 + (0 if strong else 1000 * rank), prefix="A",
                               nucleotides=args.nucleotides, pool_size=args.refs // 4)
-    by_work = strong and world > 1 and args.shard_by == "work"
+    by_work = strong and use_dist and args.shard_by == "work"
+    routed = by_work and args.layout == "routed"
     if strong and world > 1 and not by_work:
         lo, hi = shard_bounds(full.n, rank, world)
         qry = full.subset(slice(lo, hi))      # keeps the full set's repertoire numbering
@@ -290,19 +299,46 @@ def main():
     t0 = time.time()
     h.set_reference(ref, full.longest)
     t_index = time.time() - t0
-    # the first call of a context also allocates (device arenas, resident layout, positives
-    # buffer); a further call on the same context -- the steady state of a service that
-    # works through query sets -- reuses all of it.  Both are reported.
-    t0 = time.time()
-    h.set_queries(qry)
-    t_layout_first = time.time() - t0
-    t0 = time.time()
-    h.set_queries(qry)
-    t_layout = time.time() - t0
-    layout_ms = {"total": h.get_tunable("layout_total_us") / 1e3,
+
+    if routed:
+        # this rank's share of the caller's set: a contiguous N-th (any split would do)
+        lo, hi = shard_bounds(full.n, rank, world)
+        share = full.subset(slice(lo, hi))
+
+        def lay_out():
+            return exchange_queries(h, share, lo, full.n, rank, world, device="cuda")
+    else:
+        def lay_out():
+            h.set_queries(qry)
+            return None
+
+    # The first call of a context also allocates (device arenas, resident layout, positives
+    # buffer); a further call on the same context -- the steady state of a service that works
+    # through query sets -- reuses all of it.  Both are reported; at N > 1 the time of a
+    # layout is that of the slowest rank (barrier in front, maximum behind).
+    def timed_layout():
+        if use_dist:
+            dist.barrier()
+        t = time.perf_counter()
+        m = lay_out()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if use_dist:
+            x = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            dt = float(x.item())
+        return dt, m
+    t_layout_first, _ = timed_layout()
+    t_layout, moved = timed_layout()
+    layout_ms = {"total": t_layout * 1e3,
+                 "library_call_total": h.get_tunable("layout_total_us") / 1e3,
                  "host_time_in_copy_calls": h.get_tunable("layout_upload_us") / 1e3,
                  "after_last_copy": h.get_tunable("layout_tail_us") / 1e3,
-                 "first_call_incl_allocations": t_layout_first * 1e3}
+                 "first_call_incl_allocations": t_layout_first * 1e3,
+                 "how": ("routed: upload + keys of this rank's N-th, all-to-all of the records, layout of "
+                         "what was received; slowest rank" if routed else
+                         "cmpr_set_queries on this rank's queries; slowest rank"),
+                 "exchange": moved}
     R1, R2 = h.shape
     layout = h.layout()
     # every rank uses the same R1 x R2 (16 x 16 for the synthetic law).  Two matrices:
@@ -367,6 +403,32 @@ def main():
     result_matrix = matrix.cpu().numpy().astype(np.uint64).reshape(R1, R2)
     checksum = synth.checksum(result_matrix)
 
+    # Two more rates of the same workload (one GPU): the query set handed over as DEVICE arrays
+    # (cmpr_set_queries_device: layout kernels + step, nothing on PCIe) -- what compares with
+    # the reference's in-memory 'Analysing:' phase -- and the step as a synchronous call that
+    # ends with the matrix in host memory.
+    device_soa = None
+    if world == 1 and not use_dist:
+        view, keep = h.device_view(qry)
+        h.set_queries_device(view)                         # (warm: allocations kept)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        h.set_queries_device(view)
+        torch.cuda.synchronize()
+        t_dev = time.perf_counter() - t
+        first = h.overlap_matrix()
+        t = time.perf_counter()
+        for _ in range(10):
+            got = h.overlap_matrix()
+        t_sync = (time.perf_counter() - t) / 10
+        device_soa = {"set_queries_device_ms": t_dev * 1e3,
+                      "value_from_device_soa": total_queries / (t_dev + elapsed / args.steps),
+                      "step_ms_incl_d2h": t_sync * 1e3,
+                      "value_incl_d2h": total_queries / t_sync,
+                      "same_matrix": bool(np.array_equal(first, result_matrix) and
+                                          np.array_equal(got, result_matrix))}
+        del keep
+
     if rank == 0:
         wl = workload_name(args)
         baseline = None
@@ -412,14 +474,17 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": wl,
-                       "queries_total": total_queries, "queries_this_gpu": qry.n,
+                       "queries_total": total_queries, "queries_this_gpu": int(st.queries),
                        "reference_sequences": args.refs,
                        "repertoires": [int(R1), int(R2)],
                        "sharding": ("%s scaling: %s over %d GPUs, reference index "
                                     "replicated, one RCCL all-reduce of the matrix per step"
                                     % (args.scaling,
                                        "the step's work items (filter slice + the tiles that probe it) "
-                                       "dealt round-robin, all queries resident on every GPU" if by_work
+                                       "dealt by slice, the queries routed to the GPUs that work on them"
+                                       if routed else
+                                       "the step's work items dealt by slice, all queries uploaded to every GPU"
+                                       if by_work
                                        else "queries sharded", world)) if world > 1 else "single GPU",
                        "matrix_checksum": checksum,
                        "layout": layout,
@@ -437,6 +502,11 @@ def main():
             #  definition BENCH_r01 / r02 used for "value_incl_layout")
             "value_incl_layout": total_queries / (t_layout + elapsed / args.steps),
             "value_incl_layout_cold": total_queries / (t_layout_first + elapsed / args.steps),
+            # from DEVICE arrays to the matrix (no PCIe), and the synchronous step that ends
+            # with the matrix on the host
+            "value_from_device_soa": device_soa and device_soa["value_from_device_soa"],
+            "step_ms_incl_d2h": device_soa and device_soa["step_ms_incl_d2h"],
+            "device_resident_inputs": device_soa,
             # the whole result of the timed steps against the matrix the reference binary
             # printed for this very workload (tests/golden/full_size.json), at every N
             "parity_vs_reference_full_size": parity_full,

@@ -37,7 +37,7 @@ void invalidate_plan(cmpr_context *c);
 int make_plan(cmpr_context *c);
 }
 
-int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why)
+int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why, bool on_device)
 {
   if (!s) { why = "set view is NULL"; return CMPR_EINVAL; }
   if (s->n_repertoires == 0 && s->n > 0) { why = "n_repertoires is 0"; return CMPR_EINVAL; }
@@ -45,9 +45,13 @@ int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &wh
   if (s->n == 0)
     return CMPR_OK;
   if (!s->offsets || !s->repertoire) { why = "offsets/repertoire is NULL"; return CMPR_EINVAL; }
-  if (!s->residues && s->offsets[s->n] > 0) { why = "residues is NULL"; return CMPR_EINVAL; }
   if (!o.ignore_genes && (!s->v_gene || !s->j_gene)) { why = "v_gene/j_gene is NULL without ignore_genes"; return CMPR_EINVAL; }
   if (!o.ignore_counts && !s->count) { why = "count is NULL without ignore_counts"; return CMPR_EINVAL; }
+  if (on_device) {               /* (offsets[0] and offsets[n] are fetched and checked by the caller) */
+    if (!s->residues) { why = "residues is NULL"; return CMPR_EINVAL; }
+    return CMPR_OK;
+  }
+  if (!s->residues && s->offsets[s->n] > 0) { why = "residues is NULL"; return CMPR_EINVAL; }
   if (s->offsets[0] != 0) { why = "offsets[0] must be 0"; return CMPR_EINVAL; }
   return CMPR_OK;
 }
@@ -588,23 +592,15 @@ static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, u
 /* set 1: sort by length, cut into 64-query tiles, upload               */
 /* ------------------------------------------------------------------ */
 
-static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
+/* what every way of handing over queries does first (cmpr_set_queries, _device, _routed,
+   cmpr_route_queries): the old set, and what was left unasked about it, goes */
+static int retire_queries(cmpr_context *c)
 {
-  if (!c)
-    return CMPR_EINVAL;
-  if (!c->have_ref)
-    return fail(c, CMPR_ESTATE, "cmpr_set_reference must be called first");
-  std::string why;
-  int rc = validate_view(c->opt, s, why);
-  if (rc)
-    return fail(c, rc, why);
   HIP_TRY(c, hipSetDevice(c->device));
   /* launches on the old set that may still be running on a caller's stream read what the
      layout is about to overwrite */
   if (c->events_valid)
     HIP_TRY(c, hipEventSynchronize(c->ev_k1));
-  c->have_q = false;
-  c->usage_pending = c->never_overflows = false;
   /* asynchronous launches on the OLD set that nobody has asked about (cmpr_get_stats): the
      question is answered here, loudly, rather than carried over to the new set -- a sticky
      overflow word must not fail the first cmpr_get_stats on the new one, nor be lost */
@@ -620,13 +616,40 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
                                   "query set: its result was invalid (cmpr_get_stats was not asked); repeat "
                                   "the call to set the new queries");
   }
+  c->have_q = false;
+  c->usage_pending = c->never_overflows = false;
   c->last_without_redo = false;
   c->events_valid = false;
   invalidate_plan(c);
+  return CMPR_OK;
+}
+
+static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  if (!c->have_ref)
+    return fail(c, CMPR_ESTATE, "cmpr_set_reference must be called first");
+  int rc;
+  if (src.kind != LayoutSource::RECORDS) {
+    std::string why;
+    rc = validate_view(c->opt, src.view, why, src.kind == LayoutSource::DEVICE);
+    if (rc)
+      return fail(c, rc, why);
+  } else {
+    if (src.nrec && !src.d_records)
+      return fail(c, CMPR_EINVAL, "d_records is NULL");
+    if (src.nrec && src.n_rep == 0)
+      return fail(c, CMPR_EINVAL, "n_repertoires is 0");
+    if (src.nrec >= 0xffffffc0ull || src.n_total > 0xffffffffull)
+      return fail(c, CMPR_EUNSUPPORTED, "more than 2^32-64 sequences in one set");
+  }
+  if ((rc = retire_queries(c)))
+    return rc;
 
   /* upload, validation, grouping by slice, tiles, chunks: all on the device
      (query_layout.hip) */
-  if ((rc = cmpr_layout_queries(c, s)))
+  if ((rc = cmpr_layout_queries(c, src)))
     return rc;
 
   /* (kept from call to call when large enough: no hipMalloc / hipFree in the steady state) */
@@ -642,8 +665,10 @@ static int cmpr_set_queries_impl(cmpr_context *c, const cmpr_set_view *s)
   {
     /* (a work shard queues its share of the positives) */
     const uint64_t per_query = c->rows && c->opt.differences == 2 ? 32 : 4;
+    /* (routed records: what is resident IS the share) */
     const uint64_t total = c->pos_capacity > 0 ? (uint64_t)c->pos_capacity
-                                               : (1u << 20) + per_query * c->n1 / (uint64_t)c->work_shard_count;
+                                               : (1u << 20) + per_query * c->n1 /
+                                                     (c->routed ? 1ull : (uint64_t)c->work_shard_count);
     const uint64_t S = (uint64_t)c->pos_segments;
     c->pos_cap = (total + S - 1) / S;                     /* per segment */
     if ((rc = dev_reserve(c, c->pos_buf, S * (c->pos_cap + WAVE)))) return rc;
@@ -1293,7 +1318,7 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   out->matches = st[STAT_MATCHES];
   out->filter_reads = st[STAT_READS];
   /* (a work shard does its share of every query's variants) */
-  out->algorithmic_bytes = c->algorithmic_bytes / (uint64_t)c->work_shard_count;
+  out->algorithmic_bytes = c->routed ? c->algorithmic_bytes : c->algorithmic_bytes / (uint64_t)c->work_shard_count;
   out->kernel_ms = k_ms;
   out->probe_ms = p_ms;
   out->total_ms = t_ms;
@@ -1301,17 +1326,26 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   return CMPR_OK;
 }
 
-extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s,
-                                  uint32_t longest_query)
+static int set_reference_guarded(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query, bool on_device)
 {
   /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
   try {
     if (c)
       invalidate_plan(c);
-    return cmpr_set_reference_device(c, s, longest_query);
+    return cmpr_build_reference(c, s, longest_query, on_device);
   } catch (const std::bad_alloc &) {
     return fail(c, CMPR_ENOMEM, "out of host memory");
   }
+}
+
+extern "C" int cmpr_set_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query)
+{
+  return set_reference_guarded(c, s, longest_query, false);
+}
+
+extern "C" int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *d_set2, uint32_t longest_query)
+{
+  return set_reference_guarded(c, d_set2, longest_query, true);
 }
 
 extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
@@ -1324,14 +1358,90 @@ extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, ui
   }
 }
 
-extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
+static int set_queries_guarded(cmpr_context *c, const LayoutSource &src)
 {
   /* the header promises CMPR_ENOMEM, not an exception across the C boundary */
   try {
-    return cmpr_set_queries_impl(c, s);
+    return cmpr_set_queries_impl(c, src);
   } catch (const std::bad_alloc &) {
     return fail(c, CMPR_ENOMEM, "out of host memory");
   }
+}
+
+extern "C" int cmpr_set_queries(cmpr_context *c, const cmpr_set_view *s)
+{
+  LayoutSource src;
+  src.kind = LayoutSource::HOST;
+  src.view = s;
+  return set_queries_guarded(c, src);
+}
+
+extern "C" int cmpr_set_queries_device(cmpr_context *c, const cmpr_set_view *d_set1)
+{
+  LayoutSource src;
+  src.kind = LayoutSource::DEVICE;
+  src.view = d_set1;
+  return set_queries_guarded(c, src);
+}
+
+extern "C" int cmpr_set_queries_routed(cmpr_context *c, const void *d_records, uint64_t n_records,
+                                       uint32_t n_repertoires, uint64_t n_total, const double *rep_totals)
+{
+  LayoutSource src;
+  src.kind = LayoutSource::RECORDS;
+  src.d_records = d_records;
+  src.nrec = n_records;
+  src.n_rep = n_repertoires;
+  src.n_total = n_total;
+  src.totals = rep_totals;
+  return set_queries_guarded(c, src);
+}
+
+extern "C" int cmpr_route_queries(cmpr_context *c, const cmpr_set_view *share, uint64_t first_index,
+                                  uint32_t n_dest, uint64_t *counts_out, uint32_t *record_bytes_out,
+                                  double *rep_totals_out)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  try {
+    if (!c->have_ref)
+      return fail(c, CMPR_ESTATE, "cmpr_set_reference must be called first");
+    if (!counts_out || !record_bytes_out)
+      return fail(c, CMPR_EINVAL, "cmpr_route_queries: NULL output");
+    if (n_dest == 0 || n_dest > 64 || (int64_t)n_dest != c->work_shard_count)
+      return fail(c, CMPR_EINVAL, "cmpr_route_queries: n_dest must be the work_shard_count tunable (1..64)");
+    std::string why;
+    int rc = validate_view(c->opt, share, why);
+    if (rc)
+      return fail(c, rc, why);
+    if (first_index + share->n > 0xffffffffull)
+      return fail(c, CMPR_EUNSUPPORTED, "more than 2^32 sequences in the whole query set");
+    if ((rc = retire_queries(c)))
+      return rc;
+    LayoutSource src;
+    src.kind = LayoutSource::HOST;
+    src.view = share;
+    src.route = true;
+    src.first_index = first_index;
+    if ((rc = cmpr_layout_queries(c, src)))
+      return rc;
+    for (uint32_t d = 0; d < n_dest; d++)
+      counts_out[d] = c->route.counts[d];
+    *record_bytes_out = c->route.record_bytes;
+    if (rep_totals_out)
+      for (uint32_t r = 0; r < share->n_repertoires; r++)
+        rep_totals_out[r] = c->route.rep_totals[r];
+    return CMPR_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(c, CMPR_ENOMEM, "out of host memory");
+  }
+}
+
+extern "C" int cmpr_route_pack(cmpr_context *c, void *d_send, uint64_t capacity_bytes)
+{
+  if (!c)
+    return CMPR_EINVAL;
+  return cmpr_route_pack_impl(c, d_send, capacity_bytes);
 }
 
 extern "C" int cmpr_overlap_matrix_f64(cmpr_context *c, double *out)

@@ -76,6 +76,35 @@ struct StepPlan {
   size_t   lds = 0, rlds = 0;
 };
 
+/* where cmpr_layout_queries takes the query set from */
+struct LayoutSource {
+  enum Kind { HOST, DEVICE, RECORDS } kind = HOST;
+  const cmpr_set_view *view = nullptr;   /* HOST: the caller's arrays; DEVICE: device pointers on the context's device */
+  /* RECORDS (cmpr_set_queries_routed): route_record_bytes() each, in device memory */
+  const void   *d_records = nullptr;
+  uint64_t      nrec = 0;
+  uint32_t      n_rep = 0;
+  uint64_t      n_total = 0;             /* sequences of the WHOLE query set (-x: the matrix has that many rows) */
+  const double *totals = nullptr;        /* count totals per repertoire of the whole set, or NULL */
+  /* cmpr_route_queries: key the share, count the records per destination, keep it for cmpr_route_pack */
+  bool          route = false;
+  uint64_t      first_index = 0;
+};
+
+/* the keyed share cmpr_route_queries leaves in arena A for cmpr_route_pack */
+struct RouteState {
+  bool     valid = false;
+  uint64_t n = 0, first_index = 0, total_records = 0;
+  uint32_t n_dest = 0, record_bytes = 0;
+  unsigned long long counts[64] = {};
+  std::vector<double> rep_totals;
+  const uint8_t  *res = nullptr;
+  const uint64_t *off = nullptr, *cnt = nullptr;
+  const uint32_t *v = nullptr, *j = nullptr, *rep = nullptr;
+  const uint32_t *mask_lo = nullptr, *mask_hi = nullptr;
+  unsigned long long *dest = nullptr;    /* [64] counts | [64] fill cursors */
+};
+
 struct cmpr_context {
   cmpr_options opt{};
   int          device = 0;
@@ -154,6 +183,8 @@ struct cmpr_context {
 
   /* set 1 tiles */
   bool              have_q = false;
+  bool              routed = false;  /* the resident queries are this context's share (cmpr_set_queries_routed) */
+  RouteState        route;
   uint64_t          n1 = 0;
   uint32_t          R1 = 0, ntiles = 0;
   DevBuf<TileDesc>  tiles;
@@ -299,12 +330,16 @@ inline bool is_f64_score(const cmpr_options &o)
   return o.score == CMPR_SCORE_RATIO && !o.ignore_counts;
 }
 
-/* pointer / size sanity of a set view (no pass over the data) */
-int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why);
+/* pointer / size sanity of a set view (no pass over the data); on_device: the arrays are
+   device memory, nothing of them is read here */
+int validate_view(const cmpr_options &o, const cmpr_set_view *s, std::string &why, bool on_device = false);
 
 /* query_layout.hip: upload set 1, validate it and lay it out for the kernels,
    all on the device (cmpr_set_queries) */
-int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s);
+int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src);
+
+/* query_layout.hip: the records of a keyed share into the caller's buffer (cmpr_route_pack) */
+int cmpr_route_pack_impl(cmpr_context *c, void *d_send, uint64_t capacity_bytes);
 
 /* query_layout.hip: the caller's arrays into the given device buffers, validated
    there (what a host pass over the set would check); longest sequence and count
@@ -312,10 +347,10 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s);
 int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uint8_t> &res,
                              DevBuf<uint64_t> &off, DevBuf<uint32_t> &v, DevBuf<uint32_t> &j,
                              DevBuf<uint32_t> &rep, DevBuf<uint64_t> &cnt, uint32_t &longest,
-                             std::vector<double> &rep_total);
+                             std::vector<double> &rep_total, bool on_device = false, uint64_t total_dev = 0);
 
-/* ref_index.hip: cmpr_set_reference */
-int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query);
+/* ref_index.hip: cmpr_set_reference (on_device: the view holds device pointers) */
+int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query, bool on_device);
 
 /* variant 2, d = 1 (with or without -i): the filter holds pair rows (kernels_rows.h) */
 inline bool pair_rows(const cmpr_context *c)

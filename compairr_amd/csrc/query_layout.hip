@@ -92,7 +92,8 @@ static_assert(MAX_GROUPS >= MAX_CLASS_RES + 1 && MAX_GROUPS >= 8 * 3, "item grou
 /* per slot, next to its QueryRec: hashes and class key (scatter_kernel -> fill_tiles_kernel) */
 struct QAux {
   uint64_t h, hins, hdel;
-  uint32_t ck, pad;
+  uint32_t ck;
+  uint32_t src;                      /* the query's number in the arrays at hand (QL::res / off ...) */
 };
 
 struct QL {
@@ -101,6 +102,7 @@ struct QL {
   const uint64_t *off;
   const uint32_t *v, *j, *rep;
   const uint64_t *cnt;
+  const uint32_t *orig;              /* routed records: the query's number in the caller's WHOLE set (NULL: i) */
   uint64_t        n, total;          /* sequences; residues in all (offsets[n]) */
   uint32_t        n_rep, n_v_max, n_j_max;
   uint32_t        A, zpos, n_v, longest, per_slice;   /* longest: the longest a query may be (zpos - 3) */
@@ -115,7 +117,11 @@ struct QL {
   uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slices */
   uint64_t        nslices_real;
   uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
-  uint32_t        sub2_owner_pass0, pad_q;
+  uint32_t        route;             /* 1: cmpr_route_queries -- the keys kernel names the contexts a query goes
+                                        to (dest_lo / dest_hi, dest_cnt) instead of ranking it in its group */
+  uint32_t        alg_step, alg_first; /* routed records (alg_step > 1): the algorithmic bytes of the queries whose
+                                          slice context alg_first of alg_step works on */
+  unsigned long long *dest_cnt;      /* route: records per destination */
   /* per pass */
   uint32_t *cnt_g[MAXP], *base_g[MAXP], *grp[MAXP];
   uint32_t *rank;                    /* per query: its rank in its group */
@@ -183,18 +189,22 @@ __device__ inline bool owned(const QL &Q, uint32_t slice, uint32_t pass)
   return Q.wstep <= 1u || work_owner(slice, pass, Q.wstep) == Q.wfirst;
 }
 
-/* ... on the items counted by counter k (see QL: item groups)? */
-__device__ inline bool item_owned(const QL &Q, uint32_t k)
+/* the context that works on the items counted by counter k (see QL: item groups) */
+__device__ inline uint32_t item_owner(const QL &Q, uint32_t k, uint32_t step)
 {
-  if (Q.wstep <= 1u)
-    return true;
   if (Q.sub2_items)            /* (ride along with the slice's main chunk, or chunks of pass 3: one owner) */
-    return owned(Q, k / Q.ngroups, 0u);
+    return work_owner(k / Q.ngroups, 0u, step);
   uint32_t gi = 0;
   for (uint32_t x = 1; x < Q.ngroups; x++)
     if (k >= Q.goff[x])
       gi = x;
-  return owned(Q, Q.gslice0[gi] + (k - Q.goff[gi]), 3u + gi);
+  return work_owner(Q.gslice0[gi] + (k - Q.goff[gi]), 3u + gi, step);
+}
+
+/* ... on the items counted by counter k? */
+__device__ inline bool item_owned(const QL &Q, uint32_t k)
+{
+  return Q.wstep <= 1u || item_owner(Q, k, Q.wstep) == Q.wfirst;
 }
 
 /* ---- validation ---------------------------------------------------------- */
@@ -459,12 +469,15 @@ __global__ void __launch_bounds__(256)
 keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
 {
   extern __shared__ double tot_lds[];          /* n_rep doubles when they fit */
+  __shared__ uint32_t dest_lds[64];            /* route: this workgroup's records per destination */
   const bool lds_tot = Q.n_rep <= 2048;
   if (lds_tot) {
     for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
       tot_lds[r] = 0.0;
-    __syncthreads();
   }
+  if (threadIdx.x < 64)
+    dest_lds[threadIdx.x] = 0;
+  __syncthreads();
   const uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
   unsigned long long alg = 0;
   uint32_t err = 0, Lmax = 0;
@@ -534,9 +547,25 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       } else if (Q.sub2_items) {
         Q.ck_tmp[i] = ck;
       }
+      if (Q.route) {
+        /* cmpr_route_queries: the contexts this query's record goes to -- the one that works
+           on its slice and those that work on one of its items (verification reads the
+           record where the positive is resolved) */
+        unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : 0u, 0u, Q.wstep);
+        if (Q.ngroups)
+          for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+            mask |= 1ull << item_owner(Q, k, Q.wstep);
+          });
+        if (Q.route == 2u)
+          mask = Q.wstep >= 64u ? ~0ull : (1ull << Q.wstep) - 1ull;       /* (a layout every context holds in full) */
+        Q.grp[0][i] = (uint32_t)mask;
+        Q.rank[i] = (uint32_t)(mask >> 32);
+        for (unsigned long long m = mask; m; m &= m - 1ull)
+          atomicAdd(&dest_lds[__builtin_ctzll(m)], 1u);
+      }
       /* the items of the query that this context works on */
       bool any_item = false;
-      if (Q.ngroups)
+      if (Q.ngroups && !Q.route)
         for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
           if (item_owned(Q, k)) {
             atomicAdd(Q.ccnt + k, 1u);
@@ -554,12 +583,13 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       else if (any_item)        /* (spread by query number: one counter per length would serialise
                                    millions of atomics -- 27 ms per 10M queries at two shards, round 3) */
         bucket = 2 * (Q.nslices_real + (((uint32_t)i * 2654435761u) >> (32 - FOREIGN_SLICES_LOG2)));
-      if (bucket != ~0ull) {
+      if (bucket != ~0ull && !Q.route) {
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
         Q.rank[i] = atomicAdd(Q.cnt_g[0] + g, 1u);
       }
-      alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
+      if (Q.alg_step <= 1u || work_owner(slice, 0u, Q.alg_step) == Q.alg_first)
+        alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
   }
   if (err)
@@ -574,12 +604,14 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
     alg += __shfl_down(alg, o, WAVE);
   if ((threadIdx.x & 63) == 0 && alg)
     atomicAdd(Q.alg_bytes, alg);
+  __syncthreads();
   if (lds_tot) {
-    __syncthreads();
     for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
       if (tot_lds[r] != 0.0)
         unsafeAtomicAdd(Q.rep_total + r, tot_lds[r]);
   }
+  if (Q.route && threadIdx.x < 64 && dest_lds[threadIdx.x])
+    atomicAdd(Q.dest_cnt + threadIdx.x, (unsigned long long)dest_lds[threadIdx.x]);
 }
 
 /* ---- narrowed upload: back to the caller's types -------------------------- */
@@ -782,9 +814,10 @@ scatter_kernel(const QL Q)
   qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
   qr.v = Q.genes ? Q.v[i] : 0u;
   qr.j = Q.genes ? Q.j[i] : 0u;
-  qr.rep = Q.existence ? (uint32_t)i : Q.rep[i];    /* -x: the row is the sequence itself */
+  const uint32_t orig = Q.orig ? Q.orig[i] : (uint32_t)i;
+  qr.rep = Q.existence ? orig : Q.rep[i];           /* -x: the row is the sequence itself */
   qr.len = L;
-  qr.orig = (uint32_t)i;
+  qr.orig = orig;
 #pragma unroll
   for (uint32_t w = 0; w < 9; w++) {
     uint32_t d = 0;
@@ -797,7 +830,8 @@ scatter_kernel(const QL Q)
   Q.qrec[slot] = qr;
   QAux a;
   a.h = a.hins = a.hdel = 0;
-  a.ck = a.pad = 0;
+  a.ck = 0;
+  a.src = (uint32_t)i;
   if (Q.rows) {
     a.h = Q.h_tmp[i];
     a.ck = Q.ck_tmp[i];
@@ -838,7 +872,7 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
     for (uint32_t w = 0; w < 9; w++)
       qr.res[w] = 0;
     a.h = a.hins = a.hdel = 0;
-    a.ck = a.pad = 0;
+    a.ck = a.src = 0;
     Q.qrec[slot] = qr;
   }
   Q.qlen[slot] = (uint16_t)qr.len;
@@ -877,7 +911,7 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
     if (w < nd)
       dst[(size_t)w * WAVE] = padded(qr.res[w], w);
   if (nd > 9) {
-    const uint8_t *s = valid ? Q.res + Q.off[qr.orig] : Q.res;
+    const uint8_t *s = valid ? Q.res + Q.off[a.src] : Q.res;
     const uint32_t L = qr.len;
     for (uint32_t w = 9; w < nd; w++) {
       uint32_t d = 0;
@@ -1134,6 +1168,136 @@ small_mine_kernel(const QL Q, const uint32_t *small, uint32_t n, uint32_t first,
   }
 }
 
+
+/* ---- routed records (cmpr_route_queries / cmpr_route_pack / cmpr_set_queries_routed) ------ */
+
+/* One record = the query as the layout needs it: layout.h QueryRec (count, genes, repertoire,
+   length, residues 0..35, its number in the caller's WHOLE set) and, for sets with longer
+   sequences, the further residues four to a dword -- record_bytes each, a multiple of 16. */
+__host__ __device__ inline uint32_t route_record_bytes(uint32_t longest)
+{
+  return (uint32_t)sizeof(QueryRec) + (longest > 36u ? (longest - 36u + 15u) / 16u * 16u : 0u);
+}
+
+/* One thread per query of the share: its record to every destination named by the keys
+   kernel, at (first record of the destination) + (a position claimed per workgroup with one
+   atomic per destination). */
+__global__ void __launch_bounds__(256)
+route_pack_kernel(const QL Q, const uint32_t *mask_lo, const uint32_t *mask_hi, uint64_t first_index,
+                  const unsigned long long *dest_base, unsigned long long *dest_fill,
+                  unsigned char *out, uint32_t record_bytes)
+{
+  __shared__ uint32_t cnt_lds[64];
+  __shared__ unsigned long long base_lds[64];
+  if (threadIdx.x < 64)
+    cnt_lds[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long mask = 0;
+  if (i < Q.n)
+    mask = ((unsigned long long)mask_hi[i] << 32) | mask_lo[i];
+  uint32_t at[4] = {0, 0, 0, 0};        /* position inside the workgroup's run, first four destinations
+                                           (a query with more claims the others one by one, below) */
+  {
+    uint32_t k = 0;
+    for (unsigned long long m = mask; m && k < 4; m &= m - 1ull, k++)
+      at[k] = atomicAdd(&cnt_lds[__builtin_ctzll(m)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t d = threadIdx.x;
+    base_lds[d] = cnt_lds[d] ? dest_base[d] + atomicAdd(dest_fill + d, (unsigned long long)cnt_lds[d]) : 0ull;
+  }
+  __syncthreads();
+  if (!mask)
+    return;
+  const uint64_t b = Q.off[i];
+  const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
+  const uint8_t *s = Q.res + b;
+  QueryRec qr;
+  qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
+  qr.v = Q.genes ? Q.v[i] : 0u;
+  qr.j = Q.genes ? Q.j[i] : 0u;
+  qr.rep = Q.rep[i];
+  qr.len = L;
+  qr.orig = (uint32_t)(first_index + i);
+#pragma unroll
+  for (uint32_t w = 0; w < 9; w++) {
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (4 * w + k < L)
+        d |= (uint32_t)s[4 * w + k] << (8 * k);
+    qr.res[w] = d;
+  }
+  const uint32_t more = (record_bytes - (uint32_t)sizeof(QueryRec)) / 4u;     /* dwords behind the header */
+  uint32_t k = 0;
+  for (unsigned long long m = mask; m; m &= m - 1ull, k++) {
+    const uint32_t d = (uint32_t)__builtin_ctzll(m);
+    unsigned long long pos;
+    if (k < 4)
+      pos = base_lds[d] + at[k];
+    else            /* (more than four destinations: the layouts every context holds in full) */
+      pos = dest_base[d] + atomicAdd(dest_fill + d, 1ull);
+    unsigned char *o = out + (size_t)pos * record_bytes;
+    *(QueryRec *)o = qr;
+    uint32_t *x = (uint32_t *)(o + sizeof(QueryRec));
+    for (uint32_t w = 0; w < more; w++) {
+      uint32_t dw = 0;
+      for (uint32_t q = 0; q < 4; q++)
+        if (36u + 4u * w + q < L)
+          dw |= (uint32_t)s[36u + 4u * w + q] << (8 * q);
+      x[w] = dw;
+    }
+  }
+}
+
+/* records -> lengths (what the offsets are scanned from); a length that cannot be is named */
+__global__ void __launch_bounds__(256)
+unpack_len_kernel(const unsigned char *rec, uint64_t n, uint32_t record_bytes, uint32_t longest,
+                  uint16_t *len16, uint32_t *verr)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > n)
+    return;
+  uint32_t L = 0;
+  if (i < n) {
+    L = ((const QueryRec *)(rec + (size_t)i * record_bytes))->len;
+    if (L > longest) {
+      atomicCAS(verr, 0u, (uint32_t)VERR_TOO_LONG);
+      L = 0;
+    }
+  }
+  len16[i] = (uint16_t)L;                    /* ([n] = 0: the scan's last output is the total) */
+}
+
+/* records -> the arrays the layout kernels read (the caller's types) */
+__global__ void __launch_bounds__(256)
+unpack_kernel(const unsigned char *rec, uint64_t n, uint32_t record_bytes, const uint64_t *off,
+              uint8_t *res, uint32_t *v, uint32_t *j, uint32_t *rep, uint64_t *cnt, uint32_t *orig)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n)
+    return;
+  const unsigned char *r = rec + (size_t)i * record_bytes;
+  const QueryRec qr = *(const QueryRec *)r;
+  rep[i] = qr.rep;
+  orig[i] = qr.orig;
+  if (v) {
+    v[i] = qr.v;
+    j[i] = qr.j;
+  }
+  if (cnt)
+    cnt[i] = qr.cnt;
+  const uint64_t b = off[i];
+  const uint32_t L = (uint32_t)(off[i + 1] - b);
+  const uint32_t *more = (const uint32_t *)(r + sizeof(QueryRec));
+  for (uint32_t p = 0; p < L; p++) {
+    const uint32_t w = p < 36u ? qr.res[p >> 2] : more[(p - 36u) >> 2];
+    res[b + p] = (uint8_t)(w >> ((p & 3u) * 8u));
+  }
+}
+
 template <typename T>
 struct Tmp {
   DevBuf<T> b;
@@ -1165,23 +1329,39 @@ const char *verr_message(uint32_t e)
 int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uint8_t> &res,
                              DevBuf<uint64_t> &off, DevBuf<uint32_t> &v, DevBuf<uint32_t> &j,
                              DevBuf<uint32_t> &rep, DevBuf<uint64_t> &cnt, uint32_t &longest,
-                             std::vector<double> &rep_total)
+                             std::vector<double> &rep_total, bool on_device, uint64_t total_dev)
 {
   int rc;
-  const uint64_t total = s->n ? s->offsets[s->n] : 0;
+  /* (on_device: the view's arrays are device memory -- a copy inside the device; its
+     offsets[n] was fetched by the caller) */
+  const uint64_t total = on_device ? total_dev : (s->n ? s->offsets[s->n] : 0);
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   static const uint64_t zero_off[1] = {0};
-  if ((rc = dev_upload(c, res, s->residues, (size_t)total))) return rc;
-  if ((rc = dev_upload(c, off, s->n ? s->offsets : zero_off, (size_t)s->n + 1))) return rc;
-  if ((rc = dev_upload(c, rep, s->repertoire, (size_t)s->n))) return rc;
+  auto put = [&](auto &buf, const auto *from, size_t count, bool host_src = false) -> int {
+    int r = dev_alloc(c, buf, count);
+    if (r)
+      return r;
+    if (count)
+      HIP_TRY(c, hipMemcpyAsync(buf.p, from, count * sizeof(*from), host_src ? hipMemcpyHostToDevice : kind,
+                                c->stream));
+    return CMPR_OK;
+  };
+  if ((rc = put(res, s->residues, (size_t)total))) return rc;
+  if (s->n) {
+    if ((rc = put(off, s->offsets, (size_t)s->n + 1))) return rc;
+  } else if ((rc = put(off, zero_off, 1, true))) {
+    return rc;
+  }
+  if ((rc = put(rep, s->repertoire, (size_t)s->n))) return rc;
   if (!c->opt.ignore_genes) {
-    if ((rc = dev_upload(c, v, s->v_gene, (size_t)s->n))) return rc;
-    if ((rc = dev_upload(c, j, s->j_gene, (size_t)s->n))) return rc;
+    if ((rc = put(v, s->v_gene, (size_t)s->n))) return rc;
+    if ((rc = put(j, s->j_gene, (size_t)s->n))) return rc;
   } else {
     v.release();
     j.release();
   }
   if (!c->opt.ignore_counts) {
-    if ((rc = dev_upload(c, cnt, s->count, (size_t)s->n))) return rc;
+    if ((rc = put(cnt, s->count, (size_t)s->n))) return rc;
   } else {
     cnt.release();
   }
@@ -1290,7 +1470,7 @@ static hipError_t sum64(void *tmp, size_t &bytes, const uint32_t *in, unsigned l
   return hipcub::DeviceReduce::Sum(tmp, bytes, it, out, n, st);
 }
 
-int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
+int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
 {
   int rc;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1308,14 +1488,41 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
       }
     }
   } quiesce{c};
-  const uint64_t n = s->n;
-  const uint64_t total = n ? s->offsets[n] : 0;
+  const cmpr_set_view *const s = src.view;
+  const bool from_host = src.kind == LayoutSource::HOST;
+  const bool from_records = src.kind == LayoutSource::RECORDS;
+  const bool routing = src.route;                          /* cmpr_route_queries: key the share, count per destination */
   const uint32_t A = (uint32_t)c->opt.alphabet_size;
   const uint32_t Lcap = c->zpos - EXTRA_POSITIONS;        /* the longest a query may be */
+  const uint64_t n = from_records ? src.nrec : s->n;
+  const uint32_t n_rep = from_records ? src.n_rep : s->n_repertoires;
+  const uint32_t record_bytes = route_record_bytes(Lcap);
+  c->route.valid = false;
+  uint64_t total = 0;                                     /* residues in all */
+  if (from_host) {
+    total = n ? s->offsets[n] : 0;
+  } else if (from_records) {
+    total = n * (uint64_t)Lcap;                           /* (an upper bound sizes the arena; the scan gives the sum) */
+  } else if (n) {
+    uint64_t ends[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(&ends[0], s->offsets, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&ends[1], s->offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ends[0] != 0)
+      return fail(c, CMPR_EINVAL, "offsets[0] must be 0");
+    total = ends[1];
+  }
   if (n > 0x7fffffffull)                                  /* (hipCUB item counts are int) */
     return fail(c, CMPR_EUNSUPPORTED, "more than 2^31-1 sequences in one set");
-  c->n1 = n;
-  c->R1 = c->opt.existence ? (uint32_t)n : s->n_repertoires;
+  if (total > 0xffffull * n)
+    return fail(c, CMPR_EINVAL, verr_message(VERR_OFFSETS));
+  /* the caller's arrays on the device: copied there (host), unpacked there (records), or
+     where the caller has them (device; an empty set still needs its one offset) */
+  const bool soa_in_arena = src.kind != LayoutSource::DEVICE || n == 0;
+  if (!routing) {
+    c->n1 = n;
+    c->R1 = c->opt.existence ? (uint32_t)(from_records ? src.n_total : n) : n_rep;
+    c->routed = from_records;
+  }
 
   const uint32_t wstep = (uint32_t)c->work_shard_count;
   const uint32_t wfirst = (uint32_t)c->work_shard_index;
@@ -1390,21 +1597,23 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   const size_t o_sibfill = cut.take(n2s * sizeof(uint32_t));
   const size_t o_alg = cut.take(sizeof(unsigned long long));
   const size_t o_verr = cut.take(2 * sizeof(uint32_t));
-  const size_t o_reptot = cut.take((size_t)s->n_repertoires * sizeof(double));
+  const size_t o_reptot = cut.take((size_t)n_rep * sizeof(double));
+  const size_t o_dest = cut.take(2 * 64 * sizeof(unsigned long long));     /* route: counts | fill */
   const size_t o_sums = cut.take(8 * sizeof(unsigned long long));
   const size_t zero_bytes = cut.used;
-  const size_t o_res = cut.take((size_t)total + 16);
-  const size_t o_off = cut.take((size_t)(n + 1) * sizeof(uint64_t));
-  const size_t o_v = cut.take(c->opt.ignore_genes ? 0 : (size_t)n * sizeof(uint32_t));
-  const size_t o_j = cut.take(c->opt.ignore_genes ? 0 : (size_t)n * sizeof(uint32_t));
-  const size_t o_rep = cut.take((size_t)n * sizeof(uint32_t));
-  const size_t o_cnt = cut.take(c->opt.ignore_counts ? 0 : (size_t)n * sizeof(uint64_t));
+  const size_t o_res = cut.take(soa_in_arena ? (size_t)total + 16 : 0);
+  const size_t o_off = cut.take(soa_in_arena ? (size_t)(n + 1) * sizeof(uint64_t) : 0);
+  const size_t o_v = cut.take(c->opt.ignore_genes || !soa_in_arena ? 0 : (size_t)n * sizeof(uint32_t));
+  const size_t o_j = cut.take(c->opt.ignore_genes || !soa_in_arena ? 0 : (size_t)n * sizeof(uint32_t));
+  const size_t o_rep = cut.take(soa_in_arena ? (size_t)n * sizeof(uint32_t) : 0);
+  const size_t o_cnt = cut.take(c->opt.ignore_counts || !soa_in_arena ? 0 : (size_t)n * sizeof(uint64_t));
+  const size_t o_orig = cut.take(from_records ? (size_t)n * sizeof(uint32_t) : 0);
   /* narrowed upload (below): lengths, 16-bit ids, 32-bit counts as they arrive */
   const unsigned hw = std::thread::hardware_concurrency();
-  const bool narrow_fits = s->n_repertoires <= 65536 &&
+  const bool narrow_fits = from_host && n_rep <= 65536 &&
                            (c->opt.ignore_genes || (c->opt.n_v_genes <= 65536 && c->opt.n_j_genes <= 65536));
   bool narrow = narrow_fits && (c->narrow_upload == 1 || (c->narrow_upload < 0 && n >= (1u << 20) && hw >= 8));
-  const size_t o_len16 = cut.take(narrow ? (size_t)(n + 1) * sizeof(uint16_t) : 0);
+  const size_t o_len16 = cut.take(narrow || from_records ? (size_t)(n + 1) * sizeof(uint16_t) : 0);
   const size_t o_rep16 = cut.take(narrow ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_v16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_j16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
@@ -1444,7 +1653,7 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
     b = 0;
     (void)sum64(nullptr, b, nullptr, nullptr, big, c->stream);
     cub_bytes = std::max(cub_bytes, b);
-    if (narrow) {
+    if (narrow || from_records) {
       hipcub::TransformInputIterator<unsigned long long, Len16To64, const uint16_t *> it(nullptr, Len16To64());
       b = 0;
       (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, it, (unsigned long long *)nullptr, hipcub::Sum(),
@@ -1461,15 +1670,28 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
 
   QL Q;
   memset(&Q, 0, sizeof Q);
-  Q.res = (const uint8_t *)at(o_res);
-  Q.off = (const uint64_t *)at(o_off);
-  Q.v = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_v);
-  Q.j = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_j);
-  Q.rep = (const uint32_t *)at(o_rep);
-  Q.cnt = c->opt.ignore_counts ? nullptr : (const uint64_t *)at(o_cnt);
+  if (soa_in_arena) {
+    Q.res = (const uint8_t *)at(o_res);
+    Q.off = (const uint64_t *)at(o_off);
+    Q.v = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_v);
+    Q.j = c->opt.ignore_genes ? nullptr : (const uint32_t *)at(o_j);
+    Q.rep = (const uint32_t *)at(o_rep);
+    Q.cnt = c->opt.ignore_counts ? nullptr : (const uint64_t *)at(o_cnt);
+  } else {                                   /* the caller's device arrays, read where they lie */
+    Q.res = s->residues;
+    Q.off = s->offsets;
+    Q.v = c->opt.ignore_genes ? nullptr : s->v_gene;
+    Q.j = c->opt.ignore_genes ? nullptr : s->j_gene;
+    Q.rep = s->repertoire;
+    Q.cnt = c->opt.ignore_counts ? nullptr : s->count;
+  }
+  Q.orig = from_records ? (const uint32_t *)at(o_orig) : nullptr;
   Q.n = n;
   Q.total = total;
-  Q.n_rep = s->n_repertoires;
+  Q.n_rep = n_rep;
+  Q.alg_step = from_records ? (uint32_t)c->work_shard_count : 1u;
+  Q.alg_first = (uint32_t)c->work_shard_index;
+  Q.dest_cnt = (unsigned long long *)at(o_dest);
   Q.n_v_max = c->opt.n_v_genes;
   Q.n_j_max = c->opt.n_j_genes;
   Q.A = A;
@@ -1497,6 +1719,10 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   Q.nslices_real = nslices_real;
   Q.wfirst = place_mine ? wfirst : 0u;
   Q.wstep = place_mine ? wstep : 1u;
+  if (routing) {                             /* (a layout every context holds in full: every record to everyone) */
+    Q.route = place_mine || wstep == 1 ? 1u : 2u;
+    Q.wstep = wstep;
+  }
   Q.ngroups = ngroups;
   Q.sub2_items = sub2_items ? 1u : 0u;
   c->sub2_active = sub2_items;
@@ -1545,12 +1771,40 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
           not fit (a count >= 2^32, an id >= 2^16, offsets that are no CDR3 lengths) sends
           the whole set the wide way, where the keys kernel names the error if it is one. ---- */
   double upload_ms = 0;
+  if (!from_host) {
+    static const uint64_t zero_off1[1] = {0};
+    const size_t lds = n_rep <= 2048 ? n_rep * sizeof(double) : 0;
+    if (n == 0) {
+      HIP_TRY(c, hipMemcpyAsync(at(o_off), zero_off1, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    } else {
+      if (from_records) {
+        /* records -> lengths -> offsets (scan) -> the arrays the keys kernel reads */
+        const unsigned char *rec = (const unsigned char *)src.d_records;
+        hipLaunchKernelGGL(unpack_len_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, c->stream, rec, n,
+                           record_bytes, Lcap, (uint16_t *)at(o_len16), Q.verr);
+        HIP_TRY(c, hipGetLastError());
+        hipcub::TransformInputIterator<unsigned long long, Len16To64, const uint16_t *> it(
+            (const uint16_t *)at(o_len16), Len16To64());
+        size_t b = cub_bytes;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(cub_tmp, b, it, (unsigned long long *)at(o_off), hipcub::Sum(),
+                                                     0ull, (int)(n + 1), c->stream));
+        hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, rec, n, record_bytes,
+                           (const uint64_t *)at(o_off), (uint8_t *)at(o_res),
+                           c->opt.ignore_genes ? nullptr : (uint32_t *)at(o_v),
+                           c->opt.ignore_genes ? nullptr : (uint32_t *)at(o_j), (uint32_t *)at(o_rep),
+                           c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), (uint32_t *)at(o_orig));
+        HIP_TRY(c, hipGetLastError());
+      }
+      hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(n)), dim3(256), lds, c->stream, Q, (uint64_t)0, n);
+      HIP_TRY(c, hipGetLastError());
+    }
+  } else
   for (int attempt = 0;; attempt++) {
     /* (few, large ranges: every copy call costs ~20 us of host time, and the keys kernel of
        the last range is what the upload does not hide) */
     const uint64_t min_range = 1u << 18;
     const uint64_t nranges = std::max<uint64_t>(1, std::min<uint64_t>(4, n / min_range));
-    const size_t lds = s->n_repertoires <= 2048 ? s->n_repertoires * sizeof(double) : 0;
+    const size_t lds = n_rep <= 2048 ? n_rep * sizeof(double) : 0;
     HIP_TRY(c, hipEventRecord(c->ev_copy[0], c->stream));            /* (the memset above) */
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0));
     static const uint64_t zero_off[1] = {0};
@@ -1712,6 +1966,44 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   }
   const auto t_uploaded = std::chrono::steady_clock::now();
 
+  if (routing) {
+    /* cmpr_route_queries ends here: records per destination, the totals of the share, and
+       the keyed share left in arena A for cmpr_route_pack */
+    uint32_t hv[2] = {0, 0};
+    unsigned long long counts[64];
+    std::vector<double> tot(n_rep, 0.0);
+    HIP_TRY(c, hipMemcpyAsync(hv, Q.verr, sizeof hv, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(counts, Q.dest_cnt, sizeof counts, hipMemcpyDeviceToHost, c->stream));
+    if (n_rep)
+      HIP_TRY(c, hipMemcpyAsync(tot.data(), Q.rep_total, n_rep * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hv[0] == VERR_TOO_LONG)
+      return fail(c, CMPR_EINVAL, "query longer than the longest_query given to cmpr_set_reference");
+    if (hv[0])
+      return fail(c, hv[0] == VERR_LONG ? CMPR_EUNSUPPORTED : CMPR_EINVAL, verr_message(hv[0]));
+    RouteState &R = c->route;
+    R.n = n;
+    R.first_index = src.first_index;
+    R.n_dest = wstep;
+    R.record_bytes = record_bytes;
+    R.total_records = 0;
+    for (uint32_t d = 0; d < 64; d++) {
+      R.counts[d] = d < wstep ? counts[d] : 0;
+      R.total_records += R.counts[d];
+    }
+    R.rep_totals = tot;
+    R.res = Q.res; R.off = Q.off; R.v = Q.v; R.j = Q.j; R.rep = Q.rep; R.cnt = Q.cnt;
+    R.mask_lo = Q.grp[0];
+    R.mask_hi = Q.rank;
+    R.dest = Q.dest_cnt;
+    R.valid = true;
+    c->layout_upload_ms = upload_ms;
+    c->layout_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    c->layout_tail_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_uploaded).count();
+    quiesce.ok = true;
+    return CMPR_OK;
+  }
+
   /* ---- per slice: what it needs; exclusive scan; items per (group, slice) padded to
           blocks of 64; -i (variant 1): the sibling lists; all sizes in ONE round trip ---- */
   {
@@ -1753,14 +2045,14 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   SliceTot last_tot, last_pre;
   uint32_t hv[2] = {0, 0};
   unsigned long long alg_bytes = 0, hsums[4] = {0, 0, 0, 0};
-  c->tot1.assign(s->n_repertoires, 0.0);
+  c->tot1.assign(n_rep, 0.0);
   HIP_TRY(c, hipMemcpyAsync(&last_tot, Q.tot[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&last_pre, Q.pre[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(hv, Q.verr, sizeof hv, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&alg_bytes, Q.alg_bytes, sizeof alg_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(hsums, sums, sizeof hsums, hipMemcpyDeviceToHost, c->stream));
-  if (s->n_repertoires)
-    HIP_TRY(c, hipMemcpyAsync(c->tot1.data(), Q.rep_total, s->n_repertoires * sizeof(double),
+  if (n_rep)
+    HIP_TRY(c, hipMemcpyAsync(c->tot1.data(), Q.rep_total, n_rep * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const auto t_sizes = std::chrono::steady_clock::now();
@@ -1769,6 +2061,10 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
   if (hv[0])
     return fail(c, hv[0] == VERR_LONG ? CMPR_EUNSUPPORTED : CMPR_EINVAL, verr_message(hv[0]));
   c->algorithmic_bytes = alg_bytes;
+  /* (routed records: the totals of the WHOLE query set, when the caller has them, bound the
+     cells of the summed matrix; this context saw only its share) */
+  if (from_records && src.totals)
+    c->tot1.assign(src.totals, src.totals + n_rep);
 
   /* exact integer accumulation needs every cell < 2^64; a cell is at most
      (sum of counts of its row repertoire) x (sum of counts of its column one) */
@@ -2016,5 +2312,43 @@ int cmpr_layout_queries(cmpr_context *c, const cmpr_set_view *s)
             ms(t_sizes, t_reserved), ms(t_reserved, t_end), upload_ms, cut.used >> 20, cb.used >> 20);
   }
   quiesce.ok = true;
+  return CMPR_OK;
+}
+
+
+/* cmpr_route_pack: the records of the share keyed by cmpr_route_queries, grouped by
+   destination (destination d's run starts at the sum of the counts below d), into the
+   caller's device buffer. */
+int cmpr_route_pack_impl(cmpr_context *c, void *d_send, uint64_t capacity_bytes)
+{
+  RouteState &R = c->route;
+  if (!R.valid)
+    return fail(c, CMPR_ESTATE, "cmpr_route_queries must be called first");
+  if (capacity_bytes < R.total_records * R.record_bytes)
+    return fail(c, CMPR_EINVAL, "cmpr_route_pack: the buffer is smaller than the records counted");
+  if (R.total_records && !d_send)
+    return fail(c, CMPR_EINVAL, "cmpr_route_pack: d_send is NULL");
+  HIP_TRY(c, hipSetDevice(c->device));
+  R.valid = false;                          /* (the share is packed once) */
+  if (R.n == 0)
+    return CMPR_OK;
+  unsigned long long base[128];
+  unsigned long long at = 0;
+  for (uint32_t d = 0; d < 64; d++) {
+    base[d] = at;                           /* first record of the destination */
+    at += R.counts[d];
+    base[64 + d] = 0;                       /* fill cursors */
+  }
+  HIP_TRY(c, hipMemcpyAsync(R.dest, base, sizeof base, hipMemcpyHostToDevice, c->stream));
+  QL Q;
+  memset(&Q, 0, sizeof Q);
+  Q.res = R.res; Q.off = R.off; Q.v = R.v; Q.j = R.j; Q.rep = R.rep; Q.cnt = R.cnt;
+  Q.n = R.n;
+  Q.genes = c->opt.ignore_genes ? 0 : 1;
+  Q.counts = c->opt.ignore_counts ? 0 : 1;
+  hipLaunchKernelGGL(route_pack_kernel, dim3(blocks_for(R.n)), dim3(256), 0, c->stream, Q, R.mask_lo, R.mask_hi,
+                     R.first_index, R.dest, R.dest + 64, (unsigned char *)d_send, R.record_bytes);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMPR_OK;
 }

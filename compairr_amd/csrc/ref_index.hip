@@ -127,24 +127,41 @@ struct WidenU32 {
 
 }  // namespace
 
-int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query)
+int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query, bool on_device)
 {
   if (!c)
     return CMPR_EINVAL;
   std::string why;
-  int rc = validate_view(c->opt, s, why);
+  int rc = validate_view(c->opt, s, why, on_device);
   if (rc)
     return fail(c, rc, why);
   HIP_TRY(c, hipSetDevice(c->device));
+  /* launches that still read the old index on a caller's stream */
+  if (c->events_valid)
+    HIP_TRY(c, hipEventSynchronize(c->ev_k1));
   c->have_ref = false;
   c->have_q = false;
   if (s->n > 0x7fffffffull)                               /* (hipCUB item counts are int) */
     return fail(c, CMPR_EUNSUPPORTED, "more than 2^31-1 sequences in one set");
+  /* residues in all: offsets[n], which a device view keeps on the device */
+  uint64_t residues2 = 0;
+  if (s->n && !on_device) {
+    residues2 = s->offsets[s->n];
+  } else if (s->n) {
+    uint64_t ends[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(&ends[0], s->offsets, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&ends[1], s->offsets + s->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ends[0] != 0)
+      return fail(c, CMPR_EINVAL, "offsets[0] must be 0");
+    if (ends[1] > 0xffffull * s->n)
+      return fail(c, CMPR_EINVAL, "offsets not monotone");
+    residues2 = ends[1];
+  }
 
   /* ---- the set as the caller has it, validated on the device ---- */
   uint32_t longest = 0;
   if ((rc = cmpr_upload_and_validate(c, s, c->res2, c->off2, c->v2, c->j2, c->rep2, c->cnt2, longest,
-                                     c->tot2)))
+                                     c->tot2, on_device, residues2)))
     return rc;
   c->longest2 = longest;
   c->n2 = s->n;
@@ -219,7 +236,6 @@ int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *s, uint32_t 
   /* row filter: L + 1 entries per sequence, and with -i its L + 1 gap entries (kernels_rows.h) */
   /* (what the filter is SIZED for, also with pair rows, which enter fewer -- entries_filed:
      their eight-bit tests then see next to no false positive, and a slice holds more sequences) */
-  const uint64_t residues2 = s->n ? s->offsets[s->n] : 0;
   const uint64_t entries = (residues2 + s->n) * (c->rows && c->opt.indels ? 2 : 1);
   if (c->rows) {
     /* 2 bytes of filter per entry (16 entries per 32-byte word: every dword of a

@@ -1,14 +1,25 @@
-"""Multi-GPU plumbing for the hot path.
+"""Multi-GPU plumbing for the hot path, one process per GPU.
 
-Queries (set 1) are independent, the set-2 index is read-only and the matrix is
-a commutative integer sum, so the path shards by query range with ONE exchange
-step: a sum-reduction of the R1 x R2 matrix.  torch.distributed is plumbing
-only (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+The set-2 index is replicated, the matrix is a commutative integer sum, and the WORK of a step
+divides by filter slice (library tunables work_shard_count / work_shard_index).  What crosses
+the links:
+
+  * once per query set: every rank uploads and keys only ITS share of the queries
+    (cmpr_route_queries), the records move to the ranks that work on them with one
+    all-to-all over xGMI (`exchange_queries`: counts, then the records), and every rank lays
+    out what it received (cmpr_set_queries_routed);
+  * once per step: one sum-reduce of the R1 x R2 matrix (`allreduce_matrix`).
+
+The reference's counterpart is the chunk hand-out of overlap.cc:421-433 and the merge of the
+threads' private matrices, overlap.cc:510-527.  torch.distributed is plumbing only (backend
+"nccl" = RCCL on the GPU box, "gloo" in the CPU tests, which drive this module with a
+stand-in for the library context: `h` below is anything with route_queries / route_pack /
+set_queries_routed).
 """
 
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 
@@ -30,9 +41,52 @@ def allreduce_matrix(t):
     return t
 
 
+def exchange_queries(h, share, first_index: int, n_total: int, rank: int, world: int,
+                     device="cuda", group=None) -> dict:
+    """One query set over `world` contexts: this rank hands `share` (sequences first_index ..
+    first_index + share.n - 1 of the whole set of n_total) to its context `h`, the records go
+    where their work is, `h` ends up with what it works on.  Returns the sizes that moved.
+
+    With a process group up (also at world size 1, so that a one-GPU torchrun executes it)
+    the exchange is torch.distributed.all_to_all_single on `device` buffers; without one it
+    is the identity."""
+    import torch
+    import torch.distributed as dist
+    use_dist = dist.is_available() and dist.is_initialized()
+    assert (dist.get_world_size(group) if use_dist else 1) == world
+    counts, record_bytes, totals = h.route_queries(share, first_index, world)
+    counts = np.asarray(counts, dtype=np.int64)
+    nsend = int(counts.sum())
+    send = torch.empty(max(nsend, 1) * record_bytes, dtype=torch.uint8, device=device)
+    h.route_pack(send.data_ptr(), nsend * record_bytes)
+    if use_dist:
+        # how many records each rank sends me
+        sc = torch.from_numpy(counts).to(device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=group)
+        recv_counts = rc.cpu().numpy()
+        nrecv = int(recv_counts.sum())
+        recv = torch.empty(max(nrecv, 1) * record_bytes, dtype=torch.uint8, device=device)
+        dist.all_to_all_single(recv[:nrecv * record_bytes], send[:nsend * record_bytes],
+                               output_split_sizes=[int(x) * record_bytes for x in recv_counts],
+                               input_split_sizes=[int(x) * record_bytes for x in counts], group=group)
+        # duplicate_count totals per repertoire of the WHOLE set: they bound the summed cells
+        tot = torch.from_numpy(np.ascontiguousarray(totals, dtype=np.float64)).to(device)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        totals = tot.cpu().numpy()
+    else:
+        assert world == 1
+        recv, nrecv = send, nsend
+    if str(device) != "cpu":
+        torch.cuda.synchronize()
+    h.set_queries_routed(recv.data_ptr(), nrecv, share.n_repertoires, n_total, totals)
+    return {"records_sent": nsend, "records_received": nrecv, "record_bytes": record_bytes,
+            "share": share.n}
+
+
 def sharded_overlap(compute: Callable, set1, set2, rank: int, world: int, device="cpu"):
-    """Strong-scaling form: rank computes its query shard with `compute(shard,
-    set2) -> uint64 matrix`, then the matrices are summed across ranks.
+    """The literal split of the north star: rank computes a contiguous query shard with
+    `compute(shard, set2) -> uint64 matrix`, then the matrices are summed across ranks.
     Returns the full matrix (same on every rank)."""
     import torch
     lo, hi = shard_bounds(set1.n, rank, world)
@@ -40,3 +94,18 @@ def sharded_overlap(compute: Callable, set1, set2, rank: int, world: int, device
     t = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(device)
     allreduce_matrix(t)
     return t.cpu().numpy().view(np.uint64).reshape(part.shape)
+
+
+def routed_overlap(h, matrix_of: Callable, set1, rank: int, world: int, device="cuda",
+                   first_and_share: Optional[Tuple[int, object]] = None):
+    """The whole multi-GPU path once: contiguous share -> exchange -> this rank's part of the
+    matrix (`matrix_of(h) -> uint64 matrix`) -> sum over ranks."""
+    import torch
+    if first_and_share is None:
+        lo, hi = shard_bounds(set1.n, rank, world)
+        first_and_share = (lo, set1.subset(slice(lo, hi)))
+    moved = exchange_queries(h, first_and_share[1], first_and_share[0], set1.n, rank, world, device)
+    part = matrix_of(h)
+    t = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(device)
+    allreduce_matrix(t)
+    return t.cpu().numpy().view(np.uint64).reshape(part.shape), moved

@@ -24,6 +24,8 @@ EXPORTS = [
     "cmpr_get_kernel_times",
     "cmpr_rows", "cmpr_cols", "cmpr_set_tunable", "cmpr_get_tunable",
     "cmpr_count_duplicates", "cmpr_overlap_pairs",
+    "cmpr_set_reference_device", "cmpr_set_queries_device",
+    "cmpr_route_queries", "cmpr_route_pack", "cmpr_set_queries_routed",
 ]
 
 
@@ -124,6 +126,13 @@ def load_library() -> C.CDLL:
     lib.cmpr_last_error.restype = C.c_char_p
     lib.cmpr_set_reference.argtypes = [C.c_void_p, C.POINTER(_SetView), C.c_uint32]
     lib.cmpr_set_queries.argtypes = [C.c_void_p, C.POINTER(_SetView)]
+    lib.cmpr_set_reference_device.argtypes = [C.c_void_p, C.POINTER(_SetView), C.c_uint32]
+    lib.cmpr_set_queries_device.argtypes = [C.c_void_p, C.POINTER(_SetView)]
+    lib.cmpr_route_queries.argtypes = [C.c_void_p, C.POINTER(_SetView), C.c_uint64, C.c_uint32,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]
+    lib.cmpr_route_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.cmpr_set_queries_routed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64,
+                                            C.c_void_p]
     lib.cmpr_overlap_matrix.argtypes = [C.c_void_p, C.c_void_p]
     lib.cmpr_overlap_matrix_f64.argtypes = [C.c_void_p, C.c_void_p]
     lib.cmpr_overlap_matrix_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -139,7 +148,7 @@ def load_library() -> C.CDLL:
     lib.cmpr_cols.restype = C.c_uint32
     lib.cmpr_set_tunable.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cmpr_get_tunable.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
-    if lib.cmpr_abi_version() != 2:
+    if lib.cmpr_abi_version() != 3:
         raise RuntimeError("libcompairr_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -224,6 +233,51 @@ class HipOverlap:
     def set_queries(self, s: RepertoireSet) -> None:
         v = _view(s)
         self._check(self._lib.cmpr_set_queries(self._ctx, C.byref(v)))
+
+    # ---- sets that already live in HBM (include/compairr_hip.h: cmpr_set_*_device) ----
+
+    @staticmethod
+    def device_view(s: RepertoireSet, device="cuda"):
+        """(view of device pointers, the torch tensors that own the memory) of a set copied to
+        the GPU with torch -- the stand-in for a caller whose sets live in HBM."""
+        import torch
+        keep = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(device)
+                for a in (s.residues, s.offsets, s.v_gene, s.j_gene, s.repertoire, s.count)]
+        v = _SetView()
+        v.n = s.n
+        (v.residues, v.offsets, v.v_gene, v.j_gene, v.repertoire, v.count) = [t.data_ptr() for t in keep]
+        v.n_repertoires = s.n_repertoires
+        torch.cuda.synchronize()
+        return v, keep
+
+    def set_reference_device(self, view: _SetView, longest_query: int = 0) -> None:
+        self._check(self._lib.cmpr_set_reference_device(self._ctx, C.byref(view), longest_query))
+
+    def set_queries_device(self, view: _SetView) -> None:
+        self._check(self._lib.cmpr_set_queries_device(self._ctx, C.byref(view)))
+
+    # ---- one query set over N contexts (cmpr_route_queries / _pack / cmpr_set_queries_routed) ----
+
+    def route_queries(self, share: RepertoireSet, first_index: int, n_dest: int):
+        """Key `share` (its first sequence is number `first_index` of the whole set); returns
+        (records per destination, bytes per record, duplicate_count totals per repertoire)."""
+        v = _view(share)
+        counts = (C.c_uint64 * n_dest)()
+        rb = C.c_uint32()
+        tot = np.zeros(share.n_repertoires, dtype=np.float64)
+        self._check(self._lib.cmpr_route_queries(self._ctx, C.byref(v), first_index, n_dest, counts,
+                                                 C.byref(rb), tot.ctypes.data))
+        return np.array(list(counts), dtype=np.int64), rb.value, tot
+
+    def route_pack(self, d_send: int, capacity_bytes: int) -> None:
+        self._check(self._lib.cmpr_route_pack(self._ctx, C.c_void_p(d_send), capacity_bytes))
+
+    def set_queries_routed(self, d_records: int, n_records: int, n_repertoires: int, n_total: int,
+                           rep_totals: Optional[np.ndarray] = None) -> None:
+        t = None if rep_totals is None else np.ascontiguousarray(rep_totals, dtype=np.float64)
+        self._check(self._lib.cmpr_set_queries_routed(
+            self._ctx, C.c_void_p(d_records), n_records, n_repertoires, n_total,
+            None if t is None else t.ctypes.data))
 
     @property
     def shape(self):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CMPR_ABI_VERSION 2
+#define CMPR_ABI_VERSION 3
 
 enum {
   CMPR_OK          = 0,
@@ -147,9 +147,58 @@ int cmpr_set_reference(cmpr_context *ctx, const cmpr_set_view *set2,
  * (overlap.cc:799-825).  The context keeps its device allocations from call to
  * call (a second set of similar size costs no allocation).  With the work-shard
  * tunables set, only what this context works on is laid out (the queries are still
- * uploaded and keyed in full).
+ * uploaded and keyed in full; cmpr_route_queries below divides that too).
  */
 int cmpr_set_queries(cmpr_context *ctx, const cmpr_set_view *set1);
+
+/*
+ * The same two calls for sets that already live in HBM (a parser that writes to the
+ * device, a previous stage of a pipeline, another library): every pointer of the view is
+ * a DEVICE pointer on the context's device, same types and meaning as above.  Nothing
+ * crosses PCIe but two offsets (offsets[0], offsets[n]) and the layout's sizes; the set is
+ * validated on the device like a host set.  The reference set is copied (the library keeps
+ * its own arrays); the query arrays are read where they lie during the call and may be
+ * freed or overwritten once it has returned.  (The reference reads both sets where db.cc
+ * left them, db.cc:964-997 -- this is that, for a caller whose "where" is the GPU.)
+ */
+int cmpr_set_reference_device(cmpr_context *ctx, const cmpr_set_view *d_set2,
+                              uint32_t longest_query);
+int cmpr_set_queries_device(cmpr_context *ctx, const cmpr_set_view *d_set1);
+
+/*
+ * Multi-GPU layout of ONE query set over N contexts (one per GPU, tunables
+ * work_shard_count = N, work_shard_index = 0..N-1, the same reference set in each).
+ * The reference hands chunks of 1000 queries to its threads (overlap.cc:421-433) and
+ * sums their private matrices (overlap.cc:510-527); here the contexts divide the WORK of a
+ * step by filter slice, and the queries go where their work is:
+ *
+ *   1. every context is given ANY share of the set (e.g. the i-th N-th of it):
+ *      cmpr_route_queries() uploads and keys that share and says how many records go to
+ *      each of the n_dest contexts (counts_out[n_dest]; a query goes to the context that
+ *      works on its slice and to those that work on one of its class-position items --
+ *      1 to 2 destinations on CDR3 amino acids), the size of a record (*record_bytes_out,
+ *      a multiple of 16) and, if rep_totals_out is not NULL, the duplicate_count total
+ *      per repertoire of the share (n_repertoires doubles; summed over the shares they
+ *      bound the cells of the final matrix);
+ *   2. cmpr_route_pack() writes those records into a DEVICE buffer of the caller, grouped
+ *      by destination (destination d's run starts at record counts[0] + .. + counts[d-1]);
+ *   3. the caller moves the runs to their destinations -- one all-to-all over xGMI (RCCL)
+ *      or, inside one process, device-to-device copies;
+ *   4. every context receives with cmpr_set_queries_routed(): n_records records in device
+ *      memory (in any order), the number of repertoires and of sequences of the WHOLE set,
+ *      and optionally the summed totals of step 1 (NULL: this context's own share bounds
+ *      its own matrix only).
+ * After step 4 the context holds exactly what it works on; cmpr_overlap_* gives its part of
+ * the matrix, the parts add up to the whole (one sum-reduce), pair lists and -x rows carry
+ * the sequence numbers of the whole set (first_index + position in the share).
+ * Uploads and layout work divide by N; no context ever sees the whole set.
+ */
+int cmpr_route_queries(cmpr_context *ctx, const cmpr_set_view *share, uint64_t first_index,
+                       uint32_t n_dest, uint64_t *counts_out, uint32_t *record_bytes_out,
+                       double *rep_totals_out);
+int cmpr_route_pack(cmpr_context *ctx, void *d_send, uint64_t capacity_bytes);
+int cmpr_set_queries_routed(cmpr_context *ctx, const void *d_records, uint64_t n_records,
+                            uint32_t n_repertoires, uint64_t n_total, const double *rep_totals);
 
 /*
  * The per-query loop (sim_thread / process_variants / find_variant_matches,
@@ -267,9 +316,6 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              that put a new residue on a class position are grouped
                              by the slice they land in and probed there (1, and
                              the default -1), or probed where the filter lies (0)
-     "step_graph"            1: the steady-state step is replayed as one hipGraph per
-                             (output matrix, counter block) instead of three launches;
-                             default 0 (measured slower on ROCm 7.2)
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
      "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip
@@ -284,8 +330,8 @@ int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 /* Current value of a tunable (for the data-dependent ones, the value in effect
    after cmpr_set_reference / cmpr_set_queries), plus the read-only names
    "slices", "tiles", "chunks", "query_slots" (tiles x 64, padding included),
-   "never_overflows" (1: the redo pass is currently dropped), "graphs" (instantiated
-   step graphs) and, of the last cmpr_set_queries in microseconds, "layout_total_us",
+   "never_overflows" (1: the redo pass is currently dropped) and, of the last
+   cmpr_set_queries* / cmpr_route_queries in microseconds, "layout_total_us",
    "layout_upload_us" (host time inside the copy calls) and "layout_tail_us" (from the
    last copy to the end: the device work the upload did not hide). */
 int cmpr_get_tunable(cmpr_context *ctx, const char *name, int64_t *value);

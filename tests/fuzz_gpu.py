@@ -2,7 +2,8 @@
 """Randomised parity sweep on the GPU box: HIP path (through the C ABI) against the
 oracle over random inputs, options and layout tunables.  Not collected by pytest
 (run it by hand: `python tests/fuzz_gpu.py --seconds 300`); stops at the first
-mismatch and prints the configuration that produced it."""
+mismatch and prints the configuration that produced it.  A seeded, time-boxed slice of it
+runs in the GPU suite (tests/test_fuzz_gpu.py)."""
 
 import argparse
 import os
@@ -16,6 +17,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 import _oracle  # noqa: E402
+from _routed import routed_contexts  # noqa: E402
 from compairr_amd import HipOverlap, Options, synth  # noqa: E402
 
 
@@ -112,7 +114,32 @@ def main():
         shards = int(rng.integers(2, 6)) if (tun.get("variant", -1) != 0 and rng.random() < 0.2) else 1
         got, nmatch, nvar, npairs = None, 0, 0, 0
         ok = True
-        for index in range(shards):
+        # ... and sometimes the shards get their queries routed (every context keys a share,
+        # the records change hands: cmpr_route_queries / _pack / cmpr_set_queries_routed)
+        routed = shards > 1 and rng.random() < 0.5
+        if routed:
+            with HipOverlap(o) as h:
+                for k in ["variant"] + [k for k in tun if k != "variant"]:
+                    if k in tun:
+                        h.set_tunable(k, tun[k])
+                h.set_reference(b, a.longest)
+                routed = h.get_tunable("variant") != 0
+        if routed:
+            order = {k: tun[k] for k in ["variant"] + [k for k in tun if k != "variant"] if k in tun}
+            hs = routed_contexts(a, b, o, shards, order)
+            try:
+                for h in hs:
+                    m = h.overlap_matrix()
+                    st = h.stats()
+                    got = m if got is None else got + m
+                    nmatch += st.matches
+                    nvar += st.variants
+                    if n % 4 == 0:
+                        npairs += len(h.overlap_pairs())
+            finally:
+                for h in hs:
+                    h.close()
+        for index in range(0 if routed else shards):
             with HipOverlap(o) as h:
                 order = ["variant"] + [k for k in tun if k != "variant"]
                 for k in order:
@@ -144,7 +171,8 @@ def main():
             ok = npairs == ost.matches
         st = None
         if not ok:
-            print("MISMATCH after %d cases: n1=%d n2=%d opt=%s tun=%s shards=%d" % (n, a.n, b.n, o, tun, shards))
+            print("MISMATCH after %d cases: n1=%d n2=%d opt=%s tun=%s shards=%d routed=%s"
+                  % (n, a.n, b.n, o, tun, shards, routed))
             sys.exit(1)
         n += 1
     print("%d random cases, all bit-exact (%.0f s)" % (n, time.time() - t0))

@@ -40,11 +40,14 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
     plain = _run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
-                "cpu_baseline", "value_incl_layout", "parity_vs_n1"):
+                "cpu_baseline", "value_incl_layout", "value_incl_layout_cold", "value_from_device_soa",
+                "step_ms_incl_d2h", "parity_vs_reference_full_size"):
         assert key in plain, key
     assert plain["n_gpus"] == 1 and plain["steps"] == 3 and plain["value"] > 0
     assert plain["scaling"] == "strong" and plain["dtype"] == "u64"
     assert set(plain["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert plain["device_resident_inputs"]["same_matrix"] is True
+    assert plain["value_from_device_soa"] > plain["value_incl_layout"] > 0
     # the same workload through torch.distributed.run: process group on nccl (= RCCL),
     # all-reduce of the matrix inside every step
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
@@ -52,6 +55,14 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
                  "bench.py", "--gpus", "1"] + SMALL)
     assert dist["n_gpus"] == 1
     assert dist["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    # ... and the queries went through compairr_amd.dist.exchange_queries (route, pack, all-to-all, receive)
+    ex = dist["config"]["query_layout_ms"]["exchange"]
+    assert ex["records_sent"] == ex["records_received"] == 300000 and ex["record_bytes"] == 64
+    rep = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                "bench.py", "--gpus", "1", "--layout", "replicated"] + SMALL)
+    assert rep["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    assert rep["config"]["query_layout_ms"]["exchange"] is None
     # weak scaling keeps the same shard at N = 1
     weak = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "weak"] + SMALL)
     assert weak["scaling"] == "weak"

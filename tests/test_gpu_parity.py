@@ -9,6 +9,7 @@ import pytest
 
 import _full_size
 import _oracle
+from _routed import routed_contexts
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
 from conftest import (expected_of, expected_pairs_of, load_manifest, run_cli, sorted_pairs,
@@ -472,6 +473,242 @@ def test_work_shards_add_up(name, opt, nt, tun):
         assert e.value.code == 4               # CMPR_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("name,opt,nt,tun", [
+    ("aa_d1", dict(differences=1), False, {}),
+    ("aa_d1_indels", dict(differences=1, indels=True), False, {}),
+    ("aa_d2", dict(differences=2), False, {}),
+    ("nt_d1_sliced", dict(differences=1, nucleotides=True, ignore_genes=True), True, {}),
+    ("nt_d2_items", dict(differences=2, nucleotides=True, ignore_genes=True), True,
+     {"variant": 1, "slice_words_log2": 4, "class_residues": 4, "heavy_threshold": 2, "sub2_items": 1}),
+    ("aa_d1_sliced", dict(differences=1), False, {"variant": 1}),
+    ("aa_d1_small_slices", dict(differences=1), False, {"small_slice_tiles": 64}),
+])
+def test_work_shards_add_up(name, opt, nt, tun):
+    """bench.py --shard-by work: a context with work_shard_count = N does the work filed
+    under its share of the filter slices; the N matrices add up to the whole one, and
+    so do the counters -- although every context lays the queries out by itself."""
+    n = (1500 if nt else 3000) if opt.get("differences") == 2 else 60000
+    a = synth.make_set(n, 11, prefix="A", nucleotides=nt, pool_size=n // 2)
+    b = synth.make_set(n, 12, prefix="B", nucleotides=nt, pool_size=n // 2)
+    o = Options(**opt, **FULL)
+
+    def run(index, count):
+        with HipOverlap(o) as h:
+            for k, v in tun.items():
+                h.set_tunable(k, v)
+            h.set_tunable("work_shard_count", count)
+            h.set_tunable("work_shard_index", index)
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            m = h.overlap_matrix()
+            return m, h.stats().matches
+
+    whole, pairs = run(0, 1)
+    want, _ = _oracle.overlap(a, b, o, threads=8)
+    assert np.array_equal(whole, _oracle.integer_cells(want, o))
+    for count in (2, 5):
+        parts = [run(i, count) for i in range(count)]
+        assert np.array_equal(sum(p[0] for p in parts), whole), (name, count)
+        assert sum(p[1] for p in parts) == pairs
+        assert all(p[1] < pairs for p in parts)                  # nobody did everything
+    with HipOverlap(o) as h:
+        h.set_tunable("work_shard_count", 2)
+        h.set_tunable("work_shard_index", 2)
+        h.set_reference(b, a.longest)
+        with pytest.raises(hipmod.HipError):
+            h.set_queries(a)
+    with HipOverlap(o) as h:                   # the unsliced baseline kernel has no slices to deal out
+        h.set_tunable("variant", 0)
+        h.set_tunable("work_shard_count", 2)
+        h.set_reference(b, a.longest)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_queries(a)
+        assert e.value.code == 4               # CMPR_EUNSUPPORTED
+
+
+def routed_contexts(a, b, o, count, tun, shares=None):
+    """`count` contexts on this device, each given a contiguous share of `a` (or `shares`:
+    [(first index, subset)]); the records change hands with device-to-device copies -- what
+    the all-to-all of compairr_amd.dist.exchange_queries does between GPUs.  Returns the
+    contexts, laid out and ready."""
+    import torch
+    from compairr_amd.dist import shard_bounds
+    hs = []
+    for index in range(count):
+        h = HipOverlap(o)
+        for k, v in tun.items():
+            h.set_tunable(k, v)
+        h.set_tunable("work_shard_count", count)
+        h.set_tunable("work_shard_index", index)
+        h.set_reference(b, a.longest)
+        hs.append(h)
+    if shares is None:
+        shares = []
+        for index in range(count):
+            lo, hi = shard_bounds(a.n, index, count)
+            shares.append((lo, a.subset(slice(lo, hi))))
+    sends, totals, rb = [], np.zeros(a.n_repertoires), 0
+    for h, (first, share) in zip(hs, shares):
+        counts, rb, tot = h.route_queries(share, first, count)
+        totals += tot
+        buf = torch.empty(max(int(counts.sum()), 1) * rb, dtype=torch.uint8, device="cuda")
+        h.route_pack(buf.data_ptr(), int(counts.sum()) * rb)
+        sends.append((counts, buf))
+    for d, h in enumerate(hs):
+        runs = []
+        for counts, buf in sends:
+            start = int(counts[:d].sum()) * rb
+            runs.append(buf[start:start + int(counts[d]) * rb])
+        recv = torch.cat(runs) if runs else torch.empty(0, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        h.set_queries_routed(recv.data_ptr(), recv.numel() // rb, a.n_repertoires, a.n, totals)
+    return hs
+
+
+@pytest.mark.parametrize("name,opt,nt,tun", [
+    ("aa_d1", dict(differences=1), False, {}),
+    ("aa_d1_indels", dict(differences=1, indels=True), False, {}),
+    ("aa_d1_tiny_slices", dict(differences=1, indels=True), False,
+     {"slice_words_log2": 3, "class_residues": 3, "heavy_threshold": 0, "chunk_tiles": 2}),
+    ("aa_d2", dict(differences=2), False, {}),
+    ("aa_d0_x", dict(differences=0, existence=True), False, {}),
+    ("nt_d1_g", dict(differences=1, nucleotides=True, ignore_genes=True), True, {}),
+    ("nt_d1_indels_v1", dict(differences=1, indels=True, nucleotides=True), True, {"variant": 1}),
+    ("nt_d2_items", dict(differences=2, nucleotides=True, ignore_genes=True), True,
+     {"slice_words_log2": 4, "class_residues": 5, "heavy_threshold": 3, "sub2_items": 1}),
+    ("nt_d1_rows", dict(differences=1, nucleotides=True), True, {"variant": 2, "slice_words_log2": 3,
+                                                              "class_residues": 5, "heavy_threshold": 3}),
+])
+def test_routed_queries_add_up(name, opt, nt, tun):
+    """cmpr_route_queries / cmpr_route_pack / cmpr_set_queries_routed: every context uploads
+    and keys only its share of the queries, the records go where their work is, and the
+    contexts' matrices, counters and pair lists add up to the whole -- sequence numbers are
+    those of the whole set."""
+    n = (1500 if nt else 3000) if opt.get("differences") == 2 else 30000
+    a = synth.make_set(n, 11, prefix="A", nucleotides=nt, pool_size=n // 2)
+    b = synth.make_set(n, 12, prefix="B", nucleotides=nt, pool_size=n // 2)
+    if opt.get("existence"):
+        a = a.subset(slice(0, 1500))                         # (R1 = sequences: a small matrix)
+    o = Options(**opt, **FULL)
+    want, ost = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    with HipOverlap(o) as h:
+        for k, v in tun.items():
+            h.set_tunable(k, v)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        want_pairs = h.overlap_pairs()
+    for count in (1, 2, 5):
+        hs = routed_contexts(a, b, o, count, tun)
+        try:
+            parts = [h.overlap_matrix() for h in hs]
+            st = [h.stats() for h in hs]
+            assert all(p.shape == want.shape for p in parts)
+            assert np.array_equal(sum(parts), want), (name, count)
+            assert sum(x.matches for x in st) == ost.matches
+            assert sum(x.variants for x in st) == ost.variants
+            if count > 1 and ost.matches > 50 and not (tun.get("variant") == 1 and opt.get("indels")):
+                assert all(x.matches < ost.matches for x in st)         # nobody did everything
+                assert all(x.queries < a.n for x in st)                 # ... or held everything
+            pairs = np.concatenate([h.overlap_pairs() for h in hs])
+            pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+            assert np.array_equal(pairs, want_pairs), (name, count)
+            # a second launch on the routed layout, and a second query set through the same contexts
+            assert np.array_equal(sum(h.overlap_matrix() for h in hs), want)
+        finally:
+            for h in hs:
+                h.close()
+
+
+def test_routed_queries_uneven_shares_and_errors():
+    """Shares need not be contiguous N-ths: empty shares, one context holding everything, a
+    share in reverse order of ranks; and the calls out of order fail loudly."""
+    a = synth.make_set(20000, 31, prefix="A", pool_size=4000)
+    b = synth.make_set(20000, 32, prefix="B", pool_size=4000)
+    o = Options(differences=1, indels=True, **FULL)
+    want, _ = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    empty = a.subset(slice(0, 0))
+    for shares in ([(0, a), (a.n, empty), (a.n, empty)],
+                   [(a.n, empty), (0, a.subset(slice(0, 123))), (123, a.subset(slice(123, a.n)))]):
+        hs = routed_contexts(a, b, o, 3, {}, shares)
+        try:
+            assert np.array_equal(sum(h.overlap_matrix() for h in hs), want)
+        finally:
+            for h in hs:
+                h.close()
+    with HipOverlap(o) as h:
+        h.set_tunable("work_shard_count", 2)
+        h.set_reference(b, a.longest)
+        with pytest.raises(hipmod.HipError) as e:
+            h.route_pack(0, 0)                                       # nothing was routed
+        assert e.value.code == 5                                     # CMPR_ESTATE
+        with pytest.raises(hipmod.HipError) as e:
+            h.route_queries(a, 0, 3)                                 # n_dest != work_shard_count
+        assert e.value.code == 1
+        counts, rb, _ = h.route_queries(a, 0, 2)
+        assert rb == 64 and counts.sum() >= a.n
+        with pytest.raises(hipmod.HipError) as e:
+            h.route_pack(0, 0)                                       # buffer too small
+        assert e.value.code == 1
+        with pytest.raises(hipmod.HipError):
+            h.overlap_matrix()                                       # no queries are resident
+
+
+def test_device_resident_sets():
+    """cmpr_set_reference_device / cmpr_set_queries_device: both sets handed over as device
+    arrays give the matrix, the counters and the pair list of the host path; a set that is
+    not sound is refused from the device as it is from the host."""
+    import torch
+    for opt, nt in ((dict(differences=1, indels=True), False), (dict(differences=2, ignore_genes=True), True),
+                    (dict(differences=0, ignore_counts=True), False)):
+        n = 1500 if opt["differences"] == 2 else 40000
+        a = synth.make_set(n, 41, prefix="A", nucleotides=nt, pool_size=n // 2)
+        b = synth.make_set(n, 42, prefix="B", nucleotides=nt, pool_size=n // 2)
+        o = Options(nucleotides=nt, **opt, **FULL)
+        with HipOverlap(o) as h:
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            want, st0, pairs0 = h.overlap_matrix(), h.stats(), h.overlap_pairs()
+        with HipOverlap(o) as h:
+            vb, keep_b = h.device_view(b)
+            va, keep_a = h.device_view(a)
+            h.set_reference_device(vb, a.longest)
+            del keep_b                                   # (the library keeps its own copy of set 2)
+            h.set_queries_device(va)
+            for t in keep_a:
+                t.zero_()                                # ... and needs the query arrays during the call only
+            torch.cuda.synchronize()
+            assert np.array_equal(h.overlap_matrix(), want)
+            st = h.stats()
+            assert (st.matches, st.variants, st.queries) == (st0.matches, st0.variants, st0.queries)
+            assert np.array_equal(h.overlap_pairs(), pairs0)
+            assert h.count_duplicates() >= 0
+            # an empty query set from the device
+            ve, keep_e = h.device_view(a.subset(slice(0, 0)))
+            h.set_queries_device(ve)
+            assert h.overlap_matrix().sum() == 0
+    a = synth.make_set(5000, 43, prefix="A")
+    o = Options(differences=1, **FULL)
+    with HipOverlap(o) as h:
+        h.set_reference(a, a.longest)
+        bad = synth.make_set(5000, 44, prefix="B")
+        bad.repertoire[77] = 999                                       # repertoire number out of range
+        v, keep = h.device_view(bad)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_queries_device(v)
+        assert e.value.code == 1 and "repertoire" in str(e.value)
+        bad = synth.make_set(5000, 44, prefix="B")
+        bad.offsets[0] = 1
+        v, keep = h.device_view(bad)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_queries_device(v)
+        assert e.value.code == 1 and "offsets" in str(e.value)
+        with pytest.raises(hipmod.HipError) as e:
+            h.set_reference_device(v, 0)
+        assert e.value.code == 1
+
+
 def test_repeated_launches_with_and_without_redo_pass():
     """Variant 2 drops its redo launch once a finished launch has shown that the
     positives buffer has room to spare: every launch of a series gives the same matrix,
@@ -530,7 +767,13 @@ def test_overflow_without_redo_pass_is_never_silent():
         assert len(h.overlap_pairs()) == ost.matches
         # asynchronous entry point: the launch cannot look itself, cmpr_get_stats does
         t = torch.zeros(want.size, dtype=torch.int64, device="cuda")
-        s = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        # (stream NULL is the synchronous form of this entry point: checked like the others)
+        h.set_tunable("assume_never_overflows", 1)
+        h.overlap_matrix_device(t.data_ptr(), None)
+        assert np.array_equal(t.cpu().numpy().astype(np.uint64).reshape(want.shape), want)
+        assert h.stats().matches == ost.matches
+        s = torch.cuda.Stream()
         h.set_tunable("assume_never_overflows", 1)
         h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)
         h.overlap_matrix_device(t.data_ptr(), s.cuda_stream)      # (carries no redo pass either)
