@@ -20,14 +20,16 @@ HOST_SRC = $(HOST_CORE) compairr_amd/host/hip_backend.cc
 HOST_HDR = $(wildcard compairr_amd/host/*.h) include/compairr_hip.h
 KERN_DIR = compairr_amd/csrc
 KERN_HDR = $(KERN_DIR)/kernels.h $(KERN_DIR)/kernels_sliced.h $(KERN_DIR)/kernels_rows.h \
+           $(KERN_DIR)/kernels_pairs2.h \
            $(KERN_DIR)/layout.h $(KERN_DIR)/select.h $(KERN_DIR)/context.h include/compairr_hip.h
 OBJ_DIR  = compairr_amd/lib/obj
 # the probe kernels are instantiated per (kernel variant, waves per workgroup) in
 # their own translation units, so that `make -j` compiles them side by side
-TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o \
+TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o $(OBJ_DIR)/probe_pairs2.o \
            $(OBJ_DIR)/probe_v1_nw4.o $(OBJ_DIR)/probe_v1_nw8.o $(OBJ_DIR)/probe_v1_nw16.o \
            $(OBJ_DIR)/probe_v2_nw4.o $(OBJ_DIR)/probe_v2_nw8.o $(OBJ_DIR)/probe_v2_nw16.o \
-           $(OBJ_DIR)/probe_v2i_nw4.o $(OBJ_DIR)/probe_v2i_nw8.o $(OBJ_DIR)/probe_v2i_nw16.o
+           $(OBJ_DIR)/probe_v2i_nw4.o $(OBJ_DIR)/probe_v2i_nw8.o $(OBJ_DIR)/probe_v2i_nw16.o \
+           $(OBJ_DIR)/probe_v2f_nw4.o $(OBJ_DIR)/probe_v2f_nw8.o $(OBJ_DIR)/probe_v2f_nw16.o
 
 all: lib cli oracle
 
@@ -50,6 +52,10 @@ $(OBJ_DIR)/probe_v0.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=0 -c -o $@ $<
 
+$(OBJ_DIR)/probe_pairs2.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=3 -c -o $@ $<
+
 $(OBJ_DIR)/resolve.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=9 -c -o $@ $<
@@ -65,6 +71,10 @@ $(OBJ_DIR)/probe_v2_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 $(OBJ_DIR)/probe_v2i_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=1 -c -o $@ $<
+
+$(OBJ_DIR)/probe_v2f_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
+	@mkdir -p $(OBJ_DIR)
+	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=2 -c -o $@ $<
 
 $(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(OBJ_DIR)/ref_index.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^

@@ -60,8 +60,10 @@ def recorded_workload(args):
     import _full_size
     if args.scaling != "strong":
         return None
+    if args.repertoires != 16:
+        return None
     return _full_size.by_bench_args(args.refs, args.queries, args.differences, args.indels,
-                                    args.nucleotides, args.ignore_genes, args.self_cmp)
+                                    args.nucleotides, args.ignore_genes, args.self_cmp, args.law)
 
 
 def parse_args():
@@ -79,6 +81,10 @@ def parse_args():
                    help="--shard-by work under torch.distributed.run: every rank uploads and keys its N-th of "
                         "the queries and the records move to the ranks that work on them (default), or every "
                         "rank uploads and keys all queries (round 3)")
+    p.add_argument("--law", choices=["uniform", "cdr3"], default="uniform",
+                   help="generator law (compairr_amd/synth.py): the BASELINE one (uniform residues) or the "
+                        "robustness workload (conserved ends, skewed composition, Zipf clone sizes)")
+    p.add_argument("--repertoires", type=int, default=16, help="repertoires per set")
     p.add_argument("--differences", "-d", type=int, default=1)
     p.add_argument("--indels", action="store_true")
     p.add_argument("--nucleotides", action="store_true")
@@ -270,15 +276,18 @@ def main():
 
     # ---- synthetic workload (seeded; identical reference set on every rank) ----
     t0 = time.time()
+    law = dict(law=args.law) if args.law != "uniform" else {}
+    if args.repertoires != 16:
+        law["n_repertoires"] = args.repertoires
     ref = synth.make_set(args.refs, 2, prefix="B", nucleotides=args.nucleotides,
-                         pool_size=args.refs // 4)
+                         pool_size=args.refs // 4, **law)
     strong = args.scaling == "strong"
     if args.self_cmp:
         full = ref
         args.queries = ref.n
     else:
         full = synth.make_set(args.queries, 1 + (0 if strong else 1000 * rank), prefix="A",
-                              nucleotides=args.nucleotides, pool_size=args.refs // 4)
+                              nucleotides=args.nucleotides, pool_size=args.refs // 4, **law)
     by_work = strong and use_dist and args.shard_by == "work"
     routed = by_work and args.layout == "routed"
     if strong and world > 1 and not by_work:
@@ -535,7 +544,9 @@ def workload_name(args):
         human(args.queries), human(args.refs), "nucleotide" if args.nucleotides else "CDR3aa",
         args.differences, " --indels" if args.indels else " substitutions only" if args.differences else "",
         " --ignore-genes" if args.ignore_genes else ", V/J matched") + (
-        " (self comparison)" if getattr(args, "self_cmp", False) else "")
+        " (self comparison)" if getattr(args, "self_cmp", False) else "") + (
+        " [law %s]" % args.law if getattr(args, "law", "uniform") != "uniform" else "") + (
+        " [%d repertoires]" % args.repertoires if getattr(args, "repertoires", 16) != 16 else "")
 
 
 if __name__ == "__main__":

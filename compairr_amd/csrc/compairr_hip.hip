@@ -8,6 +8,7 @@
 #include "context.h"
 #include "kernels_sliced.h"
 #include "kernels_rows.h"
+#include "kernels_pairs2.h"
 #include "select.h"
 
 #include <algorithm>
@@ -31,6 +32,12 @@ std::string &cmpr_create_error()
 /* u64s behind the segment counters of the positives buffer: statistics, cursors,
    overflow flag, and the statistics + cursors of the redo pass */
 static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
+/* one counter block: the segment counters of the positives buffer, the tail above, the words
+   of the fused step and its per-segment counters (on lines of their own: they are polled) */
+static inline size_t ctr_block_words(uint64_t segments)
+{
+  return (size_t)segments * POS_CTR_STRIDE + CTR_TAIL + FUSE_WORDS + (size_t)segments * POS_CTR_STRIDE;
+}
 namespace {
 void use_counter_block(cmpr_context *c, int which);
 void invalidate_plan(cmpr_context *c);
@@ -196,6 +203,13 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipEventCreateWithFlags(&c->ev_usage, hipEventDisableTiming));
   CREATE_TRY(hipMalloc((void **)&c->d_usage, 2 * sizeof(unsigned long long)));
   CREATE_TRY(hipMemset(c->d_usage, 0, 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMalloc((void **)&c->d_phase, 4 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(c->d_phase, 0, 4 * sizeof(unsigned long long)));
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0)
+      c->wall_clock_khz = khz;
+  }
   CREATE_TRY(hipHostMalloc((void **)&c->h_usage, 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->h_usage[0] = c->h_usage[1] = 0;
   CREATE_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -237,7 +251,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
   c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
-  c->qhins.release(); c->qhdel.release(); c->items.release(); c->cpk.release(); c->slice_items.release(); c->qrec.release();
+  c->qhins.release(); c->qhdel.release(); c->items.release(); c->cpk.release(); c->qpk.release(); c->slice_items.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
   for (uint32_t i = 0; i < cmpr_context::TIME_RING; i++) {
@@ -248,6 +262,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->ev_usage) (void)hipEventDestroy(c->ev_usage);
   if (c->d_usage) (void)hipFree(c->d_usage);
+  if (c->d_phase) (void)hipFree(c->d_phase);
   if (c->h_usage) (void)hipHostFree(c->h_usage);
   c->arena_a.release();
   c->arena_b.release();
@@ -350,6 +365,20 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "deferred_resolve must be 0 or 1");
     c->deferred_resolve = value;
+  } else if (n == "d2_pairs") {
+    if (value < -1 || value > 1)
+      return fail(c, CMPR_EINVAL, "d2_pairs must be -1 (auto), 0 or 1");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set d2_pairs before cmpr_set_reference");
+    c->d2_pairs = value;
+  } else if (n == "fused_step") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "fused_step must be 0 or 1");
+    c->fused_step = value;
+  } else if (n == "merge_reduce") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "merge_reduce must be 0 or 1");
+    c->merge_reduce = value;
   } else if (n == "narrow_upload") {
     if (value < -1 || value > 1)
       return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
@@ -359,6 +388,7 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     /* TEST ONLY: the next launch runs without redo pass as if the margin had been
        shown (tests/test_gpu_parity.py forces an overflow behind it) */
     c->force_no_redo = value != 0;
+    c->usage_pending = false;               /* (a measurement in flight would overrule the pretence) */
     affects_plan = false;
   } else if (n == "resolve_blocks_per_cu") {
     if (value < 1 || value > 8)
@@ -438,6 +468,9 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->plan.valid ? (int64_t)c->plan.nw : c->waves_per_block;
   else if (n == "narrow_upload") *value = c->narrow_upload;
+  else if (n == "d2_pairs") *value = c->have_ref ? (c->d2pairs ? 1 : 0) : c->d2_pairs;
+  else if (n == "fused_step") *value = c->plan.valid ? (c->plan.ffn ? 1 : 0) : c->fused_step;
+  else if (n == "merge_reduce") *value = c->merge_reduce;
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
   else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);
@@ -620,6 +653,8 @@ static int retire_queries(cmpr_context *c)
   c->usage_pending = c->never_overflows = false;
   c->last_without_redo = false;
   c->events_valid = false;
+  c->calls = 0;
+  HIP_TRY(c, hipMemsetAsync(c->d_phase, 0, 4 * sizeof(unsigned long long), c->stream));
   invalidate_plan(c);
   return CMPR_OK;
 }
@@ -677,7 +712,7 @@ static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
        statistics + cursors of a redo pass (kernels_rows.h) */
     /* (two of them: a launch uses one and clears the other for the next launch --
        reduce_partials_kernel -- so that a step starts without a memset) */
-    if ((rc = dev_reserve(c, c->pos_ctr, 2 * (S * POS_CTR_STRIDE + CTR_TAIL)))) return rc;
+    if ((rc = dev_reserve(c, c->pos_ctr, 2 * ctr_block_words(S)))) return rc;
     c->ctr_clean = false;
     use_counter_block(c, 0);
     /* partial results of the workgroups (ProbeParams::part); cleared here, and by
@@ -703,7 +738,7 @@ namespace {
 /* the counter block a launch works with (block 0 or 1 of pos_ctr's allocation) */
 void use_counter_block(cmpr_context *c, int which)
 {
-  const size_t blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
+  const size_t blk = ctr_block_words((uint64_t)c->pos_segments);
   c->ctr_cur = c->pos_ctr.p + (size_t)which * blk;
   c->ctr_other = c->pos_ctr.p + (size_t)(1 - which) * blk;
   c->d_stats = c->ctr_cur + (size_t)c->pos_segments * POS_CTR_STRIDE;
@@ -711,6 +746,7 @@ void use_counter_block(cmpr_context *c, int which)
   c->d_overflow = c->d_stats + STAT_COUNT + 1;
   c->d_stats2 = c->d_overflow + 1;
   c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
+  c->d_fuse = c->d_stats + CTR_TAIL;
 }
 
 /* the cached plan is stale (sets or tunables changed) */
@@ -728,14 +764,15 @@ int make_plan(cmpr_context *c)
   S = StepPlan();
   const size_t cells = (size_t)c->R1 * c->R2;
   S.cells = cells;
-  S.ctr_blk = (size_t)c->pos_segments * POS_CTR_STRIDE + CTR_TAIL;
+  S.ctr_blk = ctr_block_words((uint64_t)c->pos_segments);
   S.will_launch = c->ntiles > 0 && cells > 0;
   S.deferred = c->sliced && c->deferred_resolve;
   /* (variant 2 resolving inline adds to the matrix where it lies: cleared before, not
      written by the reduce kernel) */
-  const bool rows_inline = c->rows && !S.deferred;
+  const bool rows_inline = c->rows && !c->d2pairs && !S.deferred;
   S.reduce_writes = S.will_launch && cells <= 2048 && !is_f64_score(c->opt) && !rows_inline;
-  S.redo_kind = c->rows && S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
+  /* (kernels_pairs2.h resolves what does not fit its buffer inline: no redo launch) */
+  S.redo_kind = c->rows && !c->d2pairs && S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
   S.nw = c->sliced ? (uint32_t)c->waves_per_block : WAVES_PER_BLOCK;
   if (!S.will_launch) {
     S.valid = true;
@@ -772,6 +809,7 @@ int make_plan(cmpr_context *c)
   P.qhdel = c->qhdel.p;
   P.items = c->items.p;
   P.cpk = c->cpk.p;
+  P.qpk = c->qpk.p;
   P.slice_items = c->slice_items.p;
   P.ntiles = c->ntiles;
   P.first_tile = 0;
@@ -825,6 +863,36 @@ int make_plan(cmpr_context *c)
            (size_t)c->chunk_cap * sizeof(TileRef);
     return b;
   };
+  if (c->d2pairs) {
+    /* kernels_pairs2.h: one workgroup of 16 waves per CU, two slice buffers */
+    nw = 16;
+    const size_t npairs = ((size_t)c->zpos + 1) / 2;
+    const size_t lds2 = 2 * (size_t)c->geom.rw_words * ROW_WORD_BYTES +
+                        (16 * (size_t)c->zpos + P2_PZ * npairs) * sizeof(uint64_t) +
+                        (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) + 16 * sizeof(WaveQueue) +
+                        MAX_CLASS_RES * A * sizeof(uint32_t) + 2 * sizeof(P2Slot) +
+                        2 * (size_t)c->chunk_cap * sizeof(TileRef);
+    if (lds2 > 160 * 1024)
+      return fail(c, CMPR_EUNSUPPORTED, "the pair-row kernel of d = 2 does not fit the 160 KiB LDS");
+    ProbeFn fn = select_probe_pairs2(!c->opt.ignore_genes);
+    if (lds2 > 48 * 1024)
+      HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    P.chunk_cap = c->chunk_cap;
+    uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->cus, (uint64_t)c->nchunks));
+    S.fn = fn;
+    S.grid = (uint32_t)grid;
+    S.nw = 16;
+    S.lds = lds2;
+    if (S.deferred) {
+      S.rlds = (BLOCK_THREADS / WAVE) * sizeof(CandQueue) +
+               (P.lds_matrix ? cells * sizeof(unsigned long long) : 0);
+      uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
+      S.rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
+      S.rfn = select_resolve(!c->opt.ignore_genes);
+    }
+    S.valid = true;
+    return CMPR_OK;
+  }
   size_t lds = lds_for(nw);
   while (lds > 160 * 1024 && c->sliced && nw > 4) {
     nw /= 2;                             /* long sequences: fewer wave queues */
@@ -867,6 +935,29 @@ int make_plan(cmpr_context *c)
     uint32_t rgrid = (uint32_t)c->cus * (uint32_t)c->resolve_blocks_per_cu;
     S.rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
     S.rfn = select_resolve(!c->opt.ignore_genes);
+  }
+  /* One launch per step: the fast form of variant 2 whose workgroups go on to resolve the
+     queued positives and whose last workgroup sums the partial results (kernels_rows.h
+     fused_tail) -- when the matrix is privatised in LDS (a late overflow must be able to
+     take back what was added) and a 64-bit set names the segments.  Pairs mode (matches are
+     listed where they are found) keeps the three kernels. */
+  if (c->rows && S.deferred && c->fused_step && P.lds_matrix && S.reduce_writes && P.pos_segments <= 64 &&
+      !(c->debug & DBG_SKIP_RESOLVE)) {
+    S.ffn = nw == 4 ? select_probe_v2_fused_nw4((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
+          : nw == 16 ? select_probe_v2_fused_nw16((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
+                     : select_probe_v2_fused_nw8((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes);
+    S.flds = std::max(lds, (size_t)nw * sizeof(CandQueue) + cells * sizeof(unsigned long long) + 64);
+    if (S.flds > 160 * 1024) {
+      S.ffn = nullptr;
+    } else {
+      if (S.flds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)S.ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.flds));
+      /* every workgroup of the grid is resident at once (those that are through wait for the rest) */
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)S.ffn, nw * WAVE, S.flds) != hipSuccess ||
+          (uint64_t)occ * (uint64_t)c->cus < (uint64_t)S.grid)
+        S.ffn = nullptr;
+    }
   }
   if (S.redo_kind) {
     /* the redo pass (issue_step) */
@@ -923,6 +1014,47 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     P.pos_ctr = c->ctr_cur;
   if (c->rows && S.deferred)
     P.overflow = c->d_overflow;
+  /* a launch of variant 2 without redo pass leaves word of an overflow behind */
+  unsigned long long *sticky = (S.redo_kind && !a.with_redo) ? c->d_usage + 1 : nullptr;
+  const bool fused = S.ffn != nullptr && !c->pair_count;
+  c->last_fused = fused;
+  if (fused) {
+    /* one launch: probe, resolve and the sum of the partial results (kernels_rows.h fused_tail) */
+    if (a.track_usage)
+      HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
+    P.fuse = c->d_fuse;
+    P.phase = c->d_phase;
+    P.next_ctr = c->ctr_other;
+    P.next_n64 = (uint32_t)S.ctr_blk;
+    P.reduce_cells = (uint32_t)cells;
+    P.usage = a.track_usage ? c->d_usage : nullptr;
+    P.sticky = sticky;
+    hipLaunchKernelGGL(S.ffn, dim3(S.grid), dim3(S.nw * WAVE), S.flds, st, P);
+    HIP_TRY(c, hipGetLastError());
+    c->launches = 1;
+    if (ev_km)
+      HIP_TRY(c, hipEventRecord(ev_km, st));
+    if (a.track_usage) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_usage, c->d_usage, sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipEventRecord(c->ev_usage, st));
+      c->usage_pending = true;
+      c->usage_grid = S.grid;
+      c->usage_nw = S.nw;
+    }
+    if (a.with_redo) {
+      ProbeParams P2 = P;
+      P2.pos_buf = nullptr;
+      P2.part = nullptr;                  /* (straight into matrix and stats2) */
+      P2.redo = 1;
+      P2.stats = c->d_stats2;
+      P2.tile_counter = c->d_tile_counter2;
+      hipLaunchKernelGGL(S.fn2, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P2);
+      HIP_TRY(c, hipGetLastError());
+      c->launches = 2;
+    }
+    return CMPR_OK;
+  }
   hipLaunchKernelGGL(S.fn, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P);
   HIP_TRY(c, hipGetLastError());
   c->launches = 1;
@@ -930,8 +1062,6 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     HIP_TRY(c, hipEventRecord(ev_km, st));
   if (a.track_usage)
     HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
-  /* a launch of variant 2 without redo pass leaves word of an overflow behind */
-  unsigned long long *sticky = (S.redo_kind && !a.with_redo) ? c->d_usage + 1 : nullptr;
   auto reduce_partials = [&]() {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
                        (uint32_t)(P.lds_matrix ? cells : 0), S.reduce_writes ? 1u : 0u, c->ctr_other,
@@ -943,8 +1073,18 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     HIP_TRY(c, hipGetLastError());
     return CMPR_OK;
   }
+  if (c->merge_reduce) {
+    /* the last workgroup of resolve_kernel sums the partial results: no reduce launch (kernels.h reduce_last) */
+    P.fuse = c->d_fuse;
+    P.next_ctr = c->ctr_other;
+    P.next_n64 = (uint32_t)S.ctr_blk;
+    P.reduce_cells = (uint32_t)(P.lds_matrix ? cells : 0);
+    P.usage = a.track_usage ? c->d_usage : nullptr;
+    P.sticky = sticky;
+  }
   hipLaunchKernelGGL(S.rfn, dim3(S.rgrid), dim3(BLOCK_THREADS), S.rlds, st, P);
-  reduce_partials();
+  if (!c->merge_reduce)
+    reduce_partials();
   HIP_TRY(c, hipGetLastError());
   c->launches = 2;
   if (a.track_usage) {
@@ -1043,7 +1183,18 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 
   if (!back_to_back)
     HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-  if ((rc = issue_step(c, a, st, c->ev_km)))
+  /* (the fused step is one kernel: no event between probe and resolve -- a packet the stream
+     would wait ~4.5 us for; the split comes from the kernel's own clock reads, d_phase) */
+  const bool one_kernel = S.will_launch && S.ffn != nullptr && !c->pair_count;
+  {
+    const uint32_t slot = (uint32_t)((c->calls - 1) % cmpr_context::TIME_RING);
+    const bool mid_is_end = one_kernel && !a.with_redo;
+    if (mid_is_end)
+      c->ev_km = c->ev_k1;
+    c->ring_mid[slot] = c->ev_km;
+    c->ring_fused[slot] = one_kernel;
+  }
+  if ((rc = issue_step(c, a, st, c->ev_km == c->ev_k1 ? nullptr : c->ev_km)))
     return rc;
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
   c->ctr_clean = true;
@@ -1263,11 +1414,15 @@ extern "C" int cmpr_get_kernel_times(cmpr_context *c, uint32_t max, double *kern
   /* (one less than the ring holds: the start of the oldest call may be the end event of the
      call before it, whose ring entry the newest call has just taken) */
   uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max, c->calls), cmpr_context::TIME_RING - 1);
+  unsigned long long phase[4] = {0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpy(phase, c->d_phase, sizeof phase, hipMemcpyDeviceToHost));
   for (uint64_t k = 0; k < n; k++) {
     const uint32_t slot = (uint32_t)((c->calls - n + k) % cmpr_context::TIME_RING);
     float a = 0, b = 0;
     HIP_TRY(c, hipEventElapsedTime(&a, c->ring_start[slot], c->ring_k1[slot]));
-    HIP_TRY(c, hipEventElapsedTime(&b, c->ring_start[slot], c->ring_km[slot]));
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ring_start[slot], c->ring_mid[slot]));
+    if (c->ring_fused[slot] && phase[1] > 0)      /* the probe phase's share of the fused kernel, by its own clock */
+      b = (float)(b * ((double)phase[0] / (double)phase[1]));
     if (kernel_ms)
       kernel_ms[k] = a;
     if (probe_ms)
@@ -1309,6 +1464,14 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
   float p_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&p_ms, c->ev_k0, c->ev_km));
+  if (c->last_fused) {
+    /* one kernel: its probe phase by its own clock (wall_clock64: start of the first workgroup
+       to the last workgroup's last probe) */
+    unsigned long long phase[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpy(phase, c->d_phase, sizeof phase, hipMemcpyDeviceToHost));
+    if (phase[3] > 0)
+      p_ms = (float)(p_ms * ((double)phase[2] / (double)phase[3]));
+  }
   HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_k0, ev_end));
   memset(out, 0, sizeof *out);
   out->queries = c->n1;

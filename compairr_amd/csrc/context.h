@@ -72,6 +72,8 @@ struct StepPlan {
   size_t   cells = 0, ctr_blk = 0;
   cmpr::ProbeParams P{};            /* the per-launch fields are filled in at enqueue */
   cmpr::ProbeFn fn = nullptr, fn2 = nullptr, rfn = nullptr;
+  cmpr::ProbeFn ffn = nullptr;      /* the fused step (probe + resolve + reduce in one launch), when it applies */
+  size_t   flds = 0;
   uint32_t grid = 0, nw = 0, rgrid = 0;
   size_t   lds = 0, rlds = 0;
 };
@@ -117,6 +119,9 @@ struct cmpr_context {
   hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
   hipEvent_t   ring_start[TIME_RING] = {};   /* start event of the call in this slot: its own k0, or the
                                                 previous call's k1 when the two ran back to back */
+  hipEvent_t   ring_mid[TIME_RING] = {};     /* end of its probe kernel: its km -- or, for the fused step, whose
+                                                one kernel is the whole step, its k1 (no event packet between) */
+  bool         ring_fused[TIME_RING] = {};
   uint64_t     calls = 0;            /* overlap launches so far */
   hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
   bool         events_valid = false;
@@ -144,6 +149,11 @@ struct cmpr_context {
   int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
   int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
+  int64_t fused_step = 0;         /* variant 2: ... or by the probe kernel's own workgroups once all of them are
+                                     through with their chunks (one launch per step; kernels_rows.h fused_tail).
+                                     OFF: measured slower (device-scope round trips and
+                                     whole-L2 fences cost more than the two launches they save) */
+  int64_t merge_reduce = 1;       /* the last workgroup of resolve_kernel sums the partial results (no reduce launch) */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
   int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
   int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
@@ -204,6 +214,9 @@ struct cmpr_context {
   DevBuf<cmpr::ItemRec> items;
   DevBuf<uint32_t>  slice_items;     /* sub2 items: per slice {first item, blocks} (layout.h CHUNK_WITH_ITEMS) */
   DevBuf<cmpr::ResPack> cpk;             /* sub2 items: the query's residues, 2 bits each */
+  DevBuf<cmpr::ResPack> qpk;             /* nucleotides, d = 2 on pair rows: per slot, the query's residues */
+  bool              d2pairs = false;    /* ... that kernel is in use (kernels_pairs2.h; decided with the index) */
+  int64_t           d2_pairs = -1;      /* tunable: -1 auto, 0 off, 1 on */
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;
@@ -248,6 +261,10 @@ struct cmpr_context {
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */
+  unsigned long long        *d_fuse = nullptr;         /* fused step: its words of the counter block (layout.h) */
+  unsigned long long        *d_phase = nullptr;        /* fused step: probe / kernel ticks (persistent, 4 u64) */
+  double                     wall_clock_khz = 100000.0;
+  bool                       last_fused = false;       /* the last launch was the fused kernel */
   uint32_t                  *d_tile_counter2 = nullptr;
   DevBuf<unsigned long long> part;           /* NPART x part_stride partial results */
   uint32_t                   part_stride = 0;
@@ -352,10 +369,11 @@ int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uin
 /* ref_index.hip: cmpr_set_reference (on_device: the view holds device pointers) */
 int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longest_query, bool on_device);
 
-/* variant 2, d = 1 (with or without -i): the filter holds pair rows (kernels_rows.h) */
+/* variant 2, d = 1 (with or without -i): the filter holds pair rows (kernels_rows.h); so does
+   that of nucleotides at d = 2 when kernels_pairs2.h probes it */
 inline bool pair_rows(const cmpr_context *c)
 {
-  return c->rows && c->opt.differences == 1;
+  return c->rows && (c->opt.differences == 1 || c->d2pairs);
 }
 
 #endif

@@ -622,6 +622,65 @@ reduce_partials_kernel(const ProbeParams P, uint32_t cells, uint32_t overwrite,
   }
 }
 
+__device__ __forceinline__ unsigned long long load_agent(const unsigned long long *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* What reduce_partials_kernel does, done by the LAST workgroup of the kernel that produced the
+   partial results (the one that draws ticket gridDim.x - 1 from ProbeParams::fuse[0] after its
+   own atomics have been acknowledged): no launch of its own.  Everything it reads was written
+   with device-scope atomics and is read with device-scope loads -- no cache is written back or
+   invalidated for it.  NT threads; ProbeParams::reduce_cells, next_ctr, usage, sticky as for
+   the kernel. */
+template <uint32_t NT>
+__device__ __forceinline__ void reduce_last(const ProbeParams &P, unsigned long long *t_probe)
+{
+  const uint32_t S = P.pos_segments, cells = P.reduce_cells;
+  const bool ovf = P.overflow && load_agent(P.overflow) != 0ull;
+  if (threadIdx.x == 0 && P.sticky && ovf)
+    *P.sticky = 1ull;
+  if (P.usage && P.pos_ctr)
+    for (uint32_t g = threadIdx.x; g < S; g += NT)
+      atomicMax(P.usage, load_agent(P.pos_ctr + (size_t)g * POS_CTR_STRIDE));
+  if (t_probe) {
+    t_probe[0] = ~load_agent(P.fuse + 2);
+    t_probe[1] = load_agent(P.fuse + 3);
+  }
+  __syncthreads();                               /* (the words above are read before the block is cleared) */
+  for (uint32_t k = threadIdx.x; k < P.next_n64; k += NT)
+    P.next_ctr[k] = 0;
+  /* value i of the partial slots: four lanes, a quarter of the NPART slots each */
+  const uint32_t stride = P.part_stride;
+  for (uint32_t i0 = 0; i0 < stride; i0 += NT / 4u) {
+    const uint32_t i = i0 + threadIdx.x / 4u, q = threadIdx.x & 3u;
+    unsigned long long x = 0;
+    if (i < stride) {
+#pragma unroll 1
+      for (uint32_t r0 = 0; r0 < NPART / 4; r0 += 8) {       /* eight loads in flight at a time */
+        unsigned long long v[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++)
+          v[r] = load_agent(P.part + (size_t)(q + 4u * (r0 + r)) * stride + i);
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+          x += v[r];
+          if (v[r])
+            P.part[(size_t)(q + 4u * (r0 + r)) * stride + i] = 0;
+        }
+      }
+    }
+    x += __shfl_xor(x, 1, WAVE);
+    x += __shfl_xor(x, 2, WAVE);
+    if (q == 0u && i < stride) {
+      if (i < cells)
+        P.matrix[i] = ovf ? 0ull : x;            /* (a redo pass adds to a clean matrix) */
+      else if (x && i >= stride - STAT_COUNT)
+        P.stats[i - (stride - STAT_COUNT)] += x;
+    }
+  }
+}
+
 /* Second kernel of the deferred mode.  Phase A, one lane per queued Bloom
    positive: walk the probe chain comparing keys only (find_variant_matches,
    overlap.cc:168-251) and queue every key match; phase B, whenever 64
@@ -648,8 +707,7 @@ resolve_kernel(const ProbeParams P)
      b % pos_segments, together with the gridDim.x / pos_segments - 1 others */
   /* a probe launch whose positives did not all fit is redone with inline resolve
      (kernels_rows.h): what did fit is not to be counted twice */
-  if (P.overflow && *(volatile unsigned long long *)P.overflow != 0ull)
-    return;
+  const bool skip = P.overflow && *(volatile unsigned long long *)P.overflow != 0ull;
   const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
   const uint32_t seg_block = blockIdx.x / P.pos_segments;
   const uint32_t seg_blocks = gridDim.x / P.pos_segments;
@@ -659,6 +717,8 @@ resolve_kernel(const ProbeParams P)
   const unsigned long long lim = ~ctr[1];
   if (lim < n)
     n = lim;                                  /* claims past the capacity were not written */
+  if (skip)
+    n = 0;
   const uint32_t lane = lane_id();
   LaneStats st{0ull, 0u, 0u, 0u};
   int qn = 0;
@@ -730,6 +790,19 @@ resolve_kernel(const ProbeParams P)
       if (x)
         atomicAdd(matrix_dst(P) + i, x);
     }
+  }
+  /* The sum of the partial results, by the workgroup that is through last (P.fuse != NULL:
+     the step then has no reduce launch; round 4).  Its inputs are device-scope atomics
+     (acknowledged: vmcnt), read with device-scope loads. */
+  if (P.fuse) {
+    __shared__ uint32_t ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      ticket = (uint32_t)atomicAdd(P.fuse, 1ull);
+    __syncthreads();
+    if (ticket == gridDim.x - 1u)
+      reduce_last<BLOCK_THREADS>(P, nullptr);
   }
 }
 

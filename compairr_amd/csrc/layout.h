@@ -203,6 +203,7 @@ struct Chunk {
 constexpr uint32_t CHUNK_WITH_ITEMS = 0x100u;
 constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
+constexpr uint32_t FUSE_WORDS = 16;          /* ProbeParams::fuse: global words of the fused step, one line */
 
 /* entries per position of the sliced kernel's LDS copy of the Zobrist table:
    amino-acid rows are stored twice in a line (kernels_sliced.h row_lds_others) */
@@ -307,7 +308,9 @@ struct ProbeParams {
                                       the rolling indel enumeration              */
   const ItemRec  *items;           /* variant 2 class rows / variant 1 sub2: the flat items       */
   const ResPack  *cpk;             /* variant 1 sub2 items: the query's residues, 2 bits each
-                                      (<= RESPACK_MAX positions); ItemRec::w then holds the query's hash */
+                                      (<= RESPACK_MAX positions); ItemRec::w then holds the query's hash.
+                                      kernels_pairs2.h items: the same residues beside the pair-blanked hash */
+  const ResPack  *qpk;             /* kernels_pairs2.h: per slot, the query's residues, 2 bits each */
   const uint32_t *qrep;
   const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
@@ -349,6 +352,21 @@ struct ProbeParams {
                                        whose positives did not fit: resolve_kernel
                                        skips, the redo launch does the step inline;
                                        NULL for kernels that resolve inline instead  */
+  /* fused step (kernels_rows.h probe_rows_kernel<.., FUSED>): the probe kernel's workgroups go
+     on to walk, verify and score the queued positives themselves -- segment by segment, as
+     the workgroups that fill a segment finish probing -- and the last of them sums the
+     partial results: one launch per step.  `fuse` = FUSE_WORDS u64 ([0] workgroups through
+     with everything, [1] ... with probing, [2] max of ~(start tick), [3] max of the tick
+     probing ended at), then POS_CTR_STRIDE u64 per segment ([0] writers finished, [1] next
+     block to resolve): zeroed with the counter block.  `phase` (persistent): [0] sum of probe
+     ticks, [1] sum of kernel ticks since it was cleared, [2], [3] those of the last launch. */
+  unsigned long long *fuse;
+  unsigned long long *phase;
+  unsigned long long *next_ctr;      /* the counter block of the NEXT launch, cleared by the last workgroup */
+  uint32_t            next_n64;
+  uint32_t            reduce_cells;  /* cells summed from the partial slots (0: the matrix is added to where it lies) */
+  unsigned long long *usage;         /* see reduce_partials_kernel */
+  unsigned long long *sticky;
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
   unsigned long long *pair_count;   /* NULL: matrix mode                        */

@@ -1,11 +1,14 @@
 /*
  * probe_tu.hip -- one translation unit per (kernel variant, workgroup size):
  * compiled with -DTU_VARIANT=0|1|2|9, -DTU_NW=4|8|16 (variants 1, 2) and
- * -DTU_INLINE=0|1 (variant 2: the fast form / the form that resolves inline).
- * TU_VARIANT 9 = resolve_kernel.
+ * -DTU_INLINE=0|1|2 (variant 2: the fast form / the form that resolves inline / the fused
+ * step, whose workgroups resolve the queued positives themselves).
+ * TU_VARIANT 9 = resolve_kernel, 3 = probe_pairs2_kernel.
  */
 #include "select.h"
-#if TU_VARIANT == 2
+#if TU_VARIANT == 3
+#include "kernels_pairs2.h"
+#elif TU_VARIANT == 2
 #include "kernels_rows.h"
 #elif TU_VARIANT == 1
 #include "kernels_sliced.h"
@@ -24,6 +27,9 @@ namespace cmpr {
 #elif TU_VARIANT == 1
 #define KERNEL(A_, D_, I_, G_) probe_sliced_kernel<A_, D_, I_, G_, TU_NW>
 #define SELECT_NAME CAT(select_probe_v1_nw, TU_NW)
+#elif TU_VARIANT == 2 && TU_INLINE == 2
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false, true>
+#define SELECT_NAME CAT(select_probe_v2_fused_nw, TU_NW)
 #elif TU_VARIANT == 2 && TU_INLINE
 #define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true>
 #define SELECT_NAME CAT(select_probe_v2_inline_nw, TU_NW)
@@ -36,6 +42,12 @@ namespace cmpr {
 ProbeFn select_resolve(bool genes)
 {
   return genes ? (ProbeFn)resolve_kernel<true> : (ProbeFn)resolve_kernel<false>;
+}
+#elif TU_VARIANT == 3
+/* nucleotides, d = 2, pair rows (kernels_pairs2.h): 16 waves per workgroup */
+ProbeFn select_probe_pairs2(bool genes)
+{
+  return genes ? (ProbeFn)probe_pairs2_kernel<true, 16> : (ProbeFn)probe_pairs2_kernel<false, 16>;
 }
 #else
 ProbeFn SELECT_NAME(int A, int D, bool indels, bool genes)

@@ -108,6 +108,9 @@ struct QL {
   uint32_t        A, zpos, n_v, longest, per_slice;   /* longest: the longest a query may be (zpos - 3) */
   uint32_t        genes, counts, existence, indels, differences, sliced, rows;
   uint32_t        pairs;             /* variant 2: pair rows (kernels_rows.h) */
+  uint32_t        pairs2;            /* ... probed by kernels_pairs2.h (nucleotides, d = 2): residues packed per slot
+                                        (qpk) and per item (cpk) */
+  cmpr::ResPack  *qpk;
   const uint64_t *zob;
   SliceGeom       geom;
   uint32_t        npass;             /* 1 + class-row passes (variant 2) */
@@ -894,6 +897,16 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
   } else if (Q.genes) {
     Q.qgh[slot] = a.h;
   }
+  if (Q.pairs2) {
+    /* kernels_pairs2.h reads a query's residues two bits each, one 24-byte piece per slot */
+    cmpr::ResPack pk{};
+    if (valid) {
+      const uint8_t *s = Q.res + Q.off[a.src];
+      for (uint32_t x = 0; x < qr.len && x < RESPACK_MAX; x++)
+        pk.w[x >> 4] |= ((uint32_t)s[x] & 3u) << ((x & 15u) * 2u);
+    }
+    Q.qpk[slot] = pk;
+  }
   /* residues four to a dword, position-major / lane-minor; the first nine dwords are in
      the record, longer sequences fetch the rest where the caller's residues lie */
   uint32_t *dst = Q.qres + td.res_base + lane;
@@ -998,6 +1011,12 @@ place_items_kernel(const QL Q)
   const bool heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, class_base_of(Q, i));
   uint64_t hq = 0;
   cmpr::ResPack pk{};
+  if (Q.pairs2 && heavy) {
+    const uint64_t b = Q.off[i];
+    const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
+    for (uint32_t x = 0; x < L && x < RESPACK_MAX; x++)
+      pk.w[x >> 4] |= ((uint32_t)Q.res[b + x] & 3u) << ((x & 15u) * 2u);
+  }
   if (Q.sub2_items && heavy) {
     const uint64_t b = Q.off[i];
     const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
@@ -1020,6 +1039,8 @@ place_items_kernel(const QL Q)
     if (Q.sub2_items) {
       w = hq;                                   /* the query's hash and residues travel with the item */
       Q.cpk[item] = pk;
+    } else if (Q.pairs2) {
+      Q.cpk[item] = pk;                         /* (beside the pair-blanked hash) */
     }
     ItemRec it;
     it.w = w;
@@ -1119,7 +1140,7 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
     return;
   const Chunk ck = Q.chunks[k];
   const uint32_t cpass = ck.pass & ~CHUNK_WITH_ITEMS;
-  uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : 2) : 0;
+  uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : 2) : 0;
   for (uint32_t t = 0; cpass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
     w += (uint64_t)(cpass == 0 ? td.len + 1 : cpass == 1 ? td.len + 2 : 2) * td.nvalid;
@@ -1704,6 +1725,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.existence = c->opt.existence ? 1 : 0;
   Q.indels = c->opt.indels ? 1 : 0;
   Q.pairs = pair_rows(c) ? 1 : 0;
+  Q.pairs2 = c->d2pairs ? 1u : 0u;
   Q.differences = (uint32_t)c->opt.differences;
   Q.sliced = c->sliced ? 1 : 0;
   Q.rows = c->rows ? 1 : 0;
@@ -2171,6 +2193,11 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   } else {
     c->qck.release();
   }
+  if (c->d2pairs) {
+    if ((rc = dev_reserve(c, c->qpk, slots))) return rc;
+  } else {
+    c->qpk.release();
+  }
   if (c->rows && c->opt.indels) {
     if ((rc = dev_reserve(c, c->qhins, slots))) return rc;
     if ((rc = dev_reserve(c, c->qhdel, slots))) return rc;
@@ -2187,6 +2214,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
       if ((rc = dev_reserve(c, c->cpk, ni))) return rc;
       if ((rc = dev_reserve(c, c->slice_items, 2 * (size_t)nslices_real))) return rc;
       HIP_TRY(c, hipMemsetAsync(c->slice_items.p, 0, 2 * (size_t)nslices_real * sizeof(uint32_t), c->stream));
+    } else if (c->d2pairs) {
+      if ((rc = dev_reserve(c, c->cpk, ni))) return rc;
+      c->slice_items.release();
     } else {
       c->cpk.release();
       c->slice_items.release();
@@ -2202,6 +2232,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.tile_refs = c->tile_refs.p;
   Q.small_tiles = c->small_tiles.p;
   Q.cpk = c->cpk.p;
+  Q.qpk = c->qpk.p;
   Q.slice_items = (uint2 *)c->slice_items.p;
   Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
   Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;

@@ -196,7 +196,14 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
      the 19 substitutions of a position; nucleotides (3 per position, and L + 1
      entries per sequence to pay for them) and d = 0 (one test per query, no rows
      at all) keep the per-variant filter (1). */
-  int64_t variant = c->variant >= 0 ? c->variant : (A == 20 && c->opt.differences >= 1 ? 2 : 1);
+  /* Nucleotides at d = 2 (round 4): pair rows probed by whole workgroups per tile
+     (kernels_pairs2.h) -- 1541 word reads per 45-nucleotide query where the per-variant
+     filter is probed 8910 times.  Needs the query's residues packed into RESPACK_MAX positions. */
+  const bool d2p_possible = A == 4 && c->opt.differences == 2 && !c->opt.indels &&
+                            std::max(longest, longest_query) <= RESPACK_MAX;
+  int64_t variant = c->variant >= 0 ? c->variant
+                    : (A == 20 && c->opt.differences >= 1) || (d2p_possible && c->d2_pairs != 0) ? 2 : 1;
+  c->d2pairs = variant == 2 && d2p_possible && c->d2_pairs != 0;
   /* The staged layouts keep a slice, the Zobrist tables and the wave queues in
      LDS; with very long sequences (Zobrist tables of more than ~100 KiB) that
      no longer fits and the un-sliced filter is probed where it lies (variant 0). */
@@ -218,7 +225,24 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
                          4 * sizeof(WaveQueue) + (c->rows ? 0 : 2048 * sizeof(unsigned long long)) +
                          MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +
                          64 * sizeof(TileRef) + (c->rows ? RING * (sizeof(RingSlot) + 64 * sizeof(TileRef)) : 0);
-    if (c->rows && c->slice_words_log2 < 0) {
+    size_t need_d2 = 0;
+    if (c->rows && c->d2pairs) {
+      /* kernels_pairs2.h: two slice buffers beside its tables, a matrix copy and 16 wave queues */
+      const size_t fixed2 = (16 * (size_t)c->zpos + 20 * ((size_t)c->zpos + 1) / 2) * sizeof(uint64_t) +
+                            2048 * sizeof(unsigned long long) + 16 * sizeof(WaveQueue) +
+                            MAX_CLASS_RES * A * sizeof(uint32_t) + 2 * (64 + 64 * sizeof(TileRef)) + 1024;
+      const size_t room = fixed2 < 160 * 1024 ? 160 * 1024 - fixed2 : 0;
+      uint64_t w = room / (2 * ROW_WORD_BYTES);
+      if (w >= 64)
+        w -= w % 32;                                     /* whole KiB: LDS-DMA pieces */
+      if (w < 1) {
+        c->d2pairs = false;                              /* (Zobrist tables too large: single rows, or variant 1) */
+      } else {
+        row_max_words = c->slice_words_log2 < 0 ? w : std::min<uint64_t>(1ull << c->slice_words_log2, w);
+        need_d2 = fixed2 + 2 * (size_t)row_max_words * ROW_WORD_BYTES;
+      }
+    }
+    if (c->rows && c->slice_words_log2 < 0 && !c->d2pairs) {
       /* the default slice leaves room for the queues of 16 waves; long sequences: a
          smaller slice next to the bigger Zobrist table */
       const size_t fixed16 = fixed + 12 * sizeof(WaveQueue);
@@ -226,13 +250,16 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
       row_max_words = std::min<uint64_t>(row_max_words, room / (RING * ROW_WORD_BYTES));
       row_max_words -= row_max_words % 32;               /* whole KiB: LDS-DMA pieces */
     }
-    const size_t need = fixed + (c->rows ? RING * (size_t)row_max_words * ROW_WORD_BYTES
-                                         : ((size_t)8 << swl));
+    const size_t need = c->rows && c->d2pairs ? need_d2
+                        : fixed + (c->rows ? RING * (size_t)row_max_words * ROW_WORD_BYTES
+                                           : ((size_t)8 << swl));
     if (need > 160 * 1024 || (c->rows && row_max_words < 1)) {
       c->sliced = false;
       c->rows = false;
     }
   }
+  if (!c->rows)
+    c->d2pairs = false;
   /* row filter: L + 1 entries per sequence, and with -i its L + 1 gap entries (kernels_rows.h) */
   /* (what the filter is SIZED for, also with pair rows, which enter fewer -- entries_filed:
      their eight-bit tests then see next to no false positive, and a slice holds more sequences) */
@@ -243,6 +270,8 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
        chance ~6e-4 of the time -- the optimum of a Bloom filter at 16 bits per
        entry), x 2^delta */
     bloom_bytes = std::max<uint64_t>(entries * 2, ROW_WORD_BYTES);
+    if (c->d2pairs)      /* sized for the entries filed: one per pair of positions and one per sequence */
+      bloom_bytes = std::max<uint64_t>(((residues2 + 1) / 2 + 2 * s->n) * 2, ROW_WORD_BYTES);
     const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
     if (delta > 0)
       bloom_bytes <<= delta;

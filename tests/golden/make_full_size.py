@@ -52,6 +52,12 @@ WORKLOADS = {
              dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4), ["-d", "1", "-i"]),
     # the reference's own published benchmark shape is self-vs-self (README.md:726-755)
     "self10m": (None, dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4), ["-d", "1"]),
+    # the robustness workload: configs[2] / [3] under the cdr3 law of compairr_amd/synth.py (conserved
+    # ends, skewed composition, Zipf clone sizes)
+    "cfg3_cdr3": (dict(n=10 * M, seed=1, prefix="A", pool_size=10 * M // 4, law="cdr3"),
+                  dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4, law="cdr3"), ["-d", "1"]),
+    "cfg4_cdr3": (dict(n=10 * M, seed=1, prefix="A", pool_size=10 * M // 4, law="cdr3"),
+                  dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4, law="cdr3"), ["-d", "1", "-i"]),
     # BASELINE configs[4], a sub-shape the reference finishes in minutes on 8 cores
     "cfg5_sub": (dict(n=200_000, seed=3, prefix="A", pool_size=10 * M // 4, nucleotides=True),
                  dict(n=10 * M, seed=4, prefix="B", pool_size=10 * M // 4, nucleotides=True),

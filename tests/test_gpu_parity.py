@@ -10,6 +10,7 @@ import pytest
 import _full_size
 import _oracle
 from _routed import routed_contexts
+from _routed import routed_contexts
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
 from conftest import (expected_of, expected_pairs_of, load_manifest, run_cli, sorted_pairs,
@@ -62,6 +63,15 @@ LAYOUTS = {
                             "pos_segments": 1},
     # ---- variant 2: the row filter (one filter word per position) ----
     "rows": {"variant": 2},
+    # the fused step (the probe kernel's workgroups resolve the positives themselves: one launch; off by
+    # default), also with few segments (one: every workgroup writes and resolves the same one)
+    "rows_fused": {"variant": 2, "fused_step": 1},
+    "rows_fused_1seg": {"variant": 2, "fused_step": 1, "pos_segments": 1},
+    "rows_fused_tiny": {"variant": 2, "fused_step": 1, "slice_words_log2": 3, "class_residues": 2,
+                        "heavy_threshold": 2, "pos_segments": 2, "waves_per_block": 4},
+    # the partial results summed by a launch of their own instead of resolve_kernel's last workgroup
+    "rows_sep_reduce": {"variant": 2, "merge_reduce": 0},
+    "lds_sep_reduce": {"variant": 1, "merge_reduce": 0, "slice_words_log2": 6},
     # 64-byte slices, every class split by 3 / 1 class residues: class-row passes
     "rows_tiny_k3": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
                      "heavy_threshold": 0},
@@ -104,6 +114,22 @@ NT_LAYOUTS["rows_tiny_k8"] = {"variant": 2, "slice_words_log2": 2, "class_residu
                               "heavy_threshold": 0, "chunk_tiles": 5}
 NT_LAYOUTS["rows_tiny_k5_mixed"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 5,
                                     "heavy_threshold": 3}
+# (variant 2 at d = 2 is the pair-row kernel of kernels_pairs2.h for nucleotides; these keep the single rows)
+NT_LAYOUTS["rows_single_d2"] = {"variant": 2, "d2_pairs": 0}
+NT_LAYOUTS["rows_single_d2_tiny_k5"] = {"variant": 2, "d2_pairs": 0, "slice_words_log2": 3, "class_residues": 5,
+                                        "heavy_threshold": 3}
+# ... and these vary the class positions under it: odd and even anchors, one to eight class residues
+# (class pairs that hold one or two of them; with K <= 5 the parts are keyed by three more positions)
+NT_LAYOUTS["pairs2_k1_odd"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 1, "class_anchor": 5,
+                               "heavy_threshold": 0}
+NT_LAYOUTS["pairs2_k2_odd"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 2, "class_anchor": 3,
+                               "heavy_threshold": 0, "chunk_tiles": 3}
+NT_LAYOUTS["pairs2_k3_even"] = {"variant": 2, "slice_words_log2": 4, "class_residues": 3, "class_anchor": 2,
+                                "heavy_threshold": 2}
+NT_LAYOUTS["pairs2_k6"] = {"variant": 2, "slice_words_log2": 3, "class_residues": 6, "class_anchor": 0,
+                           "heavy_threshold": 0}
+NT_LAYOUTS["pairs2_k0"] = {"variant": 2, "slice_words_log2": 5, "class_residues": 0}
+NT_LAYOUTS["pairs2_overflow"] = {"variant": 2, "slice_words_log2": 4, "pos_capacity": 64}
 
 
 def check(a, b, opt, threads=4, layouts=None):
@@ -471,98 +497,6 @@ def test_work_shards_add_up(name, opt, nt, tun):
         with pytest.raises(hipmod.HipError) as e:
             h.set_queries(a)
         assert e.value.code == 4               # CMPR_EUNSUPPORTED
-
-
-@pytest.mark.parametrize("name,opt,nt,tun", [
-    ("aa_d1", dict(differences=1), False, {}),
-    ("aa_d1_indels", dict(differences=1, indels=True), False, {}),
-    ("aa_d2", dict(differences=2), False, {}),
-    ("nt_d1_sliced", dict(differences=1, nucleotides=True, ignore_genes=True), True, {}),
-    ("nt_d2_items", dict(differences=2, nucleotides=True, ignore_genes=True), True,
-     {"variant": 1, "slice_words_log2": 4, "class_residues": 4, "heavy_threshold": 2, "sub2_items": 1}),
-    ("aa_d1_sliced", dict(differences=1), False, {"variant": 1}),
-    ("aa_d1_small_slices", dict(differences=1), False, {"small_slice_tiles": 64}),
-])
-def test_work_shards_add_up(name, opt, nt, tun):
-    """bench.py --shard-by work: a context with work_shard_count = N does the work filed
-    under its share of the filter slices; the N matrices add up to the whole one, and
-    so do the counters -- although every context lays the queries out by itself."""
-    n = (1500 if nt else 3000) if opt.get("differences") == 2 else 60000
-    a = synth.make_set(n, 11, prefix="A", nucleotides=nt, pool_size=n // 2)
-    b = synth.make_set(n, 12, prefix="B", nucleotides=nt, pool_size=n // 2)
-    o = Options(**opt, **FULL)
-
-    def run(index, count):
-        with HipOverlap(o) as h:
-            for k, v in tun.items():
-                h.set_tunable(k, v)
-            h.set_tunable("work_shard_count", count)
-            h.set_tunable("work_shard_index", index)
-            h.set_reference(b, a.longest)
-            h.set_queries(a)
-            m = h.overlap_matrix()
-            return m, h.stats().matches
-
-    whole, pairs = run(0, 1)
-    want, _ = _oracle.overlap(a, b, o, threads=8)
-    assert np.array_equal(whole, _oracle.integer_cells(want, o))
-    for count in (2, 5):
-        parts = [run(i, count) for i in range(count)]
-        assert np.array_equal(sum(p[0] for p in parts), whole), (name, count)
-        assert sum(p[1] for p in parts) == pairs
-        assert all(p[1] < pairs for p in parts)                  # nobody did everything
-    with HipOverlap(o) as h:
-        h.set_tunable("work_shard_count", 2)
-        h.set_tunable("work_shard_index", 2)
-        h.set_reference(b, a.longest)
-        with pytest.raises(hipmod.HipError):
-            h.set_queries(a)
-    with HipOverlap(o) as h:                   # the unsliced baseline kernel has no slices to deal out
-        h.set_tunable("variant", 0)
-        h.set_tunable("work_shard_count", 2)
-        h.set_reference(b, a.longest)
-        with pytest.raises(hipmod.HipError) as e:
-            h.set_queries(a)
-        assert e.value.code == 4               # CMPR_EUNSUPPORTED
-
-
-def routed_contexts(a, b, o, count, tun, shares=None):
-    """`count` contexts on this device, each given a contiguous share of `a` (or `shares`:
-    [(first index, subset)]); the records change hands with device-to-device copies -- what
-    the all-to-all of compairr_amd.dist.exchange_queries does between GPUs.  Returns the
-    contexts, laid out and ready."""
-    import torch
-    from compairr_amd.dist import shard_bounds
-    hs = []
-    for index in range(count):
-        h = HipOverlap(o)
-        for k, v in tun.items():
-            h.set_tunable(k, v)
-        h.set_tunable("work_shard_count", count)
-        h.set_tunable("work_shard_index", index)
-        h.set_reference(b, a.longest)
-        hs.append(h)
-    if shares is None:
-        shares = []
-        for index in range(count):
-            lo, hi = shard_bounds(a.n, index, count)
-            shares.append((lo, a.subset(slice(lo, hi))))
-    sends, totals, rb = [], np.zeros(a.n_repertoires), 0
-    for h, (first, share) in zip(hs, shares):
-        counts, rb, tot = h.route_queries(share, first, count)
-        totals += tot
-        buf = torch.empty(max(int(counts.sum()), 1) * rb, dtype=torch.uint8, device="cuda")
-        h.route_pack(buf.data_ptr(), int(counts.sum()) * rb)
-        sends.append((counts, buf))
-    for d, h in enumerate(hs):
-        runs = []
-        for counts, buf in sends:
-            start = int(counts[:d].sum()) * rb
-            runs.append(buf[start:start + int(counts[d]) * rb])
-        recv = torch.cat(runs) if runs else torch.empty(0, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        h.set_queries_routed(recv.data_ptr(), recv.numel() // rb, a.n_repertoires, a.n, totals)
-    return hs
 
 
 @pytest.mark.parametrize("name,opt,nt,tun", [

@@ -89,3 +89,23 @@ def test_oracle_empty_and_ragged():
     m, _ = _oracle.overlap(a, a, o)
     assert m.shape == (a.n_repertoires, a.n_repertoires)
     assert e.n == 0 and e.n_repertoires == 0
+
+
+# ---- the oracle port against the reference's matrices at BASELINE sizes ----
+# (tests/golden/full_size.json, written by tests/golden/make_full_size.py from oracle/_ref)
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg5_sub"])
+def test_oracle_port_matches_reference_at_full_size(name):
+    """cfg2 (1M x 1M aa, d = 0) and the cfg5 sub-shape (200k x 10M nucleotides, d = 2, -g): the C
+    restatement gives the matrix the reference binary printed, digit for digit."""
+    import _full_size
+    import _oracle
+    from compairr_amd import Options
+    w = _full_size.load()[name]
+    a, b = _full_size.sets_of(w)
+    opt = Options(**_full_size.options_of(w))
+    m, st = _oracle.overlap(a, b, opt, threads=8)
+    got = _oracle.integer_cells(m, opt)
+    assert _full_size.mismatch(w, got) is None, _full_size.mismatch(w, got)
+    dups = {int(l.split()[-1]): int(l.split()[1]) for l in w["warnings"]}
+    assert st.dup_set2 == dups[2] and st.dup_set1 == dups.get(1, 0)
