@@ -371,6 +371,12 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set d2_pairs before cmpr_set_reference");
     c->d2_pairs = value;
+  } else if (n == "d2_buffers") {
+    if (value < 1 || value > 2)
+      return fail(c, CMPR_EINVAL, "d2_buffers must be 1 or 2");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set d2_buffers before cmpr_set_reference");
+    c->d2_buffers = value;
   } else if (n == "fused_step") {
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "fused_step must be 0 or 1");
@@ -468,6 +474,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "chunk_tiles") *value = c->chunk_tiles > 0 ? c->chunk_tiles : 8 * c->waves_per_block;
   else if (n == "waves_per_block") *value = c->plan.valid ? (int64_t)c->plan.nw : c->waves_per_block;
   else if (n == "narrow_upload") *value = c->narrow_upload;
+  else if (n == "d2_buffers") *value = c->have_ref && c->d2pairs ? (int64_t)c->geom.nbuf : c->d2_buffers;
   else if (n == "d2_pairs") *value = c->have_ref ? (c->d2pairs ? 1 : 0) : c->d2_pairs;
   else if (n == "fused_step") *value = c->plan.valid ? (c->plan.ffn ? 1 : 0) : c->fused_step;
   else if (n == "merge_reduce") *value = c->merge_reduce;
@@ -867,7 +874,7 @@ int make_plan(cmpr_context *c)
     /* kernels_pairs2.h: one workgroup of 16 waves per CU, two slice buffers */
     nw = 16;
     const size_t npairs = ((size_t)c->zpos + 1) / 2;
-    const size_t lds2 = 2 * (size_t)c->geom.rw_words * ROW_WORD_BYTES +
+    const size_t lds2 = (size_t)c->geom.nbuf * c->geom.rw_words * ROW_WORD_BYTES +
                         (16 * (size_t)c->zpos + P2_PZ * npairs) * sizeof(uint64_t) +
                         (P.lds_matrix ? cells * sizeof(unsigned long long) : 0) + 16 * sizeof(WaveQueue) +
                         MAX_CLASS_RES * A * sizeof(uint32_t) + 2 * sizeof(P2Slot) +

@@ -217,6 +217,7 @@ struct cmpr_context {
   DevBuf<cmpr::ResPack> qpk;             /* nucleotides, d = 2 on pair rows: per slot, the query's residues */
   bool              d2pairs = false;    /* ... that kernel is in use (kernels_pairs2.h; decided with the index) */
   int64_t           d2_pairs = -1;      /* tunable: -1 auto, 0 off, 1 on */
+  int64_t           d2_buffers = 2;     /* tunable: slice buffers of that kernel (layout.h SliceGeom::nbuf) */
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;

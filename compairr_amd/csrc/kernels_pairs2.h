@@ -52,10 +52,14 @@ namespace cmpr {
  */
 constexpr uint32_t K2_CROSS = 5, K2_SAME = 6;
 constexpr uint32_t P2_NONE = 4;                  /* "no residue": the second position of a pair behind the end */
-constexpr uint32_t P2_PZ = 20;                   /* pair-blank keys per pair: (qa, qb) -> qa * 5 + qb */
+constexpr uint32_t P2_PZ = 20;                   /* pair-blank keys per pair: (qa, qb) -> qa | qb << 2; 16 + qa: no second position */
+__device__ __forceinline__ uint32_t p2_pz_index(uint32_t qa, uint32_t qb)
+{
+  return qb >= 4u ? 16u + qa : qa | (qb << 2);
+}
 
 /* LDS tables: ze[16 p + 4 r + k] = Z[p][r] ^ Z[p][(r + k) & 3] (k = 0: Z[p][r] itself);
-   pz[P2_PZ j + 5 a + b] = Z[2j][a] ^ Z[2j+1][b] (b = 4: Z[2j][a] alone) */
+   pz[P2_PZ j + (a | b << 2)] = Z[2j][a] ^ Z[2j+1][b], pz[P2_PZ j + 16 + a] = Z[2j][a] alone */
 struct P2Tables {
   uint32_t ze_addr, pz_addr;
 };
@@ -146,6 +150,35 @@ __device__ __forceinline__ void p2_drain_round(SProber &W, const P2Tables &T, in
   }
 }
 
+/* The drain of a full queue as a FUNCTION: it is called once per 64 positives, from a dozen
+   places in loops whose registers are all spoken for -- inlined there it cost them spills.
+   What it changes of the wave's state travels by value (the state itself stays in the
+   caller's registers: a reference to it would put it in memory). */
+struct P2Drained {
+  int qn;
+  unsigned long long held;
+  uint32_t hash_eq, matches;
+};
+template <bool GENES>
+__device__ __attribute__((noinline)) P2Drained p2_drain_full(const ProbeParams *Pp, WaveQueue *q,
+                                                             unsigned long long *mat_lds, uint32_t lane, int qn,
+                                                             unsigned long long held, uint32_t ze_addr,
+                                                             uint32_t pz_addr)
+{
+  SProber W{*Pp, nullptr, *q, mat_lds, lane, 0u, 0u, 0u, 0u, 0u, qn, {0ull, 0u, 0u, 0u}, held};
+  P2Tables T;
+  T.ze_addr = ze_addr;
+  T.pz_addr = pz_addr;
+  while (W.qn >= WAVE)
+    p2_drain_round<GENES>(W, T, WAVE);
+  P2Drained r;
+  r.qn = W.qn;
+  r.held = W.held;
+  r.hash_eq = W.st.hash_eq;
+  r.matches = W.st.matches;
+  return r;
+}
+
 template <bool GENES>
 __device__ __forceinline__ void p2_push(SProber &W, const P2Tables &T, bool pos, uint64_t B, uint32_t ca,
                                         uint32_t cb, uint32_t m, uint32_t nbits)
@@ -162,27 +195,55 @@ __device__ __forceinline__ void p2_push(SProber &W, const P2Tables &T, bool pos,
       W.st.bloom_pos += nbits;
     }
     W.qn += __popcll(mm);
-    while (W.qn >= WAVE)
-      p2_drain_round<GENES>(W, T, WAVE);
+    if (W.qn >= WAVE) {
+      const P2Drained r = p2_drain_full<GENES>(&W.P, &W.q, W.mat_lds, W.lane, W.qn, W.held, T.ze_addr, T.pz_addr);
+      W.qn = r.qn;
+      W.held = r.held;
+      W.st.hash_eq += r.hash_eq;
+      W.st.matches += r.matches;
+    }
   }
+}
+
+/* word wq of a packed query (eight pairs) */
+__device__ __forceinline__ uint32_t p2_pair_word(const ResPack &pk, uint32_t wq)
+{
+  uint32_t w = pk.w[0];
+  asm volatile("" : "+v"(w));
+  w = wq == 1u ? pk.w[1] : w;
+  asm volatile("" : "+v"(w));
+  w = wq == 2u ? pk.w[2] : w;
+  asm volatile("" : "+v"(w));
+  w = wq == 3u ? pk.w[3] : w;
+  asm volatile("" : "+v"(w));
+  w = wq == 4u ? pk.w[4] : w;
+  asm volatile("" : "+v"(w));
+  w = wq == 5u ? pk.w[5] : w;
+  return w;
 }
 
 /* residues of pair j of a packed query: qa | qb << 2 (four bits at 4 j) */
 __device__ __forceinline__ uint32_t p2_pair_of(const ResPack &pk, uint32_t j)
 {
   static_assert(RESPACK_MAX == 96, "six words, eight pairs each");
+  /* (a select chain kept opaque, or the compiler turns it into an indexed read of a scratch copy) */
   const uint32_t wq = j >> 3;
   uint32_t w = pk.w[0];
+  asm volatile("" : "+v"(w));
   w = wq == 1u ? pk.w[1] : w;
+  asm volatile("" : "+v"(w));
   w = wq == 2u ? pk.w[2] : w;
+  asm volatile("" : "+v"(w));
   w = wq == 3u ? pk.w[3] : w;
+  asm volatile("" : "+v"(w));
   w = wq == 4u ? pk.w[4] : w;
+  asm volatile("" : "+v"(w));
   w = wq == 5u ? pk.w[5] : w;
   return (w >> ((j & 7u) * 4u)) & 15u;
 }
 
 /*
- * LDS: [2 slice buffers, rw_words x 32 B each][ze: 16 x zpos][pz: P2_PZ x ceil(zpos / 2)]
+ * LDS: [1 or 2 slice buffers, rw_words x 32 B each][ze: 16 x zpos][pz: P2_PZ x ceil(zpos / 2)]
  *      [NW WaveQueues][CR tables][2 x {chunk descriptor, unit counter}][2 x chunk_cap tile refs]
  */
 struct P2Slot {
@@ -204,8 +265,9 @@ probe_pairs2_kernel(const ProbeParams P)
   const uint32_t slice_bytes = nwords * ROW_WORD_BYTES;
   const unsigned char *filter = (const unsigned char *)P.bloom;
   const uint32_t npairs_max = (P.zpos + 1u) / 2u;
+  const uint32_t nbuf = __builtin_amdgcn_readfirstlane(P.geom.nbuf == 1u ? 1u : 2u);   /* slice buffers (layout.h SliceGeom::nbuf) */
   P2Tables T;
-  T.ze_addr = 2u * slice_bytes;
+  T.ze_addr = nbuf * slice_bytes;
   T.pz_addr = T.ze_addr + 16u * P.zpos * 8u;
   uint64_t *ze = (uint64_t *)(smem + T.ze_addr);
   uint64_t *pz = (uint64_t *)(smem + T.pz_addr);
@@ -225,9 +287,9 @@ probe_pairs2_kernel(const ProbeParams P)
     ze[i] = k ? own ^ P.zob[pos * 4u + ((r + k) & 3u)] : own;
   }
   for (uint32_t i = threadIdx.x; i < P2_PZ * npairs_max; i += NT) {
-    const uint32_t j = i / P2_PZ, ab = i % P2_PZ, a = ab / 5u, b = ab % 5u;
+    const uint32_t j = i / P2_PZ, ab = i % P2_PZ, a = ab & 3u, b = ab < 16u ? ab >> 2 : P2_NONE;
     uint64_t x = 0;
-    if (2u * j < P.zpos && a < 4u)
+    if (2u * j < P.zpos)
       x = P.zob[(2u * j) * 4u + a];
     if (2u * j + 1u < P.zpos && b < 4u)
       x ^= P.zob[(2u * j + 1u) * 4u + b];
@@ -256,17 +318,17 @@ probe_pairs2_kernel(const ProbeParams P)
     if (wave != (Tn % NW))
       return;
     const Chunk ck = P.chunks[blockIdx.x + Tn * G];
-    const uint32_t b = Tn & 1u;
+    const uint32_t b = Tn & (nbuf - 1u);
     uint32_t l16 = lane * 16u;
     const unsigned char *src = filter + (size_t)ck.slice * slice_bytes + l16;
-    const uint32_t dst = b * slice_bytes;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(b * slice_bytes);
     for (uint32_t off = 0; off < slice_bytes; off += 1024u)
       if (off + l16 < slice_bytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(src + off), (lds_void_t *)(uintptr_t)(dst + off), 16, 0, 0);
     const uint32_t cpass = ck.pass & 0xffu;
     const uint32_t tbytes = cpass >= 3u ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
     const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + l16;
-    const uint32_t tdst = (uint32_t)(uintptr_t)(tref_lds + b * chunk_cap);
+    const uint32_t tdst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(tref_lds + b * chunk_cap));
     for (uint32_t off = 0; off < tbytes; off += 1024u)
       if (off + l16 < tbytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(tsrc + off), (lds_void_t *)(uintptr_t)(tdst + off), 16, 0, 0);
@@ -282,18 +344,22 @@ probe_pairs2_kernel(const ProbeParams P)
     }
   };
 
-  if (my_chunks)
+  if (my_chunks && nbuf == 2u)
     stage(0);
 
   /* class positions (wave-uniform per tile) */
   const uint32_t KH = P.geom.k;
 
   for (uint32_t Tn = 0; Tn < my_chunks; Tn++) {
+    if (nbuf == 1u) {
+      __syncthreads();                                     /* chunk Tn - 1 is finished: its buffer is free */
+      stage(Tn);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* this wave's share of the copies has landed */
     __syncthreads();                                       /* ... everyone's; and chunk Tn - 1 is finished */
-    if (Tn + 1u < my_chunks)
+    if (nbuf == 2u && Tn + 1u < my_chunks)
       stage(Tn + 1u);
-    const uint32_t b = Tn & 1u;
+    const uint32_t b = Tn & (nbuf - 1u);
     const uint32_t sbase = b * slice_bytes;
     const uint32_t cslice = slots[b].slice, cpass = slots[b].pass, cfirst = slots[b].first;
     const uint32_t units = slots[b].units;
@@ -396,7 +462,7 @@ probe_pairs2_kernel(const ProbeParams P)
 
         /* ---- both positions in pair j2: one word, 15 variants ---- */
         {
-          const uint64_t W0 = h ^ lds_u64(T.pz_addr + (P2_PZ * j2 + 5u * qa2 + qb2) * 8u);
+          const uint64_t W0 = h ^ lds_u64(T.pz_addr + (P2_PZ * j2 + p2_pz_index(qa2, qb2)) * 8u);
           const RowWord w = word_lds(woff_of(W0));
           uint32_t xs, xd;
           pair_bits(w, W0, xs, xd);
@@ -427,36 +493,78 @@ probe_pairs2_kernel(const ProbeParams P)
         }
 
         /* ---- one position in pair j2, the other in a pair j1 < j2 that is no class pair: the
-                query with e replaced reads the word of its pair j1, both blanked ---- */
-        for (uint32_t s = 0; s < 6u; s++) {
-          const uint32_t which = s / 3u, k = s - 3u * which + 1u;
-          const uint32_t e = p2a + which;
-          if (e >= L)
-            break;                                         /* (wave-uniform: the tile's longest query ends) */
+                query with e replaced reads the word of its pair j1, both blanked.  The six
+                (e, replacement) hashes are kept; per pair j1 ONE key read, then six independent
+                word reads in flight together ---- */
+        uint64_t h2[6];
+        const uint32_t lmA = has_a ? 15u : 0u, lmB = has_b ? 15u : 0u;   /* the lane has the position replaced */
+#pragma unroll
+        for (uint32_t c = 0; c < 6u; c++) {
+          const uint32_t which = c / 3u, k = c - 3u * which + 1u;
           const uint32_t qe = which ? (ab2 >> 2) : qa2;
-          const bool live_e = valid && e < Ll;
-          const uint64_t h2 = h ^ lds_u64(T.ze_addr + (16u * e + 4u * qe + k) * 8u);
-          const uint32_t ne = (qe + k) & 3u;
-          for (uint32_t j1 = 0; j1 < j2; j1++) {
-            if ((cls >> j1) & 1ull)
-              continue;                                    /* (an item: class pair j1 blanked, e replaced) */
-            const uint32_t ab1 = p2_pair_of(pk, j1);
-            const uint32_t qa1 = ab1 & 3u, qb1 = ab1 >> 2;      /* (j1 < j2 <= the lane's last pair: both exist when e does) */
-            const uint64_t Wk = h2 ^ lds_u64(T.pz_addr + (P2_PZ * j1 + 5u * qa1 + qb1) * 8u);
-            const RowWord w = word_lds(woff_of(Wk));
-            uint32_t xs, xd, a1, a2;
-            pair_bits(w, Wk, xs, xd);
-            pair_answers(xs, xd, qa1, qb1, a1, a2);
-            a1 &= 15u & ~(1u << qa1);
-            a2 &= 15u & ~(1u << qb1);
-            if (!live_e)
-              a1 = a2 = 0u;
-            p2_push<GENES>(W, T, (a1 | a2) != 0u, h2,
-                           K2_CROSS | (j1 << 3) | (qa1 << 10) | (qb1 << 13) | (e << 16) | (ne << 24), a1, a2,
-                           (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
-            treads += live_e ? 1u : 0u;
-            nvar += live_e ? 6u : 0u;
+          h2[c] = h ^ lds_u64(T.ze_addr + (16u * (p2a + which) + 4u * qe + k) * 8u);
+        }
+        const uint32_t ncomb = p2a + 1u < L ? 6u : 3u;     /* (wave-uniform: the tile's longest query) */
+        uint32_t n1 = 0;                                   /* pairs j1 read (wave-uniform) */
+        uint32_t cur = 0;
+        for (uint32_t j1 = 0; j1 < j2; j1++) {
+          if ((j1 & 7u) == 0u) {
+            cur = p2_pair_word(pk, j1 >> 3);
           }
+          const uint32_t ab1 = cur & 15u;
+          cur >>= 4;
+          if ((cls >> j1) & 1ull)
+            continue;                                      /* (an item: class pair j1 blanked, e replaced) */
+          n1++;
+          const uint32_t qa1 = ab1 & 3u, qb1 = ab1 >> 2;   /* (j1 < j2 <= the lane's last pair: both exist when e does) */
+          uint32_t zrow = T.pz_addr + P2_PZ * 8u * j1;
+          zrow = __builtin_amdgcn_readfirstlane(zrow);
+          const uint64_t K1 = lds_u64(zrow + ab1 * 8u);
+          const uint32_t own1 = ~(1u << qa1), own2 = ~(1u << qb1);
+          /* NR of the six at a time (all six when the pair has both positions): their words in
+             flight together, then the tests */
+          auto group = [&](auto lo_c, auto nr_c) {
+            constexpr uint32_t LO = decltype(lo_c)::value, NR = decltype(nr_c)::value;
+            uint64_t Wk[NR];
+            RowWord w[NR];
+#pragma unroll
+            for (uint32_t c = 0; c < NR; c++) {
+              Wk[c] = h2[LO + c] ^ K1;
+              w[c] = word_lds(woff_of(Wk[c]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t x1[NR], x2[NR], any = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < NR; c++) {
+              const uint32_t lmask = (LO + c) >= 3u ? lmB : lmA;
+              uint32_t xs, xd, a1, a2;
+              pair_bits(w[c], Wk[c], xs, xd);
+              pair_answers(xs, xd, qa1, qb1, a1, a2);
+              x1[c] = a1 & own1 & lmask;
+              x2[c] = a2 & own2 & lmask;
+              any |= x1[c] | x2[c];
+            }
+            if (__ballot(any != 0u)) {
+#pragma unroll
+              for (uint32_t c = 0; c < NR; c++) {
+                const uint32_t which = (LO + c) / 3u, k = (LO + c) - 3u * which + 1u;
+                const uint32_t qe = which ? (ab2 >> 2) : qa2;
+                p2_push<GENES>(W, T, (x1[c] | x2[c]) != 0u, h2[LO + c],
+                               K2_CROSS | (j1 << 3) | (qa1 << 10) | (qb1 << 13) | ((p2a + which) << 16) |
+                                   (((qe + k) & 3u) << 24),
+                               x1[c], x2[c], (uint32_t)__popc(x1[c]) + (uint32_t)__popc(x2[c]));
+              }
+            }
+          };
+          /* (six in flight were tried: the registers they take are spilled elsewhere -- slower) */
+          group(std::integral_constant<uint32_t, 0>{}, std::integral_constant<uint32_t, 3>{});
+          if (ncomb == 6u)
+            group(std::integral_constant<uint32_t, 3>{}, std::integral_constant<uint32_t, 3>{});
+        }
+        {
+          const uint32_t npos2 = (has_a ? 1u : 0u) + (has_b ? 1u : 0u);
+          treads += n1 * 3u * npos2;
+          nvar += n1 * 18u * npos2;
         }
       } else {
         /* ---- an item: class pair jc of a heavy query, both positions blanked (iw = that hash);
@@ -466,7 +574,7 @@ probe_pairs2_kernel(const ProbeParams P)
         const uint32_t qb = qbr >= A ? P2_NONE : qbr;
         const uint32_t Lq = Ll;
         /* the query's hash: the item carries the pair-blanked one */
-        h = iw ^ lds_u64(T.pz_addr + (P2_PZ * jc + 5u * (qa & 3u) + qb) * 8u);
+        h = iw ^ lds_u64(T.pz_addr + (P2_PZ * jc + p2_pz_index(qa & 3u, qb)) * 8u);
         const bool has_b = valid && pc + 1u < Lq;
         /* ---- both positions (or the one) in the class pair ---- */
         {
@@ -516,68 +624,111 @@ probe_pairs2_kernel(const ProbeParams P)
         for (int off = 32; off > 0; off >>= 1)
           Lmax = max(Lmax, (uint32_t)__shfl_xor((int)Lmax, off, WAVE));
         Lmax = __builtin_amdgcn_readfirstlane(Lmax);
-        /* ---- the other position e anywhere outside the pair: class pair blanked, e replaced.  e in
-                no class pair: the staged slice.  e in another class pair: the replacement changes
-                the key of the part -- read where the filter lies, and only from the LOWER class
-                pair (each unordered pair of positions once) ---- */
         int ci_c = -1;                                      /* the class part the pair's rows lie in */
 #pragma unroll
         for (uint32_t i = 0; i < MCR; i++)
           if (i < KH && (cpos[i] >> 1) == jc && ci_c < 0)
             ci_c = (int)i;
+        /* ---- the other position e anywhere outside the pair: class pair blanked, e replaced.
+                q[e] keys nothing of the part (no class position, none of the extra ones): the
+                staged slice -- three reads per e, in flight together.  Else the replacement
+                changes the part's key: read where the filter lies; and when e lies in another
+                class pair, only from the LOWER of the two (each pair of positions once).
+                Fast path: every query of the block holds the keyed positions unwrapped (they
+                are then the same positions for all, and jc is) -- the tests are scalar. ---- */
+        const bool uniform = __ballot(valid && Lq < P.geom.c0 + KX) == 0ull;
+        const uint32_t jcu = __builtin_amdgcn_readfirstlane(__ballot(valid) ? (uint32_t)__builtin_amdgcn_readlane(
+                                 (int)jc, (int)__builtin_ctzll(__ballot(valid) | (1ull << 63))) : 0u);
+        const uint32_t own1 = ~(1u << qa), own2 = qb == P2_NONE ? 0u : ~(1u << qb);
+        const uint32_t rb_code = qb == P2_NONE ? A : qb;
+        uint32_t nhere = 0;                                 /* positions answered from the staged slice (this lane) */
+        uint32_t cur = 0;
         for (uint32_t e = 0; e < Lmax; e++) {
+          if ((e & 15u) == 0u)
+            cur = p2_pair_word(pk, e >> 4);                /* (sixteen positions, two bits each) */
+          const uint32_t qe = cur & 3u;
+          cur >>= 2;
           const uint32_t je = e >> 1;
-          const bool live = valid && e < Lq && je != jc;
-          /* does q[e] key the part?  (a class position, or one of the extra ones) */
-          bool keyed = false;
+          bool keyed, e_cls;
+          if (uniform) {
+            if (je == jcu)
+              continue;
+            bool kk = false, cc = false;                   /* scalar */
 #pragma unroll
-          for (uint32_t i = 0; i < MCR; i++)
-            keyed = keyed || (i < KX && cpos[i] == e);
-          const bool e_cls = ((cls >> je) & 1ull) != 0;     /* e lies in another class pair: its item does
-                                                               the same pair of positions -- the lower one counts */
-          const bool here = live && !keyed && !e_cls;      /* answered from the staged slice */
-          const bool far = live && (keyed || e_cls) && (!e_cls || je > jc);   /* ... where the filter lies */
-          const uint32_t qe = (p2_pair_of(pk, je) >> ((e & 1u) * 2u)) & 3u;
+            for (uint32_t i = 0; i < MCR; i++) {
+              kk = kk || (i < KX && P.geom.c0 + i == e);
+              cc = cc || (i < KH && ((P.geom.c0 + i) >> 1) == je);
+            }
+            keyed = kk;
+            e_cls = cc;
+          } else {
+            keyed = false;
+#pragma unroll
+            for (uint32_t i = 0; i < MCR; i++)
+              keyed = keyed || (i < KX && cpos[i] == e);
+            e_cls = ((cls >> je) & 1ull) != 0;
+          }
+          const bool live = valid && e < Lq && je != jc;
+          const bool here = live && !keyed && !e_cls;
+          const bool far = live && (keyed || e_cls) && (!e_cls || je > jc);
+          const uint32_t lmask = (here || far) ? 15u : 0u;
+          const bool any_far = __ballot(far) != 0ull;
+          if (!any_far && __ballot(here) == 0ull)
+            continue;
           uint32_t key_e = 0;                               /* the part's key terms of q[e] */
-          if (__ballot(far)) {
+          if (any_far) {
 #pragma unroll
             for (uint32_t i = 0; i < MCR; i++)
               if (i < KX && cpos[i] == e)
                 key_e ^= cr_lds[i * A + qe];
           }
-          for (uint32_t k = 1; k < 4u; k++) {
-            const uint32_t ne = (qe + k) & 3u;
-            const uint64_t Wk = iw ^ lds_u64(T.ze_addr + (16u * e + 4u * qe + k) * 8u);
-            const uint32_t wo = woff_of(Wk);
-            RowWord w = word_lds(wo);
-            if (__ballot(far)) {
+          uint64_t Wk[3];
+          RowWord w[3];
+          uint32_t wo[3];
+#pragma unroll
+          for (uint32_t c = 0; c < 3u; c++) {
+            Wk[c] = iw ^ lds_u64(T.ze_addr + (16u * e + 4u * qe + c + 1u) * 8u);
+            wo[c] = woff_of(Wk[c]);
+            w[c] = word_lds(wo[c]);
+          }
+          if (any_far) {
+#pragma unroll
+            for (uint32_t c = 0; c < 3u; c++)
               if (far) {
+                const uint32_t ne = (qe + c + 1u) & 3u;
                 uint32_t key_n = 0;
 #pragma unroll
                 for (uint32_t i = 0; i < MCR; i++)
                   if (i < KX && cpos[i] == e)
                     key_n ^= cr_lds[i * A + ne];
                 /* the part's slice of this lane's pair: the staged one with e's term exchanged */
-                const uint32_t kslice = (cslice - (P.geom.smask + 1u + (uint32_t)ci_c * (P.geom.cmask + 1u)));
-                const uint32_t nslice = row_slice(P.geom, kslice ^ key_e ^ key_n, ci_c);
-                w = word_glob(nslice, wo);
+                const uint32_t kslice = cslice - (P.geom.smask + 1u + (uint32_t)ci_c * (P.geom.cmask + 1u));
+                w[c] = word_glob(row_slice(P.geom, kslice ^ key_e ^ key_n, ci_c), wo[c]);
               }
-            }
-            uint32_t xs, xd, a1, a2;
-            pair_bits(w, Wk, xs, xd);
-            pair_answers(xs, xd, qa, qb == P2_NONE ? A : qb, a1, a2);
-            a1 &= 15u & ~(1u << qa);
-            a2 &= qb == P2_NONE ? 0u : 15u & ~(1u << qb);
-            const bool cnt = here || far;
-            if (!cnt)
-              a1 = a2 = 0u;
-            p2_push<GENES>(W, T, (a1 | a2) != 0u, h ^ lds_u64(T.ze_addr + (16u * e + 4u * qe + k) * 8u),
-                           K2_CROSS | (jc << 3) | (qa << 10) | (qb << 13) | (e << 16) | (ne << 24), a1, a2,
-                           (uint32_t)__popc(a1) + (uint32_t)__popc(a2));
-            treads += cnt ? 1u : 0u;
-            nvar += cnt ? (has_b ? 6u : 3u) : 0u;
           }
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t x1[3], x2[3], any = 0;
+#pragma unroll
+          for (uint32_t c = 0; c < 3u; c++) {
+            uint32_t xs, xd, a1, a2;
+            pair_bits(w[c], Wk[c], xs, xd);
+            pair_answers(xs, xd, qa, rb_code, a1, a2);
+            x1[c] = a1 & 15u & own1 & lmask;
+            x2[c] = a2 & 15u & own2 & lmask;
+            any |= x1[c] | x2[c];
+          }
+          if (__ballot(any != 0u)) {
+            const uint64_t he = h ^ iw;                    /* (h2 = the query with e replaced = Wk ^ the pair's keys) */
+#pragma unroll
+            for (uint32_t c = 0; c < 3u; c++)
+              p2_push<GENES>(W, T, (x1[c] | x2[c]) != 0u, Wk[c] ^ he,
+                             K2_CROSS | (jc << 3) | (qa << 10) | (qb << 13) | (e << 16) | (((qe + c + 1u) & 3u) << 24),
+                             x1[c], x2[c], (uint32_t)__popc(x1[c]) + (uint32_t)__popc(x2[c]));
+          }
+          nhere += (here || far) ? 1u : 0u;
         }
+        treads += 3u * nhere;
+        nvar += 3u * nhere * (has_b ? 6u : 3u);
       }
       W.st.variants += valid ? (uint64_t)nvar : 0ull;
       reads += treads;

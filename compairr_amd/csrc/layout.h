@@ -105,7 +105,9 @@ struct SliceGeom {
   uint32_t rw_words;       /* variant 2 (kernels_rows.h): 32-byte words per
                               slice, any count <= MAX_ROW_SLICE_WORDS          */
   uint32_t cmask;          /* variant 2: slices per class part - 1 (row_slice)  */
-  uint32_t pad2;
+  uint32_t nbuf;           /* kernels_pairs2.h: slice buffers in LDS -- 2: the next chunk's slice is copied
+                              while this one is worked on; 1: slices twice the size (more queries per slice:
+                              fuller tiles), staged between two barriers */
 };
 
 /* Variant 2 files the entries of a row under the class key WITHOUT the terms of

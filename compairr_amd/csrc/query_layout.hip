@@ -1734,8 +1734,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.npass = npass;
   Q.min_mixed = mixed_ok ? c->geom.c0 + c->geom.k + (c->opt.indels ? 1u : 0u) : 0xffffffffu;
   Q.chunk_tiles = (uint32_t)chunk_tiles;
-  Q.small_max = (uint32_t)c->small_slice_tiles;
-  Q.class_unstaged = c->class_rows_unstaged ? 1u : 0u;
+  /* (kernels_pairs2.h works on staged chunks only) */
+  Q.small_max = c->d2pairs ? 0u : (uint32_t)c->small_slice_tiles;
+  Q.class_unstaged = c->class_rows_unstaged && !c->d2pairs ? 1u : 0u;
   Q.nbuckets = nbuckets;
   Q.nslices = nslices;
   Q.nslices_real = nslices_real;

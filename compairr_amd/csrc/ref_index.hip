@@ -232,14 +232,16 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
                             2048 * sizeof(unsigned long long) + 16 * sizeof(WaveQueue) +
                             MAX_CLASS_RES * A * sizeof(uint32_t) + 2 * (64 + 64 * sizeof(TileRef)) + 1024;
       const size_t room = fixed2 < 160 * 1024 ? 160 * 1024 - fixed2 : 0;
-      uint64_t w = room / (2 * ROW_WORD_BYTES);
+      const uint64_t nbuf = c->d2_buffers == 1 ? 1 : 2;
+      c->geom.nbuf = (uint32_t)nbuf;
+      uint64_t w = room / (nbuf * ROW_WORD_BYTES);
       if (w >= 64)
         w -= w % 32;                                     /* whole KiB: LDS-DMA pieces */
       if (w < 1) {
         c->d2pairs = false;                              /* (Zobrist tables too large: single rows, or variant 1) */
       } else {
         row_max_words = c->slice_words_log2 < 0 ? w : std::min<uint64_t>(1ull << c->slice_words_log2, w);
-        need_d2 = fixed2 + 2 * (size_t)row_max_words * ROW_WORD_BYTES;
+        need_d2 = fixed2 + nbuf * (size_t)row_max_words * ROW_WORD_BYTES;
       }
     }
     if (c->rows && c->slice_words_log2 < 0 && !c->d2pairs) {
@@ -295,8 +297,12 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     /* class parts (layout.h row_slice): each holds one entry per split sequence,
        the main part L + 1 - K per sequence: S n / entries slices, a power of two */
     /* (with -i a class part holds two entries per split sequence: blank row and gap row) */
+    /* (kernels_pairs2.h: a third of a query's reads go to the class parts -- they are sized for
+       their one entry per sequence at the filter's own density, 2 bytes per entry, not for the
+       single rows' count: 0.26 % of false positives per test became 2e-5, round 4) */
+    const uint64_t per_part = c->d2pairs ? bloom_bytes / 2 : entries;
     uint64_t Sc = 1;
-    while (Sc < S && Sc * entries < S * std::max<uint64_t>(s->n, 1) * (c->opt.indels ? 2 : 1))
+    while (Sc < S && Sc * per_part < S * std::max<uint64_t>(s->n, 1) * (c->opt.indels ? 2 : 1))
       Sc <<= 1;
     c->geom.cmask = (uint32_t)(Sc - 1);
   } else {
