@@ -153,7 +153,9 @@ struct cmpr_context {
                                      through with their chunks (one launch per step; kernels_rows.h fused_tail).
                                      OFF: measured slower (device-scope round trips and
                                      whole-L2 fences cost more than the two launches they save) */
-  int64_t merge_reduce = 1;       /* the last workgroup of resolve_kernel sums the partial results (no reduce launch) */
+  int64_t merge_reduce = 0;       /* the last workgroup of resolve_kernel sums the partial results (no reduce launch).
+                                     OFF: one workgroup reading 128 x 261 partial values with device-scope loads takes
+                                     ~45 us where the reduce kernel's 261 workgroups take 4.5 */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
   int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
   int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
@@ -217,7 +219,7 @@ struct cmpr_context {
   DevBuf<cmpr::ResPack> qpk;             /* nucleotides, d = 2 on pair rows: per slot, the query's residues */
   bool              d2pairs = false;    /* ... that kernel is in use (kernels_pairs2.h; decided with the index) */
   int64_t           d2_pairs = -1;      /* tunable: -1 auto, 0 off, 1 on */
-  int64_t           d2_buffers = 2;     /* tunable: slice buffers of that kernel (layout.h SliceGeom::nbuf) */
+  int64_t           d2_buffers = 1;     /* tunable: slice buffers of that kernel (layout.h SliceGeom::nbuf; cfg5: 51 ms with one, 60 with two) */
   uint64_t          algorithmic_bytes = 0;
   double            max_cell_bound = 0;   /* max_i total1[i] * max_j total2[j] */
   std::vector<double> tot1, tot2;

@@ -150,35 +150,6 @@ __device__ __forceinline__ void p2_drain_round(SProber &W, const P2Tables &T, in
   }
 }
 
-/* The drain of a full queue as a FUNCTION: it is called once per 64 positives, from a dozen
-   places in loops whose registers are all spoken for -- inlined there it cost them spills.
-   What it changes of the wave's state travels by value (the state itself stays in the
-   caller's registers: a reference to it would put it in memory). */
-struct P2Drained {
-  int qn;
-  unsigned long long held;
-  uint32_t hash_eq, matches;
-};
-template <bool GENES>
-__device__ __attribute__((noinline)) P2Drained p2_drain_full(const ProbeParams *Pp, WaveQueue *q,
-                                                             unsigned long long *mat_lds, uint32_t lane, int qn,
-                                                             unsigned long long held, uint32_t ze_addr,
-                                                             uint32_t pz_addr)
-{
-  SProber W{*Pp, nullptr, *q, mat_lds, lane, 0u, 0u, 0u, 0u, 0u, qn, {0ull, 0u, 0u, 0u}, held};
-  P2Tables T;
-  T.ze_addr = ze_addr;
-  T.pz_addr = pz_addr;
-  while (W.qn >= WAVE)
-    p2_drain_round<GENES>(W, T, WAVE);
-  P2Drained r;
-  r.qn = W.qn;
-  r.held = W.held;
-  r.hash_eq = W.st.hash_eq;
-  r.matches = W.st.matches;
-  return r;
-}
-
 template <bool GENES>
 __device__ __forceinline__ void p2_push(SProber &W, const P2Tables &T, bool pos, uint64_t B, uint32_t ca,
                                         uint32_t cb, uint32_t m, uint32_t nbits)
@@ -195,13 +166,10 @@ __device__ __forceinline__ void p2_push(SProber &W, const P2Tables &T, bool pos,
       W.st.bloom_pos += nbits;
     }
     W.qn += __popcll(mm);
-    if (W.qn >= WAVE) {
-      const P2Drained r = p2_drain_full<GENES>(&W.P, &W.q, W.mat_lds, W.lane, W.qn, W.held, T.ze_addr, T.pz_addr);
-      W.qn = r.qn;
-      W.held = r.held;
-      W.st.hash_eq += r.hash_eq;
-      W.st.matches += r.matches;
-    }
+    /* (inlined at every push site; as a function called from there -- its state passed by value --
+       the kernel was 13 % slower: round 4) */
+    while (W.qn >= WAVE)
+      p2_drain_round<GENES>(W, T, WAVE);
   }
 }
 
@@ -326,6 +294,7 @@ probe_pairs2_kernel(const ProbeParams P)
       if (off + l16 < slice_bytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(src + off), (lds_void_t *)(uintptr_t)(dst + off), 16, 0, 0);
     const uint32_t cpass = ck.pass & 0xffu;
+    const uint32_t upt = cpass >= 3u ? 1u : (ck.pass >> 16) & 0xffu;    /* units per tile: pairs of the longest */
     const uint32_t tbytes = cpass >= 3u ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
     const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + l16;
     const uint32_t tdst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(tref_lds + b * chunk_cap));
@@ -338,9 +307,10 @@ probe_pairs2_kernel(const ProbeParams P)
       slots[b].ntiles = ck.ntiles;
       slots[b].pass = cpass;
       slots[b].next_unit = 0;
-      /* a tile's units: its pairs j2 (the longest tile's count for all: surplus units return at once);
-         an item chunk's: its blocks of 64 items */
-      slots[b].units = cpass >= 3u ? ck.ntiles : ck.ntiles * npairs_max;
+      /* a tile's units: its pairs j2 (the chunk's longest tile's count for all: surplus units return
+         at once); an item chunk's: its blocks of 64 items */
+      slots[b].units = ck.ntiles * upt;
+      slots[b].pad[0] = upt;
     }
   };
 
@@ -362,7 +332,7 @@ probe_pairs2_kernel(const ProbeParams P)
     const uint32_t b = Tn & (nbuf - 1u);
     const uint32_t sbase = b * slice_bytes;
     const uint32_t cslice = slots[b].slice, cpass = slots[b].pass, cfirst = slots[b].first;
-    const uint32_t units = slots[b].units;
+    const uint32_t units = slots[b].units, upt = slots[b].pad[0];
     const TileRef *trefs = tref_lds + b * chunk_cap;
 
     auto woff_of = [&](uint64_t Wk) -> uint32_t {
@@ -396,8 +366,8 @@ probe_pairs2_kernel(const ProbeParams P)
       const bool item_unit = cpass >= 3u;
       uint32_t t = 0, L = 0, nvalid = WAVE, K = 0, j2 = 0;
       if (!item_unit) {
-        const uint32_t tk = u / npairs_max;
-        j2 = npairs_max - 1u - (u - tk * npairs_max);      /* the long units first */
+        const uint32_t tk = u / upt;
+        j2 = upt - 1u - (u - tk * upt);                    /* the long units first */
         const TileRef *tr = trefs + tk;
         t = __builtin_amdgcn_readfirstlane(tr->t);
         L = __builtin_amdgcn_readfirstlane(tr->td.len);
@@ -518,7 +488,7 @@ probe_pairs2_kernel(const ProbeParams P)
           n1++;
           const uint32_t qa1 = ab1 & 3u, qb1 = ab1 >> 2;   /* (j1 < j2 <= the lane's last pair: both exist when e does) */
           uint32_t zrow = T.pz_addr + P2_PZ * 8u * j1;
-          zrow = __builtin_amdgcn_readfirstlane(zrow);
+          asm("" : "+s"(zrow));
           const uint64_t K1 = lds_u64(zrow + ab1 * 8u);
           const uint32_t own1 = ~(1u << qa1), own2 = ~(1u << qb1);
           /* NR of the six at a time (all six when the pair has both positions): their words in

@@ -776,6 +776,13 @@ slices_kernel(const QL Q, uint32_t pi)
             ck.pass = pass + rp;
             if (Q.sub2_items && pi == 0 && k == 0)
               ck.pass |= CHUNK_WITH_ITEMS;      /* (the slice's item blocks ride along) */
+            if (Q.pairs2) {
+              /* kernels_pairs2.h hands a tile out pair by pair: the pairs of the chunk's longest tile */
+              uint32_t lmax = 0;
+              for (uint32_t t = 0; t < ck.ntiles; t++)
+                lmax = max(lmax, Q.tiles[tile_base + k * Q.chunk_tiles + t].len);
+              ck.pass |= ((lmax + 1u) / 2u) << 16;
+            }
             Q.chunks[Q.chunk0[pi] + at.chunks + k * reps + rp] = ck;
           }
       }
@@ -1139,7 +1146,7 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   if (k >= nchunks)
     return;
   const Chunk ck = Q.chunks[k];
-  const uint32_t cpass = ck.pass & ~CHUNK_WITH_ITEMS;
+  const uint32_t cpass = ck.pass & 0xffu;
   uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : 2) : 0;
   for (uint32_t t = 0; cpass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
@@ -1174,7 +1181,7 @@ chunk_mine_kernel(const Chunk *chunks, const uint32_t *idx, uint32_t n, uint32_t
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k < n) {
     const Chunk ck = chunks[idx[k]];
-    flag[k] = work_owner(ck.slice, ck.pass & ~CHUNK_WITH_ITEMS, step) == first ? 1 : 0;
+    flag[k] = work_owner(ck.slice, ck.pass & 0xffu, step) == first ? 1 : 0;
   }
 }
 

@@ -69,9 +69,9 @@ LAYOUTS = {
     "rows_fused_1seg": {"variant": 2, "fused_step": 1, "pos_segments": 1},
     "rows_fused_tiny": {"variant": 2, "fused_step": 1, "slice_words_log2": 3, "class_residues": 2,
                         "heavy_threshold": 2, "pos_segments": 2, "waves_per_block": 4},
-    # the partial results summed by a launch of their own instead of resolve_kernel's last workgroup
-    "rows_sep_reduce": {"variant": 2, "merge_reduce": 0},
-    "lds_sep_reduce": {"variant": 1, "merge_reduce": 0, "slice_words_log2": 6},
+    # the partial results summed by resolve_kernel's last workgroup instead of a launch of their own (off by default)
+    "rows_merged_reduce": {"variant": 2, "merge_reduce": 1},
+    "lds_merged_reduce": {"variant": 1, "merge_reduce": 1, "slice_words_log2": 6},
     # 64-byte slices, every class split by 3 / 1 class residues: class-row passes
     "rows_tiny_k3": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
                      "heavy_threshold": 0},
@@ -130,6 +130,10 @@ NT_LAYOUTS["pairs2_k6"] = {"variant": 2, "slice_words_log2": 3, "class_residues"
                            "heavy_threshold": 0}
 NT_LAYOUTS["pairs2_k0"] = {"variant": 2, "slice_words_log2": 5, "class_residues": 0}
 NT_LAYOUTS["pairs2_overflow"] = {"variant": 2, "slice_words_log2": 4, "pos_capacity": 64}
+# two slice buffers (the next chunk's slice copied while this one is worked on) instead of one
+NT_LAYOUTS["pairs2_two_buffers"] = {"variant": 2, "d2_buffers": 2}
+NT_LAYOUTS["pairs2_two_buffers_tiny"] = {"variant": 2, "d2_buffers": 2, "slice_words_log2": 3, "class_residues": 4,
+                                         "heavy_threshold": 1, "chunk_tiles": 2}
 
 
 def check(a, b, opt, threads=4, layouts=None):
