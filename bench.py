@@ -520,6 +520,7 @@ def main():
             # printed for this very workload (tests/golden/full_size.json), at every N
             "parity_vs_reference_full_size": parity_full,
             "roofline": roofline(wl, st, p_avg_ms, k_avg_ms,
+                                 "probe_pairs2_kernel" if layout.get("d2_pairs") else
                                  {0: "probe_kernel", 1: "probe_sliced_kernel", 2: "probe_rows_kernel"}[layout["variant"]]),
             "cpu_baseline": baseline,
             "parity_on_cpu_sample": parity,

@@ -1177,8 +1177,11 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     c->usage_pending = false;                 /* measured with another deal of the chunks */
   if (S.redo_kind && S.will_launch && c->usage_pending && hipEventQuery(c->ev_usage) == hipSuccess) {
     c->usage_pending = false;
-    const uint64_t waves_per_segment =
-        (((uint64_t)S.grid + S.P.pos_segments - 1) / S.P.pos_segments) * (uint64_t)S.nw;
+    /* (a wave's blocks go round the segments -- kernels_sliced.h pos_segment_of --, so a segment hears
+       from every wave of the grid; the fused step keeps one segment per workgroup) */
+    const uint64_t waves_per_segment = S.ffn
+        ? (((uint64_t)S.grid + S.P.pos_segments - 1) / S.P.pos_segments) * (uint64_t)S.nw
+        : (uint64_t)S.grid * (uint64_t)S.nw;
     const uint64_t margin = 2 * WAVE * (waves_per_segment + 1);
     c->never_overflows = static_deal && *c->h_usage + margin <= c->pos_cap;
     c->safe_grid = S.grid;

@@ -2090,12 +2090,12 @@ probe_rows_kernel(const ProbeParams P)
       bits = max(bits, (uint32_t)__shfl_xor((int)bits, off, WAVE));
     const uint32_t rounds = __builtin_amdgcn_readfirstlane(bits);
     unsigned long long extra = 0;
+    const uint32_t xseg = pos_segment_of(P, W.nclaims);
     if (P.pos_buf != nullptr && rounds > 1u && lane == 0)
-      extra = atomicAdd(P.pos_ctr + (size_t)(blockIdx.x & (P.pos_segments - 1)) * POS_CTR_STRIDE,
-                        (unsigned long long)(rounds - 1u) * WAVE);
+      extra = atomicAdd(P.pos_ctr + (size_t)xseg * POS_CTR_STRIDE, (unsigned long long)(rounds - 1u) * WAVE);
     for (uint32_t r = 0; r < rounds; r++) {
-      if (r >= 1u)
-        W.held = extra + (unsigned long long)(r - 1u) * WAVE;      /* (lane 0's is the one read) */
+      if (r >= 1u)                                                  /* (lane 0's is the one read) */
+        W.held = (extra + (unsigned long long)(r - 1u) * WAVE) | ((unsigned long long)xseg << 48);
       drain_round<A, D, GENES, INLINE, PAIRS>(W, zl_addr, W.qn < WAVE ? W.qn : WAVE, true);
     }
     if (rounds == 0u) {               /* the block claimed ahead goes back as a block of nulls */

@@ -50,7 +50,9 @@ struct SProber {
   uint32_t            tile_slice;
   int                 qn;
   LaneStats           st;
-  unsigned long long  held;        /* lane 0: the block of the positives buffer claimed ahead */
+  unsigned long long  held;        /* lane 0: the block of the positives buffer claimed ahead: its first entry,
+                                      and in bits 48.. the segment it lies in */
+  uint32_t            nclaims = 0; /* blocks claimed so far (wave-uniform): the segments are taken in turn */
 };
 
 /* `n` queue entries starting at `first` leave the wave: in deferred mode they
@@ -124,14 +126,26 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
    previous block is written and waited for only when the next is, so a flush costs
    no round trip.  The last flush of a wave (`last`) claims nothing and pads its
    block with null entries (POS_NULL_SLOT). */
+/* The segment of a wave's n-th block.  A workgroup used to append to ONE segment (b % segments); on skewed data --
+   the cdr3 law: a few slices hold most of the neighbours -- the workgroups of those slices overfilled theirs while
+   the others stayed empty, and the step fell back to its redo pass (10M x 10M d = 1 -i: 21 ms for 1.25; round 4).
+   Now a wave's blocks go round the segments, starting at its workgroup's.  (The fused step, whose workgroups
+   announce "my segment is complete", keeps the one segment: ProbeParams::fuse.) */
+__device__ __forceinline__ uint32_t pos_segment_of(const ProbeParams &P, uint32_t nclaims)
+{
+  return (blockIdx.x + (P.fuse ? 0u : nclaims)) & (P.pos_segments - 1);
+}
+
 __device__ __forceinline__ void claim_pos_block(SProber &W)
 {
   const ProbeParams &P = W.P;
   if (P.pos_buf == nullptr)
     return;
-  const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
+  const uint32_t seg = pos_segment_of(P, W.nclaims);
+  W.nclaims++;
   if (W.lane == 0)
-    W.held = atomicAdd(P.pos_ctr + (size_t)seg * POS_CTR_STRIDE, (unsigned long long)WAVE);
+    W.held = atomicAdd(P.pos_ctr + (size_t)seg * POS_CTR_STRIDE, (unsigned long long)WAVE) |
+             ((unsigned long long)seg << 48);
 }
 
 template <bool GENES, bool FALLBACK = true>
@@ -140,11 +154,11 @@ __device__ __forceinline__ void flush_or_resolve(SProber &W, int first, int n, b
   const ProbeParams &P = W.P;
   bool inline_resolve = FALLBACK && P.pos_buf == nullptr;
   if (!inline_resolve) {
-    const uint32_t seg = blockIdx.x & (P.pos_segments - 1);
+    const uint32_t held_hi = __builtin_amdgcn_readfirstlane((uint32_t)(W.held >> 32));
+    const uint32_t seg = held_hi >> 16;                    /* (the block claimed ahead names its segment) */
     unsigned long long *ctr = P.pos_ctr + (size_t)seg * POS_CTR_STRIDE;
     const unsigned long long base =
-        ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(W.held >> 32)) << 32) |
-        __builtin_amdgcn_readfirstlane((uint32_t)W.held);
+        ((unsigned long long)(held_hi & 0xffffu) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)W.held);
     if (!last)
       claim_pos_block(W);
     if (base < P.pos_cap) {                   /* the segment has 64 entries of slack */

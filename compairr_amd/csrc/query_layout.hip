@@ -1847,7 +1847,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
       rq[r] = nranges == 4 ? n * cut4[r] / 100 : n * r / nranges;
 
     /* the narrowing threads: thread t takes the t-th part of every range, range by range */
-    const unsigned T = narrow ? std::max(1u, std::min(32u, hw)) : 0u;
+    /* (a thread per >= 128k queries: starting 32 threads costs more than a 1M-query share's narrowing) */
+    const unsigned T = narrow ? std::max(1u, std::min(std::min(32u, hw), (unsigned)(n >> 17) + 1u)) : 0u;
     uint16_t *h_len16 = nullptr, *h_rep16 = nullptr, *h_v16 = nullptr, *h_j16 = nullptr;
     uint32_t *h_cnt32 = nullptr;
     std::atomic<uint32_t> done[4];
@@ -2030,6 +2031,12 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     c->layout_upload_ms = upload_ms;
     c->layout_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     c->layout_tail_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_uploaded).count();
+    if (getenv("COMPAIRR_HIP_DEBUG"))
+      fprintf(stderr, "compairr_hip: route_queries %.2f ms = arena A %.2f + upload (keys hidden) %.2f + counts %.2f  "
+                      "(copy calls %.2f; %llu queries, %llu records)\n", c->layout_total_ms,
+              std::chrono::duration<double, std::milli>(t_arena_a - t_begin).count(),
+              std::chrono::duration<double, std::milli>(t_uploaded - t_arena_a).count(), c->layout_tail_ms, upload_ms,
+              (unsigned long long)n, (unsigned long long)R.total_records);
     quiesce.ok = true;
     return CMPR_OK;
   }

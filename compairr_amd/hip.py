@@ -224,7 +224,7 @@ class HipOverlap:
         return {k: self.get_tunable(k) for k in
                 ("variant", "slices", "slice_words_log2", "class_residues",
                  "bloom_bits_log2_delta", "waves_per_block", "chunk_tiles",
-                 "tiles", "chunks", "small_tiles", "query_slots", "class_anchor")}
+                 "tiles", "chunks", "small_tiles", "query_slots", "class_anchor", "d2_pairs")}
 
     def set_reference(self, s: RepertoireSet, longest_query: int = 0) -> None:
         v = _view(s)

@@ -770,6 +770,9 @@ def test_shortcut_is_withdrawn_when_the_deal_changes():
     want = _oracle.integer_cells(want, o)
     with HipOverlap(o) as h:
         h.set_tunable("variant", 2)
+        # (a wave's blocks go round the segments: the margin is two blocks per wave of the grid and
+        #  segment -- 64 x 2 x 64 x 4097 entries; the default capacity of a 40000-query set is below it)
+        h.set_tunable("pos_capacity", 40_000_000)
         h.set_reference(b, a.longest)
         h.set_queries(a)
         for _ in range(4):
