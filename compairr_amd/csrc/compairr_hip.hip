@@ -725,7 +725,7 @@ static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
     /* partial results of the workgroups (ProbeParams::part); cleared here, and by
        reduce_partials_kernel after every launch */
     const size_t cells = (size_t)c->R1 * c->R2;
-    c->part_stride = (uint32_t)((cells <= 2048 && !is_f64_score(c->opt) ? cells : 0) + STAT_COUNT);
+    c->part_stride = (uint32_t)((cells <= PART_CELLS_MAX && !is_f64_score(c->opt) ? cells : 0) + STAT_COUNT);
     if ((rc = dev_reserve(c, c->part, (size_t)NPART * c->part_stride))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long),
                               c->stream));
@@ -823,6 +823,7 @@ int make_plan(cmpr_context *c)
   P.sub2_items = c->sub2_active ? 1u : 0u;
   P.part = c->part.p;
   P.part_stride = c->part_stride;
+  P.part_cells = c->part_stride - STAT_COUNT;
   P.work_first = (uint32_t)c->work_shard_index;
   P.work_step = (uint32_t)c->work_shard_count;
   P.matrix_f64 = c->matrix_f64.p;
@@ -1071,7 +1072,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
   auto reduce_partials = [&]() {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(P.part_stride), dim3(NPART), 0, st, P,
-                       (uint32_t)(P.lds_matrix ? cells : 0), S.reduce_writes ? 1u : 0u, c->ctr_other,
+                       P.part_cells, S.reduce_writes ? 1u : 0u, c->ctr_other,
                        (uint32_t)S.ctr_blk, a.track_usage ? c->d_usage : nullptr, sticky);
   };
   const bool resolve_pass = S.deferred && !(c->debug & DBG_SKIP_RESOLVE);
@@ -1085,7 +1086,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     P.fuse = c->d_fuse;
     P.next_ctr = c->ctr_other;
     P.next_n64 = (uint32_t)S.ctr_blk;
-    P.reduce_cells = (uint32_t)(P.lds_matrix ? cells : 0);
+    P.reduce_cells = P.part_cells;
     P.usage = a.track_usage ? c->d_usage : nullptr;
     P.sticky = sticky;
   }
@@ -1186,6 +1187,24 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     c->never_overflows = static_deal && *c->h_usage + margin <= c->pos_cap;
     c->safe_grid = S.grid;
     c->safe_nw = S.nw;
+    /* The fullest segment did not fit: that launch was redone resolving inline (correct, and several times
+       slower).  The buffer's size was a guess (4 positives per query); now that the number is known the
+       buffer grows to it -- once per query set, behind the launches in flight (24.2M sequences against
+       themselves, d = 1 -i: 3.1 x 10^8 positives where 9.8 x 10^7 were provided for; round 4). */
+    if (c->pos_capacity == 0 && *c->h_usage > c->pos_cap) {
+      const uint64_t Sg = (uint64_t)c->pos_segments;
+      const uint64_t want = *c->h_usage + *c->h_usage / 4 + margin;
+      if (Sg * (want + WAVE) * sizeof(PosEntry) <= (96ull << 30)) {
+        /* (launches of a context are ordered one behind the other, also across streams -- the wait for
+           the previous one is already queued on `st`) */
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if ((rc = dev_reserve(c, c->pos_buf, (size_t)(Sg * (want + WAVE)))))
+          return rc;
+        c->pos_cap = want;
+        c->plan.P.pos_cap = want;
+        c->plan.P.pos_buf = c->pos_buf.p;
+      }
+    }
   }
   a.track_usage = S.redo_kind && S.will_launch && static_deal && !c->never_overflows && !c->usage_pending;
   a.with_redo = S.redo_kind && !c->never_overflows;

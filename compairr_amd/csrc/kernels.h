@@ -673,9 +673,13 @@ __device__ __forceinline__ void reduce_last(const ProbeParams &P, unsigned long 
     x += __shfl_xor(x, 1, WAVE);
     x += __shfl_xor(x, 2, WAVE);
     if (q == 0u && i < stride) {
-      if (i < cells)
-        P.matrix[i] = ovf ? 0ull : x;            /* (a redo pass adds to a clean matrix) */
-      else if (x && i >= stride - STAT_COUNT)
+      if (i < cells) {
+        if (P.lds_matrix)
+          P.matrix[i] = ovf ? 0ull : x;          /* (a redo pass adds to a clean matrix) */
+        else if (x && !ovf)
+          P.matrix[i] += x;                      /* (a matrix too large for LDS: cleared before the launch, and
+                                                    the inline paths add to it where it lies) */
+      } else if (x && i >= stride - STAT_COUNT)
         P.stats[i - (stride - STAT_COUNT)] += x;
     }
   }
@@ -701,7 +705,8 @@ resolve_kernel(const ProbeParams P)
       mat_lds[i] = 0;
     __syncthreads();
   } else {
-    mat_lds = nullptr;
+    /* (no LDS copy: the workgroup's partial slot in HBM when the matrix is kept there, else the matrix) */
+    mat_lds = P.part && P.part_cells ? matrix_dst(P) : nullptr;
   }
   /* workgroup b of the grid (a multiple of pos_segments) works on segment
      b % pos_segments, together with the gridDim.x / pos_segments - 1 others */

@@ -204,6 +204,7 @@ struct Chunk {
    slice (ProbeParams::slice_items), behind its tiles */
 constexpr uint32_t CHUNK_WITH_ITEMS = 0x100u;
 constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */
+constexpr uint32_t PART_CELLS_MAX = 65536;   /* largest matrix kept in the slots (x NPART x 8 bytes = 64 MiB) */
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
 constexpr uint32_t FUSE_WORDS = 16;          /* ProbeParams::fuse: global words of the fused step, one line */
 
@@ -338,7 +339,12 @@ struct ProbeParams {
   int32_t         score;
   int32_t         ignore_counts;
   int32_t         lds_matrix;      /* 1: privatise the matrix in LDS          */
-  int32_t         pad1;
+  uint32_t        part_cells;      /* cells kept in the partial slots (`part`): all of them when the matrix is
+                                      privatised in LDS; a matrix too large for LDS but of at most PART_CELLS_MAX
+                                      cells is added to the workgroup's slot in HBM instead of to `matrix` itself --
+                                      a self-comparison sends every identity pair to one of R diagonal cells, and
+                                      10^5 atomics on one address serialise (24.2M sequences, 120 repertoires:
+                                      resolve 3.6 ms; round 4) */
   /* deferred resolve: Bloom positives are appended here by the probe kernel and
      walked / verified / scored by resolve_kernel at full occupancy */
   PosEntry           *pos_buf;      /* NULL: resolve inline in the probe kernel  */

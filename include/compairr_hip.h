@@ -316,13 +316,21 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              that put a new residue on a class position are grouped
                              by the slice they land in and probed there (1, and
                              the default -1), or probed where the filter lies (0)
+     "d2_pairs"              nucleotides, d = 2: -1 (default) / 1: pair rows probed by a workgroup per
+                             tile (kernels_pairs2.h; sequences of at most 96 residues), 0: off
+     "d2_buffers"            that kernel's slice buffers: 1 (default; slices twice the size: fuller
+                             tiles) or 2 (the next slice is copied while this one is worked on)
+     "fused_step"            variant 2: 1: probe, resolve and the sum of the partial results in ONE
+                             launch; default 0 (measured slower on MI355X)
+     "merge_reduce"          1: the partial results are summed by the resolve kernel's last workgroup
+                             instead of a launch of their own; default 0 (measured slower)
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
      "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip
      "assume_never_overflows" TEST ONLY: the next launch runs without redo pass as if
                              the margin had been shown
-   "variant", "bloom_bits_log2_delta", "class_residues" and "slice_words_log2"
-   must be set before cmpr_set_reference(); "chunk_tiles", "waves_per_block",
+   "variant", "bloom_bits_log2_delta", "class_residues", "slice_words_log2", "d2_pairs" and
+   "d2_buffers" must be set before cmpr_set_reference(); "chunk_tiles", "waves_per_block",
    "small_slice_tiles" and the work shard before cmpr_set_queries().  ("debug" exists
    only in a -DCMPR_ABLATION build of the library.) */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);

@@ -267,7 +267,8 @@ def test_mh_and_jaccard_sums_d0():
 
 
 def test_many_repertoires_uses_global_atomics():
-    """R1 x R2 > 2048 cells: the matrix is no longer privatised in LDS."""
+    """R1 x R2 > 2048 cells: the matrix is no longer privatised in LDS -- up to 65536 cells the workgroups add
+    to their partial slots in HBM (4480 here), beyond that to the matrix itself (the -x tests: 100000 cells)."""
     a = synth.make_set(40000, 9, prefix="A", pool_size=5000, n_repertoires=70)
     b = synth.make_set(40000, 10, prefix="B", pool_size=5000, n_repertoires=64)
     assert a.n_repertoires * b.n_repertoires > 2048
@@ -674,6 +675,28 @@ def test_repeated_launches_with_and_without_redo_pass():
                 assert st.matches == ost.matches, (cap, launch)
             pairs = h.overlap_pairs()
             assert len(pairs) == ost.matches
+
+
+def test_positives_buffer_grows_after_an_overflow():
+    """The positives buffer is sized for 4 positives per query; a set with far more (few letters, short
+    sequences: millions of neighbours) overflows it, the step is redone inline -- and the buffer
+    grows to what the launch showed, so that later launches fit (every launch gives the same matrix)."""
+    a = b = synth.tiny_set(20000, 51, letters=2, max_len=7, min_len=5, n_repertoires=3, prefix="A")
+    o = Options(differences=1, indels=True, n_v_genes=2, n_j_genes=2)
+    want, ost = _oracle.overlap(a, b, o, threads=8)
+    want = _oracle.integer_cells(want, o)
+    assert ost.matches > 2_000_000
+    with HipOverlap(o) as h:
+        h.set_tunable("variant", 2)
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        cap0 = h.get_tunable("pos_capacity")
+        assert cap0 < ost.matches
+        for launch in range(5):
+            assert np.array_equal(h.overlap_matrix(), want), launch
+            assert h.stats().matches == ost.matches
+        assert h.get_tunable("pos_capacity") > ost.matches          # grown: the last launches fitted
+        assert len(h.overlap_pairs()) == ost.matches
 
 
 def test_overflow_without_redo_pass_is_never_silent():
