@@ -406,6 +406,10 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_q)
       return fail(c, CMPR_ESTATE, "set pos_segments before cmpr_set_queries");
     c->pos_segments = value;
+  } else if (n == "pos_grow") {
+    if (value < -1 || value > 1)
+      return fail(c, CMPR_EINVAL, "pos_grow must be -1 (auto), 0 or 1");
+    c->pos_grow = value;
   } else if (n == "pos_capacity") {
     if (value < 0)
       return fail(c, CMPR_EINVAL, "pos_capacity must be >= 0");
@@ -505,6 +509,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "host_threads") *value = c->host_threads;
   else if (n == "pos_capacity") *value = (int64_t)(c->pos_cap * c->pos_segments);
   else if (n == "pos_segments") *value = c->pos_segments;
+  else if (n == "pos_grow") *value = c->pos_grow;
   else if (n == "resolve_blocks_per_cu") *value = c->resolve_blocks_per_cu;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
 #ifdef CMPR_PHASE_TIMING
@@ -955,7 +960,7 @@ int make_plan(cmpr_context *c)
           : nw == 16 ? select_probe_v2_fused_nw16((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
                      : select_probe_v2_fused_nw8((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes);
     S.flds = std::max(lds, (size_t)nw * sizeof(CandQueue) + cells * sizeof(unsigned long long) + 64);
-    if (S.flds > 160 * 1024) {
+    if (S.ffn == nullptr || S.flds > 160 * 1024) {
       S.ffn = nullptr;
     } else {
       if (S.flds > 48 * 1024)
@@ -1191,7 +1196,7 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
        slower).  The buffer's size was a guess (4 positives per query); now that the number is known the
        buffer grows to it -- once per query set, behind the launches in flight (24.2M sequences against
        themselves, d = 1 -i: 3.1 x 10^8 positives where 9.8 x 10^7 were provided for; round 4). */
-    if (c->pos_capacity == 0 && *c->h_usage > c->pos_cap) {
+    if ((c->pos_grow > 0 || (c->pos_grow < 0 && c->pos_capacity == 0)) && *c->h_usage > c->pos_cap) {
       const uint64_t Sg = (uint64_t)c->pos_segments;
       const uint64_t want = *c->h_usage + *c->h_usage / 4 + margin;
       if (Sg * (want + WAVE) * sizeof(PosEntry) <= (96ull << 30)) {

@@ -157,6 +157,8 @@ struct cmpr_context {
                                      OFF: one workgroup reading 128 x 261 partial values with device-scope loads takes
                                      ~45 us where the reduce kernel's 261 workgroups take 4.5 */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
+  int64_t pos_grow = -1;          /* the buffer grows to what a launch showed: -1 = when its size was automatic,
+                                     1 = also from a given pos_capacity (tests), 0 = never */
   int64_t resolve_blocks_per_cu = 5; /* what resolve_kernel's registers allow      */
   int64_t pos_segments = 64;      /* independently claimed parts of that buffer  */
   bool    waves_per_block_forced = false;

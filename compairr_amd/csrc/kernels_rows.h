@@ -841,6 +841,8 @@ __device__ __forceinline__ void fused_tail(const ProbeParams &P, unsigned char *
   }
 }
 
+/* (16 waves = 1024 lanes is the largest workgroup there is: five waves per SIMD would take two
+   workgroups per CU, and two rings of slices do not fit the LDS) */
 template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE, bool FUSED = false>
 __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_rows_kernel(const ProbeParams P)

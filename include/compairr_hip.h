@@ -324,6 +324,9 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              launch; default 0 (measured slower on MI355X)
      "merge_reduce"          1: the partial results are summed by the resolve kernel's last workgroup
                              instead of a launch of their own; default 0 (measured slower)
+     "pos_grow"              the positives buffer grows to what a launch showed when it overflowed:
+                             -1 (default) when its size was automatic, 1 also from a given
+                             "pos_capacity", 0 never
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
      "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip

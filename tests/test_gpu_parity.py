@@ -678,25 +678,37 @@ def test_repeated_launches_with_and_without_redo_pass():
 
 
 def test_positives_buffer_grows_after_an_overflow():
-    """The positives buffer is sized for 4 positives per query; a set with far more (few letters, short
-    sequences: millions of neighbours) overflows it, the step is redone inline -- and the buffer
-    grows to what the launch showed, so that later launches fit (every launch gives the same matrix)."""
-    a = b = synth.tiny_set(20000, 51, letters=2, max_len=7, min_len=5, n_repertoires=3, prefix="A")
-    o = Options(differences=1, indels=True, n_v_genes=2, n_j_genes=2)
+    """The positives buffer is sized by a guess (4 positives per query); when a launch overflows it the
+    step is redone inline -- and the buffer grows to what the launch showed, so that later launches fit
+    (every launch gives the same matrix).  Forced with a small given capacity and `pos_grow`."""
+    a = synth.make_set(40000, 21, prefix="A", pool_size=8000)
+    b = synth.make_set(40000, 22, prefix="B", pool_size=8000)
+    o = Options(differences=1, indels=True, **FULL)
     want, ost = _oracle.overlap(a, b, o, threads=8)
     want = _oracle.integer_cells(want, o)
-    assert ost.matches > 2_000_000
-    with HipOverlap(o) as h:
+    for segments in (64, 1):
+        with HipOverlap(o) as h:
+            h.set_tunable("variant", 2)
+            h.set_tunable("pos_segments", segments)
+            h.set_tunable("pos_capacity", 64 * segments)            # one block per segment
+            h.set_tunable("pos_grow", 1)
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            cap0 = h.get_tunable("pos_capacity")
+            for launch in range(5):
+                assert np.array_equal(h.overlap_matrix(), want), launch
+                st = h.stats()
+                assert st.matches == ost.matches
+            assert h.get_tunable("pos_capacity") > max(cap0, st.bloom_positive)      # grown: the last launches fitted
+            assert len(h.overlap_pairs()) == ost.matches
+    with HipOverlap(o) as h:                                        # a given capacity stays as it is by default
         h.set_tunable("variant", 2)
+        h.set_tunable("pos_capacity", 4096)
         h.set_reference(b, a.longest)
         h.set_queries(a)
-        cap0 = h.get_tunable("pos_capacity")
-        assert cap0 < ost.matches
-        for launch in range(5):
-            assert np.array_equal(h.overlap_matrix(), want), launch
-            assert h.stats().matches == ost.matches
-        assert h.get_tunable("pos_capacity") > ost.matches          # grown: the last launches fitted
-        assert len(h.overlap_pairs()) == ost.matches
+        for launch in range(4):
+            assert np.array_equal(h.overlap_matrix(), want)
+        assert h.get_tunable("pos_capacity") <= 4096 + 64 * 64
 
 
 def test_overflow_without_redo_pass_is_never_silent():
