@@ -36,7 +36,7 @@ static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
    of the fused step and its per-segment counters (on lines of their own: they are polled) */
 static inline size_t ctr_block_words(uint64_t segments)
 {
-  return (size_t)segments * POS_CTR_STRIDE + CTR_TAIL + FUSE_WORDS + (size_t)segments * POS_CTR_STRIDE;
+  return (size_t)segments * POS_CTR_STRIDE + CTR_TAIL + FUSE_WORDS + (size_t)segments * POS_CTR_STRIDE + DEAL_WORDS;
 }
 namespace {
 void use_counter_block(cmpr_context *c, int which);
@@ -385,6 +385,10 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "merge_reduce must be 0 or 1");
     c->merge_reduce = value;
+  } else if (n == "chunk_deal") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "chunk_deal must be 0 (static) or 1 (by a counter)");
+    c->chunk_deal = value;
   } else if (n == "narrow_upload") {
     if (value < -1 || value > 1)
       return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
@@ -482,6 +486,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "d2_pairs") *value = c->have_ref ? (c->d2pairs ? 1 : 0) : c->d2_pairs;
   else if (n == "fused_step") *value = c->plan.valid ? (c->plan.ffn ? 1 : 0) : c->fused_step;
   else if (n == "merge_reduce") *value = c->merge_reduce;
+  else if (n == "chunk_deal") *value = c->chunk_deal;
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
   else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);
@@ -759,6 +764,7 @@ void use_counter_block(cmpr_context *c, int which)
   c->d_stats2 = c->d_overflow + 1;
   c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
   c->d_fuse = c->d_stats + CTR_TAIL;
+  c->d_deal = c->ctr_cur + blk - DEAL_WORDS;
 }
 
 /* the cached plan is stale (sets or tunables changed) */
@@ -915,6 +921,7 @@ int make_plan(cmpr_context *c)
     return fail(c, CMPR_EUNSUPPORTED,
                 "sequences too long: Zobrist table does not fit the 160 KiB LDS");
   P.chunk_cap = c->chunk_cap;
+  P.deal = c->rows ? (uint32_t)c->chunk_deal : 0u;
   /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
      that resolves inline is deferred_resolve = 0 and the redo pass */
   ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !S.deferred)
@@ -1018,6 +1025,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
   ProbeParams P = S.P;
   P.matrix = a.d_out;
   P.tile_counter = c->d_tile_counter;
+  P.deal_ctr = c->d_deal;
   P.stats = c->d_stats;
   P.pair_q = c->pair_q;
   P.pair_h = c->pair_h;
@@ -1062,6 +1070,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
       P2.redo = 1;
       P2.stats = c->d_stats2;
       P2.tile_counter = c->d_tile_counter2;
+      P2.deal_ctr = c->d_deal + DEAL_WORDS / 2;
       hipLaunchKernelGGL(S.fn2, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P2);
       HIP_TRY(c, hipGetLastError());
       c->launches = 2;
@@ -1119,6 +1128,7 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     P2.redo = 1;
     P2.stats = c->d_stats2;
     P2.tile_counter = c->d_tile_counter2;
+      P2.deal_ctr = c->d_deal + DEAL_WORDS / 2;
     hipLaunchKernelGGL(S.fn2, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P2);
     HIP_TRY(c, hipGetLastError());
     c->launches = 3;
@@ -1188,7 +1198,11 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
     const uint64_t waves_per_segment = S.ffn
         ? (((uint64_t)S.grid + S.P.pos_segments - 1) / S.P.pos_segments) * (uint64_t)S.nw
         : (uint64_t)S.grid * (uint64_t)S.nw;
-    const uint64_t margin = 2 * WAVE * (waves_per_segment + 1);
+    /* (which chunks a workgroup gets may differ from launch to launch -- chunk_deal --: a wave's k-th
+       block goes to segment (its workgroup + k) mod S whatever it works on, so a segment receives
+       1/S of all blocks, give or take one block per wave; the number of blocks is that of the
+       positives / 64, give or take two per wave) */
+    const uint64_t margin = 2 * WAVE * (waves_per_segment + 1) + 4 * WAVE * ((uint64_t)S.grid * S.nw / S.P.pos_segments + 1);
     c->never_overflows = static_deal && *c->h_usage + margin <= c->pos_cap;
     c->safe_grid = S.grid;
     c->safe_nw = S.nw;

@@ -156,6 +156,8 @@ struct cmpr_context {
   int64_t merge_reduce = 0;       /* the last workgroup of resolve_kernel sums the partial results (no reduce launch).
                                      OFF: one workgroup reading 128 x 261 partial values with device-scope loads takes
                                      ~45 us where the reduce kernel's 261 workgroups take 4.5 */
+  int64_t chunk_deal = 1;         /* variant 2: 1 = beyond a workgroup's first four, chunks are handed out by a counter
+                                     in list order (heaviest first); 0 = all of them dealt statically */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
   int64_t pos_grow = -1;          /* the buffer grows to what a launch showed: -1 = when its size was automatic,
                                      1 = also from a given pos_capacity (tests), 0 = never */
@@ -271,6 +273,7 @@ struct cmpr_context {
   double                     wall_clock_khz = 100000.0;
   bool                       last_fused = false;       /* the last launch was the fused kernel */
   uint32_t                  *d_tile_counter2 = nullptr;
+  unsigned long long        *d_deal = nullptr;         /* chunk counters of probe_rows_kernel (DEAL_WORDS) */
   DevBuf<unsigned long long> part;           /* NPART x part_stride partial results */
   uint32_t                   part_stride = 0;
   const void                *attr_fn2 = nullptr;

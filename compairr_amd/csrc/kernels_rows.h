@@ -584,7 +584,10 @@ struct RingSlot {
   uint32_t done;             /* tiles of the tenant finished */
   uint32_t slice, pass;
   uint32_t first;            /* class-row chunk: its first item (blocks of 64 items, no tile refs) */
-  uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter; [1]: item chunk: its blocks) */
+  uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter; [0] of slot 1: buffers whose
+                                chain of tenants has ended; [1]: item chunk: its blocks) */
+  uint32_t next_chunk;       /* the chunk of the tenant after this one (P.deal: reserved when this one was staged) */
+  uint32_t pad2;
 };
 
 
@@ -924,16 +927,31 @@ probe_rows_kernel(const ProbeParams P)
      be staging different chunks at the same time, so the copies of up to RING
      chunks overlap -- and a workgroup short of tiles turns more of its waves into
      loaders by itself. */
-  const uint32_t my_chunks = have_chunks ? (P.nchunks - blockIdx.x + G - 1u) / G : 0u;
+  /* Which chunk is tenant T of this workgroup: with a static deal chunk blockIdx.x + (T - 1) G of
+     the list (heaviest first); with P.deal only the first RING are, and every staging reserves
+     the chunk of the tenant that will follow in the same buffer from a counter (one per DEAL_GROUPS-th
+     of the grid, each over its share of the rest of the list) -- the list is then worked off in its
+     order by whoever is free, and the launch ends within one light
+     chunk for every workgroup.  A buffer whose next chunk lies behind the end of the list gets the
+     end marker; the launch is over for a workgroup when all RING buffers carry one. */
   uint32_t *issue = (uint32_t *)&ring[0].pad[0];            /* next tag to stage, starts at 1 */
+  uint32_t *ended = (uint32_t *)&ring[1].pad[0];            /* buffers with an end marker */
+  const uint32_t nchunks = P.nchunks;
   auto try_stage = [&]() -> bool {
     const uint32_t T = *(volatile uint32_t *)issue + 1u;     /* (stored as T - 1: zero-initialised) */
-    if (T > my_chunks + 1u)
-      return false;                           /* everything, the end marker included, is issued */
+    if (*(volatile uint32_t *)ended >= RING)
+      return false;                           /* everything, the end markers included, is issued */
     const uint32_t b = (T - 1u) % RING;
     volatile RingSlot *rs = ring + b;
     const unsigned long long cl = rs->claim;
     const uint32_t hi = (uint32_t)(cl >> 32);
+    if (hi == RING_END) {
+      /* this buffer is through: the tag passes to the next one */
+      uint32_t won = 0;
+      if (lane == 0)
+        won = atomicCAS(issue, T - 1u, T) == T - 1u ? 1u : 0u;
+      return __builtin_amdgcn_readfirstlane(won) != 0u;
+    }
     if (hi != (T > RING ? T - RING : 0u) || rs->done != (uint32_t)((cl >> 16) & 0xffffu))
       return false;                           /* the buffer's tenant is not finished (or not even there) */
     uint32_t won = 0;
@@ -941,13 +959,19 @@ probe_rows_kernel(const ProbeParams P)
       won = atomicCAS(issue, T - 1u, T) == T - 1u ? 1u : 0u;
     if (!__builtin_amdgcn_readfirstlane(won))
       return false;
-    if (T == my_chunks + 1u) {
-      /* the end marker goes where the next chunk would */
+    const uint32_t idx = (P.deal && T > RING) ? rs->next_chunk : blockIdx.x + (T - 1u) * G;
+    const uint32_t grp = blockIdx.x % DEAL_GROUPS;
+    if (idx >= nchunks) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       rs->claim = ((unsigned long long)RING_END << 32) | ((unsigned long long)(T & 0xffffu) << 16);
+      if (lane == 0)
+        atomicAdd(ended, 1u);
       return true;
     }
-    const Chunk ck = P.chunks[blockIdx.x + (T - 1u) * G];
+    uint32_t reserved = 0;
+    if (P.deal && lane == 0)
+      reserved = atomicAdd((unsigned int *)(P.deal_ctr + grp * DEAL_STRIDE), 1u);
+    const Chunk ck = P.chunks[idx];
     /* (opaque: or the per-lane source pointers are hoisted out of the tile loop and
        live -- spilled -- across it for the sake of this rare path) */
     uint32_t l16 = lane * 16u;
@@ -976,6 +1000,8 @@ probe_rows_kernel(const ProbeParams P)
     /* what is claimed: a tile, or ITEM_BLOCKS blocks of an item chunk */
     const uint32_t units = ck.pass >= 3 ? (ck.ntiles + ITEM_BLOCKS - 1u) / ITEM_BLOCKS : ck.ntiles;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the copies have landed */
+    if (P.deal)
+      rs->next_chunk = RING * G + grp + DEAL_GROUPS * __builtin_amdgcn_readfirstlane(reserved);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     rs->claim = ((unsigned long long)T << 32) | ((unsigned long long)units << 16);
     return true;
@@ -1045,9 +1071,9 @@ probe_rows_kernel(const ProbeParams P)
       const unsigned long long cl = ((volatile RingSlot *)ring)[b].claim;
       const uint32_t hi = (uint32_t)(cl >> 32);
       if (hi == RING_END) {
-        if ((((uint32_t)cl >> 16) & 0xffffu) == (my_tag & 0xffffu))
-          return c;                           /* the end */
-        my_tag++;                             /* that tenant came and went */
+        if (*(volatile uint32_t *)ended >= RING)
+          return c;                           /* the end: every buffer carries the marker */
+        my_tag++;                             /* nothing more comes through this buffer */
         continue;
       }
       if (hi < my_tag) {                      /* not published yet */

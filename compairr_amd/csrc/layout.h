@@ -206,6 +206,10 @@ constexpr uint32_t CHUNK_WITH_ITEMS = 0x100u;
 constexpr uint32_t NPART = 128;              /* partial-result slots (ProbeParams::part) */
 constexpr uint32_t PART_CELLS_MAX = 65536;   /* largest matrix kept in the slots (x NPART x 8 bytes = 64 MiB) */
 constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segment */
+/* probe_rows_kernel's chunk counters (ProbeParams::deal_ctr): the workgroups of group blockIdx % DEAL_GROUPS
+   share one, on a line of its own (one counter for the whole grid: 18 000 answered atomics on one address
+   took as long as the launch); the second half belongs to the redo launch */
+constexpr uint32_t DEAL_GROUPS = 8, DEAL_STRIDE = 8, DEAL_WORDS = 2 * DEAL_GROUPS * DEAL_STRIDE;
 constexpr uint32_t FUSE_WORDS = 16;          /* ProbeParams::fuse: global words of the fused step, one line */
 
 /* entries per position of the sliced kernel's LDS copy of the Zobrist table:
@@ -288,7 +292,8 @@ struct ProbeParams {
   /* Bloom */
   const uint64_t *bloom;
   uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
-  uint32_t        pad0;
+  uint32_t        deal;              /* probe_rows_kernel: != 0: the chunks beyond a workgroup's first RING are handed
+                                        out by counters (deal_ctr), in list order: heaviest first */
   /* hash table */
   const Slot     *table;
   uint64_t        slot_mask;
@@ -375,6 +380,7 @@ struct ProbeParams {
   uint32_t            reduce_cells;  /* cells summed from the partial slots (0: the matrix is added to where it lies) */
   unsigned long long *usage;         /* see reduce_partials_kernel */
   unsigned long long *sticky;
+  unsigned long long *deal_ctr;      /* DEAL_GROUPS counters, DEAL_STRIDE words apart (see `deal`) */
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
   unsigned long long *pair_count;   /* NULL: matrix mode                        */

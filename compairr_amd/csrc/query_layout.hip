@@ -1150,7 +1150,12 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : 2) : 0;
   for (uint32_t t = 0; cpass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
-    w += (uint64_t)(cpass == 0 ? td.len + 1 : cpass == 1 ? td.len + 2 : 2) * td.nvalid;
+    /* (variant 2: a tile costs its wave the same however full it is; ~10 rows' worth per unit for claim,
+       descriptor, tile data and the identity probe.  With -i a position is a pair row plus an insertion pair) */
+    if (Q.rows)
+      w += (uint64_t)((Q.indels ? 2u : 1u) * td.len + 10u) * WAVE;
+    else
+      w += (uint64_t)(cpass == 0 ? td.len + 1 : cpass == 1 ? td.len + 2 : 2) * td.nvalid;
   }
   if (ck.pass & CHUNK_WITH_ITEMS)
     w += (uint64_t)Q.slice_items[ck.slice].y * WAVE * 48;

@@ -71,6 +71,12 @@ LAYOUTS = {
                         "heavy_threshold": 2, "pos_segments": 2, "waves_per_block": 4},
     # the partial results summed by resolve_kernel's last workgroup instead of a launch of their own (off by default)
     "rows_merged_reduce": {"variant": 2, "merge_reduce": 1},
+    # every chunk dealt statically (the default hands out all but a workgroup's first four by a counter)
+    "rows_static_deal": {"variant": 2, "chunk_deal": 0},
+    "rows_static_deal_tiny": {"variant": 2, "chunk_deal": 0, "slice_words_log2": 3, "class_residues": 2,
+                              "heavy_threshold": 2, "chunk_tiles": 2},
+    "rows_counter_deal_tiny": {"variant": 2, "chunk_deal": 1, "slice_words_log2": 3, "class_residues": 2,
+                               "heavy_threshold": 2, "chunk_tiles": 1},
     "lds_merged_reduce": {"variant": 1, "merge_reduce": 1, "slice_words_log2": 6},
     # 64-byte slices, every class split by 3 / 1 class residues: class-row passes
     "rows_tiny_k3": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,

@@ -15,6 +15,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--n", type=int, default=10_000_000)
 p.add_argument("--reps", type=int, default=4)
 p.add_argument("--indels", action="store_true")
+p.add_argument("--device", action="store_true", help="cmpr_set_queries_device on a device-resident copy")
 p.add_argument("--tunable", action="append", default=[])
 a = p.parse_args()
 ref = synth.make_set(a.n, 2, prefix="B", pool_size=a.n // 4)
@@ -27,9 +28,15 @@ with HipOverlap(opt) as h:
     t0 = time.perf_counter()
     h.set_reference(ref, qry.longest)
     print("set_reference %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+    dv = keep = None
+    if a.device:
+        dv, keep = HipOverlap.device_view(qry)
     for r in range(a.reps):
         t0 = time.perf_counter()
-        h.set_queries(qry)
+        if a.device:
+            h.set_queries_device(dv)
+        else:
+            h.set_queries(qry)
         print("set_queries %.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
     m = h.overlap_matrix()
     print("checksum", synth.checksum(m))
