@@ -222,16 +222,16 @@ validate_seq_kernel(const QL Q)
       tot_lds[r] = 0.0;
     __syncthreads();
   }
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  /* (every gridDim.x-th batch of 256: see keys_kernel) */
   uint32_t err = 0, L = 0;
-  if (i < Q.n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < Q.n && !err; i += (uint64_t)gridDim.x * 256) {
     const uint64_t a = Q.off[i], b = Q.off[i + 1];
     if (b < a)
       err = VERR_OFFSETS;
     else if (b - a > 0xffffu)
       err = VERR_LONG;
     else
-      L = (uint32_t)(b - a);
+      L = max(L, (uint32_t)(b - a));
     const uint32_t rp = Q.rep[i];
     if (!err && rp >= Q.n_rep)
       err = VERR_REP;
@@ -481,10 +481,13 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
   if (threadIdx.x < 64)
     dest_lds[threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  /* (a workgroup takes every gridDim.x-th batch of 256 queries: its sums leave it once, not once
+     per batch -- 39 000 workgroups adding to the same few words and the repertoire totals' one
+     line took 2.4 ms per 10M queries where the kernel's own work takes a fifth of that) */
   unsigned long long alg = 0;
-  uint32_t err = 0, Lmax = 0;
-  if (i < q1) {
+  uint32_t err_all = 0, Lmax = 0;
+  for (uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * 256) {
+    uint32_t err = 0;
     const uint64_t b = Q.off[i], e = Q.off[i + 1];
     uint32_t L = 0;
     if (e < b || e > Q.total)
@@ -511,8 +514,10 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
         err = VERR_RESIDUE;
     }
     Q.grp[0][i] = 0xffffffffu;
+    if (err && !err_all)
+      err_all = err;
     if (!err) {
-      Lmax = L;
+      Lmax = max(Lmax, L);
       const double x = Q.counts ? (double)Q.cnt[i] : 1.0;
       if (lds_tot)
         unsafeAtomicAdd(tot_lds + rp, x);
@@ -592,11 +597,11 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
         Q.rank[i] = atomicAdd(Q.cnt_g[0] + g, 1u);
       }
       if (Q.alg_step <= 1u || work_owner(slice, 0u, Q.alg_step) == Q.alg_first)
-        alg = (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
+        alg += (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
   }
-  if (err)
-    atomicCAS(Q.verr, 0u, err);
+  if (err_all)
+    atomicCAS(Q.verr, 0u, err_all);
   /* longest: one atomic per wave */
   uint32_t m = Lmax;
   for (int o = 32; o > 0; o >>= 1)
@@ -1342,6 +1347,12 @@ inline uint32_t blocks_for(uint64_t n)
   return (uint32_t)std::max<uint64_t>(1, (n + 255) / 256);
 }
 
+/* ... of a kernel whose workgroups loop over the batches and leave their sums once */
+inline uint32_t blocks_looping(uint64_t n)
+{
+  return std::min<uint32_t>(blocks_for(n), 2048u);
+}
+
 const char *verr_message(uint32_t e)
 {
   switch (e) {
@@ -1420,7 +1431,7 @@ int cmpr_upload_and_validate(cmpr_context *c, const cmpr_set_view *s, DevBuf<uin
   Q.verr = verr.b.p;
   Q.rep_total = tot.b.p;
   const size_t lds = s->n_repertoires <= 2048 ? s->n_repertoires * sizeof(double) : 0;
-  hipLaunchKernelGGL(validate_seq_kernel, dim3(blocks_for(s->n)), dim3(256), lds, c->stream, Q);
+  hipLaunchKernelGGL(validate_seq_kernel, dim3(blocks_looping(s->n)), dim3(256), lds, c->stream, Q);
   HIP_TRY(c, hipGetLastError());
   uint32_t hv[2] = {0, 0};
   HIP_TRY(c, hipMemcpyAsync(hv, verr.b.p, sizeof hv, hipMemcpyDeviceToHost, c->stream));
@@ -1830,7 +1841,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                            c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), (uint32_t *)at(o_orig));
         HIP_TRY(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(n)), dim3(256), lds, c->stream, Q, (uint64_t)0, n);
+      hipLaunchKernelGGL(keys_kernel, dim3(blocks_looping(n)), dim3(256), lds, c->stream, Q, (uint64_t)0, n);
       HIP_TRY(c, hipGetLastError());
     }
   } else
@@ -1980,7 +1991,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                            c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), q0, q1);
         HIP_TRY(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(keys_kernel, dim3(blocks_for(q1 - q0)), dim3(256), lds, c->stream, Q, q0, q1);
+      hipLaunchKernelGGL(keys_kernel, dim3(blocks_looping(q1 - q0)), dim3(256), lds, c->stream, Q, q0, q1);
       HIP_TRY(c, hipGetLastError());
     }
     if (n == 0) {
