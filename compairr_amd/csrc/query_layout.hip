@@ -65,6 +65,7 @@ constexpr uint32_t MAXP = 1 + MAX_CLASS_RES;     /* passes with a layout of thei
    tiles of 2^FOREIGN_SLICES_LOG2 pseudo-slices behind the real ones (no chunk lists them) */
 constexpr uint32_t FOREIGN_SLICES_LOG2 = 12;
 
+constexpr uint32_t KEYS_STAGE_BYTES = 16384;   /* keys_kernel: residues of a batch of 256 queries staged in LDS */
 enum : uint32_t { VERR_OFFSETS = 1, VERR_LONG = 2, VERR_REP = 3, VERR_GENE = 4, VERR_COUNT = 5,
                   VERR_RESIDUE = 6, VERR_TOO_LONG = 7 };
 
@@ -167,6 +168,13 @@ struct QL {
   uint32_t  nitem_slices;                 /* counters in all */
   uint32_t  cblocks;                      /* blocks of 64 items per chunk at most */
   uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
+  /* The item counters are few (one per slice of a class part: 2048 for 10M amino-acid queries = 64
+     lines of memory) and every query adds to one of them: 10^7 atomics on 64 lines took 0.7 ms in
+     keys_kernel and again in place_items_kernel.  With item_reps > 1 copies, batch (i >> 8) of the
+     queries counts in copy (i >> 8) mod item_reps; item_replicas_kernel sums the copies into ccnt
+     and gives each copy its share of the (class part, slice)'s items (rbase). */
+  uint32_t *ccnt_r, *cfill_r, *rbase;               /* [item_reps][nitem_slices] */
+  uint32_t  item_reps;
   uint32_t  cchunk0;                      /* first item chunk in the chunk list */
   cmpr::ItemRec *items;
   cmpr::ResPack *cpk;
@@ -484,9 +492,33 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
   /* (a workgroup takes every gridDim.x-th batch of 256 queries: its sums leave it once, not once
      per batch -- 39 000 workgroups adding to the same few words and the repertoire totals' one
      line took 2.4 ms per 10M queries where the kernel's own work takes a fifth of that) */
+  /* The residues of a batch lie side by side: they are copied to LDS in whole dwords and the loops
+     below read them there.  (Read where they lie, a byte per load and every load of a loop waiting for
+     the one before, a query's thread spent 86 us in this kernel -- 1.9 ms per 10M queries.) */
+  __shared__ uint32_t res_lds[KEYS_STAGE_BYTES / 4];
   unsigned long long alg = 0;
   uint32_t err_all = 0, Lmax = 0;
-  for (uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * 256) {
+  for (uint64_t base = q0 + (uint64_t)blockIdx.x * 256; base < q1; base += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = base + threadIdx.x;
+    const uint64_t sb = Q.off[base], se = Q.off[min(base + 256, q1)];
+    const uint64_t a0 = sb & ~3ull;
+    const bool stage = ((uintptr_t)Q.res & 3u) == 0 && se >= sb && se <= Q.total && se - a0 <= KEYS_STAGE_BYTES;
+    __syncthreads();                           /* (the batch before is through with the buffer) */
+    if (stage)
+      for (uint64_t k = threadIdx.x; 4 * k < se - a0; k += 256) {
+        const uint64_t at = a0 + 4 * k;
+        uint32_t d = 0;
+        if (at + 4 <= Q.total) {
+          d = *(const uint32_t *)(Q.res + at);
+        } else {
+          for (uint32_t x = 0; x < 4 && at + x < Q.total; x++)
+            d |= (uint32_t)Q.res[at + x] << (8 * x);
+        }
+        res_lds[k] = d;
+      }
+    __syncthreads();
+    if (i >= q1)
+      continue;
     uint32_t err = 0;
     const uint64_t b = Q.off[i], e = Q.off[i + 1];
     uint32_t L = 0;
@@ -505,7 +537,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       err = VERR_GENE;
     if (!err && Q.counts && Q.cnt[i] < 1)
       err = VERR_COUNT;
-    const uint8_t *s = Q.res + b;
+    const uint8_t *s = (stage && b >= sb && e <= se) ? (const uint8_t *)res_lds + (b - a0) : Q.res + b;
     if (!err) {
       bool bad = false;
       for (uint32_t p = 0; p < L; p++)
@@ -576,7 +608,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       if (Q.ngroups && !Q.route)
         for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
           if (item_owned(Q, k)) {
-            atomicAdd(Q.ccnt + k, 1u);
+            atomicAdd(Q.ccnt_r + (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k, 1u);
             any_item = true;
           }
         });
@@ -949,6 +981,23 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
   }
 }
 
+/* the copies of the item counters summed, and where each copy's items start inside their
+   (class part, slice) (QL::ccnt_r) */
+__global__ void __launch_bounds__(256)
+item_replicas_kernel(const QL Q)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (uint64_t)Q.nitem_slices)
+    return;
+  uint32_t run = 0;
+  for (uint32_t r = 0; r < Q.item_reps; r++) {
+    const size_t rk = (size_t)r * Q.nitem_slices + k;
+    Q.rbase[rk] = run;
+    run += Q.ccnt_r[rk];
+  }
+  Q.ccnt[k] = run;
+}
+
 /* variant 2, class rows: per (class part, slice) the items padded to whole blocks
    of 64, and the chunks (at most cblocks blocks each) they make */
 __global__ void __launch_bounds__(256)
@@ -1047,7 +1096,8 @@ place_items_kernel(const QL Q)
   for_each_item<true>(Q, i, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
     if (!item_owned(Q, k))
       return;
-    const uint32_t item = Q.cbase[k] + atomicAdd(Q.cfill + k, 1u);
+    const size_t rk = (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k;
+    const uint32_t item = Q.cbase[k] + Q.rbase[rk] + atomicAdd(Q.cfill_r + rk, 1u);
     if (Q.sub2_items) {
       w = hq;                                   /* the query's hash and residues travel with the item */
       Q.cpk[item] = pk;
@@ -1635,8 +1685,11 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   ArenaCut cut;
   /* (the counters that start at zero lie side by side: one memset) */
   const size_t o_gcnt = cut.take(G * npass * sizeof(uint32_t));
+  const uint32_t item_reps = ncs > 0 && ncs <= 65536 ? 32u : 1u;
   const size_t o_ccnt = cut.take(ncs * sizeof(uint32_t));
   const size_t o_cfill = cut.take(ncs * sizeof(uint32_t));
+  const size_t o_ccnt_r = cut.take(ncs * item_reps * sizeof(uint32_t));
+  const size_t o_cfill_r = cut.take(ncs * item_reps * sizeof(uint32_t));
   const size_t o_sibcnt = cut.take(n2s * sizeof(uint32_t));
   const size_t o_sibfill = cut.take(n2s * sizeof(uint32_t));
   const size_t o_alg = cut.take(sizeof(unsigned long long));
@@ -1662,6 +1715,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_v16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_j16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_cnt32 = cut.take(narrow && !c->opt.ignore_counts ? (size_t)n * sizeof(uint32_t) : 0);
+  const size_t o_rbase = cut.take(ncs * item_reps * sizeof(uint32_t));
   const size_t o_gbase = cut.take(G * npass * sizeof(uint32_t));
   const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
@@ -1797,6 +1851,10 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.ccnt = (uint32_t *)at(o_ccnt);
   Q.cbase = (uint32_t *)at(o_cbase);
   Q.cfill = (uint32_t *)at(o_cfill);
+  Q.ccnt_r = (uint32_t *)at(o_ccnt_r);
+  Q.cfill_r = (uint32_t *)at(o_cfill_r);
+  Q.rbase = (uint32_t *)at(o_rbase);
+  Q.item_reps = item_reps;
   Q.cnch = (uint32_t *)at(o_cnch);
   Q.cchpre = (uint32_t *)at(o_cchpre);
   uint32_t *const cpad = (uint32_t *)at(o_cpad);
@@ -2069,6 +2127,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                                                  (int)nslices, c->stream));
   }
   if (ngroups) {
+    hipLaunchKernelGGL(item_replicas_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad);
     HIP_TRY(c, hipGetLastError());
     size_t b = cub_bytes;
