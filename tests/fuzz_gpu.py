@@ -85,6 +85,8 @@ def random_case(rng):
         tun["variant"] = 1
     elif r < 0.6:
         tun["variant"] = 2                                # the row filter, also where it is not the default
+    if rng.random() < 0.25:
+        tun["chunk_deal"] = 0                             # every chunk dealt statically (default: by counters)
     if rng.random() < 0.2:
         tun["class_rows_unstaged"] = 1
     if rng.random() < 0.4:
