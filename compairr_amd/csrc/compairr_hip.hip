@@ -112,10 +112,23 @@ ProbeFn select_sliced_kernel(const cmpr_options &o, int nw)
   }
 }
 
-ProbeFn select_rows_kernel(const cmpr_options &o, int nw, bool inline_resolve)
+ProbeFn select_rows_kernel(const cmpr_options &o, int nw, bool inline_resolve, bool wide)
 {
   const int A = o.alphabet_size, D = o.differences;
   const bool i = o.indels != 0, g = !o.ignore_genes;
+  if (wide) {                 /* four amino-acid class residues (layout.h kernel_class_res) */
+    if (inline_resolve)
+      switch (nw) {
+      case 4:  return select_probe_v2_wide_inline_nw4(A, D, i, g);
+      case 16: return select_probe_v2_wide_inline_nw16(A, D, i, g);
+      default: return select_probe_v2_wide_inline_nw8(A, D, i, g);
+      }
+    switch (nw) {
+    case 4:  return select_probe_v2_wide_nw4(A, D, i, g);
+    case 16: return select_probe_v2_wide_nw16(A, D, i, g);
+    default: return select_probe_v2_wide_nw8(A, D, i, g);
+    }
+  }
   if (inline_resolve)
     switch (nw) {
     case 4:  return select_probe_v2_inline_nw4(A, D, i, g);
@@ -316,7 +329,7 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     c->variant = value;
   } else if (n == "class_residues") {
     if (value < -1 || value > (int64_t)max_class_res((uint32_t)c->opt.alphabet_size))
-      return fail(c, CMPR_EINVAL, "class_residues must be -1..3 (amino acids) / -1..8 (nucleotides)");
+      return fail(c, CMPR_EINVAL, "class_residues must be -1..4 (amino acids; four: variant 2, d >= 1, else three) / -1..8 (nucleotides)");
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
     c->class_residues = value;
@@ -924,8 +937,12 @@ int make_plan(cmpr_context *c)
   P.deal = c->rows ? (uint32_t)c->chunk_deal : 0u;
   /* variant 2: the fast form hands its Bloom positives to resolve_kernel; the form
      that resolves inline is deferred_resolve = 0 and the redo pass */
-  ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !S.deferred)
+  /* a layout with four amino-acid class residues runs on the wide instantiations */
+  const bool wide = c->rows && A != 4 && c->geom.k > kernel_class_res((uint32_t)A, false);
+  ProbeFn fn = c->rows ? select_rows_kernel(c->opt, nw, !S.deferred, wide)
                        : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
+  if (fn == nullptr)
+    return fail(c, CMPR_EUNSUPPORTED, "no kernel for this layout (class residues)");
   if (lds > 48 * 1024)
     HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
@@ -961,7 +978,7 @@ int make_plan(cmpr_context *c)
      fused_tail) -- when the matrix is privatised in LDS (a late overflow must be able to
      take back what was added) and a 64-bit set names the segments.  Pairs mode (matches are
      listed where they are found) keeps the three kernels. */
-  if (c->rows && S.deferred && c->fused_step && P.lds_matrix && S.reduce_writes && P.pos_segments <= 64 &&
+  if (c->rows && S.deferred && c->fused_step && !wide && P.lds_matrix && S.reduce_writes && P.pos_segments <= 64 &&
       !(c->debug & DBG_SKIP_RESOLVE)) {
     S.ffn = nw == 4 ? select_probe_v2_fused_nw4((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
           : nw == 16 ? select_probe_v2_fused_nw16((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
@@ -981,7 +998,7 @@ int make_plan(cmpr_context *c)
   }
   if (S.redo_kind) {
     /* the redo pass (issue_step) */
-    S.fn2 = select_rows_kernel(c->opt, nw, true);
+    S.fn2 = select_rows_kernel(c->opt, nw, true, wide);
     if (lds > 48 * 1024)
       HIP_TRY(c, hipFuncSetAttribute((const void *)S.fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

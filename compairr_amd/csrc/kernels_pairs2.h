@@ -225,7 +225,7 @@ probe_pairs2_kernel(const ProbeParams P)
 {
   constexpr uint32_t A = 4;
   constexpr uint32_t NT = NW * WAVE;
-  constexpr uint32_t MCR = max_class_res(A);
+  constexpr uint32_t MCR = kernel_class_res(A, false);
   extern __shared__ __align__(16) unsigned char smem[];
   if ((uint32_t)(uintptr_t)smem != 0u)
     __builtin_trap();                       /* the slices are read at absolute LDS addresses */

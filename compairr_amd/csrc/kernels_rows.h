@@ -846,7 +846,7 @@ __device__ __forceinline__ void fused_tail(const ProbeParams &P, unsigned char *
 
 /* (16 waves = 1024 lanes is the largest workgroup there is: five waves per SIMD would take two
    workgroups per CU, and two rings of slices do not fit the LDS) */
-template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE, bool FUSED = false>
+template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE, bool FUSED = false, bool WIDE = false>
 __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_rows_kernel(const ProbeParams P)
 {
@@ -861,7 +861,7 @@ probe_rows_kernel(const ProbeParams P)
   if constexpr (FUSED)
     t_start = (unsigned long long)wall_clock64();
   constexpr uint32_t NT = NW * WAVE;
-  constexpr uint32_t MCR = max_class_res(A);
+  constexpr uint32_t MCR = kernel_class_res(A, WIDE);  /* (WIDE: layout.h) */
   constexpr bool PAIRS = D == 1;                  /* the filter holds pair rows (build_rows_kernel) */
   constexpr uint32_t ZS = zs_of(A, D, PAIRS);
   /* pair rows: what stands behind the end of a query, also in residue dwords that were never

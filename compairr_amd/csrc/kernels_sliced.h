@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_sliced_kernel(const ProbeParams P)
 {
   constexpr uint32_t NT = NW * WAVE;
-  constexpr uint32_t MCR = max_class_res(A);   /* unrolled class-residue loops */
+  constexpr uint32_t MCR = kernel_class_res(A, false);   /* unrolled class-residue loops */
   constexpr uint32_t NTB = 10;                 /* nucleotide positions per block (3 mask bits each) */
   extern __shared__ __align__(16) unsigned char smem[];
   /* the Bloom slice sits at LDS address 0: its reads need no base add */

@@ -83,9 +83,15 @@ struct TileDesc {
    those probes from LDS; only variants that change the class key go to the
    filter in HBM.  The word inside a slice and the bit pattern still come from
    the Zobrist hash. */
-constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 3 for aa (20^3 splits),
+constexpr uint32_t MAX_CLASS_RES      = 8;    /* table rows; K <= 4 for aa (20^4 splits),
                                                  K <= 8 for nt (4^8 splits)            */
-__host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 3u; }
+/* the most class residues a layout may use, and the most a kernel instantiation unrolls its
+   class-residue loops for.  Amino acids: three, and four in the WIDE instantiations of
+   probe_rows_kernel -- taken only when three leave the fullest slice well over its budget (the
+   (V, J) classes of -i on skewed data: ref_index.hip); the wide form of the -i kernel pays
+   for its fourth residue with 12 bytes of scratch, so the narrow one stays the default. */
+__host__ __device__ constexpr uint32_t max_class_res(uint32_t A) { return A == 4 ? 8u : 4u; }
+__host__ __device__ constexpr uint32_t kernel_class_res(uint32_t A, bool wide) { return A == 4 ? 8u : wide ? 4u : 3u; }
 constexpr uint32_t SLICE_WORDS_LOG2   = 12;    /* 4096 words = 32 KiB per slice */
 constexpr uint32_t ROW_WORD_BYTES      = 32;   /* variant 2: filter word = 8 dwords, one bit of each per entry */
 constexpr uint32_t MAX_ROW_SLICE_WORDS = 640;  /* variant 2: at most 20 KiB per slice (a ring of 4 in LDS) */

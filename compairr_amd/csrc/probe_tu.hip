@@ -2,7 +2,8 @@
  * probe_tu.hip -- one translation unit per (kernel variant, workgroup size):
  * compiled with -DTU_VARIANT=0|1|2|9, -DTU_NW=4|8|16 (variants 1, 2) and
  * -DTU_INLINE=0|1|2 (variant 2: the fast form / the form that resolves inline / the fused
- * step, whose workgroups resolve the queued positives themselves).
+ * step, whose workgroups resolve the queued positives themselves); -DTU_WIDE: variant 2 for
+ * four amino-acid class residues (fast and inline forms).
  * TU_VARIANT 9 = resolve_kernel, 3 = probe_pairs2_kernel.
  */
 #include "select.h"
@@ -27,6 +28,12 @@ namespace cmpr {
 #elif TU_VARIANT == 1
 #define KERNEL(A_, D_, I_, G_) probe_sliced_kernel<A_, D_, I_, G_, TU_NW>
 #define SELECT_NAME CAT(select_probe_v1_nw, TU_NW)
+#elif TU_VARIANT == 2 && defined(TU_WIDE) && TU_INLINE
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true, false, true>
+#define SELECT_NAME CAT(select_probe_v2_wide_inline_nw, TU_NW)
+#elif TU_VARIANT == 2 && defined(TU_WIDE)
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false, false, true>
+#define SELECT_NAME CAT(select_probe_v2_wide_nw, TU_NW)
 #elif TU_VARIANT == 2 && TU_INLINE == 2
 #define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false, true>
 #define SELECT_NAME CAT(select_probe_v2_fused_nw, TU_NW)
@@ -53,6 +60,13 @@ ProbeFn select_probe_pairs2(bool genes)
 ProbeFn SELECT_NAME(int A, int D, bool indels, bool genes)
 {
 #define PICK(A_, D_, I_) (genes ? (ProbeFn)KERNEL(A_, D_, I_, true) : (ProbeFn)KERNEL(A_, D_, I_, false))
+#if defined(TU_WIDE)
+  /* four class residues: amino acids at d >= 1 only (layout.h kernel_class_res) */
+  if (A != 20 || D == 0)
+    return nullptr;
+  if (D == 1) return indels ? PICK(20, 1, true) : PICK(20, 1, false);
+  return PICK(20, 2, false);
+#else
   if (A == 20) {
     if (D == 0) return PICK(20, 0, false);
     if (D == 1) return indels ? PICK(20, 1, true) : PICK(20, 1, false);
@@ -61,6 +75,7 @@ ProbeFn SELECT_NAME(int A, int D, bool indels, bool genes)
   if (D == 0) return PICK(4, 0, false);
   if (D == 1) return indels ? PICK(4, 1, true) : PICK(4, 1, false);
   return PICK(4, 2, false);
+#endif
 #undef PICK
 }
 #endif

@@ -484,8 +484,11 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
         }
       HIP_TRY(c, hipMemcpyAsync(c->d_ctab.p + g.off_hv, c->ctab.data() + g.off_hv,
                                 HEAVY_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      /* amino acids: a fourth class residue only where a kernel unrolls for it (layout.h
+         kernel_class_res: the wide forms of probe_rows_kernel, d >= 1) */
+      const uint32_t kmax = (c->rows && c->opt.differences >= 1) ? max_class_res(A) : kernel_class_res(A, false);
       if (c->class_residues >= 0) {
-        g.k = (uint32_t)c->class_residues;
+        g.k = std::min<uint32_t>((uint32_t)c->class_residues, kmax);
       } else if (any_heavy) {
         /* K = fewest class residues that bring the fullest slice under the cap;
            every one costs the heavy queries one more row elsewhere */
@@ -493,7 +496,7 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
         std::vector<uint32_t> pop((size_t)S);
         double best_max = -1;
         uint32_t best_k = 1;
-        for (uint32_t k = 1; k <= max_class_res(A); k++) {
+        for (uint32_t k = 1; k <= kmax; k++) {
           HIP_TRY(c, hipMemsetAsync(d_pop.b.p, 0, (size_t)S * sizeof(uint32_t), c->stream));
           hipLaunchKernelGGL(slice_population_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
                              c->res2.p, c->off2.p, d_base.b.p, s->n, g, A, k, d_pop.b.p);
@@ -507,6 +510,12 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
             best_k = k;
           }
           if (mx <= slice_cap)
+            break;
+          /* (the wide kernels cost a little everywhere and 12 bytes of scratch with -i: the last
+             narrow K stands unless it leaves the fullest slice more than a quarter over its budget --
+             uniform 10M x 10M with -i: 694 sequences for 627, stays at three; the cdr3 law: 1 775, and
+             3 559 for 376 on 24.2M sequences: four, where the positives fall from 3.1 x 10^8 to 7.9 x 10^7) */
+          if (k == kernel_class_res(A, false) && k < kmax && mx <= 1.25 * slice_cap)
             break;
         }
         g.k = best_k;

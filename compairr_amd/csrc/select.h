@@ -27,6 +27,13 @@ ProbeFn select_probe_v2_nw16(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_inline_nw4(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_inline_nw8(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_inline_nw16(int A, int D, bool indels, bool genes);
+/* ... for layouts with four amino-acid class residues (nullptr for anything else) */
+ProbeFn select_probe_v2_wide_nw4(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_wide_nw8(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_wide_nw16(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_wide_inline_nw4(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_wide_inline_nw8(int A, int D, bool indels, bool genes);
+ProbeFn select_probe_v2_wide_inline_nw16(int A, int D, bool indels, bool genes);
 /* ... and the fused step: probe, resolve and reduce in one launch */
 ProbeFn select_probe_v2_fused_nw4(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_fused_nw8(int A, int D, bool indels, bool genes);

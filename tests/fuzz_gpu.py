@@ -57,7 +57,7 @@ def random_case(rng):
     if rng.random() < 0.7:
         tun["slice_words_log2"] = int(rng.integers(2, 13))
     if rng.random() < 0.5:
-        tun["class_residues"] = int(rng.integers(0, 9 if nt else 4))
+        tun["class_residues"] = int(rng.integers(0, 9 if nt else 5))
     if rng.random() < 0.3:
         tun["heavy_threshold"] = int(rng.integers(0, 50))
     if rng.random() < 0.4:

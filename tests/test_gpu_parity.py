@@ -71,6 +71,16 @@ LAYOUTS = {
                         "heavy_threshold": 2, "pos_segments": 2, "waves_per_block": 4},
     # the partial results summed by resolve_kernel's last workgroup instead of a launch of their own (off by default)
     "rows_merged_reduce": {"variant": 2, "merge_reduce": 1},
+    # four amino-acid class residues: the wide instantiations of the rows kernel (nucleotides: K = 4 of 8;
+    # variant 2 at d = 0 and the other variants clamp to three)
+    "rows_k4": {"variant": 2, "class_residues": 4, "heavy_threshold": 2},
+    "rows_k4_tiny": {"variant": 2, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2, "chunk_tiles": 2},
+    "rows_k4_anchor3": {"variant": 2, "class_residues": 4, "slice_words_log2": 4, "heavy_threshold": 0,
+                        "class_anchor": 3},
+    "rows_k4_inline": {"variant": 2, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2,
+                       "deferred_resolve": 0},
+    "rows_k4_overflow": {"variant": 2, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2,
+                         "pos_capacity": 64, "pos_segments": 1},
     # every chunk dealt statically (the default hands out all but a workgroup's first four by a counter)
     "rows_static_deal": {"variant": 2, "chunk_deal": 0},
     "rows_static_deal_tiny": {"variant": 2, "chunk_deal": 0, "slice_words_log2": 3, "class_residues": 2,

@@ -10,11 +10,11 @@ $H -DTU_VARIANT=1 -DTU_NW=8 compairr_amd/csrc/probe_tu.hip -o /tmp/r04isa/v1.s 2
 $H -DTU_VARIANT=3 compairr_amd/csrc/probe_tu.hip -o /tmp/r04isa/p2.s 2>/dev/null
 rm -f profiles/roofline_inputs.json
 python3 tools/pmc_summary.py gpurun_out/r04_cfg3 profiles/r04 cfg3 "synthetic 10M-vs-10M CDR3aa, d=1 substitutions only, V/J matched" \
-    /tmp/r04isa/v2.s _ZN4cmpr17probe_rows_kernelILi20ELi1ELb0ELb1ELi16ELb0ELb0EEEvNS_11ProbeParamsE > /dev/null
+    /tmp/r04isa/v2.s _ZN4cmpr17probe_rows_kernelILi20ELi1ELb0ELb1ELi16ELb0ELb0ELb0EEEvNS_11ProbeParamsE > /dev/null
 python3 tools/pmc_summary.py gpurun_out/r04_cfg2 profiles/r04 cfg2 "synthetic 1M-vs-1M CDR3aa, d=0, V/J matched" \
     /tmp/r04isa/v1.s _ZN4cmpr19probe_sliced_kernelILi20ELi0ELb0ELb1ELi8EEEvNS_11ProbeParamsE > /dev/null
 python3 tools/pmc_summary.py gpurun_out/r04_cfg4 profiles/r04 cfg4 "synthetic 10M-vs-10M CDR3aa, d=1 --indels, V/J matched" \
-    /tmp/r04isa/v2.s _ZN4cmpr17probe_rows_kernelILi20ELi1ELb1ELb1ELi16ELb0ELb0EEEvNS_11ProbeParamsE > /dev/null
+    /tmp/r04isa/v2.s _ZN4cmpr17probe_rows_kernelILi20ELi1ELb1ELb1ELi16ELb0ELb0ELb0EEEvNS_11ProbeParamsE > /dev/null
 python3 tools/pmc_summary.py gpurun_out/r04_cfg5 profiles/r04 cfg5 "synthetic 12500k-vs-100M nucleotide, d=2 substitutions only --ignore-genes" \
     /tmp/r04isa/p2.s _ZN4cmpr19probe_pairs2_kernelILb0ELi16EEEvNS_11ProbeParamsE > /dev/null
 python3 - <<'PY'
