@@ -23,6 +23,14 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
 print("pub d=2 step %.2f probe %.2f rest %.2f value %.3g parity cpu %s ref %.3g" % (d["ms_per_step"], r["kernel_ms"], r["resolve_kernel_ms"], d["value"], d["parity_on_cpu_sample"], (d.get("cpu_baseline") or {}).get("value", 0)))
 PY
+line() { python3 - $1 "$2" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]; l = d["config"]["layout"]; c = d.get("cpu_baseline") or {}
+print("%s: step %.4f (probe %.4f rest %.4f) value %.3g K=%s slices=%s positives=%s pairs=%s parity %s/%s ref %.3g" % (sys.argv[2], d["ms_per_step"], r["kernel_ms"], r["resolve_kernel_ms"], d["value"], l["class_residues"], l["slices"], r["bloom_positive_per_launch"], r["pairs_per_launch"], d["parity_vs_reference_full_size"], d["parity_on_cpu_sample"], c.get("value", 0)))
+PY
+}
+timeout 900 python3 bench.py --law cdr3 --indels > $O/cdr3_d1i.json 2> $O/cdr3_d1i.err; line $O/cdr3_d1i.json "cdr3 d=1 -i"
+timeout 1200 python3 bench.py $P --differences 1 --indels > $O/pub_d1i.json 2> $O/pub_d1i.err; line $O/pub_d1i.json "pub d=1 -i"
 timeout 900 python3 tools/emulate_routed.py > $O/routed.txt 2> $O/routed.err; cat $O/routed.txt
-timeout 400 python3 tests/fuzz_gpu.py --seconds 240 --seed 40404 > $O/fuzz_lib.txt 2>&1; tail -2 $O/fuzz_lib.txt
-timeout 400 python3 tests/fuzz_cli_gpu.py --seconds 240 --seed 50505 > $O/fuzz_cli.txt 2>&1; tail -2 $O/fuzz_cli.txt
+timeout 400 python3 tests/fuzz_gpu.py --seconds 150 --seed 40404 > $O/fuzz_lib.txt 2>&1; tail -2 $O/fuzz_lib.txt
+timeout 400 python3 tests/fuzz_cli_gpu.py --seconds 150 --seed 50505 > $O/fuzz_cli.txt 2>&1; tail -2 $O/fuzz_cli.txt
