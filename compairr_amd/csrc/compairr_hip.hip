@@ -329,7 +329,7 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     c->variant = value;
   } else if (n == "class_residues") {
     if (value < -1 || value > (int64_t)max_class_res((uint32_t)c->opt.alphabet_size))
-      return fail(c, CMPR_EINVAL, "class_residues must be -1..4 (amino acids; four: variant 2, d >= 1, else three) / -1..8 (nucleotides)");
+      return fail(c, CMPR_EINVAL, "class_residues must be -1..4 (amino acids; four: variant 2, d = 1, else three) / -1..8 (nucleotides)");
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set class_residues before cmpr_set_reference");
     c->class_residues = value;

@@ -61,11 +61,10 @@ ProbeFn SELECT_NAME(int A, int D, bool indels, bool genes)
 {
 #define PICK(A_, D_, I_) (genes ? (ProbeFn)KERNEL(A_, D_, I_, true) : (ProbeFn)KERNEL(A_, D_, I_, false))
 #if defined(TU_WIDE)
-  /* four class residues: amino acids at d >= 1 only (layout.h kernel_class_res) */
-  if (A != 20 || D == 0)
+  /* four class residues: amino acids at d = 1 only (layout.h kernel_class_res, ref_index.hip) */
+  if (A != 20 || D != 1)
     return nullptr;
-  if (D == 1) return indels ? PICK(20, 1, true) : PICK(20, 1, false);
-  return PICK(20, 2, false);
+  return indels ? PICK(20, 1, true) : PICK(20, 1, false);
 #else
   if (A == 20) {
     if (D == 0) return PICK(20, 0, false);

@@ -484,9 +484,11 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
         }
       HIP_TRY(c, hipMemcpyAsync(c->d_ctab.p + g.off_hv, c->ctab.data() + g.off_hv,
                                 HEAVY_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-      /* amino acids: a fourth class residue only where a kernel unrolls for it (layout.h
-         kernel_class_res: the wide forms of probe_rows_kernel, d >= 1) */
-      const uint32_t kmax = (c->rows && c->opt.differences >= 1) ? max_class_res(A) : kernel_class_res(A, false);
+      /* amino acids: a fourth class residue only where a kernel unrolls for it and gains by it
+         (layout.h kernel_class_res: the wide forms of probe_rows_kernel, d = 1.  The single rows of
+         d = 2 pay for every class position with an item per query and a row of double substitutions:
+         24.2M sequences against themselves, 351 ms with four where three take 233) */
+      const uint32_t kmax = (c->rows && c->opt.differences == 1) ? max_class_res(A) : kernel_class_res(A, false);
       if (c->class_residues >= 0) {
         g.k = std::min<uint32_t>((uint32_t)c->class_residues, kmax);
       } else if (any_heavy) {

@@ -297,7 +297,7 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
      "bloom_bits_log2_delta" filter bytes = hash-table slots << delta
                              (default 0 for variant 0, +2 for variant 1)
      "class_residues"        -1 (default: from the data) or 0..4 amino acids / 0..8 nucleotides (four
-                             amino-acid residues: variant 2 at d >= 1, on kernel instantiations of
+                             amino-acid residues: variant 2 at d = 1, on kernel instantiations of
                              their own; anywhere else the value is clamped to three)
      "slice_words_log2"      log2 of the (largest) slice in filter words: 64-bit
                              words, default 12 (variant 1); 256-bit words,

@@ -72,7 +72,7 @@ LAYOUTS = {
     # the partial results summed by resolve_kernel's last workgroup instead of a launch of their own (off by default)
     "rows_merged_reduce": {"variant": 2, "merge_reduce": 1},
     # four amino-acid class residues: the wide instantiations of the rows kernel (nucleotides: K = 4 of 8;
-    # variant 2 at d = 0 and the other variants clamp to three)
+    # variant 2 at d = 0 / d = 2 and the other variants clamp to three)
     "rows_k4": {"variant": 2, "class_residues": 4, "heavy_threshold": 2},
     "rows_k4_tiny": {"variant": 2, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2, "chunk_tiles": 2},
     "rows_k4_anchor3": {"variant": 2, "class_residues": 4, "slice_words_log2": 4, "heavy_threshold": 0,
