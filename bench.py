@@ -60,10 +60,8 @@ def recorded_workload(args):
     import _full_size
     if args.scaling != "strong":
         return None
-    if args.repertoires != 16:
-        return None
     return _full_size.by_bench_args(args.refs, args.queries, args.differences, args.indels,
-                                    args.nucleotides, args.ignore_genes, args.self_cmp, args.law)
+                                    args.nucleotides, args.ignore_genes, args.self_cmp, args.law, args.repertoires)
 
 
 def parse_args():

@@ -53,7 +53,7 @@ def mismatch(w: dict, matrix: np.ndarray) -> Optional[str]:
 
 
 def by_bench_args(refs: int, queries: int, differences: int, indels: bool, nucleotides: bool,
-                  ignore_genes: bool, self_cmp: bool, law: str = "uniform") -> Optional[dict]:
+                  ignore_genes: bool, self_cmp: bool, law: str = "uniform", repertoires: int = 16) -> Optional[dict]:
     """the recorded workload bench.py's arguments name, if any (bench.py seeds: set 1 = 1,
     set 2 = 2, pool = refs // 4)"""
     for w in load().values():
@@ -61,7 +61,8 @@ def by_bench_args(refs: int, queries: int, differences: int, indels: bool, nucle
         if (o["differences"], o["indels"], o["nucleotides"], o["ignore_genes"]) != \
                 (differences, indels, nucleotides, ignore_genes):
             continue
-        extra = dict(**({"nucleotides": True} if nucleotides else {}), **({"law": law} if law != "uniform" else {}))
+        extra = dict(**({"nucleotides": True} if nucleotides else {}), **({"law": law} if law != "uniform" else {}),
+                     **({"n_repertoires": repertoires} if repertoires != 16 else {}))
         if w["set2"] != dict(n=refs, seed=2, prefix="B", pool_size=refs // 4, **extra):
             continue
         if self_cmp != w["one_file_mode"]:

@@ -58,6 +58,14 @@ WORKLOADS = {
                   dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4, law="cdr3"), ["-d", "1"]),
     "cfg4_cdr3": (dict(n=10 * M, seed=1, prefix="A", pool_size=10 * M // 4, law="cdr3"),
                   dict(n=10 * M, seed=2, prefix="B", pool_size=10 * M // 4, law="cdr3"), ["-d", "1", "-i"]),
+    # the shape of the reference's published benchmark (README.md:726-755: 24 205 557 sequences in 120
+    # repertoires against themselves) on the cdr3 law: d = 0, 1, 1 with indels (d = 2 takes the reference hours)
+    "pub_d0": (None, dict(n=24_200_000, seed=2, prefix="B", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
+               ["-d", "0"]),
+    "pub_d1": (None, dict(n=24_200_000, seed=2, prefix="B", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
+               ["-d", "1"]),
+    "pub_d1i": (None, dict(n=24_200_000, seed=2, prefix="B", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
+                ["-d", "1", "-i"]),
     # BASELINE configs[4], a sub-shape the reference finishes in minutes on 8 cores
     "cfg5_sub": (dict(n=200_000, seed=3, prefix="A", pool_size=10 * M // 4, nucleotides=True),
                  dict(n=10 * M, seed=4, prefix="B", pool_size=10 * M // 4, nucleotides=True),

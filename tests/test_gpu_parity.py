@@ -920,10 +920,12 @@ def dup_warnings(w):
     return {int(l.split()[-1]): int(l.split()[1]) for l in w["warnings"]}
 
 
-@pytest.mark.parametrize("name", ["cfg2", "self10m", "cfg5_sub"])
+@pytest.mark.parametrize("name", ["cfg2", "self10m", "cfg5_sub", "pub_d1i"])
 def test_full_size_matches_reference(name):
     """cfg2 (1M x 1M aa, d = 0), the 10M self-comparison (d = 1: the reference's published
-    benchmark is self-vs-self) and a sub-shape of cfg5 (200k x 10M nucleotides, d = 2, -g):
+    benchmark is self-vs-self), a sub-shape of cfg5 (200k x 10M nucleotides, d = 2, -g) and the
+    published benchmark's shape with indels (24.2M sequences in 120 repertoires against themselves
+    on the cdr3 law, d = 1 -i: four class residues, the wide kernels):
     the matrix the reference binary printed, digit for digit, and its duplicate warnings."""
     w = FULL_SIZE[name]
     a, b = _full_size.sets_of(w)
