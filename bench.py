@@ -7,7 +7,10 @@ synthetic queries that is already resident in HBM, plus -- at N > 1 -- the RCCL
 all-reduce of the repertoire matrix.  Default workload = BASELINE.json
 configs[2]: synthetic 10M-vs-10M CDR3aa, d = 1, substitutions only.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the reference set
+N > 1: one rank per GPU -- launched by torch.distributed.run, or, when `python3 bench.py --gpus N` is typed
+without a launcher (no RANK in the environment), by bench.py itself: it starts the same
+torch.distributed.run command as a CHILD process before anything has touched the GPU and relays
+rank 0's line and the exit code (compairr_amd.dist.spawn_ranks).  The reference set
 (hash table + filter) is replicated on every GPU and the step is sharded:
   --scaling strong (default)  the SAME seeded 10M queries, total work fixed
                               (BASELINE configs[3]).  --shard-by work (default): a
@@ -95,6 +98,10 @@ def parse_args():
     p.add_argument("--self", dest="self_cmp", action="store_true",
                    help="one-file mode: the queries are the reference set itself")
     p.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE")
+    p.add_argument("--launcher", choices=["auto", "always", "never"], default="auto",
+                   help="auto: `--gpus N` with N > 1 and no RANK in the environment starts its N ranks itself "
+                        "(torch.distributed.run as a child process, before anything touches the GPU); always: "
+                        "also at N = 1 (the RCCL path at world size 1); never: expect a launcher around it")
     return p.parse_args()
 
 
@@ -245,8 +252,27 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
     return out
 
 
+def start_ranks(args):
+    """`python3 bench.py --gpus N` as the driver types it for N = 1, at N > 1: start the N ranks as a child
+    (compairr_amd.dist.spawn_ranks -> torch.distributed.run), relay rank 0's JSON line and the child's exit
+    code.  Nothing here initialises the GPU (torch.cuda.device_count() does not on this image), and this
+    process is never replaced by another program."""
+    import torch
+    from compairr_amd.dist import spawn_ranks
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d but this box shows %d HIP device%s"
+                 % (args.gpus, have, "" if have == 1 else "s"))
+    argv = [a for a in sys.argv[1:]]
+    # the child ranks must not start ranks of their own
+    argv += ["--launcher", "never"]
+    sys.exit(spawn_ranks(os.path.abspath(__file__), argv, args.gpus))
+
+
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and args.launcher != "never" and (args.gpus > 1 or args.launcher == "always"):
+        start_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,8 +291,9 @@ def main():
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (--launcher never: start it with torch.distributed.run)"
+                 % (args.gpus, world))
 
     opt = Options(differences=args.differences, indels=args.indels,
                   nucleotides=args.nucleotides, ignore_genes=args.ignore_genes,
@@ -476,6 +503,7 @@ def main():
             "value": value,
             "unit": "query sequences/s",
             "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if use_dist else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

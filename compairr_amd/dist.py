@@ -109,3 +109,50 @@ def routed_overlap(h, matrix_of: Callable, set1, rank: int, world: int, device="
     t = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(device)
     allreduce_matrix(t)
     return t.cpu().numpy().view(np.uint64).reshape(part.shape), moved
+
+
+# ---- starting the ranks (bench.py --gpus N without a launcher around it) ----
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(script: str, argv, n: int, port: Optional[int] = None):
+    """The command line the driver itself uses for N > 1: one rank per GPU of ONE node,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script] + list(argv)
+
+
+def spawn_ranks(script: str, argv, n: int, env=None, timeout: Optional[float] = None) -> int:
+    """Start `script` on `n` ranks as a CHILD process (torch.distributed.run) and relay what it
+    prints and its exit code.  To be called before anything in this process has touched the GPU
+    -- the parent never initialises HIP and is never replaced by another program (an exec from a
+    process that holds the GPU takes the box down on this pool); it only waits.  The reference
+    starts its workers at overlap.cc:926-936; this is that loop one level up, a process per GPU."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen(launcher_command(script, argv, n), env=e, stdout=subprocess.PIPE)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()                                        # (the exact child started here, nothing by pattern)
+        out, _ = p.communicate()
+        sys.stdout.write(out.decode(errors="replace"))
+        sys.stdout.flush()
+        return 124
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    return p.returncode

@@ -43,7 +43,7 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
                 "cpu_baseline", "value_incl_layout", "value_incl_layout_cold", "value_from_device_soa",
                 "step_ms_incl_d2h", "parity_vs_reference_full_size"):
         assert key in plain, key
-    assert plain["n_gpus"] == 1 and plain["steps"] == 3 and plain["value"] > 0
+    assert plain["n_gpus"] == 1 and plain["ranks_seen"] == 1 and plain["steps"] == 3 and plain["value"] > 0
     assert plain["scaling"] == "strong" and plain["dtype"] == "u64"
     assert set(plain["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert plain["device_resident_inputs"]["same_matrix"] is True
@@ -63,7 +63,22 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
                 "bench.py", "--gpus", "1", "--layout", "replicated"] + SMALL)
     assert rep["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
     assert rep["config"]["query_layout_ms"]["exchange"] is None
+    # ... and the way the driver starts N > 1 (`python3 bench.py --gpus N`, no launcher around it): bench.py starts
+    # its ranks itself as a child torch.distributed.run -- forced here at N = 1
+    own = _run([sys.executable, "bench.py", "--gpus", "1", "--launcher", "always"] + SMALL)
+    assert own["n_gpus"] == 1 and own["ranks_seen"] == 1
+    assert own["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    assert own["config"]["query_layout_ms"]["exchange"]["records_sent"] == 300000
     # weak scaling keeps the same shard at N = 1
     weak = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "weak"] + SMALL)
     assert weak["scaling"] == "weak"
     assert weak["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+
+
+def test_more_gpus_than_the_box_has_is_one_clear_line():
+    import torch
+    have = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", str(have + 1)] + SMALL, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"Traceback" not in p.stderr
+    assert b"HIP device" in p.stderr

@@ -177,3 +177,48 @@ def test_routed_exchange_gloo_equals_single(tmp_path, world):
     want, _ = _oracle.overlap(a, b, opt)
     assert np.array_equal(got, _oracle.integer_cells(want, opt))
     assert got.sum() > 0
+
+
+# ---- bench.py --gpus N starts its own ranks (compairr_amd.dist.spawn_ranks) ----
+
+def _json_lines(text):
+    import json
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_spawn_ranks_relays_the_line_and_the_exit_code(capfd):
+    from compairr_amd.dist import spawn_ranks
+    stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_stub.py")
+    rc = spawn_ranks(stub, ["--steps", "3"], 2, timeout=300)
+    out = capfd.readouterr().out
+    assert rc == 0
+    lines = _json_lines(out)
+    assert len(lines) == 1 and lines[0] == {"ranks_seen": 2, "sum": 3, "argv": ["--steps", "3"]}
+    # a rank that dies takes the job's exit code with it
+    rc = spawn_ranks(stub, ["--fail", "1"], 2, timeout=300)
+    capfd.readouterr()
+    assert rc != 0
+
+
+def test_spawn_ranks_ignores_a_stale_rank_environment(capfd):
+    from compairr_amd.dist import spawn_ranks
+    stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_stub.py")
+    env = dict(os.environ, RANK="5", WORLD_SIZE="9", MASTER_PORT="1")
+    assert spawn_ranks(stub, [], 3, env=env, timeout=300) == 0
+    assert _json_lines(capfd.readouterr().out) == [{"ranks_seen": 3, "sum": 6, "argv": []}]
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python3 bench.py --gpus 8` on a box without eight devices: one clear line, non-zero exit, no
+    traceback -- and with a launcher around it, a world size that is not --gpus is refused the same way."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 8)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    err = p.stderr.decode()
+    assert p.returncode != 0 and "Traceback" not in err
+    assert "--gpus %d but this box shows %d HIP device" % (have + 8, have) in err
+    assert not p.stdout
