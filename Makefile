@@ -29,7 +29,6 @@ TU_OBJS  = $(OBJ_DIR)/probe_v0.o $(OBJ_DIR)/resolve.o $(OBJ_DIR)/probe_pairs2.o 
            $(OBJ_DIR)/probe_v1_nw4.o $(OBJ_DIR)/probe_v1_nw8.o $(OBJ_DIR)/probe_v1_nw16.o \
            $(OBJ_DIR)/probe_v2_nw4.o $(OBJ_DIR)/probe_v2_nw8.o $(OBJ_DIR)/probe_v2_nw16.o \
            $(OBJ_DIR)/probe_v2i_nw4.o $(OBJ_DIR)/probe_v2i_nw8.o $(OBJ_DIR)/probe_v2i_nw16.o \
-           $(OBJ_DIR)/probe_v2f_nw4.o $(OBJ_DIR)/probe_v2f_nw8.o $(OBJ_DIR)/probe_v2f_nw16.o \
            $(OBJ_DIR)/probe_v2w_nw4.o $(OBJ_DIR)/probe_v2w_nw8.o $(OBJ_DIR)/probe_v2w_nw16.o \
            $(OBJ_DIR)/probe_v2wi_nw4.o $(OBJ_DIR)/probe_v2wi_nw8.o $(OBJ_DIR)/probe_v2wi_nw16.o
 
@@ -81,10 +80,6 @@ $(OBJ_DIR)/probe_v2w_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 $(OBJ_DIR)/probe_v2wi_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
 	@mkdir -p $(OBJ_DIR)
 	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=1 -DTU_WIDE -c -o $@ $<
-
-$(OBJ_DIR)/probe_v2f_nw%.o: $(KERN_DIR)/probe_tu.hip $(KERN_HDR)
-	@mkdir -p $(OBJ_DIR)
-	$(HIPCC) $(HIPFLAGS) -DTU_VARIANT=2 -DTU_NW=$* -DTU_INLINE=2 -c -o $@ $<
 
 $(LIB): $(OBJ_DIR)/main.o $(OBJ_DIR)/query_layout.o $(OBJ_DIR)/ref_index.o $(TU_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^

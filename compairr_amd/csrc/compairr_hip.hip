@@ -32,11 +32,10 @@ std::string &cmpr_create_error()
 /* u64s behind the segment counters of the positives buffer: statistics, cursors,
    overflow flag, and the statistics + cursors of the redo pass */
 static constexpr size_t CTR_TAIL = 2 * (STAT_COUNT + 1) + 1;
-/* one counter block: the segment counters of the positives buffer, the tail above, the words
-   of the fused step and its per-segment counters (on lines of their own: they are polled) */
+/* one counter block: the segment counters of the positives buffer, the tail above, the chunk counters */
 static inline size_t ctr_block_words(uint64_t segments)
 {
-  return (size_t)segments * POS_CTR_STRIDE + CTR_TAIL + FUSE_WORDS + (size_t)segments * POS_CTR_STRIDE + DEAL_WORDS;
+  return (size_t)segments * POS_CTR_STRIDE + CTR_TAIL + DEAL_WORDS;
 }
 namespace {
 void use_counter_block(cmpr_context *c, int which);
@@ -216,13 +215,6 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipEventCreateWithFlags(&c->ev_usage, hipEventDisableTiming));
   CREATE_TRY(hipMalloc((void **)&c->d_usage, 2 * sizeof(unsigned long long)));
   CREATE_TRY(hipMemset(c->d_usage, 0, 2 * sizeof(unsigned long long)));
-  CREATE_TRY(hipMalloc((void **)&c->d_phase, 4 * sizeof(unsigned long long)));
-  CREATE_TRY(hipMemset(c->d_phase, 0, 4 * sizeof(unsigned long long)));
-  {
-    int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0)
-      c->wall_clock_khz = khz;
-  }
   CREATE_TRY(hipHostMalloc((void **)&c->h_usage, 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->h_usage[0] = c->h_usage[1] = 0;
   CREATE_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -259,7 +251,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
     (void)hipStreamSynchronize(c->stream);
   invalidate_plan(c);
   c->zob.release();
-  c->res2.release(); c->off2.release(); c->cnt2.release(); c->table.release();
+  c->res2.release(); c->off2.release(); c->cnt2.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
@@ -275,7 +267,6 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->ev_usage) (void)hipEventDestroy(c->ev_usage);
   if (c->d_usage) (void)hipFree(c->d_usage);
-  if (c->d_phase) (void)hipFree(c->d_phase);
   if (c->h_usage) (void)hipHostFree(c->h_usage);
   c->arena_a.release();
   c->arena_b.release();
@@ -390,14 +381,6 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set d2_buffers before cmpr_set_reference");
     c->d2_buffers = value;
-  } else if (n == "fused_step") {
-    if (value < 0 || value > 1)
-      return fail(c, CMPR_EINVAL, "fused_step must be 0 or 1");
-    c->fused_step = value;
-  } else if (n == "merge_reduce") {
-    if (value < 0 || value > 1)
-      return fail(c, CMPR_EINVAL, "merge_reduce must be 0 or 1");
-    c->merge_reduce = value;
   } else if (n == "chunk_deal") {
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, "chunk_deal must be 0 (static) or 1 (by a counter)");
@@ -470,6 +453,12 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set bloom_bits_log2_delta before cmpr_set_reference");
     c->bloom_log2_delta = value;
+  } else if (n == "row_filter_x16") {
+    if (value < 8 || value > 128)
+      return fail(c, CMPR_EINVAL, "row_filter_x16 must be 8..128 (sixteenths of a byte per entry)");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set row_filter_x16 before cmpr_set_reference");
+    c->row_filter_x16 = value;
   } else {
     return fail(c, CMPR_EINVAL, "unknown tunable: " + n);
   }
@@ -497,8 +486,6 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "narrow_upload") *value = c->narrow_upload;
   else if (n == "d2_buffers") *value = c->have_ref && c->d2pairs ? (int64_t)c->geom.nbuf : c->d2_buffers;
   else if (n == "d2_pairs") *value = c->have_ref ? (c->d2pairs ? 1 : 0) : c->d2_pairs;
-  else if (n == "fused_step") *value = c->plan.valid ? (c->plan.ffn ? 1 : 0) : c->fused_step;
-  else if (n == "merge_reduce") *value = c->merge_reduce;
   else if (n == "chunk_deal") *value = c->chunk_deal;
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
@@ -524,6 +511,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "class_rows_unstaged") *value = c->class_rows_unstaged;
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
+  else if (n == "row_filter_x16") *value = c->row_filter_x16;
   else if (n == "host_threads") *value = c->host_threads;
   else if (n == "pos_capacity") *value = (int64_t)(c->pos_cap * c->pos_segments);
   else if (n == "pos_segments") *value = c->pos_segments;
@@ -579,8 +567,8 @@ static int cmpr_count_duplicates_impl(cmpr_context *c, const cmpr_set_view *s, u
     D.zpos = c->zpos;
     D.res = c->res2.p; D.off = c->off2.p; D.v = c->v2.p; D.j = c->j2.p; D.rep = c->rep2.p;
     D.n = c->n2;
-    D.table = c->table.p; D.slot_mask = c->slots - 1;
     D.rec = c->rec2.p;
+    D.dir_mask = (uint32_t)(c->slots - 1);
   } else {
     std::string why;
     if ((rc = validate_view(c->opt, s, why)))
@@ -684,7 +672,6 @@ static int retire_queries(cmpr_context *c)
   c->last_without_redo = false;
   c->events_valid = false;
   c->calls = 0;
-  HIP_TRY(c, hipMemsetAsync(c->d_phase, 0, 4 * sizeof(unsigned long long), c->stream));
   invalidate_plan(c);
   return CMPR_OK;
 }
@@ -776,7 +763,6 @@ void use_counter_block(cmpr_context *c, int which)
   c->d_overflow = c->d_stats + STAT_COUNT + 1;
   c->d_stats2 = c->d_overflow + 1;
   c->d_tile_counter2 = (uint32_t *)(c->d_stats2 + STAT_COUNT);
-  c->d_fuse = c->d_stats + CTR_TAIL;
   c->d_deal = c->ctr_cur + blk - DEAL_WORDS;
 }
 
@@ -816,8 +802,7 @@ int make_plan(cmpr_context *c)
   P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
   P.bloom = c->bloom.p;
   P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
-  P.table = c->table.p;
-  P.slot_mask = c->slots - 1;
+  P.dir_mask = (uint32_t)(c->slots - 1);
   P.res2 = c->res2.p;
   P.off2 = c->off2.p;
   P.v2 = c->v2.p;
@@ -973,29 +958,6 @@ int make_plan(cmpr_context *c)
     S.rgrid = std::max<uint32_t>(1, rgrid / P.pos_segments) * P.pos_segments;
     S.rfn = select_resolve(!c->opt.ignore_genes);
   }
-  /* One launch per step: the fast form of variant 2 whose workgroups go on to resolve the
-     queued positives and whose last workgroup sums the partial results (kernels_rows.h
-     fused_tail) -- when the matrix is privatised in LDS (a late overflow must be able to
-     take back what was added) and a 64-bit set names the segments.  Pairs mode (matches are
-     listed where they are found) keeps the three kernels. */
-  if (c->rows && S.deferred && c->fused_step && !wide && P.lds_matrix && S.reduce_writes && P.pos_segments <= 64 &&
-      !(c->debug & DBG_SKIP_RESOLVE)) {
-    S.ffn = nw == 4 ? select_probe_v2_fused_nw4((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
-          : nw == 16 ? select_probe_v2_fused_nw16((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes)
-                     : select_probe_v2_fused_nw8((int)A, c->opt.differences, c->opt.indels != 0, !c->opt.ignore_genes);
-    S.flds = std::max(lds, (size_t)nw * sizeof(CandQueue) + cells * sizeof(unsigned long long) + 64);
-    if (S.ffn == nullptr || S.flds > 160 * 1024) {
-      S.ffn = nullptr;
-    } else {
-      if (S.flds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute((const void *)S.ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.flds));
-      /* every workgroup of the grid is resident at once (those that are through wait for the rest) */
-      int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)S.ffn, nw * WAVE, S.flds) != hipSuccess ||
-          (uint64_t)occ * (uint64_t)c->cus < (uint64_t)S.grid)
-        S.ffn = nullptr;
-    }
-  }
   if (S.redo_kind) {
     /* the redo pass (issue_step) */
     S.fn2 = select_rows_kernel(c->opt, nw, true, wide);
@@ -1054,46 +1016,6 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     P.overflow = c->d_overflow;
   /* a launch of variant 2 without redo pass leaves word of an overflow behind */
   unsigned long long *sticky = (S.redo_kind && !a.with_redo) ? c->d_usage + 1 : nullptr;
-  const bool fused = S.ffn != nullptr && !c->pair_count;
-  c->last_fused = fused;
-  if (fused) {
-    /* one launch: probe, resolve and the sum of the partial results (kernels_rows.h fused_tail) */
-    if (a.track_usage)
-      HIP_TRY(c, hipMemsetAsync(c->d_usage, 0, sizeof(unsigned long long), st));
-    P.fuse = c->d_fuse;
-    P.phase = c->d_phase;
-    P.next_ctr = c->ctr_other;
-    P.next_n64 = (uint32_t)S.ctr_blk;
-    P.reduce_cells = (uint32_t)cells;
-    P.usage = a.track_usage ? c->d_usage : nullptr;
-    P.sticky = sticky;
-    hipLaunchKernelGGL(S.ffn, dim3(S.grid), dim3(S.nw * WAVE), S.flds, st, P);
-    HIP_TRY(c, hipGetLastError());
-    c->launches = 1;
-    if (ev_km)
-      HIP_TRY(c, hipEventRecord(ev_km, st));
-    if (a.track_usage) {
-      HIP_TRY(c, hipMemcpyAsync(c->h_usage, c->d_usage, sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipEventRecord(c->ev_usage, st));
-      c->usage_pending = true;
-      c->usage_grid = S.grid;
-      c->usage_nw = S.nw;
-    }
-    if (a.with_redo) {
-      ProbeParams P2 = P;
-      P2.pos_buf = nullptr;
-      P2.part = nullptr;                  /* (straight into matrix and stats2) */
-      P2.redo = 1;
-      P2.stats = c->d_stats2;
-      P2.tile_counter = c->d_tile_counter2;
-      P2.deal_ctr = c->d_deal + DEAL_WORDS / 2;
-      hipLaunchKernelGGL(S.fn2, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P2);
-      HIP_TRY(c, hipGetLastError());
-      c->launches = 2;
-    }
-    return CMPR_OK;
-  }
   hipLaunchKernelGGL(S.fn, dim3(S.grid), dim3(S.nw * WAVE), S.lds, st, P);
   HIP_TRY(c, hipGetLastError());
   c->launches = 1;
@@ -1112,18 +1034,8 @@ int issue_step(cmpr_context *c, const StepArgs &a, hipStream_t st, hipEvent_t ev
     HIP_TRY(c, hipGetLastError());
     return CMPR_OK;
   }
-  if (c->merge_reduce) {
-    /* the last workgroup of resolve_kernel sums the partial results: no reduce launch (kernels.h reduce_last) */
-    P.fuse = c->d_fuse;
-    P.next_ctr = c->ctr_other;
-    P.next_n64 = (uint32_t)S.ctr_blk;
-    P.reduce_cells = P.part_cells;
-    P.usage = a.track_usage ? c->d_usage : nullptr;
-    P.sticky = sticky;
-  }
   hipLaunchKernelGGL(S.rfn, dim3(S.rgrid), dim3(BLOCK_THREADS), S.rlds, st, P);
-  if (!c->merge_reduce)
-    reduce_partials();
+  reduce_partials();
   HIP_TRY(c, hipGetLastError());
   c->launches = 2;
   if (a.track_usage) {
@@ -1211,10 +1123,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
   if (S.redo_kind && S.will_launch && c->usage_pending && hipEventQuery(c->ev_usage) == hipSuccess) {
     c->usage_pending = false;
     /* (a wave's blocks go round the segments -- kernels_sliced.h pos_segment_of --, so a segment hears
-       from every wave of the grid; the fused step keeps one segment per workgroup) */
-    const uint64_t waves_per_segment = S.ffn
-        ? (((uint64_t)S.grid + S.P.pos_segments - 1) / S.P.pos_segments) * (uint64_t)S.nw
-        : (uint64_t)S.grid * (uint64_t)S.nw;
+       from every wave of the grid) */
+    const uint64_t waves_per_segment = (uint64_t)S.grid * (uint64_t)S.nw;
     /* (which chunks a workgroup gets may differ from launch to launch -- chunk_deal --: a wave's k-th
        block goes to segment (its workgroup + k) mod S whatever it works on, so a segment receives
        1/S of all blocks, give or take one block per wave; the number of blocks is that of the
@@ -1248,18 +1158,8 @@ int enqueue_overlap(cmpr_context *c, unsigned long long *d_out, hipStream_t st)
 
   if (!back_to_back)
     HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-  /* (the fused step is one kernel: no event between probe and resolve -- a packet the stream
-     would wait ~4.5 us for; the split comes from the kernel's own clock reads, d_phase) */
-  const bool one_kernel = S.will_launch && S.ffn != nullptr && !c->pair_count;
-  {
-    const uint32_t slot = (uint32_t)((c->calls - 1) % cmpr_context::TIME_RING);
-    const bool mid_is_end = one_kernel && !a.with_redo;
-    if (mid_is_end)
-      c->ev_km = c->ev_k1;
-    c->ring_mid[slot] = c->ev_km;
-    c->ring_fused[slot] = one_kernel;
-  }
-  if ((rc = issue_step(c, a, st, c->ev_km == c->ev_k1 ? nullptr : c->ev_km)))
+  c->ring_mid[(uint32_t)((c->calls - 1) % cmpr_context::TIME_RING)] = c->ev_km;
+  if ((rc = issue_step(c, a, st, c->ev_km)))
     return rc;
   HIP_TRY(c, hipEventRecord(c->ev_k1, st));
   c->ctr_clean = true;
@@ -1479,15 +1379,11 @@ extern "C" int cmpr_get_kernel_times(cmpr_context *c, uint32_t max, double *kern
   /* (one less than the ring holds: the start of the oldest call may be the end event of the
      call before it, whose ring entry the newest call has just taken) */
   uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max, c->calls), cmpr_context::TIME_RING - 1);
-  unsigned long long phase[4] = {0, 0, 0, 0};
-  HIP_TRY(c, hipMemcpy(phase, c->d_phase, sizeof phase, hipMemcpyDeviceToHost));
   for (uint64_t k = 0; k < n; k++) {
     const uint32_t slot = (uint32_t)((c->calls - n + k) % cmpr_context::TIME_RING);
     float a = 0, b = 0;
     HIP_TRY(c, hipEventElapsedTime(&a, c->ring_start[slot], c->ring_k1[slot]));
     HIP_TRY(c, hipEventElapsedTime(&b, c->ring_start[slot], c->ring_mid[slot]));
-    if (c->ring_fused[slot] && phase[1] > 0)      /* the probe phase's share of the fused kernel, by its own clock */
-      b = (float)(b * ((double)phase[0] / (double)phase[1]));
     if (kernel_ms)
       kernel_ms[k] = a;
     if (probe_ms)
@@ -1529,14 +1425,6 @@ extern "C" int cmpr_get_stats(cmpr_context *c, cmpr_stats *out)
   HIP_TRY(c, hipEventElapsedTime(&k_ms, c->ev_k0, c->ev_k1));
   float p_ms = 0;
   HIP_TRY(c, hipEventElapsedTime(&p_ms, c->ev_k0, c->ev_km));
-  if (c->last_fused) {
-    /* one kernel: its probe phase by its own clock (wall_clock64: start of the first workgroup
-       to the last workgroup's last probe) */
-    unsigned long long phase[4] = {0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpy(phase, c->d_phase, sizeof phase, hipMemcpyDeviceToHost));
-    if (phase[3] > 0)
-      p_ms = (float)(p_ms * ((double)phase[2] / (double)phase[3]));
-  }
   HIP_TRY(c, hipEventElapsedTime(&t_ms, c->ev_k0, ev_end));
   memset(out, 0, sizeof *out);
   out->queries = c->n1;

@@ -72,8 +72,6 @@ struct StepPlan {
   size_t   cells = 0, ctr_blk = 0;
   cmpr::ProbeParams P{};            /* the per-launch fields are filled in at enqueue */
   cmpr::ProbeFn fn = nullptr, fn2 = nullptr, rfn = nullptr;
-  cmpr::ProbeFn ffn = nullptr;      /* the fused step (probe + resolve + reduce in one launch), when it applies */
-  size_t   flds = 0;
   uint32_t grid = 0, nw = 0, rgrid = 0;
   size_t   lds = 0, rlds = 0;
 };
@@ -119,9 +117,7 @@ struct cmpr_context {
   hipEvent_t   ring_k0[TIME_RING] = {}, ring_km[TIME_RING] = {}, ring_k1[TIME_RING] = {};
   hipEvent_t   ring_start[TIME_RING] = {};   /* start event of the call in this slot: its own k0, or the
                                                 previous call's k1 when the two ran back to back */
-  hipEvent_t   ring_mid[TIME_RING] = {};     /* end of its probe kernel: its km -- or, for the fused step, whose
-                                                one kernel is the whole step, its k1 (no event packet between) */
-  bool         ring_fused[TIME_RING] = {};
+  hipEvent_t   ring_mid[TIME_RING] = {};     /* end of its probe kernel: its km */
   uint64_t     calls = 0;            /* overlap launches so far */
   hipEvent_t   ev_k0 = nullptr, ev_km = nullptr, ev_k1 = nullptr;   /* = the ring entry of the last call */
   bool         events_valid = false;
@@ -133,6 +129,8 @@ struct cmpr_context {
   int64_t variant = -1;           /* 0: one global Bloom; 1: LDS-staged slices; 2: LDS-staged
                                      row filter (kernels_rows.h); -1: by alphabet */
   int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
+  int64_t row_filter_x16 = 32;    /* variant 2: filter bytes per entry, in sixteenths (32 = 2 bytes: 16 bits per
+                                     entry, eight of them set) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
   int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
   int64_t heavy_threshold = -1;   /* class population above which it is split;
@@ -147,15 +145,8 @@ struct cmpr_context {
   int64_t small_slice_tiles = 0;  /* slices with <= this many tiles are not staged (wave phase): never pays since round 2 */
   int64_t class_rows_unstaged = 0; /* variant 2: class-row tiles read the filter where it lies */
   int64_t host_threads = 0;       /* threads of the host-side layout passes; set in cmpr_create */
-  int64_t table_log2_delta = 1;   /* table slots = 2^delta x the 70 % rule       */
+  int64_t table_log2_delta = 1;   /* directory buckets = 2^delta x the 70 % rule of hashtable.cc:24 */
   int64_t deferred_resolve = 1;   /* Bloom positives walked by a second kernel   */
-  int64_t fused_step = 0;         /* variant 2: ... or by the probe kernel's own workgroups once all of them are
-                                     through with their chunks (one launch per step; kernels_rows.h fused_tail).
-                                     OFF: measured slower (device-scope round trips and
-                                     whole-L2 fences cost more than the two launches they save) */
-  int64_t merge_reduce = 0;       /* the last workgroup of resolve_kernel sums the partial results (no reduce launch).
-                                     OFF: one workgroup reading 128 x 261 partial values with device-scope loads takes
-                                     ~45 us where the reduce kernel's 261 workgroups take 4.5 */
   int64_t chunk_deal = 1;         /* variant 2: 1 = beyond a workgroup's first four, chunks are handed out by a counter
                                      in list order (heaviest first); 0 = all of them dealt statically */
   int64_t pos_capacity = 0;       /* entries of the positives buffer; 0 = auto   */
@@ -192,10 +183,9 @@ struct cmpr_context {
   DevBuf<uint8_t>   res2;
   DevBuf<uint64_t>  off2, cnt2, bloom;
   DevBuf<uint32_t>  v2, j2, rep2;
-  DevBuf<Slot>      table;
-  DevBuf<unsigned char> rec2;      /* RefRec stream (header + residues) */
-  DevBuf<uint32_t>  voff2;          /* position of sequence i in it, REC_UNIT units */
-  uint64_t          slots = 0, bloom_words = 0;
+  DevBuf<unsigned char> rec2;      /* the record table (layout.h RefRec; ref_index.hip) */
+  DevBuf<uint32_t>  voff2;          /* slot of sequence i in it */
+  uint64_t          slots = 0, bloom_words = 0;     /* slots: buckets of the record table (a power of two) */
 
   /* set 1 tiles */
   bool              have_q = false;
@@ -268,10 +258,6 @@ struct cmpr_context {
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */
   unsigned long long        *d_overflow = nullptr, *d_stats2 = nullptr;   /* redo pass (kernels_rows.h) */
-  unsigned long long        *d_fuse = nullptr;         /* fused step: its words of the counter block (layout.h) */
-  unsigned long long        *d_phase = nullptr;        /* fused step: probe / kernel ticks (persistent, 4 u64) */
-  double                     wall_clock_khz = 100000.0;
-  bool                       last_fused = false;       /* the last launch was the fused kernel */
   uint32_t                  *d_tile_counter2 = nullptr;
   unsigned long long        *d_deal = nullptr;         /* chunk counters of probe_rows_kernel (DEAL_WORDS) */
   DevBuf<unsigned long long> part;           /* NPART x part_stride partial results */

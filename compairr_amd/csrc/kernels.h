@@ -111,12 +111,34 @@ __device__ __forceinline__ uint32_t bloom_off(uint64_t h)
   return (uint32_t)(h >> 32);
 }
 
-__device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
+__host__ __device__ __forceinline__ uint32_t table_home(uint64_t key, uint64_t mask)
 {
   /* high half, independent of the Bloom address bits (hashtable.h:36-41); the
      chain starts on a 4-slot boundary, so that the four slots a walk reads per
-     round are one aligned 64-byte piece of memory, not two */
+     round are one aligned 64-byte piece of memory, not two.  (The open-addressing table
+     is only built for cmpr_count_duplicates on a set that is not the resident reference.) */
   return (uint32_t)((key >> 32) & mask & ~3ull);
+}
+
+/* The record table of set 2 (ref_index.hip): bucket of a key -- its high half, as the
+   reference takes the table position from it (hashtable.h:36-41) -- and the 15 bits of
+   the key a record carries beside its length (RefRec::len): a record of the right bucket
+   with another tag is not looked at further. */
+__host__ __device__ __forceinline__ uint32_t dir_bucket(uint64_t key, uint32_t mask)
+{
+  return (uint32_t)(key >> 32) & mask;
+}
+__host__ __device__ __forceinline__ uint32_t dir_tag(uint64_t key)
+{
+  return (uint32_t)key & 0x7fffu;
+}
+/* What a lookup of bucket `b` does with the record it finds in a slot: the walk starts at
+   slot b and goes on slot by slot.  WALK_MINE: a record of this bucket -- look at it (if its
+   tag is the key's); the walk goes on iff walk_more(). */
+__host__ __device__ __forceinline__ bool walk_ends(uint32_t idx, uint32_t len, uint32_t home, uint32_t b)
+{
+  /* empty slot; a record of a later bucket (the records lie in bucket order); the last of this bucket's */
+  return idx == REC_EMPTY || home > b || (home == b && !(len & REC_MORE));
 }
 
 /* ------------------------------------------------------------------ */
@@ -133,9 +155,8 @@ struct BuildParams {
   const uint64_t *off;
   const uint32_t *v;
   const uint32_t *j;
-  const uint32_t *voff;            /* table value of sequence i (NULL: i)   */
   uint64_t        n;
-  Slot           *table;
+  Slot           *table;           /* NULL: no table (the resident reference has its record directory) */
   uint64_t        slot_mask;
   uint64_t       *bloom;           /* NULL: build the table only            */
   uint32_t        bloom_byte_mask;
@@ -166,17 +187,19 @@ build_index_kernel(const BuildParams B)
   for (uint32_t p = 0; p < L; p++)
     h ^= B.zob[B.A * p + B.res[b + p]];
 
-  const uint64_t key = table_key(h);
-  uint64_t slot = table_home(key, B.slot_mask);
-  for (;;) {
-    unsigned long long prev =
-        atomicCAS((unsigned long long *)&B.table[slot].key,
-                  (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-    if (prev == EMPTY_KEY)
-      break;
-    slot = (slot + 1) & B.slot_mask;
+  if (B.table) {
+    const uint64_t key = table_key(h);
+    uint64_t slot = table_home(key, B.slot_mask);
+    for (;;) {
+      unsigned long long prev =
+          atomicCAS((unsigned long long *)&B.table[slot].key,
+                    (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+      if (prev == EMPTY_KEY)
+        break;
+      slot = (slot + 1) & B.slot_mask;
+    }
+    B.table[slot].val = (uint32_t)i;
   }
-  B.table[slot].val = B.voff ? B.voff[i] : (uint32_t)i;
 
   if (!B.bloom)
     return;                            /* table only: duplicate counting, row filter */
@@ -206,9 +229,10 @@ struct DupParams {
   const uint64_t *off;
   const uint32_t *v, *j, *rep;
   uint64_t        n;
-  const Slot     *table;
+  const Slot     *table;           /* a set of its own: open-addressing table of sequence numbers */
   uint64_t        slot_mask;
-  const unsigned char *rec;        /* non-NULL: table values are RefRec positions */
+  const unsigned char *rec;        /* the resident reference: its record table */
+  uint32_t        dir_mask;
   unsigned long long *count;
 };
 
@@ -229,14 +253,32 @@ count_duplicates_kernel(const DupParams B)
       h ^= B.zob[B.A * p + B.res[b + p]];
     const uint64_t key = table_key(h);
     uint64_t slot = table_home(key, B.slot_mask);
+    /* the resident reference: the records of the key's bucket, one after the other */
+    const uint32_t bk = dir_bucket(key, B.dir_mask);
+    uint32_t piece = bk;
+    bool ended = false;
     for (;;) {
-      const Slot sl = B.table[slot];
-      const uint64_t k = sl.key;
-      if (k == EMPTY_KEY)
-        break;
+      uint64_t k, o;
+      if (B.rec) {
+        if (ended)
+          break;
+        const RefRec *r = (const RefRec *)B.rec + piece;
+        const uint32_t ri = r->idx, rl = r->len, rh = r->home;
+        ended = walk_ends(ri, rl, rh, bk);
+        if (ri == REC_EMPTY)
+          break;
+        k = (rh == bk && (rl >> REC_TAG_SHIFT) == dir_tag(key)) ? key : ~key;
+        o = ri;
+        piece++;
+      } else {
+        const Slot sl = B.table[slot];
+        k = sl.key;
+        o = sl.val;
+        if (k == EMPTY_KEY)
+          break;
+        slot = (slot + 1) & B.slot_mask;
+      }
       if (k == key) {
-        const uint64_t o = B.rec ? ((const RefRec *)(B.rec + (size_t)sl.val * REC_UNIT))->idx
-                                 : sl.val;
         if (o < i && B.rep[o] == B.rep[i] &&
             (!B.use_genes || (B.v[o] == B.v[i] && B.j[o] == B.j[i]))) {
           const uint64_t ob = B.off[o];
@@ -251,7 +293,6 @@ count_duplicates_kernel(const DupParams B)
           }
         }
       }
-      slot = (slot + 1) & B.slot_mask;
     }
   }
   const uint64_t m = __ballot(dup);
@@ -263,6 +304,9 @@ count_duplicates_kernel(const DupParams B)
 struct PackParams {
   const uint64_t *off, *cnt;
   const uint32_t *v, *j, *rep, *voff;
+  const uint32_t *tag;             /* dir_tag of the sequence's key */
+  const uint32_t *home;            /* its bucket */
+  const uint32_t *more;            /* != 0: the next slot holds another record of the bucket */
   const uint8_t  *res;
   uint64_t        n;
   unsigned char  *out;
@@ -277,18 +321,16 @@ pack_records_kernel(const PackParams B)
   const uint64_t b = B.off[i];
   RefRec r;
   r.idx = (uint32_t)i;
-  r.len = (uint32_t)(B.off[i + 1] - b);
+  const uint32_t L = (uint32_t)(B.off[i + 1] - b);
+  r.len = L | (B.more[i] ? REC_MORE : 0u) | (B.tag[i] << REC_TAG_SHIFT);
   r.cnt = B.cnt ? B.cnt[i] : 1ull;
   r.v = B.v ? B.v[i] : 0u;
   r.j = B.j ? B.j[i] : 0u;
   r.rep = B.rep[i];
-  r.pad = 0;
-  unsigned char *o = B.out + (size_t)B.voff[i] * REC_UNIT;
-  *(RefRec *)o = r;
-  o += sizeof(RefRec);
-  const uint32_t padded = (r.len + REC_UNIT - 1) / REC_UNIT * REC_UNIT;
-  for (uint32_t p = 0; p < padded; p++)
-    o[p] = p < r.len ? B.res[b + p] : (unsigned char)0xff;
+  r.home = B.home[i];
+  for (uint32_t p = 0; p < REC_RES; p++)
+    r.res[p] = p < L ? B.res[b + p] : (unsigned char)0xff;
+  ((RefRec *)B.out)[B.voff[i]] = r;
 }
 
 /* ------------------------------------------------------------------ */
@@ -398,54 +440,40 @@ __device__ __forceinline__ void score_match(const ProbeParams &P, uint32_t qs, u
   }
 }
 
-/* Lane e of the wave resolves queue entry `e`: walk the probe chain
-   (find_variant_matches, overlap.cc:168-251), verify, score, accumulate.
-   The chain is read four slots at a time (independent loads). */
+/* Lane e of the wave resolves queue entry `e`: the records of the variant hash's bucket
+   (find_variant_matches, overlap.cc:168-251, over the record directory), verify, score,
+   accumulate. */
 template <bool GENES>
 __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, uint32_t ca,
                             uint32_t cb, unsigned long long *mat_lds, LaneStats &st)
 {
   const uint64_t key = table_key(hash);
-  /* everything of the query that a match needs is fetched now, next to the
-     first table read, not after it: one memory round trip less per match */
+  const uint32_t bk = dir_bucket(key, P.dir_mask);
   const TileDesc td = P.tiles[qs >> 6];
   const uint32_t ql = qs & 63u;
   const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
   const uint32_t q_rep = P.qrep[qs];
   const uint32_t q_len = P.qlen[qs];           /* own length (tiles may mix lengths) */
   const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
-  uint64_t s = table_home(key, P.slot_mask);
-  for (;;) {
-    Slot k[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      k[i] = P.table[(s + i) & P.slot_mask];
-    bool end = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (end)
-        break;
-      if (k[i].key == EMPTY_KEY) {
-        end = true;
-        break;
-      }
-      if (k[i].key != key)
-        continue;
-      const unsigned char *rp = P.rec2 + (size_t)k[i].val * REC_UNIT;
-      const RefRec rec = *(const RefRec *)rp;
-      const uint32_t hit = rec.idx;
+  for (uint32_t piece = bk;; piece++) {
+    RefRec rec = *((const RefRec *)P.rec2 + piece);
+    if (rec.idx == REC_EMPTY)
+      break;
+    const bool last = walk_ends(rec.idx, rec.len, rec.home, bk);
+    if (rec.home == bk && (rec.len >> REC_TAG_SHIFT) == dir_tag(key)) {
+      rec.len &= 0xffffu;
       st.hash_eq++;
       bool ok = true;
       if (GENES)
         ok = (q_v == rec.v) && (q_j == rec.j);
-      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, rp + sizeof(RefRec))) {
+      /* (the residues where the set lies: this is the rare path, and they are all there) */
+      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, P.res2 + P.off2[rec.idx])) {
         st.matches++;
-        score_match(P, qs, hit, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
+        score_match(P, qs, rec.idx, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
       }
     }
-    if (end)
+    if (last)
       break;
-    s = (s + 4) & P.slot_mask;
   }
 }
 
@@ -461,7 +489,10 @@ __device__ __forceinline__ void resolve_entry(const ProbeParams &P, const WaveQu
 /* (query, variant, set-2 sequence) triples whose table key equals the variant
    hash, waiting for verification -- one queue per wave, in LDS */
 struct CandQueue {
-  uint32_t slot[QCAP], qbase[QCAP], ca[QCAP], cb[QCAP], hit[QCAP];
+  uint32_t slot[QCAP], ca[QCAP], cb[QCAP];
+  uint32_t tagb[QCAP];                 /* the key's bucket | its tag << 17 ... (see verify_candidate) */
+  uint32_t piece[QCAP];                /* the table slot to look at */
+  uint32_t bucket[QCAP];
 };
 
 /* n low bytes set (n <= 0: none, n >= 4: all) */
@@ -508,23 +539,34 @@ __device__ __forceinline__ uint32_t block_mismatch(uint32_t c, const uint32_t q[
   return bad;
 }
 
-/* Verification + scoring of one candidate per lane.  Everything a candidate
-   needs is requested at once -- the hit's record with its first 32 residues and
-   the query's record with its first 36, one 64-byte piece each -- so a CDR3 is
-   verified after ONE memory round trip of two requests; sequences longer than
-   32 take one more per 16 residues. */
+/* Verification + scoring of one candidate per lane: the table slot `piece` (a record with its
+   first 32 residues) and, when that is a record of the candidate's key, the query's record with
+   its first 36 -- one 64-byte line each; sequences longer than 32 take their further residues
+   from where set 2 lies.  Returns true when the walk of bucket `bk` goes on in the next slot. */
 template <bool GENES>
-__device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t qbase,
-                                                 uint32_t ca, uint32_t cb, uint32_t hit,
+__device__ __forceinline__ bool verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t ca,
+                                                 uint32_t cb, uint32_t tag, uint32_t bk, uint32_t piece,
                                                  unsigned long long *mat_lds, LaneStats &st)
 {
-  const uint4 *rp = (const uint4 *)(P.rec2 + (size_t)hit * REC_UNIT);
+  const uint4 *rp = (const uint4 *)P.rec2 + (size_t)piece * 4;
   const uint4 h0 = rp[0], h1 = rp[1], t0 = rp[2], t1 = rp[3];
   /* the query's record (layout.h QueryRec): count, genes, repertoire, length and
      its first 36 residues in ONE 64-byte piece, like the hit's */
   const uint4 *qp = (const uint4 *)P.qrec + (size_t)qs * 4;
+  if (CMPR_DBG(P, DBG_RES_NO_VERIFY)) {
+    st.hash_eq += (h0.x ^ h1.x ^ t0.x ^ t1.x ^ qp[0].x ^ qp[1].x ^ qp[2].x ^ qp[3].x) == 0x12345u ? 1u : 0u;
+    return false;
+  }
+  RefRec rec;
+  rec.cnt = ((unsigned long long)h0.y << 32) | h0.x;
+  rec.idx = h0.z; rec.len = h0.w; rec.v = h1.x; rec.j = h1.y; rec.rep = h1.z; rec.home = h1.w;
+  const bool more = !walk_ends(rec.idx, rec.len, rec.home, bk);
+  if (rec.idx == REC_EMPTY || rec.home != bk || (rec.len >> REC_TAG_SHIFT) != tag)
+    return more;                                 /* nothing here / another bucket's / another key's */
+  st.hash_eq++;
+  /* (the query's record is asked for only now: a false positive of the filter -- on skewed data up to
+     half of the positives -- costs one memory line, not two) */
   const uint4 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
-  (void)qbase;
   uint32_t q[10];
   q[0] = 0;
   q[1] = a1.z; q[2] = a1.w; q[3] = a2.x; q[4] = a2.y; q[5] = a2.z; q[6] = a2.w;
@@ -533,13 +575,9 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
   const uint32_t q_rep = a1.x;
   const uint32_t L = a1.y;
   const unsigned long long q_cnt = ((unsigned long long)a0.y << 32) | a0.x;
-
-  RefRec rec;
-  rec.cnt = ((unsigned long long)h0.y << 32) | h0.x;
-  rec.idx = h0.z; rec.len = h0.w; rec.v = h1.x; rec.j = h1.y; rec.rep = h1.z;
   const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
   const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
-  const uint32_t M = rec.len;
+  const uint32_t M = rec.len & 0xffffu;
   const uint32_t want = kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L);
   bool ok = M == want;
   if (GENES)
@@ -547,16 +585,19 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
   const uint32_t r0[4] = {t0.x, t0.y, t0.z, t0.w}, r1w[4] = {t1.x, t1.y, t1.z, t1.w};
   uint32_t bad = block_mismatch(0, q, r0, kind, p1, r1, p2, r2, M) |
                  block_mismatch(1, q + 4, r1w, kind, p1, r1, p2, r2, M);
-  if (ok && M > 32) {
-    /* residues past the 36th: from the query's tile (rare -- a CDR3 is shorter) */
+  if (ok && bad == 0 && M > REC_RES) {
+    /* residues past the 32nd: the hit's from set 2 as it lies, the query's from its tile
+       (rare -- a CDR3 is shorter) */
+    const uint8_t *hr = P.res2 + P.off2[rec.idx];
     const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
     for (uint32_t c = 2; 16 * c < M; c++) {
-      const uint4 t = rp[2 + c];
+      uint32_t rr[4] = {0, 0, 0, 0};
+      for (uint32_t x = 0; x < 16u && 16u * c + x < M; x++)
+        rr[x >> 2] |= (uint32_t)hr[16u * c + x] << (8u * (x & 3u));
       uint32_t qq[6];
 #pragma unroll
       for (int k = 0; k < 6; k++)
         qq[k] = qr[(size_t)(4 * c - 1 + k) * WAVE];
-      const uint32_t rr[4] = {t.x, t.y, t.z, t.w};
       bad |= block_mismatch(c, qq, rr, kind, p1, r1, p2, r2, M);
     }
   }
@@ -564,6 +605,33 @@ __device__ __forceinline__ void verify_candidate(const ProbeParams &P, uint32_t 
     st.matches++;
     score_match(P, qs, rec.idx, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
   }
+  return more;
+}
+
+/* One round of the candidate queue: lanes 0 .. n-1 take the n entries on top (n = 64 but
+   for the last rounds), look at one table slot each, and queue up again for the next slot
+   while their walk goes on.  Returns the new fill (wave-uniform). */
+template <bool GENES>
+__device__ __forceinline__ int verify_round(const ProbeParams &P, CandQueue &cq, int qn, int n, uint32_t lane,
+                                            unsigned long long *mat_lds, LaneStats &st)
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int base = qn - n;
+  const bool mine = (int)lane < n;
+  uint32_t qs = 0, ca = 0, cb = 0, tag = 0, bk = 0, piece = 0;
+  bool more = false;
+  if (mine) {
+    const int x = base + (int)lane;
+    qs = cq.slot[x]; ca = cq.ca[x]; cb = cq.cb[x]; tag = cq.tagb[x]; bk = cq.bucket[x]; piece = cq.piece[x];
+    more = verify_candidate<GENES>(P, qs, ca, cb, tag, bk, piece, mat_lds, st);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint64_t mm = __ballot(more);
+  if (more) {
+    const int x = base + (int)rank_below(mm);
+    cq.slot[x] = qs; cq.ca[x] = ca; cq.cb[x] = cb; cq.tagb[x] = tag; cq.bucket[x] = bk; cq.piece[x] = piece + 1u;
+  }
+  return base + __popcll(mm);
 }
 
 /* destinations of a workgroup's results (ProbeParams::part) */
@@ -622,75 +690,12 @@ reduce_partials_kernel(const ProbeParams P, uint32_t cells, uint32_t overwrite,
   }
 }
 
-__device__ __forceinline__ unsigned long long load_agent(const unsigned long long *p)
-{
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-/* What reduce_partials_kernel does, done by the LAST workgroup of the kernel that produced the
-   partial results (the one that draws ticket gridDim.x - 1 from ProbeParams::fuse[0] after its
-   own atomics have been acknowledged): no launch of its own.  Everything it reads was written
-   with device-scope atomics and is read with device-scope loads -- no cache is written back or
-   invalidated for it.  NT threads; ProbeParams::reduce_cells, next_ctr, usage, sticky as for
-   the kernel. */
-template <uint32_t NT>
-__device__ __forceinline__ void reduce_last(const ProbeParams &P, unsigned long long *t_probe)
-{
-  const uint32_t S = P.pos_segments, cells = P.reduce_cells;
-  const bool ovf = P.overflow && load_agent(P.overflow) != 0ull;
-  if (threadIdx.x == 0 && P.sticky && ovf)
-    *P.sticky = 1ull;
-  if (P.usage && P.pos_ctr)
-    for (uint32_t g = threadIdx.x; g < S; g += NT)
-      atomicMax(P.usage, load_agent(P.pos_ctr + (size_t)g * POS_CTR_STRIDE));
-  if (t_probe) {
-    t_probe[0] = ~load_agent(P.fuse + 2);
-    t_probe[1] = load_agent(P.fuse + 3);
-  }
-  __syncthreads();                               /* (the words above are read before the block is cleared) */
-  for (uint32_t k = threadIdx.x; k < P.next_n64; k += NT)
-    P.next_ctr[k] = 0;
-  /* value i of the partial slots: four lanes, a quarter of the NPART slots each */
-  const uint32_t stride = P.part_stride;
-  for (uint32_t i0 = 0; i0 < stride; i0 += NT / 4u) {
-    const uint32_t i = i0 + threadIdx.x / 4u, q = threadIdx.x & 3u;
-    unsigned long long x = 0;
-    if (i < stride) {
-#pragma unroll 1
-      for (uint32_t r0 = 0; r0 < NPART / 4; r0 += 8) {       /* eight loads in flight at a time */
-        unsigned long long v[8];
-#pragma unroll
-        for (uint32_t r = 0; r < 8; r++)
-          v[r] = load_agent(P.part + (size_t)(q + 4u * (r0 + r)) * stride + i);
-#pragma unroll
-        for (uint32_t r = 0; r < 8; r++) {
-          x += v[r];
-          if (v[r])
-            P.part[(size_t)(q + 4u * (r0 + r)) * stride + i] = 0;
-        }
-      }
-    }
-    x += __shfl_xor(x, 1, WAVE);
-    x += __shfl_xor(x, 2, WAVE);
-    if (q == 0u && i < stride) {
-      if (i < cells) {
-        if (P.lds_matrix)
-          P.matrix[i] = ovf ? 0ull : x;          /* (a redo pass adds to a clean matrix) */
-        else if (x && !ovf)
-          P.matrix[i] += x;                      /* (a matrix too large for LDS: cleared before the launch, and
-                                                    the inline paths add to it where it lies) */
-      } else if (x && i >= stride - STAT_COUNT)
-        P.stats[i - (stride - STAT_COUNT)] += x;
-    }
-  }
-}
-
-/* Second kernel of the deferred mode.  Phase A, one lane per queued Bloom
-   positive: walk the probe chain comparing keys only (find_variant_matches,
-   overlap.cc:168-251) and queue every key match; phase B, whenever 64
-   candidates are queued: verify and score them, one per lane.  Keeping the
-   walk free of the verification's dependent loads is what matters: the kernel
-   is bound by memory round trips per wave, not by bytes. */
+/* Second kernel of the deferred mode.  One lane per queued Bloom positive: the slot its
+   variant hash's bucket names in the record table (find_variant_matches, overlap.cc:168-251)
+   and the query's record, requested together; verified and scored where the slot holds a
+   record of that key; a walk that goes on (displaced records in front, more records of the
+   bucket) queues up again, so that every further round trip is made by 64 busy lanes too.
+   One random memory line per positive for the hit, one (near its tile's others) for the query. */
 template <bool GENES>
 __global__ void __launch_bounds__(BLOCK_THREADS, 4)      /* <= 128 VGPRs: 4 waves per SIMD */
 resolve_kernel(const ProbeParams P)
@@ -736,47 +741,30 @@ resolve_kernel(const ProbeParams P)
       e = pos[base + lane];
     active = active && e.slot != POS_NULL_SLOT;      /* padding of a block of 64 */
     const uint64_t key = table_key(e.hash);
-    uint64_t s = table_home(key, P.slot_mask);
-    while (__ballot(active)) {
-      Slot k[4];
+    uint32_t bk = dir_bucket(key, P.dir_mask);
+    if (CMPR_DBG(P, DBG_RES_SEQ_REC))
+      bk = (uint32_t)(base + lane) & P.dir_mask;
+    if (CMPR_DBG(P, DBG_RES_SEQ_QREC))
+      e.slot = (uint32_t)((base + lane) % 8000000ull);
+    /* every positive is a candidate: its bucket's first slot is where the walk starts */
+    const uint64_t mm = __ballot(active);
+    if (mm) {
       if (active) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          k[i] = P.table[(s + i) & P.slot_mask];
+        const int x = qn + (int)rank_below(mm);
+        cq.slot[x] = e.slot;
+        cq.ca[x] = e.ca;
+        cq.cb[x] = e.cb;
+        cq.tagb[x] = dir_tag(key);
+        cq.bucket[x] = bk;
+        cq.piece[x] = bk;
       }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (active && k[i].key == EMPTY_KEY)
-          active = false;
-        const bool m = active && k[i].key == key;
-        const uint64_t mm = __ballot(m);
-        if (mm) {
-          if (m) {
-            const int x = qn + (int)rank_below(mm);
-            cq.slot[x] = e.slot;
-            cq.qbase[x] = e.qbase;
-            cq.ca[x] = e.ca;
-            cq.cb[x] = e.cb;
-            cq.hit[x] = k[i].val;
-            st.hash_eq++;
-          }
-          qn += __popcll(mm);
-          if (qn >= WAVE) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            qn -= WAVE;
-            verify_candidate<GENES>(P, cq.slot[qn + lane], cq.qbase[qn + lane], cq.ca[qn + lane],
-                                    cq.cb[qn + lane], cq.hit[qn + lane], mat_lds, st);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          }
-        }
-      }
-      s = (s + 4) & P.slot_mask;
+      qn += __popcll(mm);
+      while (qn >= WAVE)
+        qn = verify_round<GENES>(P, cq, qn, WAVE, lane, mat_lds, st);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if ((int)lane < qn)
-    verify_candidate<GENES>(P, cq.slot[lane], cq.qbase[lane], cq.ca[lane], cq.cb[lane],
-                            cq.hit[lane], mat_lds, st);
+  while (qn > 0)
+    qn = verify_round<GENES>(P, cq, qn, qn < WAVE ? qn : WAVE, lane, mat_lds, st);
   {
     unsigned long long sum[2] = {st.hash_eq, st.matches};
 #pragma unroll
@@ -795,19 +783,6 @@ resolve_kernel(const ProbeParams P)
       if (x)
         atomicAdd(matrix_dst(P) + i, x);
     }
-  }
-  /* The sum of the partial results, by the workgroup that is through last (P.fuse != NULL:
-     the step then has no reduce launch; round 4).  Its inputs are device-scope atomics
-     (acknowledged: vmcnt), read with device-scope loads. */
-  if (P.fuse) {
-    __shared__ uint32_t ticket;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-      ticket = (uint32_t)atomicAdd(P.fuse, 1ull);
-    __syncthreads();
-    if (ticket == gridDim.x - 1u)
-      reduce_last<BLOCK_THREADS>(P, nullptr);
   }
 }
 

@@ -591,262 +591,9 @@ struct RingSlot {
 };
 
 
-/* ------------------------------------------------------------------ */
-/* fused step: the probe kernel's workgroups resolve the positives      */
-/* ------------------------------------------------------------------ */
-/*
- * One launch per step (round 4).  A workgroup that is through with its chunks does not
- * leave: it announces that (its positives are written and released at device scope) and
- * turns into part of resolve_kernel -- every wave walks the hash table for the queued
- * positives of whichever SEGMENT of the positives buffer is complete, i.e. all of whose
- * writers (workgroups b with b % segments == s) have announced, claiming blocks of the
- * segment with one atomic.  Early workgroups thus fill the tail of the probe phase with
- * the latency-bound walks; what is left when the last workgroup stops probing is spread
- * over the whole chip.  The workgroup that finishes last sums the partial matrices and
- * counters (what reduce_partials_kernel does between launches of the three-kernel step)
- * and clears the counter block of the next launch.
- *
- * Nothing here waits for a workgroup that is not running: the grid is exactly what is
- * resident at once (make_plan), so every workgroup a spinning wave waits for makes progress.
- */
-constexpr uint32_t FUSE_CLAIM_BLOCKS = 4;      /* blocks of 64 positives per claim */
-constexpr unsigned long long FUSE_PATIENCE = 20000;   /* 200 us without another workgroup finishing its probes */
-
-template <bool GENES, int NW>
-__device__ __forceinline__ void fused_tail(const ProbeParams &P, unsigned char *smem, uint32_t lane,
-                                           uint32_t wave, unsigned long long t_start)
-{
-  constexpr uint32_t NT = NW * WAVE;
-  const uint32_t S = P.pos_segments, G = gridDim.x;
-  unsigned long long *const seg = P.fuse + FUSE_WORDS;           /* per segment: [0] writers done, [1] next block */
-
-  /* ---- this workgroup's positives are out: release them, announce.  Device-scope fences are
-          whole-L2 operations on this chip (one L2 per XCD: a release writes it back, an acquire
-          invalidates it), so there is ONE of each per workgroup: every wave waits for its own
-          stores to reach the L2, the barrier collects them, thread 0 writes the L2 back. ---- */
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long now = (unsigned long long)wall_clock64();
-    atomicMax(P.fuse + 2, ~t_start);
-    atomicMax(P.fuse + 3, now);
-    __threadfence();
-    atomicAdd(seg + (size_t)(blockIdx.x & (S - 1)) * POS_CTR_STRIDE, 1ull);
-    atomicAdd(P.fuse + 1, 1ull);
-  }
-
-  /* ---- resolve: LDS is free now (slices, keys, queues): candidate queues + matrix ---- */
-  CandQueue &cq = ((CandQueue *)smem)[wave];
-  unsigned long long *mat_lds = (unsigned long long *)(smem + NW * sizeof(CandQueue));
-  const uint32_t cells = P.reduce_cells;
-  /* (no static __shared__ in this kernel: the dynamic LDS starts at address 0) */
-  volatile uint32_t *ticket_lds = (volatile uint32_t *)(mat_lds + cells);
-  for (uint32_t i = threadIdx.x; i < cells; i += NT)
-    mat_lds[i] = 0;
-  /* Until EVERY workgroup is through with its probes: resolving the complete segments earlier
-     would fill the tail of the probe phase, but each look at foreign entries needs an acquire,
-     and that invalidates the L2 the workgroups still probing on this XCD are working from
-     (measured: probe phase 0.36 -> 0.50 ms, round 4).  Not for ever, though: when this kernel
-     shares the device (another context's step on another stream), the workgroups waited for may
-     be waiting for THESE compute units -- a workgroup that has seen nobody finish for
-     FUSE_PATIENCE ticks (100 MHz) goes on with what is complete; what it leaves undone is done
-     by the workgroups that stop probing later (the last of them finds every segment complete). */
-  if (wave == 0) {
-    unsigned long long seen0 = 0, since = (unsigned long long)wall_clock64();
-    for (;;) {
-      const unsigned long long d = load_agent(P.fuse + 1);
-      if (d >= G)
-        break;
-      const unsigned long long now = (unsigned long long)wall_clock64();
-      if (d != seen0) {
-        seen0 = d;
-        since = now;
-      } else if (now - since > FUSE_PATIENCE) {
-        break;
-      }
-      __builtin_amdgcn_s_sleep(64);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* the one acquire of this workgroup (its L1, its XCD's L2) */
-  }
-  __syncthreads();
-
-  LaneStats st{0ull, 0u, 0u, 0u};
-  int qn = 0;
-  auto walk_block = [&](const PosEntry *pos, unsigned long long base, unsigned long long n) {
-    bool active = base + lane < n;
-    PosEntry e{};
-    if (active)
-      e = pos[base + lane];
-    active = active && e.slot != POS_NULL_SLOT;
-    const uint64_t key = table_key(e.hash);
-    uint64_t s = table_home(key, P.slot_mask);
-    while (__ballot(active)) {
-      Slot k[4];
-      if (active) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          k[i] = P.table[(s + i) & P.slot_mask];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (active && k[i].key == EMPTY_KEY)
-          active = false;
-        const bool m = active && k[i].key == key;
-        const uint64_t mm = __ballot(m);
-        if (mm) {
-          if (m) {
-            const int x = qn + (int)rank_below(mm);
-            cq.slot[x] = e.slot;
-            cq.qbase[x] = e.qbase;
-            cq.ca[x] = e.ca;
-            cq.cb[x] = e.cb;
-            cq.hit[x] = k[i].val;
-            st.hash_eq++;
-          }
-          qn += __popcll(mm);
-          if (qn >= WAVE) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            qn -= WAVE;
-            verify_candidate<GENES>(P, cq.slot[qn + lane], cq.qbase[qn + lane], cq.ca[qn + lane],
-                                    cq.cb[qn + lane], cq.hit[qn + lane], mat_lds, st);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          }
-        }
-      }
-      s = (s + 4) & P.slot_mask;
-    }
-  };
-
-  /* Every look at the segments is ONE round trip: lane l reads segment l's four words (writers
-     done, next block, entries claimed, first claim that did not fit) -- device-scope loads come
-     from beyond the L2, ~2 us each, and a wave that asked segment after segment would spend
-     its time asking.  A segment is worked on when all its writers have announced and blocks
-     of it are left; the acquire that makes its entries visible is paid once per look that
-     finds something new, not per segment. */
-  unsigned long long pending = S >= 64u ? ~0ull : (1ull << S) - 1ull;
-  const uint32_t first = ((blockIdx.x & (S - 1)) + wave * (S >= (uint32_t)NW ? S / NW : 1u)) & (S - 1);
-  const uint32_t my_writers = lane < S ? G / S + (lane < G % S ? 1u : 0u) : 0u;
-  unsigned long long seen = 0;                   /* workgroups through with probing, as of the last look */
-  bool overflowed = false;
-  bool late = false;                             /* this wave has waited for segments after the workgroup's acquire */
-  while (pending && !overflowed) {
-    unsigned long long done = 0, next = 0, n = 0, lim = 0;
-    if (lane < S) {
-      done = load_agent(seg + (size_t)lane * POS_CTR_STRIDE);
-      next = load_agent(seg + (size_t)lane * POS_CTR_STRIDE + 1);
-      n = load_agent(P.pos_ctr + (size_t)lane * POS_CTR_STRIDE);
-      lim = ~load_agent(P.pos_ctr + (size_t)lane * POS_CTR_STRIDE + 1);
-    }
-    const unsigned long long ovf_word = load_agent(P.overflow);
-    if (lim < n)
-      n = lim;                                   /* claims past the capacity were not written */
-    const bool complete = lane < S && done >= my_writers;
-    const unsigned long long complete_m = __ballot(complete) & pending;
-    pending &= ~__ballot(complete && next * WAVE >= n);          /* complete and handed out: nothing left */
-    unsigned long long todo = complete_m & pending;
-    if (ovf_word != 0ull) {                      /* the launch will be redone resolving inline */
-      overflowed = true;
-      break;
-    }
-    if (todo) {
-      if (late)                                  /* (complete only since this workgroup's acquire) */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      /* the first such segment from `first` round the ring (the waves of the grid start at
-         different ones), until it is handed out; then another look -- a claim that fails costs
-         a round trip, a look prunes every exhausted segment at once */
-      const unsigned long long rot = first ? (todo >> first) | (todo << (64u - first)) : todo;
-      {
-        const uint32_t sg = ((uint32_t)__builtin_ctzll(rot) + first) & 63u;
-        const unsigned long long nsg =
-            ((unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)(n >> 32), (int)sg) << 32) |
-            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n, (int)sg);
-        const PosEntry *pos = P.pos_buf + (size_t)sg * (P.pos_cap + WAVE);
-        for (;;) {
-          unsigned long long blk = 0;
-          if (lane == 0)
-            blk = atomicAdd(seg + (size_t)sg * POS_CTR_STRIDE + 1, (unsigned long long)FUSE_CLAIM_BLOCKS);
-          blk = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(blk >> 32)) << 32) |
-                __builtin_amdgcn_readfirstlane((uint32_t)blk);
-          if (blk * WAVE >= nsg) {
-            pending &= ~(1ull << sg);
-            break;
-          }
-          for (uint32_t q = 0; q < FUSE_CLAIM_BLOCKS && (blk + q) * WAVE < nsg; q++)
-            walk_block(pos, (blk + q) * WAVE, nsg);
-        }
-      }
-      continue;                                  /* look again: more may be complete by now */
-    }
-    if (pending) {
-      /* Nothing complete that is not handed out: until another workgroup stops probing -- but
-         not for ever.  Every workgroup of the grid is resident when this kernel has the
-         device to itself; when it shares it (another context's step on another stream)
-         the workgroups waited for may be waiting for THESE compute units.  A wave that has
-         seen no workgroup finish for FUSE_PATIENCE ticks (100 MHz) leaves; what it leaves
-         undone is done by the workgroups that stop probing later -- the last of them finds
-         every segment complete. */
-      const unsigned long long since = (unsigned long long)wall_clock64();
-      bool gave_up = false;
-      unsigned long long now_done;
-      while ((now_done = load_agent(P.fuse + 1)) == seen) {
-        __builtin_amdgcn_s_sleep(96);
-        if ((unsigned long long)wall_clock64() - since > FUSE_PATIENCE) {
-          gave_up = true;
-          break;
-        }
-      }
-      if (gave_up)
-        break;
-      seen = now_done;
-      late = true;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if ((int)lane < qn && !overflowed)
-    verify_candidate<GENES>(P, cq.slot[lane], cq.qbase[lane], cq.ca[lane], cq.cb[lane], cq.hit[lane], mat_lds, st);
-  {
-    unsigned long long sum[2] = {st.hash_eq, st.matches};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      unsigned long long x = sum[k];
-      for (int off = 32; off > 0; off >>= 1)
-        x += __shfl_down(x, off, WAVE);
-      if (lane == 0 && x)
-        atomicAdd(stats_dst(P) + (k == 0 ? STAT_HASH_EQ : STAT_MATCHES), x);
-    }
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < cells; i += NT) {
-    const unsigned long long x = mat_lds[i];
-    if (x)
-      atomicAdd(matrix_dst(P) + i, x);
-  }
-
-  /* ---- the last workgroup through sums the partial results ---- */
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0)
-    *ticket_lds = (uint32_t)atomicAdd(P.fuse, 1ull);
-  __syncthreads();
-  if (*ticket_lds != G - 1u)
-    return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  unsigned long long *tp = (unsigned long long *)(ticket_lds + 2);      /* (LDS: read by thread 0 below) */
-  reduce_last<NT>(P, threadIdx.x == 0 ? tp : nullptr);
-  __syncthreads();
-  const unsigned long long t0 = tp[0], t1 = tp[1];
-  if (threadIdx.x == 0 && P.phase) {
-    const unsigned long long now = (unsigned long long)wall_clock64();
-    P.phase[0] += t1 - t0;
-    P.phase[1] += now - t0;
-    P.phase[2] = t1 - t0;
-    P.phase[3] = now - t0;
-  }
-}
-
 /* (16 waves = 1024 lanes is the largest workgroup there is: five waves per SIMD would take two
    workgroups per CU, and two rings of slices do not fit the LDS) */
-template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE, bool FUSED = false, bool WIDE = false>
+template <int A, int D, bool INDELS, bool GENES, int NW, bool INLINE, bool WIDE = false>
 __global__ void __launch_bounds__(NW * WAVE, 4)
 probe_rows_kernel(const ProbeParams P)
 {
@@ -856,10 +603,6 @@ probe_rows_kernel(const ProbeParams P)
      did not fit the buffer (it does nothing unless that launch was flagged). */
   if (INLINE && P.redo && *(volatile unsigned long long *)P.overflow == 0ull)
     return;
-  static_assert(!(INLINE && FUSED), "the fused step is the fast form");
-  [[maybe_unused]] unsigned long long t_start = 0;
-  if constexpr (FUSED)
-    t_start = (unsigned long long)wall_clock64();
   constexpr uint32_t NT = NW * WAVE;
   constexpr uint32_t MCR = kernel_class_res(A, WIDE);  /* (WIDE: layout.h) */
   constexpr bool PAIRS = D == 1;                  /* the filter holds pair rows (build_rows_kernel) */
@@ -2146,9 +1889,6 @@ probe_rows_kernel(const ProbeParams P)
         atomicAdd(stats_dst(P) + k, x);
     }
   }
-
-  if constexpr (FUSED)
-    fused_tail<GENES, NW>(P, smem, lane, wave, t_start);
 }
 
 }  // namespace cmpr

@@ -72,15 +72,16 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
   const int e = first + (int)W.lane;
   const uint64_t key = table_key(W.q.hash[e]);
   const uint32_t qs = W.q.slot[e], ca = W.q.ca[e], cb = W.q.cb[e];
-  uint64_t s = table_home(key, P.slot_mask);
+  const uint32_t bk = dir_bucket(key, P.dir_mask);
 #pragma unroll 1
-  for (;;) {
-    const uint64_t k = P.table[s].key;
-    if (k == EMPTY_KEY)
+  for (uint32_t piece = bk;; piece++) {
+    const RefRec *rec = (const RefRec *)P.rec2 + piece;
+    const uint32_t ri = rec->idx, rl = rec->len, rh = rec->home;
+    if (ri == REC_EMPTY)
       break;
-    if (k == key) {
-      const unsigned char *rp = P.rec2 + (size_t)P.table[s].val * REC_UNIT;
-      const RefRec *rec = (const RefRec *)rp;
+    const bool last = walk_ends(ri, rl, rh, bk);
+    if (rh == bk && (rl >> REC_TAG_SHIFT) == dir_tag(key)) {
+      const uint8_t *rp = P.res2 + P.off2[ri];       /* (the rare path: the residues where the set lies) */
       W.st.hash_eq++;
       bool ok = true;
       if (GENES)
@@ -88,7 +89,7 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
       if (ok) {
         const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
         const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
-        const uint32_t L = P.qlen[qs], M = rec->len;
+        const uint32_t L = P.qlen[qs], M = rl & 0xffffu;
         ok = M == (kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L));
         const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
 #pragma unroll 1
@@ -104,16 +105,17 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
                                               : (kind == K_INS ? (x < p1 ? x : x - 1) : x);
             want = (qr[(size_t)(qp >> 2) * WAVE] >> ((qp & 3u) * 8)) & 0xffu;
           }
-          ok = want == (uint32_t)rp[sizeof(RefRec) + x];
+          ok = want == (uint32_t)rp[x];
         }
         if (ok) {
           W.st.matches++;
-          score_match(P, qs, rec->idx, (uint64_t)P.R2 * P.qrep[qs] + rec->rep,
+          score_match(P, qs, ri, (uint64_t)P.R2 * P.qrep[qs] + rec->rep,
                       P.ignore_counts ? 1ull : P.qcnt[qs], rec->cnt, W.mat_lds);
         }
       }
     }
-    s = (s + 1) & P.slot_mask;
+    if (last)
+      break;
   }
 }
 
@@ -129,11 +131,10 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
 /* The segment of a wave's n-th block.  A workgroup used to append to ONE segment (b % segments); on skewed data --
    the cdr3 law: a few slices hold most of the neighbours -- the workgroups of those slices overfilled theirs while
    the others stayed empty, and the step fell back to its redo pass (10M x 10M d = 1 -i: 21 ms for 1.25; round 4).
-   Now a wave's blocks go round the segments, starting at its workgroup's.  (The fused step, whose workgroups
-   announce "my segment is complete", keeps the one segment: ProbeParams::fuse.) */
+   Now a wave's blocks go round the segments, starting at its workgroup's.  */
 __device__ __forceinline__ uint32_t pos_segment_of(const ProbeParams &P, uint32_t nclaims)
 {
-  return (blockIdx.x + (P.fuse ? 0u : nclaims)) & (P.pos_segments - 1);
+  return (blockIdx.x + nclaims) & (P.pos_segments - 1);
 }
 
 __device__ __forceinline__ void claim_pos_block(SProber &W)

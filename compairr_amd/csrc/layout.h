@@ -216,7 +216,6 @@ constexpr uint32_t POS_CTR_STRIDE = 16;      /* u64s: one 128-byte line per segm
    share one, on a line of its own (one counter for the whole grid: 18 000 answered atomics on one address
    took as long as the launch); the second half belongs to the redo launch */
 constexpr uint32_t DEAL_GROUPS = 8, DEAL_STRIDE = 8, DEAL_WORDS = 2 * DEAL_GROUPS * DEAL_STRIDE;
-constexpr uint32_t FUSE_WORDS = 16;          /* ProbeParams::fuse: global words of the fused step, one line */
 
 /* entries per position of the sliced kernel's LDS copy of the Zobrist table:
    amino-acid rows are stored twice in a line (kernels_sliced.h row_lds_others) */
@@ -257,19 +256,24 @@ struct PosEntry {
    has no positive for carry this slot */
 constexpr uint32_t POS_NULL_SLOT = 0xffffffffu;
 
-/* One set-2 sequence as the verification step reads it: a 32-byte header
-   followed by its residues (one byte each, padded to 16): header + residues of
-   a CDR3 are 48-64 contiguous bytes, usually ONE memory line per verified hit
-   instead of one for the record and another for the residues.  The hash table
-   stores the record's position in this stream in 16-byte units. */
+/* One set-2 sequence as the verification step reads it, and one slot of the record table
+   (ref_index.hip): a 32-byte header and the first 32 residues, one byte each -- ONE 64-byte
+   memory line per looked-up CDR3.  A longer sequence has its further residues where the set
+   lies (ProbeParams::res2 / off2). */
+constexpr uint32_t REC_RES = 32;              /* residues inside the record */
+constexpr uint32_t REC_EMPTY = 0xffffffffu;   /* RefRec::idx of an empty slot */
+constexpr uint32_t REC_MORE = 1u << 16;       /* RefRec::len: the next slot holds another record of this bucket */
+constexpr uint32_t REC_TAG_SHIFT = 17;        /* RefRec::len bits 17..31: 15 bits of the key (kernels.h dir_tag) */
 struct RefRec {
   uint64_t cnt;       /* duplicate_count (1 with -f)                        */
-  uint32_t idx;       /* the sequence's number in set 2                     */
-  uint32_t len;
+  uint32_t idx;       /* the sequence's number in set 2 (REC_EMPTY: nothing here) */
+  uint32_t len;       /* bits 0..15 the length, REC_MORE, tag              */
   uint32_t v, j;      /* 0 with -g                                          */
   uint32_t rep;
-  uint32_t pad;
+  uint32_t home;      /* bucket of the sequence's key: the slot its record lies in unless displaced */
+  uint8_t  res[REC_RES];
 };
+static_assert(sizeof(RefRec) == 64, "a record is one 64-byte line");
 constexpr uint32_t REC_UNIT = 16;
 
 /* One set-1 sequence as the verification step reads it (resolve_kernel): 64 bytes
@@ -284,11 +288,6 @@ struct QueryRec {
   uint32_t orig;      /* the query's index in the caller's set 1            */
 };
 
-__host__ __device__ inline uint32_t rec_units(uint32_t len)
-{
-  return (uint32_t)(sizeof(RefRec) / REC_UNIT) + (len + REC_UNIT - 1) / REC_UNIT;
-}
-
 /* per-launch kernel arguments */
 struct ProbeParams {
   /* Zobrist */
@@ -300,9 +299,9 @@ struct ProbeParams {
   uint32_t        bloom_byte_mask;   /* (words - 1) << 3                     */
   uint32_t        deal;              /* probe_rows_kernel: != 0: the chunks beyond a workgroup's first RING are handed
                                         out by counters (deal_ctr), in list order: heaviest first */
-  /* hash table */
-  const Slot     *table;
-  uint64_t        slot_mask;
+  /* record table of set 2 (ref_index.hip): the records of hash bucket b lie from slot b of rec2 on */
+  uint32_t        dir_mask;         /* buckets - 1 */
+  uint32_t        pad0;
   /* set 2 records */
   const uint8_t  *res2;
   const uint64_t *off2;
@@ -310,7 +309,7 @@ struct ProbeParams {
   const uint32_t *j2;
   const uint32_t *rep2;
   const uint64_t *cnt2;
-  const unsigned char *rec2;        /* RefRec stream; table val * REC_UNIT = position */
+  const unsigned char *rec2;        /* the record table: RefRec slots */
   /* set 1 tiles */
   const TileDesc *tiles;
   const uint32_t *qres;
@@ -371,21 +370,6 @@ struct ProbeParams {
                                        whose positives did not fit: resolve_kernel
                                        skips, the redo launch does the step inline;
                                        NULL for kernels that resolve inline instead  */
-  /* fused step (kernels_rows.h probe_rows_kernel<.., FUSED>): the probe kernel's workgroups go
-     on to walk, verify and score the queued positives themselves -- segment by segment, as
-     the workgroups that fill a segment finish probing -- and the last of them sums the
-     partial results: one launch per step.  `fuse` = FUSE_WORDS u64 ([0] workgroups through
-     with everything, [1] ... with probing, [2] max of ~(start tick), [3] max of the tick
-     probing ended at), then POS_CTR_STRIDE u64 per segment ([0] writers finished, [1] next
-     block to resolve): zeroed with the counter block.  `phase` (persistent): [0] sum of probe
-     ticks, [1] sum of kernel ticks since it was cleared, [2], [3] those of the last launch. */
-  unsigned long long *fuse;
-  unsigned long long *phase;
-  unsigned long long *next_ctr;      /* the counter block of the NEXT launch, cleared by the last workgroup */
-  uint32_t            next_n64;
-  uint32_t            reduce_cells;  /* cells summed from the partial slots (0: the matrix is added to where it lies) */
-  unsigned long long *usage;         /* see reduce_partials_kernel */
-  unsigned long long *sticky;
   unsigned long long *deal_ctr;      /* DEAL_GROUPS counters, DEAL_STRIDE words apart (see `deal`) */
   /* pairs mode (cmpr_overlap_pairs): matches are listed, not scored */
   uint32_t           *pair_q, *pair_h;
@@ -412,7 +396,10 @@ struct ProbeParams {
    rejected. */
 enum : uint32_t { DBG_SKIP_HBM_ROWS = 1, DBG_SKIP_EMIT = 2, DBG_SKIP_RESOLVE = 4,
                   DBG_SKIP_LDS_ROWS = 8, DBG_SKIP_INS_ROWS = 16, DBG_SKIP_DEL_ROWS = 32,
-                  DBG_SKIP_TILES = 64, DBG_SKIP_CLASS_TILES = 128, DBG_SKIP_MAIN_TILES = 256 };
+                  DBG_SKIP_TILES = 64, DBG_SKIP_CLASS_TILES = 128, DBG_SKIP_MAIN_TILES = 256,
+                  /* resolve_kernel: the directory entry / the record / the query's record read at consecutive
+                     places instead of where they are -- what does the randomness of each access cost? */
+                  DBG_RES_SEQ_DIR = 512, DBG_RES_SEQ_REC = 1024, DBG_RES_SEQ_QREC = 2048, DBG_RES_NO_VERIFY = 4096 };
 #ifdef CMPR_ABLATION
 #define CMPR_DBG(P, bit) (((P).debug & (bit)) != 0)
 #else

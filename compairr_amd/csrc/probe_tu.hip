@@ -1,8 +1,7 @@
 /*
  * probe_tu.hip -- one translation unit per (kernel variant, workgroup size):
  * compiled with -DTU_VARIANT=0|1|2|9, -DTU_NW=4|8|16 (variants 1, 2) and
- * -DTU_INLINE=0|1|2 (variant 2: the fast form / the form that resolves inline / the fused
- * step, whose workgroups resolve the queued positives themselves); -DTU_WIDE: variant 2 for
+ * -DTU_INLINE=0|1 (variant 2: the fast form / the form that resolves inline); -DTU_WIDE: variant 2 for
  * four amino-acid class residues (fast and inline forms).
  * TU_VARIANT 9 = resolve_kernel, 3 = probe_pairs2_kernel.
  */
@@ -29,14 +28,11 @@ namespace cmpr {
 #define KERNEL(A_, D_, I_, G_) probe_sliced_kernel<A_, D_, I_, G_, TU_NW>
 #define SELECT_NAME CAT(select_probe_v1_nw, TU_NW)
 #elif TU_VARIANT == 2 && defined(TU_WIDE) && TU_INLINE
-#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true, false, true>
+#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true, true>
 #define SELECT_NAME CAT(select_probe_v2_wide_inline_nw, TU_NW)
 #elif TU_VARIANT == 2 && defined(TU_WIDE)
-#define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false, false, true>
-#define SELECT_NAME CAT(select_probe_v2_wide_nw, TU_NW)
-#elif TU_VARIANT == 2 && TU_INLINE == 2
 #define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, false, true>
-#define SELECT_NAME CAT(select_probe_v2_fused_nw, TU_NW)
+#define SELECT_NAME CAT(select_probe_v2_wide_nw, TU_NW)
 #elif TU_VARIANT == 2 && TU_INLINE
 #define KERNEL(A_, D_, I_, G_) probe_rows_kernel<A_, D_, I_, G_, TU_NW, true>
 #define SELECT_NAME CAT(select_probe_v2_inline_nw, TU_NW)

@@ -115,23 +115,66 @@ slice_population_kernel(const uint8_t *res, const uint64_t *off, const uint32_t 
   atomicAdd(pop + (ck & g.smask), 1u);
 }
 
-/* 64-byte pieces of a sequence's record (layout.h RefRec): header + residues,
-   rounded up -- every record starts a 64-byte piece, so a verified hit of a
-   CDR3 costs one request */
+/* ---- the record table (round 5): set 2 as an ORDERED linear-probing table of whole records ----
+   The reference keeps an open-addressing table of (hash, sequence number) pairs and looks the
+   sequence up behind it (hashtable.h:22-72, overlap.cc:168-251): two dependent random reads per
+   hit, three with the query's record.  Here the 64-byte record of a sequence (layout.h RefRec)
+   IS the table entry: bucket b of the sequence's key names the slot its record would lie in,
+   a record that finds the slot taken lies in the next free one, and the records are placed in
+   the order of their buckets -- record k of the bucket-sorted list at
+       p_k = max(b_k, p_{k-1} + 1) = k + max_{j <= k} (b_j - j),
+   a prefix maximum -- so that a lookup of bucket b starts at slot b, skips what was displaced
+   there from earlier buckets (home < b), finds its own records side by side and stops at the first
+   slot that is empty or belongs to a later bucket: ONE random memory line per hit at the load this
+   table is built for (<= 0.35), the rare further slots next to it. */
 __global__ void __launch_bounds__(256)
-record_pieces_kernel(const uint64_t *off, uint64_t n, uint32_t *pieces)
+ref_keys_kernel(const BuildParams B, uint32_t bucket_mask, uint32_t *bucket, uint32_t *tag, uint32_t *seq)
 {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n)
-    pieces[i] = (rec_units((uint32_t)(off[i + 1] - off[i])) + 3u) / 4u;
+  if (i >= B.n)
+    return;
+  const uint64_t b = B.off[i];
+  const uint32_t L = (uint32_t)(B.off[i + 1] - b);
+  uint64_t h = 0;
+  if (B.use_genes) {
+    const uint64_t *vk = B.zob + (uint64_t)B.A * B.zpos;
+    h = vk[B.v[i]] ^ vk[B.n_v + B.j[i]];
+  }
+  for (uint32_t p = 0; p < L; p++)
+    h ^= B.zob[B.A * p + B.res[b + p]];
+  const uint64_t key = table_key(h);
+  bucket[i] = dir_bucket(key, bucket_mask);
+  tag[i] = dir_tag(key);
+  seq[i] = (uint32_t)i;
 }
 
+/* b_k - k of the bucket-sorted list (both < 2^31) */
 __global__ void __launch_bounds__(256)
-record_positions_kernel(const uint32_t *piece_pre, uint64_t n, uint32_t *voff)
+bucket_lead_kernel(const uint32_t *sorted_bucket, uint64_t n, int32_t *lead)
 {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n)
-    voff[i] = piece_pre[i] * 4u;              /* in 16-byte units */
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n)
+    lead[k] = (int32_t)sorted_bucket[k] - (int32_t)k;
+}
+
+struct MaxI32 {
+  __host__ __device__ int32_t operator()(const int32_t &a, const int32_t &b) const { return a > b ? a : b; }
+};
+
+/* slot of the k-th record of the list, and "the next slot holds a record of the same bucket" */
+__global__ void __launch_bounds__(256)
+record_slots_kernel(const uint32_t *sorted_bucket, const int32_t *lead_max, const uint32_t *perm, uint64_t n,
+                    uint32_t *slot_of_seq, uint32_t *more_of_seq, uint32_t *last_slot)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n)
+    return;
+  const uint32_t p = (uint32_t)((int64_t)k + lead_max[k]);
+  const uint32_t i = perm[k];
+  slot_of_seq[i] = p;
+  more_of_seq[i] = (k + 1 < n && sorted_bucket[k + 1] == sorted_bucket[k]) ? 1u : 0u;
+  if (k == n - 1)
+    *last_slot = p;
 }
 
 struct WidenU32 {
@@ -284,9 +327,9 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
        word then has ~40 % of its bits set and a test of eight of them passes by
        chance ~6e-4 of the time -- the optimum of a Bloom filter at 16 bits per
        entry), x 2^delta */
-    bloom_bytes = std::max<uint64_t>(entries * 2, ROW_WORD_BYTES);
+    bloom_bytes = std::max<uint64_t>(entries * (uint64_t)c->row_filter_x16 / 16, ROW_WORD_BYTES);
     if (c->d2pairs)      /* sized for the entries filed: one per pair of positions and one per sequence */
-      bloom_bytes = std::max<uint64_t>(((residues2 + 1) / 2 + 2 * s->n) * 2, ROW_WORD_BYTES);
+      bloom_bytes = std::max<uint64_t>(((residues2 + 1) / 2 + 2 * s->n) * (uint64_t)c->row_filter_x16 / 16, ROW_WORD_BYTES);
     const int64_t delta = c->bloom_log2_delta == -100 ? 0 : c->bloom_log2_delta;
     if (delta > 0)
       bloom_bytes <<= delta;
@@ -528,66 +571,82 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
   if (c->rows)          /* main part + one class part per class residue */
     c->bloom_words = ((uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1)) *
                      c->geom.rw_words * (ROW_WORD_BYTES / 8);
-  if ((rc = dev_alloc(c, c->table, (size_t)c->slots))) return rc;
+  if (c->slots > (1ull << 30))
+    return fail(c, CMPR_EUNSUPPORTED, "reference set too large for a 32-bit record table");
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->table.p, 0xff, c->slots * sizeof(Slot), c->stream));
   /* inverted polarity (bloompat.cc:54-57) for variants 0, 1; the row filter sets bits */
   HIP_TRY(c, hipMemsetAsync(c->bloom.p, c->rows ? 0 : 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
 
+  BuildParams B{};
+  B.zob = c->zob.p;
+  B.A = A;
+  B.zpos = c->zpos;
+  B.n_v = n_v;
+  B.use_genes = c->opt.ignore_genes ? 0u : 1u;
+  B.res = c->res2.p;
+  B.off = c->off2.p;
+  B.v = c->v2.p;
+  B.j = c->j2.p;
+  B.n = s->n;
+  Tmp<uint32_t> tags, buckets, more;
   {
-    /* positions in the verification stream (layout.h RefRec): every record starts a
-       64-byte piece -- an exclusive scan of the pieces per record */
-    Tmp<uint32_t> pieces, pre;
+    /* The record table (see ref_keys_kernel): bucket and tag of every sequence, a stable radix sort of
+       the sequence numbers by bucket, the prefix maximum that places the records, the table itself. */
+    Tmp<uint32_t> seq, bkt_sorted, perm, last;
+    Tmp<int32_t> lead, lead_max;
     Tmp<char> tmp;
-    uint64_t units = 0;
+    uint64_t nslots = c->slots + 1;             /* (a lookup may start at any bucket; one empty slot behind the last) */
     if ((rc = dev_alloc(c, c->voff2, std::max<size_t>((size_t)s->n, 1)))) return rc;
     if (s->n) {
-      if ((rc = dev_alloc(c, pieces.b, (size_t)s->n))) return rc;
-      if ((rc = dev_alloc(c, pre.b, (size_t)s->n))) return rc;
-      hipLaunchKernelGGL(record_pieces_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
-                         c->off2.p, s->n, pieces.b.p);
+      const size_t n = (size_t)s->n;
+      if ((rc = dev_alloc(c, buckets.b, n))) return rc;
+      if ((rc = dev_alloc(c, seq.b, n))) return rc;
+      if ((rc = dev_alloc(c, tags.b, n))) return rc;
+      if ((rc = dev_alloc(c, more.b, n))) return rc;
+      if ((rc = dev_alloc(c, bkt_sorted.b, n))) return rc;
+      if ((rc = dev_alloc(c, perm.b, n))) return rc;
+      if ((rc = dev_alloc(c, last.b, 1))) return rc;
+      hipLaunchKernelGGL(ref_keys_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, B,
+                         (uint32_t)(c->slots - 1), buckets.b.p, tags.b.p, seq.b.p);
       HIP_TRY(c, hipGetLastError());
+      int bits = 0;
+      while ((1ull << bits) < c->slots)
+        bits++;
       size_t tb = 0;
-      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.b.p, pre.b.p, (int)s->n, c->stream);
+      (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, buckets.b.p, bkt_sorted.b.p, seq.b.p, perm.b.p, (int)s->n,
+                                               0, std::max(bits, 1), c->stream);
       if ((rc = dev_alloc(c, tmp.b, tb))) return rc;
-      HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.b.p, tb, pieces.b.p, pre.b.p, (int)s->n, c->stream));
-      hipLaunchKernelGGL(record_positions_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream,
-                         pre.b.p, s->n, c->voff2.p);
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(tmp.b.p, tb, buckets.b.p, bkt_sorted.b.p, seq.b.p, perm.b.p,
+                                                    (int)s->n, 0, std::max(bits, 1), c->stream));
+      if ((rc = dev_alloc(c, lead.b, n))) return rc;
+      if ((rc = dev_alloc(c, lead_max.b, n))) return rc;
+      hipLaunchKernelGGL(bucket_lead_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, bkt_sorted.b.p,
+                         s->n, lead.b.p);
       HIP_TRY(c, hipGetLastError());
-      /* the total in 64 bits, beside the 32-bit prefix sums: those may not wrap unnoticed */
-      Tmp<unsigned long long> total;
-      Tmp<char> tmp2;
-      if ((rc = dev_alloc(c, total.b, 1))) return rc;
-      hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> it(pieces.b.p, WidenU32());
-      size_t tb2 = 0;
-      (void)hipcub::DeviceReduce::Sum(nullptr, tb2, it, total.b.p, (int)s->n, c->stream);
-      if ((rc = dev_alloc(c, tmp2.b, tb2))) return rc;
-      HIP_TRY(c, hipcub::DeviceReduce::Sum(tmp2.b.p, tb2, it, total.b.p, (int)s->n, c->stream));
-      unsigned long long npieces = 0;
-      HIP_TRY(c, hipMemcpyAsync(&npieces, total.b.p, sizeof npieces, hipMemcpyDeviceToHost, c->stream));
+      size_t tb1 = 0;
+      (void)hipcub::DeviceScan::InclusiveScan(nullptr, tb1, lead.b.p, lead_max.b.p, MaxI32(), (int)s->n, c->stream);
+      if (tb1 > tb) {
+        if ((rc = dev_alloc(c, tmp.b, tb1))) return rc;
+        tb = tb1;
+      }
+      HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(tmp.b.p, tb1, lead.b.p, lead_max.b.p, MaxI32(), (int)s->n,
+                                                   c->stream));
+      hipLaunchKernelGGL(record_slots_kernel, dim3(blocks_for(s->n)), dim3(256), 0, c->stream, bkt_sorted.b.p,
+                         lead_max.b.p, perm.b.p, s->n, c->voff2.p, more.b.p, last.b.p);
+      HIP_TRY(c, hipGetLastError());
+      uint32_t last_slot = 0;
+      HIP_TRY(c, hipMemcpyAsync(&last_slot, last.b.p, sizeof last_slot, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      units = (uint64_t)npieces * 4;
+      nslots = std::max<uint64_t>(nslots, (uint64_t)last_slot + 2);
     }
-    units += 8;                 /* verify_candidate reads 64 bytes whatever the length */
-    if (units >> 32)
+    if (nslots >> 32)
       return fail(c, CMPR_EUNSUPPORTED, "reference set too large for 32-bit record positions");
-    if ((rc = dev_alloc(c, c->rec2, std::max<size_t>((size_t)units * REC_UNIT, REC_UNIT)))) return rc;
+    if ((rc = dev_alloc(c, c->rec2, (size_t)nslots * sizeof(RefRec)))) return rc;
+    /* (all ones: RefRec::idx of an empty slot) */
+    HIP_TRY(c, hipMemsetAsync(c->rec2.p, 0xff, (size_t)nslots * sizeof(RefRec), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));     /* (the temporaries go away) */
   }
   if (s->n) {
-    BuildParams B{};
-    B.zob = c->zob.p;
-    B.A = A;
-    B.zpos = c->zpos;
-    B.n_v = n_v;
-    B.use_genes = c->opt.ignore_genes ? 0u : 1u;
-    B.voff = c->voff2.p;
-    B.res = c->res2.p;
-    B.off = c->off2.p;
-    B.v = c->v2.p;
-    B.j = c->j2.p;
-    B.n = s->n;
-    B.table = c->table.p;
-    B.slot_mask = c->slots - 1;
     B.bloom = c->rows ? nullptr : c->bloom.p;
     B.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
     B.sliced = c->sliced ? 1u : 0u;
@@ -595,14 +654,14 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     B.pairs = pair_rows(c) ? 1u : 0u;
     B.geom = c->geom;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
-    hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0,
-                       c->stream, B);
-    HIP_TRY(c, hipGetLastError());
     if (c->rows) {
       B.bloom = c->bloom.p;
       hipLaunchKernelGGL(build_rows_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
-      HIP_TRY(c, hipGetLastError());
+    } else {
+      /* (variants 0, 1: the per-variant filter; no table) */
+      hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
     }
+    HIP_TRY(c, hipGetLastError());
   }
   if (s->n) {
     PackParams K{};
@@ -614,6 +673,9 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     K.j = c->opt.ignore_genes ? nullptr : c->j2.p;
     K.rep = c->rep2.p;
     K.n = s->n;
+    K.tag = tags.b.p;
+    K.home = buckets.b.p;
+    K.more = more.b.p;
     K.out = c->rec2.p;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, K);

@@ -34,10 +34,6 @@ ProbeFn select_probe_v2_wide_nw16(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_wide_inline_nw4(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_wide_inline_nw8(int A, int D, bool indels, bool genes);
 ProbeFn select_probe_v2_wide_inline_nw16(int A, int D, bool indels, bool genes);
-/* ... and the fused step: probe, resolve and reduce in one launch */
-ProbeFn select_probe_v2_fused_nw4(int A, int D, bool indels, bool genes);
-ProbeFn select_probe_v2_fused_nw8(int A, int D, bool indels, bool genes);
-ProbeFn select_probe_v2_fused_nw16(int A, int D, bool indels, bool genes);
 /* nucleotides, d = 2 on pair rows (kernels_pairs2.h) */
 ProbeFn select_probe_pairs2(bool genes);
 /* resolve_kernel (kernels.h) */

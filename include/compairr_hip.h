@@ -322,10 +322,6 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              tile (kernels_pairs2.h; sequences of at most 96 residues), 0: off
      "d2_buffers"            that kernel's slice buffers: 1 (default; slices twice the size: fuller
                              tiles) or 2 (the next slice is copied while this one is worked on)
-     "fused_step"            variant 2: 1: probe, resolve and the sum of the partial results in ONE
-                             launch; default 0 (measured slower on MI355X)
-     "merge_reduce"          1: the partial results are summed by the resolve kernel's last workgroup
-                             instead of a launch of their own; default 0 (measured slower)
      "chunk_deal"            variant 2: 1 (default): beyond a workgroup's first four, chunks are handed out
                              by counters in list order (heaviest first) -- on skewed data (the cdr3 law,
                              d = 1 -i) the probe kernel takes 1.5 ms where a static deal takes 2.5; 0: static

@@ -63,14 +63,6 @@ LAYOUTS = {
                             "pos_segments": 1},
     # ---- variant 2: the row filter (one filter word per position) ----
     "rows": {"variant": 2},
-    # the fused step (the probe kernel's workgroups resolve the positives themselves: one launch; off by
-    # default), also with few segments (one: every workgroup writes and resolves the same one)
-    "rows_fused": {"variant": 2, "fused_step": 1},
-    "rows_fused_1seg": {"variant": 2, "fused_step": 1, "pos_segments": 1},
-    "rows_fused_tiny": {"variant": 2, "fused_step": 1, "slice_words_log2": 3, "class_residues": 2,
-                        "heavy_threshold": 2, "pos_segments": 2, "waves_per_block": 4},
-    # the partial results summed by resolve_kernel's last workgroup instead of a launch of their own (off by default)
-    "rows_merged_reduce": {"variant": 2, "merge_reduce": 1},
     # four amino-acid class residues: the wide instantiations of the rows kernel (nucleotides: K = 4 of 8;
     # variant 2 at d = 0 / d = 2 and the other variants clamp to three)
     "rows_k4": {"variant": 2, "class_residues": 4, "heavy_threshold": 2},
@@ -87,7 +79,6 @@ LAYOUTS = {
                               "heavy_threshold": 2, "chunk_tiles": 2},
     "rows_counter_deal_tiny": {"variant": 2, "chunk_deal": 1, "slice_words_log2": 3, "class_residues": 2,
                                "heavy_threshold": 2, "chunk_tiles": 1},
-    "lds_merged_reduce": {"variant": 1, "merge_reduce": 1, "slice_words_log2": 6},
     # 64-byte slices, every class split by 3 / 1 class residues: class-row passes
     "rows_tiny_k3": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
                      "heavy_threshold": 0},
