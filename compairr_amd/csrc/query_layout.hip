@@ -25,7 +25,7 @@
  *   fill_tiles_kernel   per tile (one wave): reads those records in slot order and
  *                       writes every per-slot array and the position-major residues
  *                       coalesced, padding lanes included (no memset of the layout)
- *   place_items_kernel  variant 2 / sub2: the flat items (kernels_rows.h), 16 bytes each
+ *                       ... and, variant 2 / sub2, its flat items (kernels_rows.h), 16 bytes each
  *   sibling_*_kernel    -i: tiles regrouped by the slice their insertion /
  *                       deletion variants fall into
  *   chunk order         heaviest chunks first (hipCUB radix sort)
@@ -121,6 +121,7 @@ struct QL {
   uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slices */
   uint64_t        nslices_real;
   uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
+  uint32_t        dbg;               /* -DCMPR_ABLATION builds: LDBG_* (timing experiments, results become wrong) */
   uint32_t        route;             /* 1: cmpr_route_queries -- the keys kernel names the contexts a query goes
                                         to (dest_lo / dest_hi, dest_cnt) instead of ranking it in its group */
   uint32_t        alg_step, alg_first; /* routed records (alg_step > 1): the algorithmic bytes of the queries whose
@@ -170,7 +171,7 @@ struct QL {
   uint32_t *ccnt, *cbase, *cfill, *cnch, *cchpre;   /* [nitem_slices] */
   /* The item counters are few (one per slice of a class part: 2048 for 10M amino-acid queries = 64
      lines of memory) and every query adds to one of them: 10^7 atomics on 64 lines took 0.7 ms in
-     keys_kernel and again in place_items_kernel.  With item_reps > 1 copies, batch (i >> 8) of the
+     keys_kernel and again when the items were placed.  With item_reps > 1 copies, batch (i >> 8) of the
      queries counts in copy (i >> 8) mod item_reps; item_replicas_kernel sums the copies into ccnt
      and gives each copy its share of the (class part, slice)'s items (rbase). */
   uint32_t *ccnt_r, *cfill_r, *rbase;               /* [item_reps][nitem_slices] */
@@ -183,6 +184,15 @@ struct QL {
   double             *rep_total;
   unsigned long long *alg_bytes;
 };
+
+/* keys_kernel with parts left out (the "debug" tunable's bits 16.., -DCMPR_ABLATION builds only) */
+enum : uint32_t { LDBG_NO_RANK = 1u << 16, LDBG_NO_ITEM_COUNT = 1u << 17, LDBG_NO_HASH = 1u << 18,
+                  LDBG_NO_TOTALS = 1u << 19, LDBG_NO_CLASSKEY = 1u << 20, LDBG_NO_TMP_WRITES = 1u << 21 };
+#ifdef CMPR_ABLATION
+#define LDBG(Q, bit) (((Q).dbg & (bit)) != 0)
+#else
+#define LDBG(Q, bit) false
+#endif
 
 /* Work sharding (tunables work_shard_index / _count): which context of `step` takes
    the work filed under a slice in a pass.  By slice, not by position in the work
@@ -297,6 +307,33 @@ validate_res_kernel(const uint8_t *res, uint64_t total, uint32_t A, uint32_t *ve
 
 /* ---- keys ---------------------------------------------------------------- */
 
+/* The residues of queries base .. base + 255 lie side by side: copied to LDS in whole dwords, read there
+   (a byte per load from where they lie, every load of a loop waiting for the one before, was most of
+   what keys_kernel and scatter_kernel took).  Returns false when they cannot be staged (a set whose
+   residues are not dword-aligned, a batch of very long sequences). */
+__device__ inline bool stage_residues(const QL &Q, uint64_t base, uint64_t last, uint32_t *res_lds, uint64_t &a0,
+                                      uint64_t &sb, uint64_t &se)
+{
+  sb = Q.off[base];
+  se = Q.off[last];
+  a0 = sb & ~3ull;
+  const bool stage = ((uintptr_t)Q.res & 3u) == 0 && se >= sb && se <= Q.total && se - a0 <= KEYS_STAGE_BYTES;
+  if (stage)
+    for (uint64_t k = threadIdx.x; 4 * k < se - a0; k += 256) {
+      const uint64_t at = a0 + 4 * k;
+      uint32_t d = 0;
+      if (at + 4 <= Q.total) {
+        d = *(const uint32_t *)(Q.res + at);
+      } else {
+        for (uint32_t x = 0; x < 4 && at + x < Q.total; x++)
+          d |= (uint32_t)Q.res[at + x] << (8 * x);
+      }
+      res_lds[k] = d;
+    }
+  return stage;
+}
+
+
 /* number of variants the reference enumerates for one query
    (generate_variants, variants.cc:260-428) */
 __device__ inline uint64_t variants_of(const QL &Q, const uint8_t *s, uint32_t L)
@@ -336,12 +373,10 @@ __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
    false: the hash argument is not computed) and once to place, so both see the
    same items. */
 template <bool HASH, typename F>
-__device__ inline void for_each_item(const QL &Q, uint64_t i, uint32_t ck, bool heavy, F f)
+__device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, uint32_t L, uint32_t ck, bool heavy, F f)
 {
+  /* (s: the query's residues -- where the set lies, or the caller's staged copy in LDS) */
   const SliceGeom &g = Q.geom;
-  const uint64_t b = Q.off[i];
-  const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-  const uint8_t *s = Q.res + b;
   const uint32_t K = g.k, A = Q.A;
   if (L == 0 || K == 0 || Q.differences < 1)
     return;
@@ -500,22 +535,9 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
   uint32_t err_all = 0, Lmax = 0;
   for (uint64_t base = q0 + (uint64_t)blockIdx.x * 256; base < q1; base += (uint64_t)gridDim.x * 256) {
     const uint64_t i = base + threadIdx.x;
-    const uint64_t sb = Q.off[base], se = Q.off[min(base + 256, q1)];
-    const uint64_t a0 = sb & ~3ull;
-    const bool stage = ((uintptr_t)Q.res & 3u) == 0 && se >= sb && se <= Q.total && se - a0 <= KEYS_STAGE_BYTES;
+    uint64_t a0, sb, se;
     __syncthreads();                           /* (the batch before is through with the buffer) */
-    if (stage)
-      for (uint64_t k = threadIdx.x; 4 * k < se - a0; k += 256) {
-        const uint64_t at = a0 + 4 * k;
-        uint32_t d = 0;
-        if (at + 4 <= Q.total) {
-          d = *(const uint32_t *)(Q.res + at);
-        } else {
-          for (uint32_t x = 0; x < 4 && at + x < Q.total; x++)
-            d |= (uint32_t)Q.res[at + x] << (8 * x);
-        }
-        res_lds[k] = d;
-      }
+    const bool stage = stage_residues(Q, base, min(base + 256, q1), res_lds, a0, sb, se);
     __syncthreads();
     if (i >= q1)
       continue;
@@ -558,8 +580,10 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       const uint32_t vg = Q.genes ? Q.v[i] : 0u, jg = Q.genes ? Q.j[i] : 0u;
       uint32_t ck = 0;
       bool heavy = false;
-      if (Q.sliced)
+      if (Q.sliced && !LDBG(Q, LDBG_NO_CLASSKEY))
         ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, vg, jg, &heavy);
+      else if (Q.sliced)
+        ck = (uint32_t)i * 2654435761u;
       if (Q.rows) {
         /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that
            seed the rolling indel enumeration (:90-104, :122-136) */
@@ -569,7 +593,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
           h = gk[vg] ^ gk[Q.n_v + jg];
         }
         uint64_t hins = h, hdel = h;
-        for (uint32_t p = 0; p < L; p++) {
+        for (uint32_t p = 0; p < (LDBG(Q, LDBG_NO_HASH) ? 0u : L); p++) {
           const uint32_t r = s[p];
           h ^= Q.zob[Q.A * p + r];
           if (Q.indels) {
@@ -578,12 +602,14 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
               hdel ^= Q.zob[Q.A * (p - 1) + r];
           }
         }
-        Q.h_tmp[i] = h;
-        if (Q.indels) {
-          Q.hins_tmp[i] = hins;
-          Q.hdel_tmp[i] = hdel;
+        if (!LDBG(Q, LDBG_NO_TMP_WRITES)) {
+          Q.h_tmp[i] = h;
+          if (Q.indels) {
+            Q.hins_tmp[i] = hins;
+            Q.hdel_tmp[i] = hdel;
+          }
+          Q.ck_tmp[i] = ck;
         }
-        Q.ck_tmp[i] = ck;
       } else if (Q.sub2_items) {
         Q.ck_tmp[i] = ck;
       }
@@ -593,7 +619,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
            record where the positive is resolved) */
         unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : 0u, 0u, Q.wstep);
         if (Q.ngroups)
-          for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+          for_each_item<false>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
             mask |= 1ull << item_owner(Q, k, Q.wstep);
           });
         if (Q.route == 2u)
@@ -605,8 +631,8 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       }
       /* the items of the query that this context works on */
       bool any_item = false;
-      if (Q.ngroups && !Q.route)
-        for_each_item<false>(Q, i, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+      if (Q.ngroups && !Q.route && !LDBG(Q, LDBG_NO_ITEM_COUNT))
+        for_each_item<false>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
           if (item_owned(Q, k)) {
             atomicAdd(Q.ccnt_r + (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k, 1u);
             any_item = true;
@@ -626,10 +652,10 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       if (bucket != ~0ull && !Q.route) {
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
-        Q.rank[i] = atomicAdd(Q.cnt_g[0] + g, 1u);
+        Q.rank[i] = LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u);
       }
       if (Q.alg_step <= 1u || work_owner(slice, 0u, Q.alg_step) == Q.alg_first)
-        alg += (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
+        alg += LDBG(Q, LDBG_NO_TOTALS) ? 0ull : (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
   }
   if (err_all)
@@ -840,23 +866,31 @@ slices_kernel(const QL Q, uint32_t pi)
 /* ---- placement ------------------------------------------------------------ */
 
 /* One thread per query: its record and its hashes to slot = group base + rank, as two
-   whole pieces of memory (64 + 32 bytes) -- the only scattered writes of the layout. */
+   whole pieces of memory (64 + 32 bytes) -- the only scattered writes of the layout --, and
+   its items (variant 2 / sub2: the flat items of kernels_rows.h, 16 bytes each; a pass of their
+   own over the queries until round 5). */
 __global__ void __launch_bounds__(256)
 scatter_kernel(const QL Q)
 {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint32_t res_lds[KEYS_STAGE_BYTES / 4 + 16];
+  const uint64_t base = (uint64_t)blockIdx.x * 256;
+  const uint64_t i = base + threadIdx.x;
+  uint64_t a0, sb, se;
+  const bool stage = stage_residues(Q, base, min(base + 256, Q.n), res_lds, a0, sb, se);
+  __syncthreads();
   if (i >= Q.n)
     return;
   const uint32_t g = Q.grp[0][i];
-  if (g == 0xffffffffu) {                    /* not worked on by this context */
+  if (g == 0xffffffffu) {                    /* not worked on by this context (no item of it either) */
     Q.slot_of[i] = 0xffffffffu;
     return;
   }
   const uint32_t slot = Q.base_g[0][g] + Q.rank[i];
   Q.slot_of[i] = slot;
-  const uint64_t b = Q.off[i];
-  const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-  const uint8_t *s = Q.res + b;
+  const uint64_t b = Q.off[i], e = Q.off[i + 1];
+  const uint32_t L = (uint32_t)(e - b);
+  const bool in_lds = stage && b >= sb && e <= se;
+  const uint8_t *s = in_lds ? (const uint8_t *)res_lds + (b - a0) : Q.res + b;
   QueryRec qr;
   qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
   qr.v = Q.genes ? Q.v[i] : 0u;
@@ -865,14 +899,28 @@ scatter_kernel(const QL Q)
   qr.rep = Q.existence ? orig : Q.rep[i];           /* -x: the row is the sequence itself */
   qr.len = L;
   qr.orig = orig;
+  if (in_lds) {
+    /* nine dwords from ten aligned ones (the staged copy keeps the set's byte phase) */
+    const uint32_t o = (uint32_t)(b - a0), w0 = o >> 2, sh = o & 3u;
+    uint32_t lo = res_lds[w0];
 #pragma unroll
-  for (uint32_t w = 0; w < 9; w++) {
-    uint32_t d = 0;
+    for (uint32_t w = 0; w < 9; w++) {
+      const uint32_t hi = res_lds[w0 + w + 1u];          /* (within the array's slack; masked below) */
+      const uint32_t d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      const int n = (int)L - (int)(4u * w);
+      qr.res[w] = d & (n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
+      lo = hi;
+    }
+  } else {
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++)
-      if (4 * w + k < L)
-        d |= (uint32_t)s[4 * w + k] << (8 * k);
-    qr.res[w] = d;
+    for (uint32_t w = 0; w < 9; w++) {
+      uint32_t d = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        if (4 * w + k < L)
+          d |= (uint32_t)s[4 * w + k] << (8 * k);
+      qr.res[w] = d;
+    }
   }
   Q.qrec[slot] = qr;
   QAux a;
@@ -891,6 +939,47 @@ scatter_kernel(const QL Q)
     a.h = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
   }
   Q.aux[slot] = a;
+  if (Q.ngroups == 0)
+    return;
+
+  /* ---- the query's items: the row's (variant's) hash, what to exclude / where / what kind, and
+          the query's slot in pass 0 ---- */
+  const uint32_t ck = (Q.rows || Q.sub2_items) ? Q.ck_tmp[i] : 0u;
+  const bool heavy = Q.geom.k > 0 &&
+                     class_is_heavy(Q.geom.ctab, Q.geom, class_base(Q.geom.ctab, Q.geom, Q.genes != 0, L, qr.v, qr.j));
+  uint64_t hq = 0;
+  cmpr::ResPack pk{};
+  if (Q.pairs2 && heavy)
+    for (uint32_t x = 0; x < L && x < RESPACK_MAX; x++)
+      pk.w[x >> 4] |= ((uint32_t)s[x] & 3u) << ((x & 15u) * 2u);
+  if (Q.sub2_items && heavy && L <= RESPACK_MAX) {
+    if (Q.genes) {
+      const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+      hq = gk[qr.v] ^ gk[Q.n_v + qr.j];
+    }
+    for (uint32_t x = 0; x < L; x++) {
+      const uint32_t r = s[x];
+      hq ^= Q.zob[Q.A * x + r];
+      pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
+    }
+  }
+  for_each_item<true>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
+    if (!item_owned(Q, k))
+      return;
+    const size_t rk = (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k;
+    const uint32_t item = Q.cbase[k] + Q.rbase[rk] + atomicAdd(Q.cfill_r + rk, 1u);
+    if (Q.sub2_items) {
+      w = hq;                                   /* the query's hash and residues travel with the item */
+      Q.cpk[item] = pk;
+    } else if (Q.pairs2) {
+      Q.cpk[item] = pk;                         /* (beside the pair-blanked hash) */
+    }
+    ItemRec it;
+    it.w = w;
+    it.main = slot;
+    it.rp = crp;
+    Q.items[item] = it;
+  });
 }
 
 /* One wave per tile, one lane per slot: the records scatter_kernel left, read in slot
@@ -1055,61 +1144,6 @@ class_chunks_kernel(const QL Q)
     ck.pass = 3 + gi;
     Q.chunks[Q.cchunk0 + Q.cchpre[k] + q] = ck;
   }
-}
-
-/* an item: the row's (variant's) hash, what to exclude / where / what kind, and the
-   query's slot in pass 0 */
-__global__ void __launch_bounds__(256)
-place_items_kernel(const QL Q)
-{
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= Q.n)
-    return;
-  const uint32_t slot = Q.slot_of[i];
-  if (slot == 0xffffffffu)                   /* (no item of it is worked on here either) */
-    return;
-  const uint32_t ck = Q.ck_tmp[i];
-  const bool heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, class_base_of(Q, i));
-  uint64_t hq = 0;
-  cmpr::ResPack pk{};
-  if (Q.pairs2 && heavy) {
-    const uint64_t b = Q.off[i];
-    const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-    for (uint32_t x = 0; x < L && x < RESPACK_MAX; x++)
-      pk.w[x >> 4] |= ((uint32_t)Q.res[b + x] & 3u) << ((x & 15u) * 2u);
-  }
-  if (Q.sub2_items && heavy) {
-    const uint64_t b = Q.off[i];
-    const uint32_t L = (uint32_t)(Q.off[i + 1] - b);
-    if (L <= RESPACK_MAX) {
-      if (Q.genes) {
-        const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-        hq = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
-      }
-      for (uint32_t x = 0; x < L; x++) {
-        const uint32_t r = Q.res[b + x];
-        hq ^= Q.zob[Q.A * x + r];
-        pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
-      }
-    }
-  }
-  for_each_item<true>(Q, i, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
-    if (!item_owned(Q, k))
-      return;
-    const size_t rk = (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k;
-    const uint32_t item = Q.cbase[k] + Q.rbase[rk] + atomicAdd(Q.cfill_r + rk, 1u);
-    if (Q.sub2_items) {
-      w = hq;                                   /* the query's hash and residues travel with the item */
-      Q.cpk[item] = pk;
-    } else if (Q.pairs2) {
-      Q.cpk[item] = pk;                         /* (beside the pair-blanked hash) */
-    }
-    ItemRec it;
-    it.w = w;
-    it.main = slot;
-    it.rp = crp;
-    Q.items[item] = it;
-  });
 }
 
 /* ---- -i: tiles regrouped by the slice their indel variants fall into ------- */
@@ -1804,6 +1838,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.pairs = pair_rows(c) ? 1 : 0;
   Q.pairs2 = c->d2pairs ? 1u : 0u;
   Q.differences = (uint32_t)c->opt.differences;
+  Q.dbg = (uint32_t)c->debug;
   Q.sliced = c->sliced ? 1 : 0;
   Q.rows = c->rows ? 1 : 0;
   Q.zob = c->zob.p;
@@ -2339,10 +2374,6 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   if (ntiles) {
     hipLaunchKernelGGL(fill_tiles_kernel, dim3((uint32_t)((ntiles + 3) / 4)), dim3(256), 0, c->stream, Q,
                        (uint32_t)ntiles);
-    HIP_TRY(c, hipGetLastError());
-  }
-  if (n && ngroups) {
-    hipLaunchKernelGGL(place_items_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
   }
   if (ngroups) {
