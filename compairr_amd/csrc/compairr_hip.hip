@@ -1464,6 +1464,48 @@ extern "C" int cmpr_set_reference_device(cmpr_context *c, const cmpr_set_view *d
   return set_reference_guarded(c, d_set2, longest_query, true);
 }
 
+/* query_layout.hip / ref_index.hip: one attribute query of a kernel of theirs (loads the code object) */
+void cmpr_touch_layout_kernels();
+void cmpr_touch_index_kernels();
+
+extern "C" int cmpr_warm_up(const cmpr_options *o)
+{
+  if (!o)
+    return CMPR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return CMPR_EDEVICE;
+  if (o->device >= ndev)
+    return CMPR_EINVAL;
+  if (o->device >= 0 && hipSetDevice(o->device) != hipSuccess)
+    return CMPR_EDEVICE;
+  (void)hipFree(nullptr);                              /* the device's context */
+  /* the code objects a step of these options runs (each translation unit is one, loaded at first use) */
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, (const void *)reduce_partials_kernel);
+  cmpr_touch_index_kernels();
+  cmpr_touch_layout_kernels();
+  const int A = o->alphabet_size, D = o->differences;
+  const bool i = o->indels != 0, g = !o->ignore_genes;
+  if ((A == 20 || A == 4) && D >= 0 && D <= 2 && (!i || D == 1)) {
+    ProbeFn fns[3] = {select_resolve(g), nullptr, nullptr};
+    if (A == 20 && D >= 1) {
+      fns[1] = select_probe_v2_nw16(A, D, i, g);
+      fns[2] = select_probe_v2_inline_nw16(A, D, i, g);
+    } else if (A == 4 && D == 2) {
+      fns[1] = select_probe_pairs2(g);
+    } else {
+      fns[1] = select_probe_v1_nw8(A, D, i, g);
+      fns[2] = select_probe_v1_nw4(A, D, i, g);
+    }
+    for (ProbeFn f : fns)
+      if (f)
+        (void)hipFuncGetAttributes(&fa, (const void *)f);
+  }
+  (void)hipGetLastError();
+  return CMPR_OK;
+}
+
 extern "C" int cmpr_count_duplicates(cmpr_context *c, const cmpr_set_view *s, uint64_t *out)
 {
   /* the header promises CMPR_ENOMEM, not an exception across the C boundary */

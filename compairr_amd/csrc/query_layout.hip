@@ -2505,3 +2505,9 @@ int cmpr_route_pack_impl(cmpr_context *c, void *d_send, uint64_t capacity_bytes)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMPR_OK;
 }
+
+void cmpr_touch_layout_kernels()
+{
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, (const void *)fill_tiles_kernel);
+}

@@ -686,3 +686,8 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
   return CMPR_OK;
 }
 
+void cmpr_touch_index_kernels()
+{
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, (const void *)length_hist_kernel);
+}

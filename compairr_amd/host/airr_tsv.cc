@@ -118,8 +118,7 @@ void parse_header(char *line, const Options &o, Columns &c, FILE *log, bool need
       if (!c.j_call) fprintf(log, " j_call");
     }
     if (!seqcol) fprintf(log, " %s", o.seq_header);
-    fprintf(log, "\n");
-    exit(1);
+    exit_with_message(log, true, "\n");
   }
   /* db.cc:283-295 */
   bool any_missing = false;
@@ -360,8 +359,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
 {
   std::vector<char> text;
   if (!read_whole_file(filename, text)) {
-    fprintf(log, "\nError: Unable to open input data file (%s).\n", filename);
-    exit(1);
+    exit_with_message(log, true, std::string("\nError: Unable to open input data file (") + filename + ").\n");
   }
   const size_t size = text.size() - 1;
   if (size == 0)
@@ -441,8 +439,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
   /* the first error in file order is the one the serial reference would hit */
   for (size_t r = 0; r < nranges; r++)
     if (part[r].failed) {
-      fputs(part[r].error.c_str(), log);
-      exit(1);
+      exit_with_message(log, true, part[r].error);
     }
 
   /* merge in file order: global first-appearance numbering */

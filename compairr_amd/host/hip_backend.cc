@@ -32,6 +32,7 @@ struct Api {
   int (*get_stats)(cmpr_context *, cmpr_stats *) = nullptr;
   int (*count_duplicates)(cmpr_context *, const cmpr_set_view *, uint64_t *) = nullptr;
   int (*overlap_pairs)(cmpr_context *, uint64_t, uint32_t *, uint32_t *, uint64_t *) = nullptr;
+  int (*warm_up)(const cmpr_options *) = nullptr;
 };
 
 template <typename F>
@@ -74,6 +75,25 @@ public:
       dlclose(api_.handle);
   }
   const char *name() const override { return "HIP gfx950 (libcompairr_hip.so)"; }
+
+  void prewarm(const Options &o) override
+  {
+    cmpr_options co;
+    memset(&co, 0, sizeof co);
+    co.differences = (int32_t)std::min<int64_t>(o.differences, INT32_MAX);
+    co.indels = o.indels;
+    co.ignore_genes = o.ignore_genes;
+    co.alphabet_size = o.alphabet_size;
+    if (o.devices.empty()) {
+      co.device = (int32_t)o.device;
+      (void)api_.warm_up(&co);
+      return;
+    }
+    for (size_t g = 0; g < o.devices.size(); g++) {
+      co.device = o.devices[g];
+      (void)api_.warm_up(&co);
+    }
+  }
 
   bool overlap(const Options &o, const GeneTables &genes, const RepertoireSet &set1,
                const RepertoireSet &set2, bool same, std::vector<double> &cells,
@@ -344,7 +364,8 @@ OverlapBackend *make_hip_backend(const char *argv0, std::string &error)
       !bind(api.handle, "cmpr_overlap_matrix_f64", api.overlap_matrix_f64, error) ||
       !bind(api.handle, "cmpr_get_stats", api.get_stats, error) ||
       !bind(api.handle, "cmpr_count_duplicates", api.count_duplicates, error) ||
-      !bind(api.handle, "cmpr_overlap_pairs", api.overlap_pairs, error)) {
+      !bind(api.handle, "cmpr_overlap_pairs", api.overlap_pairs, error) ||
+      !bind(api.handle, "cmpr_warm_up", api.warm_up, error)) {
     dlclose(api.handle);
     return nullptr;
   }

@@ -3,6 +3,8 @@
  * /root/reference/src/compairr.cc:292-706 (args_init), :200-246 (args_show),
  * :248-283 (args_usage); the code is this repository's own.
  */
+#include <atomic>
+#include <unistd.h>
 #include "options.h"
 
 #include <getopt.h>
@@ -26,11 +28,38 @@ const char *score_description(int64_t s)
   return (s >= 0 && s < SCORE_END) ? kScoreDescr[s] : "?";
 }
 
+thread_local DeferredExit *g_deferred_exit = nullptr;
+static std::atomic<int> g_reader_threads(0);
+
+void reader_thread_active(bool on)
+{
+  g_reader_threads += on ? 1 : -1;
+}
+
+void exit_with_message(FILE *stream, bool stream_is_log, const std::string &text)
+{
+  if (g_deferred_exit) {
+    /* (a message for the log joins what the reader thread has logged so far, in its place) */
+    g_deferred_exit->failed = true;
+    g_deferred_exit->to_log = stream_is_log;
+    if (stream_is_log)
+      fputs(text.c_str(), stream);
+    else
+      g_deferred_exit->text = text;
+    throw ReaderAbort();
+  }
+  fputs(text.c_str(), stream);
+  if (g_reader_threads.load() > 0) {
+    fflush(NULL);
+    _exit(1);
+  }
+  exit(1);
+}
+
 void fatal(const char *msg)
 {
   /* util.cc:84-88 */
-  fprintf(stderr, "\nError: %s\n", msg);
-  exit(1);
+  exit_with_message(stderr, false, std::string("\nError: ") + msg + "\n");
 }
 
 void print_header(FILE *f)

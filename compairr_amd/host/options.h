@@ -72,5 +72,22 @@ const char *score_description(int64_t score);
 
 [[noreturn]] void fatal(const char *msg);
 
+/* The second input file is read on a thread of its own while the first is being read
+   (overlap_host.cc).  The reference reads them one after the other, so an error in file 1
+   is what it reports even when file 2 is broken too: the reader thread does not print and
+   exit, it keeps its message (`text` as it is to be written, to stderr or to the log) and
+   unwinds; the main thread acts on it once file 1 has been read without error. */
+struct DeferredExit {
+  bool        failed = false;
+  bool        to_log = false;      /* message goes to the log stream, not stderr */
+  std::string text;
+};
+struct ReaderAbort {};
+extern thread_local DeferredExit *g_deferred_exit;     /* non-NULL on a reader thread */
+/* a reader thread is running: the main thread leaves with _exit (no static destructors under its feet) */
+void reader_thread_active(bool on);
+/* error exit of the file reader: `text` to `stream`, status 1 (or deferred, see above) */
+[[noreturn]] void exit_with_message(FILE *stream, bool stream_is_log, const std::string &text);
+
 }  // namespace cmprhost
 #endif

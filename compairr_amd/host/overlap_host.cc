@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 namespace cmprhost {
 
@@ -159,10 +160,44 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
     return rc;
   }
 
-  /* ---- read (overlap.cc:611-825) ---- */
+  /* ---- read (overlap.cc:611-825) ----
+     The reference reads file 1, then file 2, then starts its threads.  Here three things run side by
+     side: file 1 on this thread, file 2 on a thread of its own (its log lines are kept and written
+     where the reference writes them; an error in it is acted on only after file 1 has been read
+     without one -- options.h DeferredExit), and the backend's data-independent start-up. */
   GeneTables genes;
   RepertoireSet set1, set2_storage;
   RepertoireTotals tot1, tot2_storage;
+  const bool same = !(o.input2 && strcmp(o.input1, o.input2));
+
+  std::thread warm([&]() { backend.prewarm(o); });
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } warm_joiner{warm};
+
+  GeneTables genes2;                      /* file 2's genes in ITS first-appearance order, merged below */
+  DeferredExit exit2;
+  char *log2_text = nullptr;
+  size_t log2_len = 0;
+  FILE *log2 = nullptr;
+  double seconds2 = 0;
+  std::thread reader2;
+  /* (standard input can be read once, by one reader; it is file 1's when both name it) */
+  const bool concurrent = !same && strcmp(o.input2, "-") != 0 && (log2 = open_memstream(&log2_text, &log2_len)) != nullptr;
+  if (concurrent) {
+    reader_thread_active(true);
+    reader2 = std::thread([&]() {
+      g_deferred_exit = &exit2;
+      const auto r0 = std::chrono::steady_clock::now();
+      try {
+        read_airr_tsv(o.input2, o, genes2, "2", log2, set2_storage, false, o.pairs != nullptr);
+      } catch (const ReaderAbort &) {
+      }
+      seconds2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+      g_deferred_exit = nullptr;
+    });
+  }
 
   fprintf(log, "Immune receptor repertoire set 1\n\n");
   auto t0 = std::chrono::steady_clock::now();
@@ -178,13 +213,36 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
           "line with the -x or --existence command.");      /* overlap.cc:699-703 */
 
   fprintf(log, "Immune receptor repertoire set 2\n\n");
-  const bool same = !(o.input2 && strcmp(o.input1, o.input2));
   if (!same) {
-    t0 = std::chrono::steady_clock::now();
-    read_airr_tsv(o.input2, o, genes, "2", log, set2_storage, false, o.pairs != nullptr);
-    t1 = std::chrono::steady_clock::now();
-    fprintf(log, "Reading sequences: %.9lfs\n\n",
-            std::chrono::duration<double>(t1 - t0).count());
+    if (concurrent) {
+      reader2.join();
+      reader_thread_active(false);
+      fclose(log2);
+      if (log2_text)
+        fwrite(log2_text, 1, log2_len, log);
+      free(log2_text);
+      if (exit2.failed) {
+        fputs(exit2.text.c_str(), stderr);
+        fflush(NULL);
+        exit(1);
+      }
+      /* file 2's genes join file 1's in the order they first appeared (db.cc:121-125) */
+      std::vector<uint32_t> mv(genes2.v.names.size()), mj(genes2.j.names.size());
+      for (size_t k = 0; k < mv.size(); k++)
+        mv[k] = genes.v.intern(genes2.v.names[k].c_str());
+      for (size_t k = 0; k < mj.size(); k++)
+        mj[k] = genes.j.intern(genes2.j.names[k].c_str());
+      for (uint32_t &x : set2_storage.v_gene)
+        x = mv[x];
+      for (uint32_t &x : set2_storage.j_gene)
+        x = mj[x];
+    } else {
+      t0 = std::chrono::steady_clock::now();
+      read_airr_tsv(o.input2, o, genes, "2", log, set2_storage, false, o.pairs != nullptr);
+      t1 = std::chrono::steady_clock::now();
+      seconds2 = std::chrono::duration<double>(t1 - t0).count();
+    }
+    fprintf(log, "Reading sequences: %.9lfs\n\n", seconds2);
     totals_of(set2_storage, tot2_storage);
     if (set2_storage.repertoires.names.empty())
       fatal("Repertoire set missing repertoire_id.");
@@ -208,6 +266,8 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   BackendReport rep;
   std::string error;
   PairList pairs;
+  if (warm.joinable())
+    warm.join();
   if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error,
                        o.pairs ? &pairs : nullptr)) {
     fprintf(stderr, "\nError: %s\n", error.c_str());

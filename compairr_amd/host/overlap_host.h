@@ -34,6 +34,10 @@ class OverlapBackend {
 public:
   virtual ~OverlapBackend() {}
   virtual const char *name() const = 0;
+  /* Called on a thread of its own while the input files are being read: whatever of the
+     backend's start-up does not depend on the data (the HIP runtime and the device context
+     take ~0.4 s).  Must not fail loudly -- overlap() reports what is wrong. */
+  virtual void prewarm(const Options &) {}
   /* Fills cells[R1 * R2] with the values the reference keeps in
      repertoire_matrix (doubles; row = set-1 repertoire number, column =
      set-2 repertoire number).  `same` = one-file mode (set2 is set1).

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CMPR_ABI_VERSION 3
+#define CMPR_ABI_VERSION 4
 
 enum {
   CMPR_OK          = 0,
@@ -269,6 +269,17 @@ int cmpr_overlap_pairs(cmpr_context *ctx, uint64_t capacity, uint32_t *query_out
  * resident sets.
  */
 int cmpr_count_duplicates(cmpr_context *ctx, const cmpr_set_view *set, uint64_t *out);
+
+/*
+ * (ABI v4)  What a process pays once before its first launch, asked for early: the HIP
+ * runtime, the device's context, the code objects of the kernels the given options will run.
+ * The reference has no counterpart -- its threads start in microseconds (overlap.cc:926-936);
+ * a GPU process needs ~0.4 s here, which a caller can spend while it still reads its input
+ * (compairr_amd/host/overlap_host.cc does, on a thread of its own).  Only `differences`,
+ * `indels`, `alphabet_size`, `ignore_genes` and `device` of `options` are looked at.  Creates
+ * nothing the caller has to free.  Thread-safe against every other entry point.
+ */
+int cmpr_warm_up(const cmpr_options *options);
 
 /* Statistics of the last overlap call (synchronises the context's events). */
 int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);

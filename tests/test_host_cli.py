@@ -65,3 +65,58 @@ def test_standard_input_as_a_set(threads):
                                stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()
         assert p.stdout == want
+
+
+def _both(args, tmp_path):
+    """the same command line through this build's host program (oracle backend) and the reference binary"""
+    ours = os.path.join(ROOT, "tests", "bin", "compairr_oracle_cli")
+    ref = os.path.join(ROOT, "oracle", "_ref", "compairr")
+    out = []
+    for exe in (ours, ref):
+        if not os.path.exists(exe):
+            out.append(None)
+            continue
+        log = str(tmp_path / (os.path.basename(exe) + ".log"))
+        p = subprocess.run([exe] + args + ["-l", log], cwd=GOLDEN_INPUTS, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        out.append((p.returncode, p.stdout, p.stderr, open(log).read() if os.path.exists(log) else ""))
+    return out
+
+
+def _error_lines(text):
+    return [l for l in text.splitlines() if ("rror" in l or "Missing" in l) and not l.startswith(("Log file", "Repertoire set"))]
+
+
+def test_errors_of_two_files_come_in_the_reference_order(tmp_path):
+    """The two input files are read side by side (overlap_host.cc); what is reported is what the reference,
+    which reads them one after the other, reports: file 1's error when both are broken, file 2's -- behind
+    the log lines of file 1 -- when only it is, and nothing of file 2 when file 1 is missing."""
+    good = os.path.join(GOLDEN_INPUTS, "seta.tsv")
+    bad1 = str(tmp_path / "bad1.tsv")
+    bad2 = str(tmp_path / "bad2.tsv")
+    with open(good) as fh:
+        lines = fh.read().splitlines()
+    header = lines[0].split("\t")
+    ci = header.index("duplicate_count")
+    row = lines[2].split("\t")
+    row[ci] = "-5"
+    with open(bad1, "w") as fh:
+        fh.write("\n".join(lines[:2] + ["\t".join(row)] + lines[3:]) + "\n")
+    with open(bad2, "w") as fh:                      # (no v_call column)
+        vi = header.index("v_call")
+        fh.write("\n".join("\t".join(c for k, c in enumerate(l.split("\t")) if k != vi) for l in lines) + "\n")
+    for a, b in ((bad1, bad2), (good, bad2), (bad1, good), (str(tmp_path / "absent.tsv"), bad2), (good, str(tmp_path / "absent.tsv"))):
+        ours, ref = _both(["-m", a, b, "-d", "1"], tmp_path)
+        assert ours[0] == 1 and ours[1] == b""
+        text = (ours[2].decode() + ours[3])
+        if a == bad1:
+            assert "duplicate_count" in text and "Missing essential" not in text
+        elif a == good and b == bad2:
+            assert "Missing essential column(s)" in text and "v_call" in text
+            # file 1's block of the log stands in front of file 2's error
+            assert text.index("Immune receptor repertoire set 1") < text.index("Missing essential")
+        else:
+            assert "Unable to open input data file" in text
+        if ref is not None:
+            assert ref[0] == ours[0]
+            assert _error_lines(ref[2].decode() + ref[3]) == _error_lines(text)
