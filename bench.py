@@ -238,7 +238,14 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
         return out
     best = max(units, key=lambda u: units[u][0] / units[u][1])
     a, p, unit = units[best]
+    # the same vector-instruction rate against the guide's flat peak (MI355X_MICROARCH.md: a wave64
+    # instruction issues over 2 cycles per SIMD with >= 2 waves: SIMDs x clock / 2), whatever the mix --
+    # the mix-priced `frac` weights the kernel's STATIC listing (tools/isa_mix.py), not what executes
+    guide = None
+    if "valu" in units:
+        guide = units["valu"][0] / (cal["simds"] * cal["nominal_clock_hz"] / 2.0)
     out.update({"bound": best, "achieved": a, "peak": p, "unit": unit, "frac": a / p,
+                "frac_guide_peak": guide,
                 "utilisation": {u: v[0] / v[1] for u, v in units.items()},
                 "share_of_the_profiled_launch": share,
                 "valu_issue_cycles_per_instruction": k.get("mix_cycles_per_valu_inst"),

@@ -12,6 +12,7 @@
  */
 #include "airr_tsv.h"
 
+#include <sys/stat.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -336,7 +337,12 @@ bool read_whole_file(const char *filename, std::vector<char> &text)
   if (!fp)
     return false;
   size_t used = 0;
-  text.resize(1 << 20);
+  /* a regular file: one allocation of its size (a vector that doubles copies a 250 MB file twice over) */
+  struct stat sb;
+  if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0)
+    text.resize((size_t)sb.st_size + 2);
+  else
+    text.resize(1 << 20);
   for (;;) {
     if (used + 1 >= text.size())
       text.resize(text.size() * 2);
@@ -442,48 +448,73 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
       exit_with_message(log, true, part[r].error);
     }
 
-  /* merge in file order: global first-appearance numbering */
-  size_t n = 0, nres = 0;
-  for (const RangeResult &p : part) {
-    n += p.lengths.size();
-    nres += p.residues.size();
+  /* merge in file order: global first-appearance numbering.  The names are few and merged serially, in
+     file order; the per-sequence arrays are copied by one thread per range to the places a prefix sum of
+     the ranges' sizes gives them (10M sequences: a serial merge took as long as the parsing). */
+  std::vector<size_t> n0(nranges + 1, 0), r0(nranges + 1, 0);
+  for (size_t r = 0; r < nranges; r++) {
+    n0[r + 1] = n0[r] + part[r].lengths.size();
+    r0[r + 1] = r0[r] + part[r].residues.size();
   }
-  d.residues.reserve(nres);
-  d.offsets.reserve(n + 1);
-  d.v_gene.reserve(n);
-  d.j_gene.reserve(n);
-  d.repertoire.reserve(n);
-  d.count.reserve(n);
-  std::vector<uint32_t> mr, mv, mj;
-  for (const RangeResult &p : part) {
+  const size_t n = n0[nranges], nres = r0[nranges];
+  std::vector<std::vector<uint32_t> > mr(nranges), mv(nranges), mj(nranges);
+  for (size_t r = 0; r < nranges; r++) {
+    const RangeResult &p = part[r];
     /* a sequence interns its repertoire, then V, then J; the three tables are
        independent, so mapping each range-local table in its own first-appearance
        order reproduces the global order */
-    mr.resize(p.reps.names.size());
-    for (size_t k = 0; k < mr.size(); k++)
-      mr[k] = d.repertoires.intern(p.reps.names[k].c_str());
-    mv.resize(p.vs.names.size());
-    for (size_t k = 0; k < mv.size(); k++)
-      mv[k] = genes.v.intern(p.vs.names[k].c_str());
-    mj.resize(p.js.names.size());
-    for (size_t k = 0; k < mj.size(); k++)
-      mj[k] = genes.j.intern(p.js.names[k].c_str());
-    d.residues.insert(d.residues.end(), p.residues.begin(), p.residues.end());
+    mr[r].resize(p.reps.names.size());
+    for (size_t k = 0; k < mr[r].size(); k++)
+      mr[r][k] = d.repertoires.intern(p.reps.names[k].c_str());
+    mv[r].resize(p.vs.names.size());
+    for (size_t k = 0; k < mv[r].size(); k++)
+      mv[r][k] = genes.v.intern(p.vs.names[k].c_str());
+    mj[r].resize(p.js.names.size());
+    for (size_t k = 0; k < mj[r].size(); k++)
+      mj[r][k] = genes.j.intern(p.js.names[k].c_str());
     d.sequence_id.insert(d.sequence_id.end(), p.ids.begin(), p.ids.end());
     d.keep.insert(d.keep.end(), p.keep.begin(), p.keep.end());
-    for (size_t k = 0; k < p.lengths.size(); k++) {
-      const uint32_t len = p.lengths[k];
-      d.offsets.push_back(d.offsets.back() + len);
-      d.repertoire.push_back(mr[p.rep[k]]);
-      d.v_gene.push_back(mv[p.v[k]]);
-      d.j_gene.push_back(mj[p.j[k]]);
-      d.count.push_back(p.count[k]);
-      d.total_count += p.count[k];
-      if (len > d.longest) d.longest = len;
-      if (len < d.shortest) d.shortest = len;
-    }
     d.ignored_unknown += p.ignored_unknown;
     d.ignored_empty += p.ignored_empty;
+  }
+  d.residues.resize(nres);
+  d.offsets.resize(n + 1);
+  d.offsets[0] = 0;
+  d.v_gene.resize(n);
+  d.j_gene.resize(n);
+  d.repertoire.resize(n);
+  d.count.resize(n);
+  {
+    std::vector<uint64_t> tot(nranges, 0);
+    std::vector<uint32_t> lmax(nranges, 0), lmin(nranges, 0xffffffffu);
+    std::vector<std::thread> pool;
+    for (size_t r = 0; r < nranges; r++)
+      pool.emplace_back([&, r]() {
+        const RangeResult &p = part[r];
+        if (!p.residues.empty())
+          memcpy(d.residues.data() + r0[r], p.residues.data(), p.residues.size());
+        uint64_t off = r0[r];
+        for (size_t k = 0; k < p.lengths.size(); k++) {
+          const uint32_t len = p.lengths[k];
+          const size_t i = n0[r] + k;
+          off += len;
+          d.offsets[i + 1] = off;
+          d.repertoire[i] = mr[r][p.rep[k]];
+          d.v_gene[i] = mv[r][p.v[k]];
+          d.j_gene[i] = mj[r][p.j[k]];
+          d.count[i] = p.count[k];
+          tot[r] += p.count[k];
+          if (len > lmax[r]) lmax[r] = len;
+          if (len < lmin[r]) lmin[r] = len;
+        }
+      });
+    for (auto &t : pool)
+      t.join();
+    for (size_t r = 0; r < nranges; r++) {
+      d.total_count += tot[r];
+      if (lmax[r] > d.longest) d.longest = lmax[r];
+      if (lmin[r] < d.shortest) d.shortest = lmin[r];
+    }
   }
 
   /* db.cc:847-887 */

@@ -3,6 +3,9 @@
  * reference's command line and AIRR-TSV I/O for --matrix
  * (/root/reference/src/compairr.cc:743-798) with the per-query loop on the GPU.
  */
+#include <stdio.h>
+#include <unistd.h>
+
 #include <memory>
 
 #include "hip_backend.h"
@@ -14,5 +17,10 @@ int main(int argc, char **argv)
       cmprhost::make_hip_backend(argv[0], error));
   if (!backend)
     cmprhost::fatal(error.c_str());
-  return cmprhost::compairr_main(argc, argv, *backend);
+  const int rc = cmprhost::compairr_main(argc, argv, *backend);
+  /* Everything is written and closed (compairr_main closes its files).  Leaving through _exit skips
+     what only costs time now: unloading the HIP runtime and its device context (~0.15 s), freeing
+     gigabytes of vectors page by page. */
+  fflush(NULL);
+  _exit(rc);
 }
