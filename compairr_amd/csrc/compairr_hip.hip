@@ -252,6 +252,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   invalidate_plan(c);
   c->zob.release();
   c->res2.release(); c->off2.release(); c->cnt2.release();
+  c->page_tab.release();
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
@@ -453,6 +454,18 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set bloom_bits_log2_delta before cmpr_set_reference");
     c->bloom_log2_delta = value;
+  } else if (n == "slice_pages") {
+    if (value < -1 || value > (int64_t)PAGE_E_MAX)
+      return fail(c, CMPR_EINVAL, "slice_pages must be -1..3");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set slice_pages before cmpr_set_reference");
+    c->slice_pages = value;
+  } else if (n == "page_budget") {
+    if (value < 0 || value > (1 << 24))
+      return fail(c, CMPR_EINVAL, "page_budget must be 0..2^24");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set page_budget before cmpr_set_reference");
+    c->page_budget = value;
   } else if (n == "row_filter_x16") {
     if (value < 8 || value > 128)
       return fail(c, CMPR_EINVAL, "row_filter_x16 must be 8..128 (sixteenths of a byte per entry)");
@@ -512,6 +525,9 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
   else if (n == "row_filter_x16") *value = c->row_filter_x16;
+  else if (n == "slice_pages") *value = c->slice_pages;
+  else if (n == "page_budget") *value = c->page_budget;
+  else if (n == "page_slices") *value = (int64_t)c->page_slices;
   else if (n == "host_threads") *value = c->host_threads;
   else if (n == "pos_capacity") *value = (int64_t)(c->pos_cap * c->pos_segments);
   else if (n == "pos_segments") *value = c->pos_segments;

@@ -131,6 +131,8 @@ struct cmpr_context {
   int64_t bloom_log2_delta = -100; /* -100: default (0 for variant 0, +2 sliced) */
   int64_t row_filter_x16 = 32;    /* variant 2: filter bytes per entry, in sixteenths (32 = 2 bytes: 16 bits per
                                      entry, eight of them set) */
+  int64_t slice_pages = -1;       /* variant 2, d = 1: overfull slices get up to 2^this pages; -1 = up to 8, 0 = none */
+  int64_t page_budget = 0;        /* entries a slice may hold before it gets pages; 0 = 24 per word (tests: small) */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
   int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
   int64_t heavy_threshold = -1;   /* class population above which it is split;
@@ -166,6 +168,8 @@ struct cmpr_context {
   SliceGeom             geom{};
   std::vector<uint32_t> ctab;     /* host copy of the class tables             */
   DevBuf<uint32_t>      d_ctab;
+  DevBuf<uint32_t>      page_tab;         /* variant 2, d = 1: pages of the overfull slices (layout.h SliceGeom) */
+  uint64_t              page_slices = 0;  /* overflow pages behind the regular slices */
   DevBuf<Chunk>         chunks;
   DevBuf<cmpr::TileRef> tile_refs;    /* what the chunks list */
   DevBuf<uint32_t>      small_tiles;

@@ -164,6 +164,7 @@ struct BuildParams {
   uint32_t        indels;          /* row filter: also the gap entries (kernels_rows.h) */
   uint32_t        pairs;           /* row filter: pair rows (d = 1 without -i, kernels_rows.h) */
   uint32_t        pad;
+  uint32_t       *count;           /* build_rows_kernel: non-NULL = count the entries per slice instead of filing them */
   SliceGeom       geom;
 };
 

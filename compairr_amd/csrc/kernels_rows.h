@@ -213,7 +213,11 @@ build_rows_kernel(const BuildParams B)
   const uint32_t nwords = g.rw_words;
   unsigned long long *words = (unsigned long long *)B.bloom;
   auto enter = [&](uint64_t Wk, uint32_t code, uint32_t slice) {
-    const uint64_t w = (uint64_t)slice * nwords + row_word(Wk, nwords);
+    if (B.count) {                            /* (the geometry pass: entries per slice) */
+      atomicAdd(B.count + slice, 1u);
+      return;
+    }
+    const uint64_t w = (uint64_t)paged_slice(g, slice, Wk) * nwords + row_word(Wk, nwords);
     uint64_t q[4];
     row_entry_bits(Wk, code, q);
 #pragma unroll
@@ -225,7 +229,11 @@ build_rows_kernel(const BuildParams B)
     /* pair rows: one entry per pair of positions, filed under the class key without the
        terms of the class positions inside the pair, in the class part of the first of them */
     auto enter_pair = [&](uint64_t Wk, uint32_t a, uint32_t b2, uint32_t slice) {
-      const uint64_t w = (uint64_t)slice * nwords + row_word(Wk, nwords);
+      if (B.count) {
+        atomicAdd(B.count + slice, 1u);
+        return;
+      }
+      const uint64_t w = (uint64_t)paged_slice(g, slice, Wk) * nwords + row_word(Wk, nwords);
       uint64_t q[4];
       pair_entry_bits(Wk, a, b2, q);
 #pragma unroll
@@ -587,7 +595,7 @@ struct RingSlot {
   uint32_t pad[2];           /* ([0] of slot 0: the workgroup's staging counter; [0] of slot 1: buffers whose
                                 chain of tenants has ended; [1]: item chunk: its blocks) */
   uint32_t next_chunk;       /* the chunk of the tenant after this one (P.deal: reserved when this one was staged) */
-  uint32_t pad2;
+  uint32_t page;             /* the page of its slice the tenant holds | e of the slice << 4 (layout.h SliceGeom; 0: no pages) */
 };
 
 
@@ -730,18 +738,20 @@ probe_rows_kernel(const ProbeParams P)
     const unsigned char *tsrc = (const unsigned char *)(P.tile_refs + ck.first_tile) + l16;
     const uint32_t tdst = (uint32_t)(uintptr_t)(tref_lds + b * chunk_cap);
     /* (a class-row chunk has no tile references: its "tiles" are blocks of 64 items) */
-    const uint32_t tbytes = ck.pass >= 3 ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
+    const uint32_t cpass = ck.pass & ((1u << CHUNK_PAGE_SHIFT) - 1u);     /* (above: the page, layout.h) */
+    const uint32_t tbytes = cpass >= 3 ? 0u : ck.ntiles * (uint32_t)sizeof(TileRef);
     for (uint32_t off = 0; off < tbytes; off += 1024u)
       if (off + l16 < tbytes)
         __builtin_amdgcn_global_load_lds((glob_void_t *)(tsrc + off),
                                          (lds_void_t *)(uintptr_t)(tdst + off), 16, 0, 0);
     rs->done = 0;
     rs->slice = ck.slice;
-    rs->pass = ck.pass;
+    rs->pass = cpass;
+    rs->page = ((ck.pass >> CHUNK_PAGE_SHIFT) & 7u) | (((ck.pass >> CHUNK_PAGE_E_SHIFT) & 3u) << 4);
     rs->first = ck.first_tile;
     rs->pad[1] = ck.ntiles;
     /* what is claimed: a tile, or ITEM_BLOCKS blocks of an item chunk */
-    const uint32_t units = ck.pass >= 3 ? (ck.ntiles + ITEM_BLOCKS - 1u) / ITEM_BLOCKS : ck.ntiles;
+    const uint32_t units = cpass >= 3 ? (ck.ntiles + ITEM_BLOCKS - 1u) / ITEM_BLOCKS : ck.ntiles;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the copies have landed */
     if (P.deal)
       rs->next_chunk = RING * G + grp + DEAL_GROUPS * __builtin_amdgcn_readfirstlane(reserved);
@@ -996,6 +1006,20 @@ probe_rows_kernel(const ProbeParams P)
       uint32_t treads = 0;
       const uint32_t *qr = P.qres + tres + lane;
       const bool class_tile = tpass_real >= 3;
+      /* Pages (layout.h SliceGeom): the staged buffer holds ONE page of the unit's slice; a probe counts in
+         this pass iff its hash names that page -- (hash & pgm) == pgv -- and the unit comes by once per page.
+         No pages (nearly every slice): pgm = pgv = 0, every probe counts.  What a unit stands for (its variant
+         count) is counted in the pass of page 0. */
+      uint32_t pgm = 0, pgv = 0;
+      if (PAIRS && staged) {
+        const uint32_t pg = __builtin_amdgcn_readfirstlane(ring[cur_c.b].page);
+        pgm = ((1u << (pg >> 4)) - 1u) << PAGE_HASH_SHIFT;
+        pgv = (pg & 7u) << PAGE_HASH_SHIFT;
+      }
+      const bool page0 = pgv == 0u;
+      auto on_page = [&](uint64_t Wk) -> uint32_t {       /* all ones / zero */
+        return (((uint32_t)Wk & pgm) == pgv) ? ~0u : 0u;
+      };
       /* a class-row item carries the row's blanked hash, the query's slot in pass 0
          (~0: padding behind the items of a slice) and its residue | position << 8
          (query_layout.hip) */
@@ -1121,7 +1145,7 @@ probe_rows_kernel(const ProbeParams P)
         /* ---- the unchanged sequence (variants.cc:260-268) ---- */
         {
           const RowWord w = fetch_own(h);
-          const bool hit = ((row_bits(w, h) >> A) & 1u) != 0;
+          const bool hit = ((row_bits(w, h) >> A) & 1u) != 0 && on_page(h) != 0u;
           q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, valid && hit, h, pack_a(K_SAME, 0, 0), 0, 1u, 1u);
           nvar += 1;
         }
@@ -1225,12 +1249,14 @@ probe_rows_kernel(const ProbeParams P)
                 const uint32_t before = j == 0 ? carry : rb[j - 1];
                 const uint32_t ta = (ra[j] != before ? delmask : AMASK) & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
                 const uint32_t tb = (rb[j] != ra[j] ? delmask : AMASK) & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
-                xa[j] = a1 & ta;
-                xb[j] = a2 & tb;
+                const uint32_t pm = on_page(Wk[j]);
+                xa[j] = a1 & ta & pm;
+                xb[j] = a2 & tb & pm;
                 ndel += (ta >> (A + 1)) + (tb >> (A + 1));
               } else {
-                xa[j] = a1 & am & (uint32_t)bfe_i32(lv, 2 * j, 1);
-                xb[j] = a2 & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
+                const uint32_t pm = on_page(Wk[j]);
+                xa[j] = a1 & am & (uint32_t)bfe_i32(lv, 2 * j, 1) & pm;
+                xb[j] = a2 & am & (uint32_t)bfe_i32(lv, 2 * j + 1, 1) & pm;
               }
               wc = wn;
             }
@@ -1525,8 +1551,8 @@ probe_rows_kernel(const ProbeParams P)
                   nv += d1 + d2;
                 }
               }
-              a1 &= m1;
-              a2 &= m2;
+              a1 &= m1 & on_page(iw);
+              a2 &= m2 & on_page(iw);
               nvar += ival ? nv : 0u;
               if (CMPR_DBG(P, DBG_SKIP_EMIT))
                 a1 = a2 = 0;
@@ -1718,7 +1744,8 @@ probe_rows_kernel(const ProbeParams P)
               hg ^= k1[j] ^ k2[j] ^ k3[j] ^ k4[j];     /* the gap hash of g + 2 */
               wor[j] = woff_of(hrow[j]);
               itp[j] = false;
-              slr[j] = cslice;
+              slr[j] = tslice;                         /* (the slice as the class keys name it; the staged buffer
+                                                          holds one page of it: cslice is where that page lies) */
               if constexpr (!INNER) {
                 if (K != 0u && (!unwrapped || g0 <= mi_max)) {          /* wave-uniform: see mi_max */
                   uint32_t key = base_t;
@@ -1735,7 +1762,7 @@ probe_rows_kernel(const ProbeParams P)
                      that position's class part (query_layout.hip) */
                   itp[j] = hvy && inside;
                   slr[j] = row_slice(P.geom, key, -1);
-                  any_glob = any_glob || (g <= L && __ballot(valid && !itp[j] && slr[j] != cslice) != 0);
+                  any_glob = any_glob || (g <= L && __ballot(valid && !itp[j] && slr[j] != tslice) != 0);
                 }
               }
             }
@@ -1750,8 +1777,8 @@ probe_rows_kernel(const ProbeParams P)
               RowWord w = wc;
               if constexpr (!INNER) {
                 if (any_glob) {                                /* rare: a lane's pair lies in another slice */
-                  if (valid && !itp[j] && slr[j] != cslice)
-                    w = word_glob(filter + (size_t)slr[j] * slice_bytes, wor[j]);
+                  if (valid && !itp[j] && slr[j] != tslice)
+                    w = word_glob(filter + (size_t)paged_slice(P.geom, slr[j], hrow[j]) * slice_bytes, wor[j]);
                 }
               }
               uint32_t xs, xd, a1, a2;
@@ -1761,8 +1788,13 @@ probe_rows_kernel(const ProbeParams P)
               a1 &= AMASK & ~(1u << rbefore[j]) & (uint32_t)bfe_i32(lv, 2 * j, 1);
               a2 &= AMASK & ~(1u << rg[j]) & (uint32_t)bfe_i32(lv, 2 * j + 1, 1);
               const bool here = INNER || !itp[j];
-              xa[j] = here ? a1 : 0u;
-              xb[j] = here ? a2 : 0u;
+              /* (pages: a pair of the staged slice counts in the pass of its page; one read where it lies --
+                 from the page its hash names -- in the pass of page 0) */
+              uint32_t pm = on_page(hrow[j]);
+              if constexpr (!INNER)
+                pm = slr[j] != tslice ? (page0 ? ~0u : 0u) : pm;
+              xa[j] = here ? a1 & pm : 0u;
+              xb[j] = here ? a2 & pm : 0u;
               wc = wn;
             }
             treads += valid ? (uint32_t)PB : 0u;
@@ -1818,7 +1850,7 @@ probe_rows_kernel(const ProbeParams P)
         }
       }
 
-      W.st.variants += valid ? (uint64_t)nvar : 0ull;
+      W.st.variants += (valid && page0) ? (uint64_t)nvar : 0ull;
       reads += treads;
     }
     if (staged) {

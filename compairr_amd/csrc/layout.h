@@ -114,7 +114,38 @@ struct SliceGeom {
   uint32_t nbuf;           /* kernels_pairs2.h: slice buffers in LDS -- 2: the next chunk's slice is copied
                               while this one is worked on; 1: slices twice the size (more queries per slice:
                               fuller tiles), staged between two barriers */
+  /* Pages (variant 2, d = 1; round 5).  A slice that holds more entries than its words are good for -- skewed
+     data: the commonest combination of class residues of a big (V, J) class -- is given 2^e pages of rw_words
+     words each: an entry goes to the page its hash names (page_of), page 0 where the slice lies, the others in
+     an overflow area behind the nsl regular slices.  page_tab[s] = e | first overflow slice << 4 (device
+     memory; NULL: no slice has pages).  A tile of such a slice is worked on once per page (a chunk per page:
+     Chunk::pass bits), each variant counting in the pass of its own page. */
+  const uint32_t *page_tab;
+  uint32_t nsl;            /* regular slices: main part + class parts */
+  uint32_t pad_pages;
 };
+constexpr uint32_t PAGE_E_MAX = 3;            /* at most 8 pages per slice */
+constexpr uint32_t PAGE_HASH_SHIFT = 20;      /* page = bits 20.. of the entry's hash: used neither by the word
+                                                 index (top 16) nor by the rotation amounts (kernels_rows.h) */
+constexpr uint32_t CHUNK_PAGE_SHIFT = 20;     /* Chunk::pass (variant 2): bits 20..22 the page the chunk stages, */
+constexpr uint32_t CHUNK_PAGE_E_SHIFT = 24;   /* bits 24..25 e of its slice (0: the slice has no pages) */
+__host__ __device__ inline uint32_t page_of(uint64_t Wk, uint32_t e)
+{
+  return ((uint32_t)Wk >> PAGE_HASH_SHIFT) & ((1u << e) - 1u);
+}
+/* where page `pg` of slice `s` lies, in slices */
+__host__ __device__ inline uint32_t page_slice(const SliceGeom &g, uint32_t s, uint32_t pt, uint32_t pg)
+{
+  return pg == 0u ? s : g.nsl + (pt >> 4) + pg - 1u;
+}
+/* ... of an entry / a probe with hash Wk filed under slice s */
+__host__ __device__ inline uint32_t paged_slice(const SliceGeom &g, uint32_t s, uint64_t Wk)
+{
+  if (g.page_tab == nullptr)
+    return s;
+  const uint32_t pt = g.page_tab[s];
+  return page_slice(g, s, pt, page_of(Wk, pt & 15u));
+}
 
 /* Variant 2 files the entries of a row under the class key WITHOUT the terms of
    the blanked position.  Rows whose blanked position is class position i of a

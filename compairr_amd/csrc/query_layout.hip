@@ -812,8 +812,12 @@ slices_kernel(const QL Q, uint32_t pi)
     /* (variant 2 with -i: the deletion and insertion rows of a tile follow its
        substitution rows in the same unit, on the same staged slice -- its class keys
        have no length term -- so there is one chunk per slice, not one per pass) */
-    const uint32_t reps = 1u;
-    if (!Q.indels && (ntiles <= Q.small_max || (pi > 0 && Q.class_unstaged))) {
+    /* (a slice with pages -- layout.h SliceGeom -- is staged once per page: a chunk per page and run of
+       tiles, the page and the slice's e in the chunk's pass word) */
+    const uint32_t pt = (Q.rows && Q.geom.page_tab) ? Q.geom.page_tab[sl] : 0u;
+    const uint32_t pe = pt & 15u;
+    const uint32_t reps = 1u << pe;
+    if (!Q.indels && pe == 0u && (ntiles <= Q.small_max || (pi > 0 && Q.class_unstaged))) {
       nsmall = ntiles;
       if (WRITE)
         for (uint32_t t = 0; t < ntiles; t++)
@@ -833,10 +837,10 @@ slices_kernel(const QL Q, uint32_t pi)
         for (uint32_t k = 0; k < nc1; k++)
           for (uint32_t rp = 0; rp < reps; rp++) {
             Chunk ck;
-            ck.slice = (uint32_t)sl;
+            ck.slice = page_slice(Q.geom, (uint32_t)sl, pt, rp);
             ck.first_tile = Q.list0[pi] + at.list + k * Q.chunk_tiles;
             ck.ntiles = min(Q.chunk_tiles, ntiles - k * Q.chunk_tiles);
-            ck.pass = pass + rp;
+            ck.pass = pass | (rp << CHUNK_PAGE_SHIFT) | (pe << CHUNK_PAGE_E_SHIFT);
             if (Q.sub2_items && pi == 0 && k == 0)
               ck.pass |= CHUNK_WITH_ITEMS;      /* (the slice's item blocks ride along) */
             if (Q.pairs2) {
@@ -1087,6 +1091,25 @@ item_replicas_kernel(const QL Q)
   Q.ccnt[k] = run;
 }
 
+/* the slice of the filter the items of counter k are filed under, and its pages (layout.h SliceGeom):
+   returns e (0: no pages) */
+__device__ inline uint32_t item_slice_pages(const QL &Q, uint64_t k, uint32_t *slice, uint32_t *pt_out)
+{
+  if (Q.sub2_items || !Q.rows)
+    return 0u;
+  uint32_t gi = 0;
+  for (uint32_t x = 1; x < Q.ngroups; x++)
+    if (k >= Q.goff[x])
+      gi = x;
+  const uint32_t ls = Q.gslice0[gi] + (uint32_t)(k - Q.goff[gi]);
+  const uint32_t pt = Q.geom.page_tab ? Q.geom.page_tab[ls] : 0u;
+  if (slice)
+    *slice = ls;
+  if (pt_out)
+    *pt_out = pt;
+  return pt & 15u;
+}
+
 /* variant 2, class rows: per (class part, slice) the items padded to whole blocks
    of 64, and the chunks (at most cblocks blocks each) they make */
 __global__ void __launch_bounds__(256)
@@ -1108,7 +1131,7 @@ class_pad_kernel(const QL Q, uint32_t *padded)
     if (Q.tot[0][k / Q.ngroups].chunks > 0)
       blocks = 0;                            /* (ride along with the slice's first main chunk) */
   }
-  Q.cnch[k] = (blocks + Q.cblocks - 1) / Q.cblocks;
+  Q.cnch[k] = ((blocks + Q.cblocks - 1) / Q.cblocks) << item_slice_pages(Q, k, nullptr, nullptr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1136,14 +1159,17 @@ class_chunks_kernel(const QL Q)
     Q.slice_items[sl] = make_uint2(0u, 0u);
   }
   const uint32_t nc = (blocks + Q.cblocks - 1) / Q.cblocks;
-  for (uint32_t q = 0; q < nc; q++) {
-    Chunk ck;
-    ck.slice = Q.sub2_items ? (uint32_t)(k / Q.ngroups) : Q.gslice0[gi] + (uint32_t)(k - Q.goff[gi]);
-    ck.first_tile = Q.cbase[k] + q * Q.cblocks * WAVE;      /* first item */
-    ck.ntiles = min(Q.cblocks, blocks - q * Q.cblocks);     /* blocks of 64 items */
-    ck.pass = 3 + gi;
-    Q.chunks[Q.cchunk0 + Q.cchpre[k] + q] = ck;
-  }
+  uint32_t ls = 0, pt = 0;
+  const uint32_t pe = item_slice_pages(Q, k, &ls, &pt);
+  for (uint32_t q = 0; q < nc; q++)
+    for (uint32_t rp = 0; rp < (1u << pe); rp++) {
+      Chunk ck;
+      ck.slice = Q.sub2_items ? (uint32_t)(k / Q.ngroups) : page_slice(Q.geom, ls, pt, rp);
+      ck.first_tile = Q.cbase[k] + q * Q.cblocks * WAVE;      /* first item */
+      ck.ntiles = min(Q.cblocks, blocks - q * Q.cblocks);     /* blocks of 64 items */
+      ck.pass = (3 + gi) | (rp << CHUNK_PAGE_SHIFT) | (pe << CHUNK_PAGE_E_SHIFT);
+      Q.chunks[Q.cchunk0 + Q.cchpre[k] + (q << pe) + rp] = ck;
+    }
 }
 
 /* ---- -i: tiles regrouped by the slice their indel variants fall into ------- */

@@ -568,9 +568,78 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
   }
-  if (c->rows)          /* main part + one class part per class residue */
-    c->bloom_words = ((uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1)) *
-                     c->geom.rw_words * (ROW_WORD_BYTES / 8);
+  c->geom.page_tab = nullptr;
+  c->geom.nsl = 0;
+  c->geom.pad_pages = 0;
+  c->page_tab.release();
+  c->page_slices = 0;
+  if (c->rows) {        /* main part + one class part per class residue */
+    const uint64_t nsl = (uint64_t)c->geom.smask + 1 + (uint64_t)c->geom.k * (c->geom.cmask + 1);
+    c->geom.nsl = (uint32_t)nsl;
+    /* ---- pages (layout.h SliceGeom): the slices that would hold more entries than their words are good
+            for -- the class residues split a big class as evenly as its residues are distributed, and on
+            skewed data that is not evenly: 24.2M sequences, d = 1 -i, the fullest slice at 1.7 x its budget
+            with FOUR class residues and 45 % of the step's positives false (round 4) -- get 2^e pages.
+            One counting pass of the kernel that files the entries (same code, BuildParams::count). ---- */
+    if (c->opt.differences == 1 && !c->d2pairs && c->slice_pages != 0 && s->n > 0 && nsl < (1ull << 27)) {
+      Tmp<uint32_t> d_cnt;
+      if ((rc = dev_alloc(c, d_cnt.b, (size_t)nsl))) return rc;
+      HIP_TRY(c, hipMemsetAsync(d_cnt.b.p, 0, (size_t)nsl * sizeof(uint32_t), c->stream));
+      BuildParams Bc{};
+      Bc.zob = c->zob.p;
+      Bc.A = A;
+      Bc.zpos = c->zpos;
+      Bc.n_v = n_v;
+      Bc.use_genes = c->opt.ignore_genes ? 0u : 1u;
+      Bc.res = c->res2.p;
+      Bc.off = c->off2.p;
+      Bc.v = c->v2.p;
+      Bc.j = c->j2.p;
+      Bc.n = s->n;
+      Bc.sliced = 1u;
+      Bc.indels = c->opt.indels ? 1u : 0u;
+      Bc.pairs = 1u;
+      Bc.geom = c->geom;
+      Bc.count = d_cnt.b.p;
+      hipLaunchKernelGGL(build_rows_kernel, dim3((uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS)),
+                         dim3(BLOCK_THREADS), 0, c->stream, Bc);
+      HIP_TRY(c, hipGetLastError());
+      std::vector<uint32_t> cnt((size_t)nsl);
+      HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt.b.p, (size_t)nsl * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      /* a slice's budget: 20 entries per word (the filter is sized for 16 single-row entries per word on
+         average; pair rows file fewer).  The class residues are chosen so that the fullest slice stays under
+         24 per word, and on skewed data a hump of slices ends up just under that: at 20 .. 24 entries per
+         word an eight-bit test passes by chance 2-6 times per thousand, and those few slices made 40 % of
+         the positives of 10M x 10M on the cdr3 law with -i (13.2M -> 7.8M with this budget; round 5) */
+      const uint64_t budget = c->page_budget > 0 ? (uint64_t)c->page_budget : (uint64_t)c->geom.rw_words * 20;
+      const uint32_t emax = (uint32_t)std::min<int64_t>(c->slice_pages < 0 ? PAGE_E_MAX : c->slice_pages, PAGE_E_MAX);
+      std::vector<uint32_t> tab((size_t)nsl);
+      uint64_t ovf = 0, paged = 0;
+      uint32_t fullest = 0;
+      for (uint64_t k = 0; k < nsl; k++) {
+        uint32_t e = 0;
+        while (e < emax && (uint64_t)cnt[k] > (budget << e))
+          e++;
+        tab[k] = e | ((uint32_t)ovf << 4);
+        ovf += (1u << e) - 1u;
+        paged += e ? 1 : 0;
+        fullest = std::max(fullest, cnt[k]);
+      }
+      if (getenv("COMPAIRR_HIP_DEBUG"))
+        fprintf(stderr, "compairr_hip: pages: %llu of %llu slices over their budget of %llu entries (fullest %u), "
+                        "%llu overflow pages\n", (unsigned long long)paged, (unsigned long long)nsl,
+                (unsigned long long)budget, fullest, (unsigned long long)ovf);
+      if (ovf > 0 && ovf < (1ull << 27)) {
+        if ((rc = dev_upload(c, c->page_tab, tab.data(), tab.size()))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));         /* (the host vector goes away) */
+        c->geom.page_tab = c->page_tab.p;
+        c->page_slices = ovf;
+      }
+    }
+    c->bloom_words = (nsl + c->page_slices) * c->geom.rw_words * (ROW_WORD_BYTES / 8);
+  }
   if (c->slots > (1ull << 30))
     return fail(c, CMPR_EUNSUPPORTED, "reference set too large for a 32-bit record table");
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;

@@ -73,6 +73,20 @@ LAYOUTS = {
                        "deferred_resolve": 0},
     "rows_k4_overflow": {"variant": 2, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2,
                          "pos_capacity": 64, "pos_segments": 1},
+    # pages (layout.h SliceGeom; round 5): every slice that holds more than `page_budget` entries is spread
+    # over up to 2^3 pages, its tiles and item blocks worked on once per page (d = 1, with and without -i;
+    # other d: no pages) -- budgets so small that most slices have pages, also with one class residue less
+    # than the data asks for, single-page cap, tiny slices, the inline and the overflow paths
+    "rows_pages": {"variant": 2, "page_budget": 16},
+    "rows_pages_cap1": {"variant": 2, "page_budget": 8, "slice_pages": 1},
+    "rows_pages_tiny": {"variant": 2, "page_budget": 4, "slice_words_log2": 3, "class_residues": 2,
+                        "heavy_threshold": 2, "chunk_tiles": 2},
+    "rows_pages_k3_anchor3": {"variant": 2, "page_budget": 6, "slice_words_log2": 4, "class_residues": 3,
+                              "heavy_threshold": 0, "class_anchor": 3},
+    "rows_pages_k4": {"variant": 2, "page_budget": 5, "class_residues": 4, "slice_words_log2": 3, "heavy_threshold": 2},
+    "rows_pages_inline": {"variant": 2, "page_budget": 10, "deferred_resolve": 0, "slice_words_log2": 4},
+    "rows_pages_overflow": {"variant": 2, "page_budget": 10, "pos_capacity": 64, "slice_words_log2": 4},
+    "rows_pages_off": {"variant": 2, "slice_pages": 0},
     # every chunk dealt statically (the default hands out all but a workgroup's first four by a counter)
     "rows_static_deal": {"variant": 2, "chunk_deal": 0},
     "rows_static_deal_tiny": {"variant": 2, "chunk_deal": 0, "slice_words_log2": 3, "class_residues": 2,
