@@ -92,6 +92,12 @@ def parse_args():
     p.add_argument("--ignore-genes", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=0,
                    help="queries in the CPU-baseline sample (0 = auto, -1 = skip)")
+    p.add_argument("--cpu-refs", type=int, default=0,
+                   help="reference sequences in the CPU-baseline sample (0 = all of them).  The reference binary "
+                        "reads its sets from TSV files: 100M reference sequences take it > 10 minutes of parsing "
+                        "and indexing before its per-query loop starts -- cfg5's baseline is timed against the "
+                        "first N of them (the loop's cost per query does not depend on their number but for cache "
+                        "effects: one hash-table lookup per variant)")
     p.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto",
                    help="CPU baseline: the reference binary (oracle/_ref, fed TSV files) or the oracle "
                         "port (oracle/liboracle.so, sets in memory); auto = the binary when present")
@@ -126,12 +132,14 @@ def cpu_baseline(ref, queries, opt, sample, args):
     is fed the sample as AIRR TSV files and its own 'Analysing:' log time is
     taken -- exactly the per-query loop, overlap.cc:906-938.
     kind "port": the oracle port (oracle/liboracle.so) when the binary is absent.
-    Returns (dict, integer matrix, sample set)."""
+    Returns (dict, integer matrix, sample set, print format, reference set used)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 256))           # the reference caps -t at 256
     q = queries.subset(slice(0, sample))
+    if args.cpu_refs and args.cpu_refs < ref.n:
+        ref = ref.subset(slice(0, args.cpu_refs))        # (the parity check below runs on the same subset)
     exe = os.path.join(ROOT, "oracle", "_ref", "compairr")
     if os.path.exists(exe) and args.cpu_kind != "port":
         import re
@@ -157,12 +165,12 @@ def cpu_baseline(ref, queries, opt, sample, args):
                     for j, b in enumerate(ref.repertoire_ids):
                         m[i, j] = cell.get((a, b), 0.0)
                 return ({"value": q.n / sec, "unit": "query sequences/s", "cores": threads,
-                         "kind": "reference",
+                         "kind": "reference", "reference_sequences_in_sample": int(ref.n),
                          "sample": "CompAIRR 1.13.0 binary (oracle/_ref), -t %d, first %d queries "
                                    "of the workload vs all %d reference sequences; its own "
                                    "'Analysing:' time %.2f s (whole run incl. TSV parse %.1f s)"
                                    % (threads, q.n, ref.n, sec, wall)},
-                        m, q, "%.10g")
+                        m, q, "%.10g", ref)
     m, st = _oracle.overlap(q, ref, opt, threads=threads)
     rate = q.n / st.seconds_analysis if st.seconds_analysis > 0 else 0.0
     return ({"value": rate, "unit": "query sequences/s", "cores": threads, "kind": "port",
@@ -170,7 +178,7 @@ def cpu_baseline(ref, queries, opt, sample, args):
                        "per-query loop only (reference 'Analysing:' region) %.2f s, "
                        "index build %.2f s excluded" % (q.n, ref.n, st.seconds_analysis,
                                                         st.seconds_index)},
-            _oracle.integer_cells(m, opt).astype(np.float64), q, None)
+            _oracle.integer_cells(m, opt).astype(np.float64), q, None, ref)
 
 
 def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
@@ -482,9 +490,11 @@ def main():
             # ~10-30 s of CPU work: single-core rates of the reference loop
             per_q = {0: 3e7, 1: 2.3e5, 2: 2.6e3}[args.differences] / (2 if args.indels else 1)
             sample = args.cpu_sample or int(min(args.queries, max(1000, per_q * 20)))
-            baseline, want, q, fmt = cpu_baseline(ref, qry, opt, sample, args)
+            baseline, want, q, fmt, ref_used = cpu_baseline(ref, qry, opt, sample, args)
             # the same sample on the GPU must give the same cells: bit for bit against
             # the port, digit for digit (the reference prints %.10lg) against the binary
+            if ref_used is not ref:
+                h.set_reference(ref_used, full.longest)    # (a bounded reference sample: --cpu-refs)
             h.set_queries(q)
             got = h.overlap_matrix().astype(np.float64)
             if fmt:

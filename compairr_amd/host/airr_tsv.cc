@@ -12,6 +12,7 @@
  */
 #include "airr_tsv.h"
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -325,35 +326,81 @@ void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
   }
 }
 
-bool read_whole_file(const char *filename, std::vector<char> &text)
+/* the file's bytes and a closing NUL (the last line may lack its LF) */
+struct FileText {
+  char  *p = nullptr;
+  size_t size = 0;            /* bytes of the file */
+  ~FileText() { free(p); }
+  char *data() { return p; }
+};
+
+/* A regular file: one allocation of its size, filled by `threads` readers side by side (pread) -- a vector
+   that doubles copies a 250 MB file twice over, value-initialises it first, and one thread reads it at
+   3 GB/s.  Anything else (a pipe, standard input): read to its end into a growing buffer. */
+bool read_whole_file(const char *filename, size_t threads, FileText &text)
 {
-  FILE *fp = nullptr;
-  if (strcmp(filename, "-") == 0) {
-    int fd = dup(STDIN_FILENO);
-    fp = fd < 0 ? nullptr : fdopen(fd, "rb");
-  } else {
-    fp = fopen(filename, "rb");
-  }
-  if (!fp)
+  int fd = strcmp(filename, "-") == 0 ? dup(STDIN_FILENO) : open(filename, O_RDONLY);
+  if (fd < 0)
     return false;
-  size_t used = 0;
-  /* a regular file: one allocation of its size (a vector that doubles copies a 250 MB file twice over) */
   struct stat sb;
-  if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0)
-    text.resize((size_t)sb.st_size + 2);
-  else
-    text.resize(1 << 20);
-  for (;;) {
-    if (used + 1 >= text.size())
-      text.resize(text.size() * 2);
-    size_t got = fread(text.data() + used, 1, text.size() - used - 1, fp);
-    if (got == 0)
-      break;
-    used += got;
+  if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && lseek(fd, 0, SEEK_CUR) == 0) {
+    const size_t n = (size_t)sb.st_size;
+    text.p = (char *)malloc(n + 1);
+    if (text.p) {
+      const size_t parts = std::max<size_t>(1, std::min<size_t>(threads, n / (4 << 20) + 1));
+      std::vector<size_t> got(parts, 0);
+      std::vector<std::thread> pool;
+      for (size_t r = 0; r < parts; r++)
+        pool.emplace_back([&, r]() {
+          size_t at = n * r / parts;
+          const size_t end = n * (r + 1) / parts;
+          while (at < end) {
+            const ssize_t k = pread(fd, text.p + at, end - at, (off_t)at);
+            if (k <= 0)
+              break;
+            at += (size_t)k;
+          }
+          got[r] = at - n * r / parts;
+        });
+      for (auto &t : pool)
+        t.join();
+      size_t used = 0;
+      bool whole = true;
+      for (size_t r = 0; r < parts; r++) {
+        whole = whole && got[r] == n * (r + 1) / parts - n * r / parts;
+        used += got[r];
+      }
+      if (whole) {
+        close(fd);
+        text.size = used;
+        text.p[used] = 0;
+        return true;
+      }
+      /* (the file shrank under our feet: read it the plain way) */
+      free(text.p);
+      text.p = nullptr;
+    }
   }
-  fclose(fp);
-  text.resize(used + 1);
-  text[used] = 0;              /* the last line may lack its LF */
+  size_t cap = 1 << 20, used = 0;
+  text.p = (char *)malloc(cap);
+  while (text.p) {
+    if (used + 1 >= cap) {
+      cap *= 2;
+      char *q = (char *)realloc(text.p, cap);
+      if (!q)
+        break;
+      text.p = q;
+    }
+    const ssize_t k = read(fd, text.p + used, cap - used - 1);
+    if (k <= 0)
+      break;
+    used += (size_t)k;
+  }
+  close(fd);
+  if (!text.p)
+    return false;
+  text.size = used;
+  text.p[used] = 0;
   return true;
 }
 
@@ -363,11 +410,11 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
                    const char *default_rep, FILE *log, RepertoireSet &d, bool need_id,
                    bool keep_id)
 {
-  std::vector<char> text;
-  if (!read_whole_file(filename, text)) {
+  FileText text;
+  if (!read_whole_file(filename, (size_t)std::max<int64_t>(1, o.threads), text)) {
     exit_with_message(log, true, std::string("\nError: Unable to open input data file (") + filename + ").\n");
   }
-  const size_t size = text.size() - 1;
+  const size_t size = text.size;
   if (size == 0)
     fatal("Unable to read from the input file");   /* db.cc:758-759 */
 

@@ -111,8 +111,19 @@ double cell_value(const Options &o, double cell, const RepertoireTotals &t1,
 
 }  // namespace
 
+/* COMPAIRR_HOST_TIMING=1: where the host program's wall-clock time goes, on stderr */
+static void host_mark(const char *what)
+{
+  static const bool on = getenv("COMPAIRR_HOST_TIMING") != nullptr;
+  static const auto t_first = std::chrono::steady_clock::now();
+  if (on)
+    fprintf(stderr, "[host %8.3f ms] %s\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count(), what);
+}
+
 int compairr_main(int argc, char **argv, OverlapBackend &backend)
 {
+  host_mark("main");
   Options o;
   parse_command_line(argc, argv, o);
 
@@ -205,8 +216,10 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   auto t1 = std::chrono::steady_clock::now();
   fprintf(log, "Reading sequences: %.9lfs\n\n",
           std::chrono::duration<double>(t1 - t0).count());
+  host_mark("file 1 read");
   totals_of(set1, tot1);
   log_repertoires(log, set1, tot1);
+  host_mark("file 1 totals");
 
   if (o.existence && set1.repertoires.names.size() > 1)
     fatal("Multiple repertoires are not allowed in the first file specified on the command "
@@ -255,6 +268,7 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   const RepertoireSet &set2 = same ? set1 : set2_storage;
   const RepertoireTotals &tot2 = same ? tot1 : tot2_storage;
 
+  host_mark("both sets ready");
   fprintf(log, "Unique V genes:    %lu\n", (unsigned long)genes.v.names.size());
   fprintf(log, "Unique J genes:    %lu\n", (unsigned long)genes.j.names.size());
 
@@ -268,11 +282,13 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   PairList pairs;
   if (warm.joinable())
     warm.join();
+  host_mark("backend warm");
   if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error,
                        o.pairs ? &pairs : nullptr)) {
     fprintf(stderr, "\nError: %s\n", error.c_str());
     return 1;
   }
+  host_mark("backend done");
   /* the reference's duplicate warnings (overlap.cc:846-851, 872-873) */
   if (rep.dup_set1 > 0)
     fprintf(log, "Warning: %lu duplicates detected in repertoire set 1\n",

@@ -18,7 +18,7 @@ PY
 ls -la $T
 for args in "-d 1" "-d 1 -i"; do
   t0=$(date +%s%N)
-  $R/bin/compairr -m $T/a.tsv $T/b.tsv $args -t 64 -o $T/ours.out -l $T/ours.log
+  COMPAIRR_HOST_TIMING=1 $R/bin/compairr -m $T/a.tsv $T/b.tsv $args -t 64 -o $T/ours.out -l $T/ours.log
   echo "ours  $args: $(( ($(date +%s%N) - t0) / 1000000 )) ms wall"
   grep -E "Reading sequences|Hashing|Query layout|Analysing|GPU kernel|Writing" $T/ours.log
   if [ -x $R/oracle/_ref/compairr ]; then
