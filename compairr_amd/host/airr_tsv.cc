@@ -144,7 +144,18 @@ inline const char *field(const std::vector<char *> &f, int col)
 struct LocalNames {
   std::unordered_map<std::string, uint32_t> index;
   std::vector<std::string> names;           /* first-appearance order */
+  /* (the value seen last is the commonest next one -- a file is mostly runs of one repertoire, and the gene
+     of a line is often the gene of the line before: no map look-up then) */
+  uint32_t last_no = 0xffffffffu;
   uint32_t intern(const char *s)
+  {
+    if (last_no != 0xffffffffu && names[last_no] == s)
+      return last_no;
+    const uint32_t no = intern_slow(s);
+    last_no = no;
+    return no;
+  }
+  uint32_t intern_slow(const char *s)
   {
     auto it = index.find(s);
     if (it != index.end())
@@ -306,8 +317,16 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
 /* parses the lines of text[begin, end) (ends at a line end or at EOF) */
 void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
                  const Options &o, const Columns &c, const char *default_rep,
-                 RangeResult &out, bool need_id)
+                 RangeResult &out, bool need_id, size_t nlines)
 {
+  /* (the lines of the range were counted for the error messages' sake: room for one sequence each, no vector
+     grows -- and copies itself -- while the range is parsed) */
+  out.lengths.reserve(nlines);
+  out.v.reserve(nlines);
+  out.j.reserve(nlines);
+  out.rep.reserve(nlines);
+  out.count.reserve(nlines);
+  out.residues.reserve(nlines ? (end - begin) / 6 + 64 : 0);
   std::vector<char *> fields;
   uint64_t lineno = first_lineno;
   size_t pos = begin;
@@ -458,8 +477,8 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
   }
   /* line number of the first line of every range (error messages) */
   std::vector<uint64_t> first_line(nranges, lineno + 1);
+  std::vector<uint64_t> lines(nranges, 0);
   {
-    std::vector<uint64_t> lines(nranges, 0);
     std::vector<std::thread> pool;
     for (size_t r = 0; r < nranges; r++)
       pool.emplace_back([&, r]() {
@@ -483,7 +502,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     for (size_t r = 0; r < nranges; r++)
       pool.emplace_back([&, r]() {
         parse_range(text.data(), cut[r], cut[r + 1], first_line[r], o, cols, default_rep,
-                    part[r], need_id);
+                    part[r], need_id, (size_t)lines[r] + 1);
       });
     for (auto &t : pool)
       t.join();
