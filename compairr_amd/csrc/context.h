@@ -133,6 +133,8 @@ struct cmpr_context {
                                      entry, eight of them set) */
   int64_t slice_pages = -1;       /* variant 2, d = 1: overfull slices get up to 2^this pages; -1 = up to 8, 0 = none */
   int64_t page_budget = 0;        /* entries a slice may hold before it gets pages; 0 = 24 per word (tests: small) */
+  int64_t bucket_bitmap = -1;     /* resolve_kernel asks the bucket bitmap before it reads a slot of the record table:
+                                     -1 = where most positives are false (d = 2), 0 never, 1 always */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
   int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */
   int64_t heavy_threshold = -1;   /* class population above which it is split;
@@ -187,6 +189,7 @@ struct cmpr_context {
   DevBuf<uint8_t>   res2;
   DevBuf<uint64_t>  off2, cnt2, bloom;
   DevBuf<uint32_t>  v2, j2, rep2;
+  DevBuf<uint32_t>  bmap2;          /* one bit per bucket of the record table: it holds a record */
   DevBuf<unsigned char> rec2;      /* the record table (layout.h RefRec; ref_index.hip) */
   DevBuf<uint32_t>  voff2;          /* slot of sequence i in it */
   uint64_t          slots = 0, bloom_words = 0;     /* slots: buckets of the record table (a power of two) */

@@ -308,6 +308,8 @@ struct PackParams {
   const uint32_t *tag;             /* dir_tag of the sequence's key */
   const uint32_t *home;            /* its bucket */
   const uint32_t *more;            /* != 0: the next slot holds another record of the bucket */
+  uint32_t       *bmap;            /* one bit per bucket: set for the buckets that hold a record */
+  uint32_t        packed;          /* 1: nucleotides, two bits per residue (layout.h REC_RES_NT) */
   const uint8_t  *res;
   uint64_t        n;
   unsigned char  *out;
@@ -329,9 +331,18 @@ pack_records_kernel(const PackParams B)
   r.j = B.j ? B.j[i] : 0u;
   r.rep = B.rep[i];
   r.home = B.home[i];
-  for (uint32_t p = 0; p < REC_RES; p++)
-    r.res[p] = p < L ? B.res[b + p] : (unsigned char)0xff;
+  if (B.packed) {
+    for (uint32_t p = 0; p < REC_RES; p++)
+      r.res[p] = 0;
+    for (uint32_t p = 0; p < L && p < REC_RES_NT; p++)
+      r.res[p >> 2] |= (unsigned char)((B.res[b + p] & 3u) << ((p & 3u) * 2u));
+  } else {
+    for (uint32_t p = 0; p < REC_RES; p++)
+      r.res[p] = p < L ? B.res[b + p] : (unsigned char)0xff;
+  }
   ((RefRec *)B.out)[B.voff[i]] = r;
+  if (B.bmap && !B.more[i])                        /* (once per bucket: by its last record) */
+    atomicOr(B.bmap + (r.home >> 5), 1u << (r.home & 31u));
 }
 
 /* ------------------------------------------------------------------ */
@@ -583,16 +594,38 @@ __device__ __forceinline__ bool verify_candidate(const ProbeParams &P, uint32_t 
   bool ok = M == want;
   if (GENES)
     ok = ok && (q_v == rec.v) && (q_j == rec.j);
-  const uint32_t r0[4] = {t0.x, t0.y, t0.z, t0.w}, r1w[4] = {t1.x, t1.y, t1.z, t1.w};
+  /* the record's residues: a byte each, or (nucleotides) two bits each -- 16 positions per dword, spread to
+     the four byte-dwords block_mismatch compares */
+  const uint32_t pk[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  auto spread = [](uint32_t x, uint32_t out[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b8 = (x >> (8 * k)) & 0xffu;
+      out[k] = (b8 & 3u) | ((b8 & 0xcu) << 6) | ((b8 & 0x30u) << 12) | ((b8 & 0xc0u) << 18);
+    }
+  };
+  uint32_t r0[4] = {t0.x, t0.y, t0.z, t0.w}, r1w[4] = {t1.x, t1.y, t1.z, t1.w};
+  const bool packed = P.rec_packed != 0u;
+  if (packed) {
+    spread(pk[0], r0);
+    spread(pk[1], r1w);
+  }
   uint32_t bad = block_mismatch(0, q, r0, kind, p1, r1, p2, r2, M) |
                  block_mismatch(1, q + 4, r1w, kind, p1, r1, p2, r2, M);
   if (ok && bad == 0 && M > REC_RES) {
-    /* residues past the 32nd: the hit's from set 2 as it lies, the query's from its tile
-       (rare -- a CDR3 is shorter) */
-    const uint8_t *hr = P.res2 + P.off2[rec.idx];
+    /* residues past the 32nd: nucleotides up to the 128th from the record, everything else from set 2 as
+       it lies; the query's from its tile (rare for amino acids -- a CDR3 is shorter) */
+    const uint8_t *hr = P.res2 + ((!packed || M > REC_RES_NT) ? P.off2[rec.idx] : 0ull);
     const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
     for (uint32_t c = 2; 16 * c < M; c++) {
       uint32_t rr[4] = {0, 0, 0, 0};
+      if (packed && c < 8u) {
+        uint32_t x = pk[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++)
+          x = c == k ? pk[k] : x;
+        spread(x, rr);
+      } else
       for (uint32_t x = 0; x < 16u && 16u * c + x < M; x++)
         rr[x >> 2] |= (uint32_t)hr[16u * c + x] << (8u * (x & 3u));
       uint32_t qq[6];
@@ -747,7 +780,11 @@ resolve_kernel(const ProbeParams P)
       bk = (uint32_t)(base + lane) & P.dir_mask;
     if (CMPR_DBG(P, DBG_RES_SEQ_QREC))
       e.slot = (uint32_t)((base + lane) % 8000000ull);
-    /* every positive is a candidate: its bucket's first slot is where the walk starts */
+    /* a positive whose bucket holds a record is a candidate: the bucket's slot is where the walk starts.
+       (The filter's false positives name an empty bucket two times out of three; with single rows at d = 2
+       six of seven positives are false.) */
+    if (P.bmap && active)
+      active = ((P.bmap[bk >> 5] >> (bk & 31u)) & 1u) != 0u;
     const uint64_t mm = __ballot(active);
     if (mm) {
       if (active) {

@@ -291,7 +291,9 @@ constexpr uint32_t POS_NULL_SLOT = 0xffffffffu;
    (ref_index.hip): a 32-byte header and the first 32 residues, one byte each -- ONE 64-byte
    memory line per looked-up CDR3.  A longer sequence has its further residues where the set
    lies (ProbeParams::res2 / off2). */
-constexpr uint32_t REC_RES = 32;              /* residues inside the record */
+constexpr uint32_t REC_RES = 32;              /* residues inside the record (amino acids: a byte each) */
+constexpr uint32_t REC_RES_NT = 128;          /* ... nucleotides: two bits each, four to a byte (a CDR3 of 45 nucleotides is
+                                                 verified from the slot alone, like one of 15 amino acids) */
 constexpr uint32_t REC_EMPTY = 0xffffffffu;   /* RefRec::idx of an empty slot */
 constexpr uint32_t REC_MORE = 1u << 16;       /* RefRec::len: the next slot holds another record of this bucket */
 constexpr uint32_t REC_TAG_SHIFT = 17;        /* RefRec::len bits 17..31: 15 bits of the key (kernels.h dir_tag) */
@@ -332,7 +334,10 @@ struct ProbeParams {
                                         out by counters (deal_ctr), in list order: heaviest first */
   /* record table of set 2 (ref_index.hip): the records of hash bucket b lie from slot b of rec2 on */
   uint32_t        dir_mask;         /* buckets - 1 */
-  uint32_t        pad0;
+  uint32_t        rec_packed;       /* 1: nucleotides -- a record holds its first REC_RES_NT residues, two bits each */
+  const uint32_t *bmap;             /* one bit per bucket: it holds a record (NULL: not consulted).  A filter's false
+                                       positive names an empty bucket two times out of three; the bits of 2^25 buckets
+                                       are 4 MiB -- answered from cache, where the table's slot is a line of HBM */
   /* set 2 records */
   const uint8_t  *res2;
   const uint64_t *off2;

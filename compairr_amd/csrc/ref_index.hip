@@ -711,6 +711,8 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     if (nslots >> 32)
       return fail(c, CMPR_EUNSUPPORTED, "reference set too large for 32-bit record positions");
     if ((rc = dev_alloc(c, c->rec2, (size_t)nslots * sizeof(RefRec)))) return rc;
+    if ((rc = dev_alloc(c, c->bmap2, (size_t)(c->slots / 32 + 1)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->bmap2.p, 0, (size_t)(c->slots / 32 + 1) * sizeof(uint32_t), c->stream));
     /* (all ones: RefRec::idx of an empty slot) */
     HIP_TRY(c, hipMemsetAsync(c->rec2.p, 0xff, (size_t)nslots * sizeof(RefRec), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));     /* (the temporaries go away) */
@@ -745,6 +747,8 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     K.tag = tags.b.p;
     K.home = buckets.b.p;
     K.more = more.b.p;
+    K.bmap = c->bmap2.p;
+    K.packed = A == 4 ? 1u : 0u;
     K.out = c->rec2.p;
     const uint32_t grid = (uint32_t)((s->n + BLOCK_THREADS - 1) / BLOCK_THREADS);
     hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, K);

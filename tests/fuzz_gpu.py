@@ -87,6 +87,8 @@ def random_case(rng):
         tun["variant"] = 2                                # the row filter, also where it is not the default
     if rng.random() < 0.25:
         tun["chunk_deal"] = 0                             # every chunk dealt statically (default: by counters)
+    if rng.random() < 0.3:
+        tun["bucket_bitmap"] = int(rng.integers(0, 2))    # the bucket bitmap in front of the record table
     if rng.random() < 0.35:
         tun["page_budget"] = int(rng.integers(1, 200))    # overfull slices get pages (variant 2, d = 1)
         if rng.random() < 0.3:

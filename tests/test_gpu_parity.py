@@ -87,6 +87,9 @@ LAYOUTS = {
     "rows_pages_inline": {"variant": 2, "page_budget": 10, "deferred_resolve": 0, "slice_words_log2": 4},
     "rows_pages_overflow": {"variant": 2, "page_budget": 10, "pos_capacity": 64, "slice_words_log2": 4},
     "rows_pages_off": {"variant": 2, "slice_pages": 0},
+    # the bucket bitmap asked / not asked in front of every slot of the record table (default: at d = 2 only)
+    "rows_bitmap_on": {"variant": 2, "bucket_bitmap": 1},
+    "lds_bitmap_off": {"variant": 1, "bucket_bitmap": 0, "slice_words_log2": 5},
     # every chunk dealt statically (the default hands out all but a workgroup's first four by a counter)
     "rows_static_deal": {"variant": 2, "chunk_deal": 0},
     "rows_static_deal_tiny": {"variant": 2, "chunk_deal": 0, "slice_words_log2": 3, "class_residues": 2,
