@@ -1441,6 +1441,17 @@ probe_rows_kernel(const ProbeParams P)
               const uint32_t te_own = e_cls ? class_term(e, re) : 0u;
               const bool live = pb < Ll;                          /* pb < Ll implies pa < Ll */
               nvar += live ? (uint32_t)((A - 1) * (A - 1)) : 0u;
+              /* Exactly one class position (it is b): every row of the pair lies in ONE slice of b's class part,
+                 the slice the query's ITEM of that position is grouped by -- the item reads them there, from LDS
+                 (below, passes >= 3; round 5).  Here they were 37 % of a query's reads, each a random 32 bytes of
+                 the filter in HBM: 24.2M sequences against themselves, 230 ms.  Left to this loop: queries whose
+                 class positions wrap or that do not fit a record (36 residues), lane by lane. */
+              bool rd = live;
+              if (b_cls && !e_cls) {
+                rd = live && !(Ll >= P.geom.c0 + K && Ll <= 36u);
+                if (!__ballot(rd))
+                  continue;
+              }
               for (uint32_t k0 = 1; k0 < (uint32_t)A; k0 += RB) {
                 uint64_t m0 = 0, m1 = 0;
 #pragma unroll
@@ -1459,7 +1470,7 @@ probe_rows_kernel(const ProbeParams P)
                       w = fetch_at(Wk, sl, staged && sl == tslice);
                     }
                     uint32_t x = row_bits(w, Wk) & AMASK & ~(1u << rb);
-                    x = live ? x : 0u;
+                    x = rd ? x : 0u;
                     if (j < RPW)
                       m0 |= (uint64_t)x << (A * j);
                     else
@@ -1502,6 +1513,9 @@ probe_rows_kernel(const ProbeParams P)
           /* the unit's further blocks: requested together now, worked on after the
              first (whose data came with the claim) */
           const uint32_t nblk = un.nblk;
+          /* (d = 2: a block is ~230 word reads per item -- its successor's 16 bytes are fetched when it is
+             their turn, not kept in twelve registers meanwhile) */
+          constexpr bool AHEAD = D < 2;
           uint64_t ea[ITEM_BLOCKS - 1];
           uint32_t eb[ITEM_BLOCKS - 1], ec[ITEM_BLOCKS - 1];
 #pragma unroll
@@ -1509,7 +1523,7 @@ probe_rows_kernel(const ProbeParams P)
             ea[r - 1] = 0;
             eb[r - 1] = 0xffffffffu;
             ec[r - 1] = 0;
-            if (r < nblk) {
+            if (AHEAD && r < nblk) {
               const ItemRec it = P.items[tres + r * WAVE + lane];
               ea[r - 1] = it.w;
               eb[r - 1] = it.main;
@@ -1592,15 +1606,98 @@ probe_rows_kernel(const ProbeParams P)
               x = 0;
             q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, x != 0, iw, pack_a(kind, p, 0), 0, x,
                                         (uint32_t)__popc(x));
-            /* next block's data moves up */
-            iw = ea[0];
-            im = eb[0];
-            ic = ec[0];
+            if constexpr (D >= 2) {
+              /* ---- d = 2: the double substitutions with THIS class position blanked and one other, non-class
+                      position e substituted (variants.cc:370-399) -- every one of their rows lies in the slice
+                      staged for this block (the item's own: the key loses the blanked position's term, and e
+                      carries none).  iw = the query's hash with the class position blanked; the query's residues
+                      come with its record.  The variants were counted by the tile (main pass). ---- */
+              const uint32_t KI = P.geom.k;
+              const QueryRec *rq = P.qrec + (ival ? im : 0u);
+              const uint32_t Lq = ival ? rq->len : 0u;
+              const bool ext = ival && kind == K_SUB && Lq >= P.geom.c0 + KI && Lq <= 36u;
+              if (__ballot(ext)) {
+                uint32_t lmax = ext ? Lq : 0u;            /* the longest query among the lanes that take part */
+                for (int off = 32; off > 0; off >>= 1)
+                  lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off, WAVE));
+                lmax = __builtin_amdgcn_readfirstlane(lmax);
+                /* (the record's residue dwords one after the other, the next one in flight while four
+                   positions are worked on: nine registers of them spilled) */
+                uint32_t dcur = ext ? rq->res[0] : 0u, dnext = 0;
+                for (uint32_t e = 0; e < lmax; e++) {
+                  if ((e & 3u) == 0u) {
+                    if (e)
+                      dcur = dnext;
+                    dnext = (ext && e + 4u < 36u) ? rq->res[(e >> 2) + 1u] : 0u;
+                  }
+                  if (e >= P.geom.c0 && e < P.geom.c0 + KI)
+                    continue;                      /* a class position: both of them class -- the tile reads those */
+                  const uint32_t re = (dcur >> ((e & 3u) * 8u)) & 31u;
+                  const bool lv2 = ext && e < Lq;
+                  const uint32_t ea2 = zl_addr + (ZS * e + (lv2 ? re : 0u)) * 8u;
+                  const uint64_t hb2 = iw ^ lds_u64(ea2);
+                  for (uint32_t k0 = 1; k0 < (uint32_t)A; k0 += RB) {
+                    uint64_t m0 = 0, m1 = 0;
 #pragma unroll
-            for (uint32_t q = 0; q + 2 < ITEM_BLOCKS; q++) {
-              ea[q] = ea[q + 1];
-              eb[q] = eb[q + 1];
-              ec[q] = ec[q + 1];
+                    for (int j = 0; j < RB; j++) {
+                      const uint32_t k = k0 + (uint32_t)j;
+                      if (k < (uint32_t)A) {
+                        const uint64_t Wk = hb2 ^ lds_u64(ea2 + 8u * k);     /* e <- (re + k) mod A */
+                        const uint32_t wo2 = woff_of(Wk);
+                        treads += lv2 ? 1u : 0u;
+                        const RowWord w2 = staged ? word_lds(wo2) : word_glob(own_glob, wo2);
+                        uint32_t xb = row_bits(w2, Wk) & AMASK & ~(1u << icr);
+                        xb = lv2 ? xb : 0u;
+                        if (CMPR_DBG(P, DBG_SKIP_EMIT))
+                          xb = 0;
+                        if (j < RPW)
+                          m0 |= (uint64_t)xb << (A * j);
+                        else
+                          m1 |= (uint64_t)xb << (A * (j - RPW));
+                      }
+                    }
+                    while (__ballot((m0 | m1) != 0)) {
+                      const bool pos = (m0 | m1) != 0;
+                      const bool first = m0 != 0;
+                      const uint64_t mm = first ? m0 : m1;
+                      const uint32_t idx = pos ? (uint32_t)__ffsll((unsigned long long)mm) - 1u : 0u;
+                      uint32_t j = idx / (uint32_t)A;
+                      const uint32_t v = idx - j * (uint32_t)A;
+                      j += (pos && !first) ? (uint32_t)RPW : 0u;
+                      const uint32_t k = k0 + j;
+                      uint32_t wres = re + k;
+                      wres = wres >= (uint32_t)A ? wres - (uint32_t)A : wres;
+                      const uint64_t hv = hb2 ^ lds_u64(ea2 + 8u * k) ^ lds_u64(zl_addr + (ZS * p + v) * 8u);
+                      /* (position, residue) pairs in increasing position order */
+                      const bool cfirst = p < e;
+                      const uint32_t p1 = cfirst ? p : e, r1 = cfirst ? v : wres;
+                      const uint32_t p2 = cfirst ? e : p, r2 = cfirst ? wres : v;
+                      q_push<A, D, GENES, INLINE, PAIRS>(W, zl_addr, pos, hv, pack_a(K_SUB2, p1, r1), p2 | (r2 << 24), 1u, 1u);
+                      if (first)
+                        m0 &= m0 - 1ull;
+                      else
+                        m1 &= m1 - 1ull;
+                    }
+                  }
+                }
+              }
+            }
+            /* next block's data moves up */
+            if constexpr (AHEAD) {
+              iw = ea[0];
+              im = eb[0];
+              ic = ec[0];
+#pragma unroll
+              for (uint32_t q = 0; q + 2 < ITEM_BLOCKS; q++) {
+                ea[q] = ea[q + 1];
+                eb[q] = eb[q + 1];
+                ec[q] = ec[q + 1];
+              }
+            } else if (r + 1u < nblk) {
+              const ItemRec it = P.items[tres + (r + 1u) * WAVE + lane];
+              iw = it.w;
+              im = it.main;
+              ic = it.rp;
             }
           }
         }

@@ -1262,7 +1262,8 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
     return;
   const Chunk ck = Q.chunks[k];
   const uint32_t cpass = ck.pass & 0xffu;
-  uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : 2) : 0;
+  /* (variant 2 at d = 2 on single rows: an item reads ~12 x 19 words of its slice, kernels_rows.h) */
+  uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : (Q.rows && Q.differences == 2) ? 230 : 2) : 0;
   for (uint32_t t = 0; cpass < 3 && t < ck.ntiles; t++) {
     const TileDesc td = Q.tile_refs[ck.first_tile + t].td;
     /* (variant 2: a tile costs its wave the same however full it is; ~10 rows' worth per unit for claim,
