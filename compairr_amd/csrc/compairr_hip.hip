@@ -470,6 +470,12 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (value < -1 || value > 1)
       return fail(c, CMPR_EINVAL, "bucket_bitmap must be -1 (auto), 0 or 1");
     c->bucket_bitmap = value;
+  } else if (n == "fill_slices") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, "fill_slices must be 0 or 1");
+    if (c->have_ref)
+      return fail(c, CMPR_ESTATE, "set fill_slices before cmpr_set_reference");
+    c->fill_slices = value;
   } else if (n == "row_filter_x16") {
     if (value < 8 || value > 128)
       return fail(c, CMPR_EINVAL, "row_filter_x16 must be 8..128 (sixteenths of a byte per entry)");
@@ -529,6 +535,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "deferred_resolve") *value = c->deferred_resolve;
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
   else if (n == "row_filter_x16") *value = c->row_filter_x16;
+  else if (n == "fill_slices") *value = c->fill_slices;
   else if (n == "bucket_bitmap") *value = c->bucket_bitmap;
   else if (n == "slice_pages") *value = c->slice_pages;
   else if (n == "page_budget") *value = c->page_budget;

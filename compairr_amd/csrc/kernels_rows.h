@@ -1447,6 +1447,8 @@ probe_rows_kernel(const ProbeParams P)
                  the filter in HBM: 24.2M sequences against themselves, 230 ms.  Left to this loop: queries whose
                  class positions wrap or that do not fit a record (36 residues), lane by lane. */
               bool rd = live;
+              if (b_cls && e_cls && CMPR_DBG(P, DBG_SKIP_HBM_ROWS))
+                continue;                    /* (ablation: the rows of two class positions, read where the filter lies) */
               if (b_cls && !e_cls) {
                 rd = live && !(Ll >= P.geom.c0 + K && Ll <= 36u);
                 if (!__ballot(rd))

@@ -344,6 +344,14 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     if (words >= 64)
       words = (words + 31) / 32 * 32;                  /* whole KiB: LDS-DMA pieces */
     words = std::max<uint64_t>(1, std::min<uint64_t>(words, row_max_words));
+    /* d = 2 on single rows: the slices are as large as the LDS takes them, whatever the entry count asks for.
+       S is a power of two, so a slice is between half full and full of what it may hold; the room left is
+       free here -- a tile is ~2000 word reads per lane, the copy of its slice nothing beside them -- and a
+       query's 38 000 variant tests meet a filter up to twice as sparse: 24.2M sequences against themselves,
+       370 -> 640 words per slice, positives 1.09 x 10^9 -> 2 x 10^8 for 1.55 x 10^8 pairs, step 130 -> 95 ms
+       (round 5).  At d = 1 the copies are what the kernel waits for: the slices stay as small as they can be. */
+    if (c->opt.differences == 2 && !c->d2pairs && c->slice_words_log2 < 0 && c->fill_slices != 0 && S > 1)
+      words = row_max_words;
     if (S > (1ull << 31))
       return fail(c, CMPR_EUNSUPPORTED, "row filter with more than 2^31 slices");
     c->geom.rw_words = (uint32_t)words;
