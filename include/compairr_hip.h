@@ -336,16 +336,30 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
      "chunk_deal"            variant 2: 1 (default): beyond a workgroup's first four, chunks are handed out
                              by counters in list order (heaviest first) -- on skewed data (the cdr3 law,
                              d = 1 -i) the probe kernel takes 1.5 ms where a static deal takes 2.5; 0: static
+     "table_log2_delta"      buckets of the record table = 2^delta x the 70 % rule of hashtable.cc:24 (default 1:
+                             at most 0.35 full -- one memory line per looked-up sequence); 0..3
+     "bucket_bitmap"         resolve_kernel asks a bitmap (one bit per bucket: it holds a record) before it
+                             reads a slot of the record table: -1 (default) where most Bloom positives are
+                             false (d = 2), 0 never, 1 always
+     "slice_pages"           variant 2, d = 1: a slice of the row filter that holds more than "page_budget"
+                             entries is spread over up to 2^this pages by hash bits, its tiles worked on once
+                             per page (-1 = default: 3; 0: no pages); "page_budget": entries, 0 = default
+                             (20 per 32-byte word)
+     "fill_slices"           variant 2, d = 2 on single rows: 1 (default) the slices take all the words their
+                             LDS buffer holds (a sparser filter for the 38 000 tests of a query), 0 as many
+                             as the entries ask for
+     "row_filter_x16"        variant 2: bytes of filter per entry in sixteenths (default 32 = 2 bytes)
      "pos_grow"              the positives buffer grows to what a launch showed when it overflowed:
                              -1 (default) when its size was automatic, 1 also from a given
                              "pos_capacity", 0 never
      "deferred_resolve", "resolve_blocks_per_cu", "pos_segments", "pos_capacity",
-     "heavy_threshold", "class_anchor", "class_rows_unstaged", "table_log2_delta",
+     "heavy_threshold", "class_anchor", "class_rows_unstaged",
      "host_threads"          see compairr_amd/csrc/compairr_hip.hip
      "assume_never_overflows" TEST ONLY: the next launch runs without redo pass as if
                              the margin had been shown
-   "variant", "bloom_bits_log2_delta", "class_residues", "slice_words_log2", "d2_pairs" and
-   "d2_buffers" must be set before cmpr_set_reference(); "chunk_tiles", "waves_per_block",
+   "variant", "bloom_bits_log2_delta", "class_residues", "slice_words_log2", "d2_pairs", "d2_buffers",
+   "table_log2_delta", "slice_pages", "page_budget", "fill_slices" and "row_filter_x16" must be set before
+   cmpr_set_reference(); "chunk_tiles", "waves_per_block",
    "small_slice_tiles" and the work shard before cmpr_set_queries().  ("debug" exists
    only in a -DCMPR_ABLATION build of the library.) */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
