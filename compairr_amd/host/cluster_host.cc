@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -70,8 +71,13 @@ int run_cluster(const Options &o, OverlapBackend &backend, FILE *log, FILE *out)
 
   GeneTables genes;
   RepertoireSet set;
+  /* (the backend's data-independent start-up runs while the file is read: overlap_host.h prewarm) */
+  reader_thread_active(true);          /* (an error exit meanwhile leaves through _exit: options.h) */
+  std::thread warm([&]() { backend.prewarm(o); });
   auto t0 = std::chrono::steady_clock::now();
   read_airr_tsv(o.input1, o, genes, "1", log, set, false, true);   /* cluster.cc:232 */
+  warm.join();
+  reader_thread_active(false);
   fprintf(log, "Reading sequences: %.9lfs\n",
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   const uint64_t n = set.size();

@@ -181,10 +181,13 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   RepertoireTotals tot1, tot2_storage;
   const bool same = !(o.input2 && strcmp(o.input1, o.input2));
 
+  /* (while a helper thread runs, an error exit leaves through _exit: no static destructor of the HIP runtime
+     under the feet of a thread that is just starting it -- options.h reader_thread_active) */
+  reader_thread_active(true);
   std::thread warm([&]() { backend.prewarm(o); });
   struct Joiner {
     std::thread &t;
-    ~Joiner() { if (t.joinable()) t.join(); }
+    ~Joiner() { if (t.joinable()) { t.join(); reader_thread_active(false); } }
   } warm_joiner{warm};
 
   GeneTables genes2;                      /* file 2's genes in ITS first-appearance order, merged below */
@@ -280,8 +283,10 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
   BackendReport rep;
   std::string error;
   PairList pairs;
-  if (warm.joinable())
+  if (warm.joinable()) {
     warm.join();
+    reader_thread_active(false);
+  }
   host_mark("backend warm");
   if (!backend.overlap(o, genes, set1, set2, same, cells, rep, error,
                        o.pairs ? &pairs : nullptr)) {
