@@ -12,6 +12,7 @@
  */
 #include "airr_tsv.h"
 
+#include <chrono>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <stdarg.h>
@@ -429,14 +430,25 @@ bool read_whole_file(const char *filename, size_t threads, FileText &text)
 
 }  // namespace
 
+/* COMPAIRR_HOST_TIMING=1: the reader's phases, on stderr */
+static void reader_mark(const char *file, const char *what, std::chrono::steady_clock::time_point t0)
+{
+  static const bool on = getenv("COMPAIRR_HOST_TIMING") != nullptr;
+  if (on)
+    fprintf(stderr, "[reader %s] %-12s %8.3f ms\n", file, what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
 void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
                    const char *default_rep, FILE *log, RepertoireSet &d, bool need_id,
                    bool keep_id)
 {
+  const auto t_begin = std::chrono::steady_clock::now();
   FileText text;
   if (!read_whole_file(filename, (size_t)std::max<int64_t>(1, o.threads), text)) {
     exit_with_message(log, true, std::string("\nError: Unable to open input data file (") + filename + ").\n");
   }
+  reader_mark(filename, "file read", t_begin);
   const size_t size = text.size;
   if (size == 0)
     fatal("Unable to read from the input file");   /* db.cc:758-759 */
@@ -500,6 +512,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
       first_line[r] = first_line[r - 1] + lines[r - 1];
   }
 
+  reader_mark(filename, "lines counted", t_begin);
   std::vector<RangeResult> part(nranges);
   {
     std::vector<std::thread> pool;
@@ -512,6 +525,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
       t.join();
   }
 
+  reader_mark(filename, "parsed", t_begin);
   /* the first error in file order is the one the serial reference would hit */
   for (size_t r = 0; r < nranges; r++)
     if (part[r].failed) {
@@ -587,6 +601,7 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     }
   }
 
+  reader_mark(filename, "merged", t_begin);
   /* db.cc:847-887 */
   if (d.ignored_unknown > 0)
     fprintf(log, "%lu sequences with unknown symbols ignored.\n", (unsigned long)d.ignored_unknown);
