@@ -476,6 +476,10 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (c->have_ref)
       return fail(c, CMPR_ESTATE, "set fill_slices before cmpr_set_reference");
     c->fill_slices = value;
+  } else if (n == "direct_slices_log2") {
+    if (value < -1 || value > 12)
+      return fail(c, CMPR_EINVAL, "direct_slices_log2 must be -1 (auto) or 0..12");
+    c->direct_slices_log2 = value;
   } else if (n == "row_filter_x16") {
     if (value < 8 || value > 128)
       return fail(c, CMPR_EINVAL, "row_filter_x16 must be 8..128 (sixteenths of a byte per entry)");
@@ -536,6 +540,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "table_log2_delta") *value = c->table_log2_delta;
   else if (n == "row_filter_x16") *value = c->row_filter_x16;
   else if (n == "fill_slices") *value = c->fill_slices;
+  else if (n == "direct_slices_log2") *value = c->direct_slices_log2;
   else if (n == "bucket_bitmap") *value = c->bucket_bitmap;
   else if (n == "slice_pages") *value = c->slice_pages;
   else if (n == "page_budget") *value = c->page_budget;
@@ -867,8 +872,11 @@ int make_plan(cmpr_context *c)
   P.part = c->part.p;
   P.part_stride = c->part_stride;
   P.part_cells = c->part_stride - STAT_COUNT;
-  P.work_first = (uint32_t)c->work_shard_index;
-  P.work_step = (uint32_t)c->work_shard_count;
+  /* (variant 0 at d >= 1 lays every query out and takes every count-th tile; at d = 0 -- and in the sliced
+     layouts -- what is laid out is what this context works on) */
+  const bool direct = !c->sliced && c->opt.differences == 0;
+  P.work_first = direct ? 0u : (uint32_t)c->work_shard_index;
+  P.work_step = direct ? 1u : (uint32_t)c->work_shard_count;
   P.matrix_f64 = c->matrix_f64.p;
   P.R1 = c->R1;
   P.R2 = c->R2;
@@ -966,9 +974,10 @@ int make_plan(cmpr_context *c)
     HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
   uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
-  if (c->rows) {
+  if (c->rows || direct) {
     /* variant 2 deals its chunks out statically over the workgroups of the grid:
-       exactly as many as are resident at once (registers count too) */
+       exactly as many as are resident at once (registers count too); so does the d = 0
+       kernel its tiles (a second round of workgroups would start when the first is through) */
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, nw * WAVE, lds) ==
             hipSuccess && occ > 0)

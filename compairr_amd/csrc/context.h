@@ -135,6 +135,7 @@ struct cmpr_context {
   int64_t page_budget = 0;        /* entries a slice may hold before it gets pages; 0 = 24 per word (tests: small) */
   int64_t bucket_bitmap = -1;     /* resolve_kernel asks the bucket bitmap before it reads a slot of the record table:
                                      -1 = where most positives are false (d = 2), 0 never, 1 always */
+  int64_t direct_slices_log2 = -1; /* d = 0 on variant 0: pseudo-slices of the query layout (-1: by the number of queries) */
   int64_t fill_slices = 1;        /* variant 2 at d = 2 (single rows): the slices take all the words their LDS buffer holds */
   int64_t class_residues = -1;    /* -1: choose from the data                  */
   int64_t class_anchor = -1;      /* c0, -1: from set 2's lengths              */

@@ -555,7 +555,7 @@ __device__ __forceinline__ uint32_t block_mismatch(uint32_t c, const uint32_t q[
    first 32 residues) and, when that is a record of the candidate's key, the query's record with
    its first 36 -- one 64-byte line each; sequences longer than 32 take their further residues
    from where set 2 lies.  Returns true when the walk of bucket `bk` goes on in the next slot. */
-template <bool GENES>
+template <bool GENES, bool EAGER = false>
 __device__ __forceinline__ bool verify_candidate(const ProbeParams &P, uint32_t qs, uint32_t ca,
                                                  uint32_t cb, uint32_t tag, uint32_t bk, uint32_t piece,
                                                  unsigned long long *mat_lds, LaneStats &st)
@@ -565,6 +565,12 @@ __device__ __forceinline__ bool verify_candidate(const ProbeParams &P, uint32_t 
   /* the query's record (layout.h QueryRec): count, genes, repertoire, length and
      its first 36 residues in ONE 64-byte piece, like the hit's */
   const uint4 *qp = (const uint4 *)P.qrec + (size_t)qs * 4;
+  /* EAGER (the first look of the filterless d = 0 kernel: lane = query, the 64 records one run of memory):
+     requested together with the slot, one round trip instead of two */
+  uint4 a0, a1, a2, a3;
+  if (EAGER) {
+    a0 = qp[0]; a1 = qp[1]; a2 = qp[2]; a3 = qp[3];
+  }
   if (CMPR_DBG(P, DBG_RES_NO_VERIFY)) {
     st.hash_eq += (h0.x ^ h1.x ^ t0.x ^ t1.x ^ qp[0].x ^ qp[1].x ^ qp[2].x ^ qp[3].x) == 0x12345u ? 1u : 0u;
     return false;
@@ -578,7 +584,9 @@ __device__ __forceinline__ bool verify_candidate(const ProbeParams &P, uint32_t 
   st.hash_eq++;
   /* (the query's record is asked for only now: a false positive of the filter -- on skewed data up to
      half of the positives -- costs one memory line, not two) */
-  const uint4 a0 = qp[0], a1 = qp[1], a2 = qp[2], a3 = qp[3];
+  if (!EAGER) {
+    a0 = qp[0]; a1 = qp[1]; a2 = qp[2]; a3 = qp[3];
+  }
   uint32_t q[10];
   q[0] = 0;
   q[1] = a1.z; q[2] = a1.w; q[3] = a2.x; q[4] = a2.y; q[5] = a2.z; q[6] = a2.w;
@@ -896,8 +904,9 @@ probe_kernel(const ProbeParams P)
   const uint32_t cells = P.lds_matrix ? P.R1 * P.R2 : 0u;   /* LDS copy only: <= 2048 cells */
   WaveQueue *queues = (WaveQueue *)(mat_all + (P.lds_matrix ? cells : 0));
 
-  for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)
-    zl[i] = P.zob[i];
+  if (D != 0)                            /* (d = 0: the layout has hashed the queries) */
+    for (uint32_t i = threadIdx.x; i < nz; i += BLOCK_THREADS)
+      zl[i] = P.zob[i];
   if (P.lds_matrix)
     for (uint32_t i = threadIdx.x; i < cells; i += BLOCK_THREADS)
       mat_all[i] = 0;
@@ -905,12 +914,71 @@ probe_kernel(const ProbeParams P)
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
-  Prober W{P, queues[wave], P.lds_matrix ? mat_all : nullptr,
+  /* (no LDS copy of the matrix: the workgroup's partial slot in HBM when the matrix is kept there -- a
+     self-comparison sends every identity pair to a diagonal cell --, else the matrix itself) */
+  Prober W{P, queues[wave], P.lds_matrix ? mat_all : (P.part && P.part_cells ? matrix_dst(P) : nullptr),
            lane, 0u, 0, {0ull, 0u, 0u, 0u}};
   const uint64_t *zs = P.zob;            /* wave-uniform lookups: scalar loads */
   const uint64_t *gene_keys = P.zob + nz;
 
-  for (;;) {
+  /* d = 0: every tile is the same work, dealt out statically (one counter for 4 x 10^5 tiles
+     would serialise the launch); the wave's queue holds the walks that go on (CandQueue) */
+  static_assert(sizeof(CandQueue) <= sizeof(WaveQueue), "the d = 0 kernel keeps a CandQueue where the others keep a WaveQueue");
+  CandQueue &cq = *(CandQueue *)&queues[wave];
+  int cqn = 0;
+  if (D == 0) {
+    /* ---- d = 0: the unchanged sequence is the only variant (generate_variants_0,
+            variants.cc:260-268), and it is looked up where its bucket lies, no filter word in
+            front: one test per query, and the word would cost the memory line the table's slot
+            costs.  Lane = query: the layout has left its hash in qgh, its record lies next to its
+            neighbours' (requested together with the slot), the slot is the one random line
+            (find_variant_matches, overlap.cc:168-251).  The bucket's own slot is looked at here,
+            all lanes busy; a walk that goes on (a displaced record of an earlier bucket in front,
+            more records of this bucket behind) queues up with the next slot like resolve_kernel's,
+            so that every further round trip is made by 64 busy lanes too (a wave that walked its 64
+            buckets to the end of the longest waited 6-10 round trips per tile).  The next tile's
+            hashes are on their way while this tile's slots are. ---- */
+    const uint32_t step = gridDim.x * WAVES_PER_BLOCK;
+    uint32_t t = (blockIdx.x * WAVES_PER_BLOCK + wave) * P.work_step + P.work_first;
+    uint64_t hn = 0;
+    uint32_t nvn = 0;
+    if (t < P.ntiles) {
+      hn = P.qgh[(size_t)(t + P.first_tile) * WAVE + lane];
+      nvn = P.tiles[t + P.first_tile].nvalid;
+    }
+    const uint32_t ca = pack_a(K_SAME, 0, 0);
+    while (t < P.ntiles) {
+      const uint64_t h = hn;
+      const bool valid = lane < nvn;
+      const uint32_t qslot = (t + P.first_tile) * WAVE + lane;
+      t += step * P.work_step;
+      if (t < P.ntiles) {
+        hn = P.qgh[(size_t)(t + P.first_tile) * WAVE + lane];
+        nvn = P.tiles[t + P.first_tile].nvalid;
+      }
+      const uint64_t key = table_key(h);
+      const uint32_t bk = dir_bucket(key, P.dir_mask), tag = dir_tag(key);
+      W.st.variants += valid ? 1ull : 0ull;
+      W.st.bloom_pos += valid ? 1u : 0u;
+      bool more = false;
+      if (valid)
+        more = verify_candidate<GENES, true>(P, qslot, ca, 0u, tag, bk, bk, W.mat_lds, W.st);
+      const uint64_t mm = __ballot(more);
+      if (mm) {
+        if (more) {
+          const int x = cqn + (int)rank_below(mm);
+          cq.slot[x] = qslot; cq.ca[x] = ca; cq.cb[x] = 0u; cq.tagb[x] = tag; cq.bucket[x] = bk;
+          cq.piece[x] = bk + 1u;
+        }
+        cqn += __popcll(mm);
+        while (cqn >= WAVE)
+          cqn = verify_round<GENES>(P, cq, cqn, WAVE, lane, W.mat_lds, W.st);
+      }
+    }
+    while (cqn > 0)
+      cqn = verify_round<GENES>(P, cq, cqn, cqn < WAVE ? cqn : WAVE, lane, W.mat_lds, W.st);
+  }
+  for (; D != 0;) {
     uint32_t t = 0;
     if (lane == 0)
       t = atomicAdd(P.tile_counter, 1u);
@@ -1032,7 +1100,7 @@ probe_kernel(const ProbeParams P)
 
   /* leftovers: fewer than 64 entries */
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if ((int)lane < W.qn)
+  if (D != 0 && (int)lane < W.qn)
     resolve_entry<GENES>(P, W.q, (int)lane, W.mat_lds, W.st);
 
   /* statistics: wave reduction, one atomic per counter per wave */

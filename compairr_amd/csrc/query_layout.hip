@@ -121,6 +121,9 @@ struct QL {
   uint64_t        nslices;           /* slices laid out as tiles: the real ones + the foreign pseudo-slices */
   uint64_t        nslices_real;
   uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
+  uint32_t        direct;            /* d = 0 on the un-sliced kernel: the query's hash is computed here (qgh), the
+                                        queries are grouped by pseudo-slice (bits of the hash & pmask) and length */
+  uint32_t        pmask;
   uint32_t        dbg;               /* -DCMPR_ABLATION builds: LDBG_* (timing experiments, results become wrong) */
   uint32_t        route;             /* 1: cmpr_route_queries -- the keys kernel names the contexts a query goes
                                         to (dest_lo / dest_hi, dest_cnt) instead of ranking it in its group */
@@ -203,6 +206,9 @@ __host__ __device__ inline uint32_t work_owner(uint32_t slice, uint32_t pass, ui
 {
   return (uint32_t)((((uint64_t)slice * 2654435761u + pass * 40503u) >> 7) % step);
 }
+
+/* the direct layout of d = 0 (QL::direct): a query's work shard is named by these bits of its pseudo-slice key */
+constexpr uint32_t DIRECT_OWNER_MASK = 1023u;
 
 /* does this context work on what is filed under `slice` in `pass`? */
 __device__ inline bool owned(const QL &Q, uint32_t slice, uint32_t pass)
@@ -584,7 +590,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
         ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, vg, jg, &heavy);
       else if (Q.sliced)
         ck = (uint32_t)i * 2654435761u;
-      if (Q.rows) {
+      if (Q.rows || Q.direct) {
         /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that
            seed the rolling indel enumeration (:90-104, :122-136) */
         uint64_t h = 0;
@@ -602,7 +608,12 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
               hdel ^= Q.zob[Q.A * (p - 1) + r];
           }
         }
-        if (!LDBG(Q, LDBG_NO_TMP_WRITES)) {
+        if (Q.direct) {
+          /* d = 0 without a filter: no slices to group by -- the pseudo-slice only spreads the group
+             counters (one per length would take every query's atomic) and names the work shard */
+          ck = (uint32_t)(h >> 40);
+          Q.h_tmp[i] = h;
+        } else if (!LDBG(Q, LDBG_NO_TMP_WRITES)) {
           Q.h_tmp[i] = h;
           if (Q.indels) {
             Q.hins_tmp[i] = hins;
@@ -617,7 +628,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
         /* cmpr_route_queries: the contexts this query's record goes to -- the one that works
            on its slice and those that work on one of its items (verification reads the
            record where the positive is resolved) */
-        unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : 0u, 0u, Q.wstep);
+        unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : (ck & DIRECT_OWNER_MASK), 0u, Q.wstep);
         if (Q.ngroups)
           for_each_item<false>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
             mask |= 1ull << item_owner(Q, k, Q.wstep);
@@ -642,10 +653,12 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
          one of its items is worked on here, a tile of the foreign pseudo-slice (no
          chunk lists it: the record is all that is needed); else none */
       const uint64_t gl = Q.longest - L;
-      const uint32_t slice = Q.sliced ? (ck & Q.geom.smask) : 0u;
+      const uint32_t slice = Q.sliced ? (ck & Q.geom.smask) : (ck & Q.pmask);
       uint64_t bucket = ~0ull;
-      if (owned(Q, slice, 0u))
-        bucket = Q.sliced ? 2 * (uint64_t)slice + (heavy ? 1 : 0) : 0;
+      /* (whose work a query of the direct layout is does not depend on how many pseudo-slices this call
+         groups its queries by: the context that routes a record and the one that receives it agree) */
+      if (owned(Q, Q.sliced ? slice : (ck & DIRECT_OWNER_MASK), 0u))
+        bucket = Q.sliced ? 2 * (uint64_t)slice + (heavy ? 1 : 0) : slice;
       else if (any_item)        /* (spread by query number: one counter per length would serialise
                                    millions of atomics -- 27 ms per 10M queries at two shards, round 3) */
         bucket = 2 * (Q.nslices_real + (((uint32_t)i * 2654435761u) >> (32 - FOREIGN_SLICES_LOG2)));
@@ -730,7 +743,7 @@ slices_kernel(const QL Q, uint32_t pi)
   unsigned long long res = 0;
   uint64_t work_lens = 0;
   for (uint32_t hv = 0; hv < (Q.sliced ? 2u : 1u); hv++) {
-    const uint64_t bucket = Q.sliced ? 2 * sl + hv : 0;
+    const uint64_t bucket = Q.sliced ? 2 * sl + hv : sl;
     const uint32_t tile_k = hv ? Q.geom.k : 0u;
     const uint32_t *c = cnt + bucket * Q.per_slice;
     /* lengths >= min_mixed share tiles: longest first, cut every 64 */
@@ -938,6 +951,8 @@ scatter_kernel(const QL Q)
       a.hins = Q.hins_tmp[i];
       a.hdel = Q.hdel_tmp[i];
     }
+  } else if (Q.direct) {
+    a.h = Q.h_tmp[i];
   } else if (Q.genes) {
     const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
     a.h = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
@@ -1031,7 +1046,7 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
       Q.qhins[slot] = a.hins;
       Q.qhdel[slot] = a.hdel;
     }
-  } else if (Q.genes) {
+  } else if (Q.genes || Q.direct) {
     Q.qgh[slot] = a.h;
   }
   if (Q.pairs2) {
@@ -1683,16 +1698,31 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const uint32_t wfirst = (uint32_t)c->work_shard_index;
   if (wfirst >= wstep)
     return fail(c, CMPR_EINVAL, "work_shard_index must be below work_shard_count");
-  if (wstep > 1 && !c->sliced)
-    return fail(c, CMPR_EUNSUPPORTED, "work shards need a sliced layout (kernel variant 1 or 2)");
+  /* d = 0 on the un-sliced kernel (no filter: kernels.h probe_kernel, D == 0): the hash is computed here and
+     the queries are grouped by length and by PSEUDO-SLICE -- bits of the hash: one group counter per length
+     would take every query's atomic, one thread would write every tile (slices_kernel), and a work shard is
+     named by bits of the same key.  One per 32 768 queries (the part-filled last tile of each group is the
+     price: ~3 % of the slots). */
+  const bool direct = !c->sliced && c->opt.differences == 0;
+  if (wstep > 1 && !c->sliced && !direct)
+    return fail(c, CMPR_EUNSUPPORTED, "work shards need a sliced layout (kernel variant 1 or 2), or d = 0");
+  uint64_t pseudo = 1;
+  if (direct) {
+    if (c->direct_slices_log2 >= 0)
+      pseudo = 1ull << c->direct_slices_log2;
+    else {
+      while (pseudo < 1024 && pseudo * 32768 < n)
+        pseudo <<= 1;
+    }
+  }
   /* variant 1 with -i lists every tile under two sibling slices of other owners: there
      every context lays out everything and takes its share of the chunk list */
   const bool indel_passes = c->sliced && c->opt.indels && !c->rows;
   const bool place_mine = wstep > 1 && !indel_passes;
 
-  const uint64_t nslices_real = c->sliced ? (uint64_t)c->geom.smask + 1 : 1;
-  const uint64_t nslices = nslices_real + (place_mine ? (1ull << FOREIGN_SLICES_LOG2) : 0);   /* + the foreign pseudo-slices */
-  const uint64_t nbuckets = c->sliced ? 2 * nslices : 1;
+  const uint64_t nslices_real = c->sliced ? (uint64_t)c->geom.smask + 1 : pseudo;
+  const uint64_t nslices = nslices_real + (place_mine && c->sliced ? (1ull << FOREIGN_SLICES_LOG2) : 0);   /* + the foreign pseudo-slices */
+  const uint64_t nbuckets = c->sliced ? 2 * nslices : nslices;
   const uint64_t per_slice = (uint64_t)Lcap + 1;
   if (nbuckets * per_slice >= 0x7fffffffull)
     return fail(c, CMPR_EUNSUPPORTED, "too many (slice, length) groups");
@@ -1785,7 +1815,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_tot = cut.take(nslices * sizeof(SliceTot));
   const size_t o_pre = cut.take(nslices * sizeof(SliceTot));
   const bool need_ck = c->rows || sub2_items;
-  const size_t o_h = cut.take(c->rows ? (size_t)n * sizeof(uint64_t) : 0);
+  const size_t o_h = cut.take(c->rows || direct ? (size_t)n * sizeof(uint64_t) : 0);
   const size_t o_ck = cut.take(need_ck ? (size_t)n * sizeof(uint32_t) : 0);
   const size_t o_hins = cut.take(c->rows && c->opt.indels ? (size_t)n * sizeof(uint64_t) : 0);
   const size_t o_hdel = cut.take(c->rows && c->opt.indels ? (size_t)n * sizeof(uint64_t) : 0);
@@ -1881,6 +1911,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.nslices_real = nslices_real;
   Q.wfirst = place_mine ? wfirst : 0u;
   Q.wstep = place_mine ? wstep : 1u;
+  Q.direct = direct ? 1u : 0u;
+  Q.pmask = (uint32_t)(pseudo - 1);
   if (routing) {                             /* (a layout every context holds in full: every record to everyone) */
     Q.route = place_mine || wstep == 1 ? 1u : 2u;
     Q.wstep = wstep;
@@ -2331,7 +2363,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     c->qv.release();
     c->qj.release();
   }
-  if (!c->opt.ignore_genes || c->rows) {
+  if (!c->opt.ignore_genes || c->rows || (!c->sliced && c->opt.differences == 0)) {
     if ((rc = dev_reserve(c, c->qgh, slots))) return rc;
   } else {
     c->qgh.release();

@@ -249,15 +249,18 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
      length of the probe chains does: HBM is plentiful, round trips are not */
   c->slots = std::max<uint64_t>(c->slots << c->table_log2_delta, 4);
   /* Kernel variant: the row filter (2) for amino acids -- one word read answers
-     the 19 substitutions of a position; nucleotides (3 per position, and L + 1
-     entries per sequence to pay for them) and d = 0 (one test per query, no rows
-     at all) keep the per-variant filter (1). */
+     the 19 substitutions of a position; nucleotides at d = 1 (3 per position, and L + 1
+     entries per sequence to pay for them) keep the per-variant filter (1). */
   /* Nucleotides at d = 2 (round 4): pair rows probed by whole workgroups per tile
      (kernels_pairs2.h) -- 1541 word reads per 45-nucleotide query where the per-variant
      filter is probed 8910 times.  Needs the query's residues packed into RESPACK_MAX positions. */
   const bool d2p_possible = A == 4 && c->opt.differences == 2 && !c->opt.indels &&
                             std::max(longest, longest_query) <= RESPACK_MAX;
+  /* d = 0 (round 5, late): no filter at all -- one test per query, and the filter's word would cost the
+     memory line the table's slot costs: the un-sliced kernel (0) looks the query up where its bucket lies
+     (kernels.h probe_kernel, D == 0), lane = query, no positives buffer, no second kernel. */
   int64_t variant = c->variant >= 0 ? c->variant
+                    : c->opt.differences == 0 ? 0
                     : (A == 20 && c->opt.differences >= 1) || (d2p_possible && c->d2_pairs != 0) ? 2 : 1;
   c->d2pairs = variant == 2 && d2p_possible && c->d2_pairs != 0;
   /* The staged layouts keep a slice, the Zobrist tables and the wave queues in

@@ -299,11 +299,13 @@ uint32_t cmpr_rows(const cmpr_context *ctx);      /* R1, after set_queries   */
 uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
 
 /* Tuning knobs (unknown names -> CMPR_EINVAL).  Results never depend on them.
-     "variant"               0: one Bloom filter probed in HBM; 1: class-keyed
+     "variant"               0: one Bloom filter probed in HBM -- at d = 0 no filter at
+                             all, the query looked up where its bucket lies (default
+                             for d = 0); 1: class-keyed
                              32 KiB slices staged in LDS, one filter word per
-                             variant (default for nucleotides); 2: the same
+                             variant (default for nucleotides at d >= 1); 2: the same
                              slices over the row filter, one filter word per
-                             position (default for amino acids); -1: default
+                             position (default for amino acids at d >= 1); -1: default
      "blocks_per_cu"         resident workgroups per CU the grid is sized for
      "bloom_bits_log2_delta" filter bytes = hash-table slots << delta
                              (default 0 for variant 0, +2 for variant 1)
@@ -349,6 +351,9 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
                              LDS buffer holds (a sparser filter for the 38 000 tests of a query), 0 as many
                              as the entries ask for
      "row_filter_x16"        variant 2: bytes of filter per entry in sixteenths (default 32 = 2 bytes)
+     "direct_slices_log2"    d = 0 (variant 0, the default there: no filter, every query looked up where its
+                             bucket lies): the layout groups the queries by length and by 2^this pseudo-slices
+                             -- bits of the hash --; -1 (default) one per 32 768 queries
      "pos_grow"              the positives buffer grows to what a launch showed when it overflowed:
                              -1 (default) when its size was automatic, 1 also from a given
                              "pos_capacity", 0 never
@@ -360,7 +365,7 @@ uint32_t cmpr_cols(const cmpr_context *ctx);      /* R2, after set_reference */
    "variant", "bloom_bits_log2_delta", "class_residues", "slice_words_log2", "d2_pairs", "d2_buffers",
    "table_log2_delta", "slice_pages", "page_budget", "fill_slices" and "row_filter_x16" must be set before
    cmpr_set_reference(); "chunk_tiles", "waves_per_block",
-   "small_slice_tiles" and the work shard before cmpr_set_queries().  ("debug" exists
+   "small_slice_tiles", "direct_slices_log2" and the work shard before cmpr_set_queries().  ("debug" exists
    only in a -DCMPR_ABLATION build of the library.) */
 int cmpr_set_tunable(cmpr_context *ctx, const char *name, int64_t value);
 

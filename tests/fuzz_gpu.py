@@ -93,6 +93,8 @@ def random_case(rng):
         tun["page_budget"] = int(rng.integers(1, 200))    # overfull slices get pages (variant 2, d = 1)
         if rng.random() < 0.3:
             tun["slice_pages"] = int(rng.integers(0, 4))
+    if rng.random() < 0.5:
+        tun["direct_slices_log2"] = int(rng.integers(0, 7))   # pseudo-slices of the d = 0 layout (variant 0)
     if rng.random() < 0.2:
         tun["class_rows_unstaged"] = 1
     if rng.random() < 0.4:

@@ -66,6 +66,11 @@ WORKLOADS = {
                ["-d", "1"]),
     "pub_d1i": (None, dict(n=24_200_000, seed=2, prefix="B", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
                 ["-d", "1", "-i"]),
+    # d = 2 on the published shape: the whole 24.2M-sequence set as set 2 (its filter, its pages, its class parts),
+    # a 500 000-sequence set 1 the reference finishes in a minute on 8 cores
+    "pub_d2_sub": (dict(n=500_000, seed=1, prefix="A", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
+                   dict(n=24_200_000, seed=2, prefix="B", pool_size=24_200_000 // 4, law="cdr3", n_repertoires=120),
+                   ["-d", "2"]),
     # BASELINE configs[4], a sub-shape the reference finishes in minutes on 8 cores
     "cfg5_sub": (dict(n=200_000, seed=3, prefix="A", pool_size=10 * M // 4, nucleotides=True),
                  dict(n=10 * M, seed=4, prefix="B", pool_size=10 * M // 4, nucleotides=True),

@@ -16,6 +16,7 @@ wide and coalesced; resolve_kernel's random 64-byte lines are taken as counted.
 """
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -79,7 +80,10 @@ for k in ("probe", "resolve"):
         # the guide's x 2 on FETCH_SIZE is for 128-byte requests tallied at 64: the probe kernel's wide,
         # coalesced reads (slice copies, tile data).  resolve_kernel asks for single random 64-byte lines:
         # its raw figure stands
-        e["fetch_factor"] = 1 if k == "resolve" else 2
+        # ... and so does the filterless d = 0 kernel's (probe_kernel<A, 0, ..>: one random slot per query;
+        # its coalesced reads of the queries' records are then undercounted, not the slots doubled)
+        direct = re.search(r"probe_kernel<\d+, 0,", name) is not None
+        e["fetch_factor"] = 1 if (k == "resolve" or direct) else 2
         e["hbm_bytes_per_launch"] = e["fetch_factor"] * fetch + write
         e["raw_fetch_bytes"] = fetch
         e["raw_write_bytes"] = write
