@@ -29,4 +29,14 @@ for args in "-d 1" "-d 1 -i"; do
     cmp $T/ours.out $T/ref.out && echo "outputs identical"
   fi
 done
+# the spread of the host program's wall clock: five more runs of each
+for args in "-d 1" "-d 1 -i" "-d 0"; do
+  w=""
+  for rep in 1 2 3 4 5; do
+    t0=$(date +%s%N)
+    $R/bin/compairr -m $T/a.tsv $T/b.tsv $args -t 64 -o $T/ours2.out -l $T/ours2.log
+    w="$w $(( ($(date +%s%N) - t0) / 1000000 ))"
+  done
+  echo "ours  $args, five more runs:$w ms wall"
+done
 rm -rf $T
