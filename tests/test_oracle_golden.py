@@ -4,6 +4,8 @@ every matrix the REAL reference (oracle/_ref/compairr, compiled from
 test/expected.tsv (case ref_test_sh) -- and must agree with an independent
 brute-force evaluation of the pair definition."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -109,3 +111,13 @@ def test_oracle_port_matches_reference_at_full_size(name):
     assert _full_size.mismatch(w, got) is None, _full_size.mismatch(w, got)
     dups = {int(l.split()[-1]): int(l.split()[1]) for l in w["warnings"]}
     assert st.dup_set2 == dups[2] and st.dup_set1 == dups.get(1, 0)
+
+
+def test_every_pinned_workload_is_asserted_on_the_gpu():
+    """Every workload of tests/golden/full_size.json is named by a `-m gpu` test that holds the HIP
+    path against it (test_full_size_matches_reference's list or a properties test): a fixture nobody
+    reads pins nothing."""
+    import _full_size
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py")).read()
+    for name in _full_size.load():
+        assert '"%s"' % name in src, name
