@@ -337,6 +337,30 @@ def test_long_sequences():
     assert st.matches >= n + 2 * (n // 2)
 
 
+@pytest.mark.parametrize("nt,L", [(True, 200), (True, 130), (False, 50), (False, 33)])
+def test_long_sequences_d0(nt, L):
+    """d = 0 (no filter: the query looked up where its bucket lies) on sequences longer than a record
+    slot holds -- 32 amino acids, 128 nucleotides -- and than a query's record does (36): the tails are
+    compared where set 2 lies and in the tile's position-major residues.  Half of the sequences are
+    copies of their predecessor, a quarter differ from it in the LAST residue only."""
+    rng = np.random.default_rng(6)
+    n = 400
+    A = 4 if nt else 20
+    res = rng.integers(0, A, size=n * L, dtype=np.uint8)
+    for k in range(1, n, 2):
+        res[k * L:(k + 1) * L] = res[(k - 1) * L:k * L]
+        if k % 4 == 3:
+            res[(k + 1) * L - 1] = (res[(k + 1) * L - 1] + 1) % A
+    from compairr_amd.sets import AA, NT, RepertoireSet
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    s = RepertoireSet(res, offs, np.zeros(n, np.uint32), np.zeros(n, np.uint32),
+                      (np.arange(n) % 3).astype(np.uint32), np.full(n, 2, np.uint64),
+                      ["a", "b", "c"], ["V"], ["J"], NT if nt else AA)
+    o = Options(differences=0, nucleotides=nt, n_v_genes=1, n_j_genes=1)
+    st = check(s, s, o, layouts={"auto": {}, "hbm_pseudo8": {"variant": 0, "direct_slices_log2": 3}, "lds": {"variant": 1}})
+    assert st.matches == n + 2 * (n // 4)
+
+
 def test_items_next_to_sequences_too_long_for_an_item():
     """Nucleotides, d = 2, class-position pairs as items: an item carries 96 residues, so
     longer queries keep those pairs in the main pass -- lane by lane, in tiles that mix
