@@ -294,17 +294,27 @@ def test_mh_and_jaccard_sums_d0():
         check(a, b, Options(differences=0, score=s, **FULL))
 
 
-def test_many_repertoires_uses_global_atomics():
+@pytest.mark.parametrize("d,indels", [(1, True), (0, False)])
+def test_many_repertoires_uses_global_atomics(d, indels):
     """R1 x R2 > 2048 cells: the matrix is no longer privatised in LDS -- up to 65536 cells the workgroups add
-    to their partial slots in HBM (4480 here), beyond that to the matrix itself (the -x tests: 100000 cells)."""
+    to their partial slots in HBM (4480 here), beyond that to the matrix itself (the -x tests: 100000 cells;
+    here 300 x 300 at d = 0)."""
     a = synth.make_set(40000, 9, prefix="A", pool_size=5000, n_repertoires=70)
     b = synth.make_set(40000, 10, prefix="B", pool_size=5000, n_repertoires=64)
     assert a.n_repertoires * b.n_repertoires > 2048
-    check(a, b, Options(differences=1, indels=True, **FULL))
+    check(a, b, Options(differences=d, indels=indels, **FULL))
+    if d == 0:
+        a = synth.make_set(40000, 9, prefix="A", pool_size=5000, n_repertoires=300)
+        b = synth.make_set(40000, 10, prefix="B", pool_size=5000, n_repertoires=300)
+        assert a.n_repertoires * b.n_repertoires > 65536
+        check(a, b, Options(differences=0, **FULL), layouts={"auto": {}, "hbm_pseudo8": LAYOUTS["hbm_pseudo8"],
+                                                            "lds": LAYOUTS["lds"]})
+        check(a, a, Options(differences=0, **FULL), layouts={"auto": {}})
 
 
-def test_ragged_and_empty():
-    o = Options(differences=1, indels=True, **FULL)
+@pytest.mark.parametrize("d,indels", [(1, True), (0, False)])
+def test_ragged_and_empty(d, indels):
+    o = Options(differences=d, indels=indels, **FULL)
     a = synth.make_set(1000, 1, prefix="A", pool_size=1000)
     b = synth.make_set(1, 2, prefix="B", pool_size=1000)
     check(a, b, o)                     # one reference sequence
