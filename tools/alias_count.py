@@ -77,7 +77,7 @@ def count_shared_word(queries, S):
     q outside the pair (p, p + 1) set sum bit a + b and difference bit a - b under the very a_k of the query, and a
     test passes when ITS sum bit and ITS difference bit are set -- by one entry (a hit, or the +- 16 alias) or by
     two different ones.  (tests, hits, false positives from entries of the query's own word-and-key)."""
-    tests = hits = false = 0
+    tests = hits = false = false4 = 0
     for k in queries:
         head, q = k[:2], bytearray(k[2:])
         L = len(q)
@@ -96,6 +96,8 @@ def count_shared_word(queries, S):
                 continue
             sums = {(a + b) & 31 for a, b in ent}
             diffs = {(a - b) & 31 for a, b in ent}
+            firsts = {a for a, b in ent}
+            seconds = {b for a, b in ent}
             es = set(ent)
             for v in range(20):
                 if v != ra:
@@ -104,13 +106,16 @@ def count_shared_word(queries, S):
                     hit = (v, rb) in es
                     hits += hit
                     false += pos and not hit
+                    # FOUR forms, two dwords each: sum, difference, the first residue alone, the second alone
+                    false4 += pos and not hit and v in firsts and rb in seconds
                 if v != rb:
                     tests += 1
                     pos = ((ra + v) & 31) in sums and ((ra - v) & 31) in diffs
                     hit = (ra, v) in es
                     hits += hit
                     false += pos and not hit
-    return tests, hits, false
+                    false4 += pos and not hit and ra in firsts and v in seconds
+    return tests, hits, false, false4
 
 
 def main():
@@ -138,13 +143,16 @@ def main():
         print("%s: %d queries, %d variant tests, %d hits, %d alias-only positives = %.1f %% of (hits + aliases); "
               "per 10M queries: %.2e hits, %.2e aliases" % (name, SAMPLE, tests, hits, alias,
                                                             100.0 * alias / max(1, hits + alias), hits * scale, alias * scale), flush=True)
-    sub = ka[:max(1, SAMPLE // 6)]
-    tests, hits, false = count_shared_word(sub, S)
+    sub = ka[:max(1, SAMPLE // 3)]
+    tests, hits, false, false4 = count_shared_word(sub, S)
     scale = a.n / len(sub)
     print("every entry under the query's own blanked hash (alphabet-order codes): %d queries, %d tests, %d hits, %d false "
           "positives (one entry's sum bit with another's difference bit, or the +- 16 alias) = %.1f %% of the positives; "
           "per 10M queries: %.2e hits, %.2e false" % (len(sub), tests, hits, false, 100.0 * false / max(1, hits + false),
                                                       hits * scale, false * scale), flush=True)
+    print("... with FOUR forms of two dwords each (a + b, a - b, a alone, b alone; a test still looks at eight bits): "
+          "%d false positives = %.1f %% of the positives; per 10M queries: %.2e" %
+          (false4, 100.0 * false4 / max(1, hits + false4), false4 * scale), flush=True)
     print("total %.0f s" % (time.time() - t0))
 
 
