@@ -1,38 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- query sequences/sec through the --matrix hot path on MI355X.
 
-One "step" = one pass of the hot path (variant enumeration -> Zobrist hash ->
-Bloom test -> hash-table walk -> verify -> matrix accumulate) over one batch of
-synthetic queries that is already resident in HBM, plus -- at N > 1 -- the RCCL
-all-reduce of the repertoire matrix.  Default workload = BASELINE.json
-configs[2]: synthetic 10M-vs-10M CDR3aa, d = 1, substitutions only.
+One "step" = one QUERY SET through the hot path: the set's arrays (the SoA of
+include/compairr_hip.h, already resident in HBM when the timed region starts) are laid
+out for the kernels (cmpr_set_queries_device: keys, regrouping by filter slice, tiles,
+items -- per-query-set GPU work that lies between "first kernel launch" and "matrix
+ready" of SURVEY 8d) and then passed once over the reference index (variant
+enumeration -> Zobrist hash -> Bloom test -> record-table walk -> verify -> matrix
+accumulate), plus -- at N > 1 -- the RCCL all-reduce of the repertoire matrix.
+`value` = queries x steps / wall time of exactly that.  `--step resident` times the
+launches alone over one laid-out set (rounds 1-5's headline; reported by every run as
+`value_resident_step`).  Default workload = BASELINE.json configs[2]: synthetic
+10M-vs-10M CDR3aa, d = 1, substitutions only.
 
 N > 1: one rank per GPU -- launched by torch.distributed.run, or, when `python3 bench.py --gpus N` is typed
 without a launcher (no RANK in the environment), by bench.py itself: it starts the same
 torch.distributed.run command as a CHILD process before anything has touched the GPU and relays
 rank 0's line and the exit code (compairr_amd.dist.spawn_ranks).  The reference set
-(hash table + filter) is replicated on every GPU and the step is sharded:
+(record table + filter) is replicated on every GPU and the query set is sharded:
   --scaling strong (default)  the SAME seeded 10M queries, total work fixed
-                              (BASELINE configs[3]).  --shard-by work (default): a
-                              rank takes the work filed under its share of the filter
-                              slices (library tunables work_shard_index / _count) --
-                              the per-step cost of streaming the filter through LDS
-                              divides by N too -- and the queries go where their work
-                              is: every rank uploads and keys a contiguous N-th of
-                              them, one all-to-all over xGMI moves the records, every
-                              rank lays out what it received
-                              (compairr_amd.dist.exchange_queries; --layout
-                              replicated: every rank uploads and keys all of them).
-                              --shard-by queries: N contiguous query shards, the
-                              way overlap.cc:421-433 hands out query chunks; every
-                              rank then streams the whole filter for 1/N of the
-                              queries.
+                              (BASELINE configs[3]).  --shard-by queries (default, the
+                              north star's split): N contiguous query shards, the way
+                              overlap.cc:421-433 hands out query chunks; a rank lays out
+                              and works on its N-th of the set, no data-path collective
+                              but the matrix reduce.  --shard-by work: a rank takes the
+                              work filed under its share of the filter slices (library
+                              tunables work_shard_index / _count) and the queries go
+                              where their work is: every rank uploads and keys a
+                              contiguous N-th of them, one all-to-all over xGMI moves
+                              the records, every rank lays out what it received
+                              (compairr_amd.dist.exchange_queries; --layout replicated:
+                              every rank uploads and keys all of them) -- the shorter
+                              resident step, the dearer query set.
   --scaling weak              every rank its own 10M-query shard.
-The only collective is one all-reduce (sum, int64) of the R1 x R2 matrix per
-step; it runs on a second stream, ordered by events, so that the all-reduce of a
-step overlaps the kernels of the next (two matrices).  In strong mode the reduced matrix is
+The only collective of the default split is one all-reduce (sum, int64) of the R1 x R2
+matrix per step; it runs on a second stream, ordered by events, so that the all-reduce of a
+step overlaps the work of the next (two matrices).  In strong mode the reduced matrix is
 the N = 1 matrix; it is compared, at every N, with the matrix the reference binary printed
-for the same workload (tests/golden/full_size.json, "parity_vs_reference_full_size").
+for the same workload (tests/golden/full_size.json, "parity_vs_reference_full_size"); a
+mismatch there or on the CPU sample ends the run with exit status 1.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), with
 `roofline` (the dominant kernel against its binding unit, from the committed
@@ -76,8 +82,11 @@ def parse_args():
     p.add_argument("--queries", type=int, default=10_000_000,
                    help="set-1 sequences (strong: in total; weak: per GPU)")
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    p.add_argument("--shard-by", choices=["work", "queries"], default="work",
+    p.add_argument("--shard-by", choices=["work", "queries"], default="queries",
                    help="strong scaling at N > 1: what the ranks divide (see the module docstring)")
+    p.add_argument("--step", choices=["query-set", "resident"], default="query-set",
+                   help="what one timed step is: a query set from its device arrays to the matrix (layout + "
+                        "launch; the default), or one launch over the resident layout (rounds 1-5)")
     p.add_argument("--layout", choices=["routed", "replicated"], default="routed",
                    help="--shard-by work under torch.distributed.run: every rank uploads and keys its N-th of "
                         "the queries and the records move to the ranks that work on them (default), or every "
@@ -182,23 +191,24 @@ def cpu_baseline(ref, queries, opt, sample, args):
 
 
 def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
-    """The probe kernel (the step's dominant kernel) against the unit that binds it.
+    """The probe kernel against the unit that binds it.
 
     Per-launch work of each unit at N = 1 comes from the committed rocprofv3 counter
     summary of THIS workload (profiles/roofline_inputs.json, one entry per workload,
     written by tools/pmc_summary.py: wave-level VALU instructions, LDS-array cycles, HBM
     bytes per the guide's FETCH_SIZE / WRITE_SIZE recipe), scaled by this rank's share
     of the step (live filter reads / the profile's: 1 at N = 1, ~1/N for a shard);
-    the time is the live HIP-event time of the kernel.  Peaks: HBM 8 TB/s; LDS one array
-    cycle per CU and clock; VALU = SIMDs x nominal clock / the calibrated issue cost of the
-    kernel's own instruction mix (tools/calib.hip per instruction class -- plain VOP1/VOP2
-    and v_bitop3 issue every ~2.2 cycles per wave64 at >= 4 waves per SIMD, v_alignbit,
-    multiplies, 64-bit shifts and most three-operand VOP3 every ~4.1 -- weighted by
-    tools/isa_mix.py over the kernel's ISA).  `bound` is the unit with the highest
-    utilisation, `frac` that utilisation.  `counters_stale` says the library sources
-    have changed since the counters were taken.  `algorithmic_equiv` keeps SURVEY 8d's
-    figure (8 bytes per variant, as the reference reads its filter): not a physical
-    rate -- this kernel answers a row of variants with one LDS read."""
+    the time is the live HIP-event time of the kernel.  Peaks, all from
+    /opt/skills/guides/MI355X_MICROARCH.md: HBM 8 TB/s; LDS one array cycle per CU and
+    clock; VALU = SIMDs x nominal clock / 2 (a wave64 instruction issues over 2 cycles per
+    SIMD).  `bound` is the unit with the highest utilisation, `frac` that utilisation.
+    (`frac_mix_priced`: the same vector-instruction rate against a peak priced with this
+    repository's own per-class issue costs -- tools/calib.hip, weighted over the kernel's
+    STATIC instruction listing by tools/isa_mix.py -- rounds 3-5's `frac`; secondary.)
+    `counters_stale` says the library sources have changed since the counters were taken.
+    `algorithmic_equiv` keeps SURVEY 8d's figure (8 bytes per variant, as the reference
+    reads its filter): not a physical rate -- this kernel answers a row of variants with one
+    LDS read."""
     t = probe_ms * 1e-3
     out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
            "traffic": None, "kernel": kernel_name,
@@ -207,8 +217,9 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
            "algorithmic_bytes_per_launch": st.algorithmic_bytes,
            "algorithmic_equiv": {"GB/s": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,
                                  "of_hbm_peak": st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "note": "SURVEY 8d bytes (8 B per variant) / probe + resolve time; "
-                                         "exceeds 1 where variants are not answered by HBM reads"},
+                                 "note": "SURVEY 8d bytes (8 B per variant) / probe + resolve time; NOT a rate of this "
+                                         "kernel: it exceeds 1 because a row of variants is answered by one LDS read, "
+                                         "not by 8 bytes of HBM each"},
            "variants_per_launch": st.variants, "filter_reads_per_launch": st.filter_reads,
            "bloom_positive_per_launch": st.bloom_positive, "pairs_per_launch": st.matches}
     path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
@@ -232,10 +243,14 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
     elif k.get("variants") and st.variants:
         share = st.variants / k["variants"]
     units = {}
+    mix_priced = None
     if k.get("valu_insts"):
-        cyc = k.get("mix_cycles_per_valu_inst") or cal["valu_cycles_slow"]
-        peak = cal["simds"] * cal["nominal_clock_hz"] / cyc
+        # the guide's flat peak: a wave64 instruction issues over 2 cycles per SIMD (>= 2 waves per SIMD)
+        peak = cal["simds"] * cal["nominal_clock_hz"] / 2.0
         units["valu"] = (k["valu_insts"] * share / t, peak, "wave-instructions/s")
+        cyc = k.get("mix_cycles_per_valu_inst")
+        if cyc:
+            mix_priced = units["valu"][0] / (cal["simds"] * cal["nominal_clock_hz"] / cyc)
     if k.get("lds_active_cycles"):
         peak = cal["cus"] * cal["nominal_clock_hz"]        # (both units at the nominal clock)
         units["lds"] = (k["lds_active_cycles"] * share / t, peak, "LDS-array cycles/s")
@@ -246,25 +261,63 @@ def roofline(workload, st, probe_ms, kernel_ms, kernel_name):
         return out
     best = max(units, key=lambda u: units[u][0] / units[u][1])
     a, p, unit = units[best]
-    # the same vector-instruction rate against the guide's flat peak (MI355X_MICROARCH.md: a wave64
-    # instruction issues over 2 cycles per SIMD with >= 2 waves: SIMDs x clock / 2), whatever the mix --
-    # the mix-priced `frac` weights the kernel's STATIC listing (tools/isa_mix.py), not what executes
-    guide = None
-    if "valu" in units:
-        guide = units["valu"][0] / (cal["simds"] * cal["nominal_clock_hz"] / 2.0)
     out.update({"bound": best, "achieved": a, "peak": p, "unit": unit, "frac": a / p,
-                "frac_guide_peak": guide,
+                "frac_mix_priced": mix_priced,
                 "utilisation": {u: v[0] / v[1] for u, v in units.items()},
                 "share_of_the_profiled_launch": share,
-                "valu_issue_cycles_per_instruction": k.get("mix_cycles_per_valu_inst"),
+                "valu_issue_cycles_per_instruction_static_mix": k.get("mix_cycles_per_valu_inst"),
                 # SQ_ACTIVE_INST_* / SQ_BUSY_CU_CYCLES of the committed profile run (not live):
                 # vector instructions per CU cycle -- 1.0 = one per SIMD every 4 cycles
                 "busy_fraction_from_counters": k.get("busy_fraction_from_counters"),
                 "counters_from": k.get("source"),
                 "note": "achieved = per-launch work of the binding unit (committed rocprofv3 PMC summary "
                         "of this workload x this rank's share) / live HIP-event time of the probe kernel; "
-                        "peak: see bench.py roofline()"})
+                        "peaks from MI355X_MICROARCH.md"})
     return out
+
+
+def layout_rooflines(workload, n, residues, slots, items, indels, times):
+    """The layout's three big kernels against the HBM roofline (they move bytes and nothing else):
+    achieved = ALGORITHMIC bytes of the kernel -- what its contract makes it read and write once, DESIGN.md
+    section 3 -- / its live HIP-event time; traffic = the committed FETCH_SIZE / WRITE_SIZE counters of the same
+    kernel when profiles/roofline_inputs.json holds them.
+      keys_kernel     per query: reads its residues, offset 8, v 4, j 4, repertoire 4, count 8; writes group 4,
+                      rank 4, hash 8 (24 with -i), class key 4; one 4-byte counter read-modify-write (8)
+      scatter_kernel  per query: the same reads + group, rank, hash(es), class key, group base 4; writes the
+                      64-byte record and its slot number 4; per item 16
+      fill_tiles      per slot (padding lanes included): reads the 64-byte record; writes residues (position-
+                      major, ~the query's length rounded up to 4), length 2, number 4, repertoire 4, v 4, j 4,
+                      count 8, hash 8 (24 with -i), class key 4"""
+    hb = 24 if indels else 8
+    alg = {"keys": residues + n * (28 + 8 + hb + 4 + 8),
+           "scatter": residues + n * (28 + 8 + hb + 4 + 4 + 64 + 4) + items * 16,
+           "tiles": slots * (64 + 2 + 4 + 4 + 4 + 4 + 8 + hb + 4) + (residues + 2 * n) * slots // max(n, 1)}
+    path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh).get("workloads", {}).get(workload, {}).get("layout_kernels", {})
+    except Exception:
+        prof = {}
+    out = {}
+    for k, name in (("keys", "keys_kernel"), ("scatter", "scatter_kernel"), ("tiles", "fill_tiles_kernel")):
+        ms = times.get(k)
+        if not ms:
+            continue
+        a = alg[k] / (ms * 1e-3) / 1e9
+        out[k] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                  "traffic": (prof.get(name) or {}).get("hbm_bytes"), "kernel": name, "kernel_ms": ms,
+                  "algorithmic_bytes_per_launch": alg[k]}
+    return out
+
+
+LAYOUT_PARTS = ("keys", "sizes", "scatter", "tiles", "order")
+
+
+def layout_kernel_times(h):
+    """HIP-event times (ms) of the last cmpr_set_queries_device, recorded by the library on its own stream
+    (tunable layout_timing): keys_kernel | per-slice sizes, scans, the host's round trip, slices_kernel |
+    scatter_kernel | fill_tiles_kernel | item chunks and the chunk order."""
+    return {k: h.get_tunable("layout_%s_us" % k) / 1e3 for k in LAYOUT_PARTS}
 
 
 def start_ranks(args):
@@ -386,16 +439,25 @@ def main():
                  "first_call_incl_allocations": t_layout_first * 1e3,
                  "how": ("routed: upload + keys of this rank's N-th, all-to-all of the records, layout of "
                          "what was received; slowest rank" if routed else
-                         "cmpr_set_queries on this rank's queries; slowest rank"),
+                         "cmpr_set_queries (host buffers) on this rank's queries; slowest rank"),
                  "exchange": moved}
+    # ---- this rank's query set as DEVICE arrays: what a timed step starts from ----
+    per_set = args.step == "query-set"
+    view = keep = None
+    if not routed:
+        view, keep = h.device_view(qry)
+        h.set_tunable("layout_timing", 1)                  # (events around the layout's kernels: ~25 us per call)
+        h.set_queries_device(view)                         # (warm: allocations kept)
+        torch.cuda.synchronize()
     R1, R2 = h.shape
     layout = h.layout()
+    h_items = h.get_tunable("items") if layout["variant"] == 2 else 0
     # every rank uses the same R1 x R2 (16 x 16 for the synthetic law).  Two matrices:
     # step i fills one while the all-reduce of step i - 1 still works on the other
     mats = [torch.zeros(R1 * R2, dtype=torch.int64, device="cuda") for _ in range(2)]
-    # one explicit stream for the kernels, one for the collective: nothing in a step is
-    # ordered by the host, and the all-reduce of a step (latency-bound: 2 KiB) overlaps
-    # the kernels of the next
+    # one explicit stream for the launches, one for the collective: nothing in a step is
+    # ordered by the host but the layout's own two waits (its sizes, its end), and the
+    # all-reduce of a step (latency-bound: 2 KiB) overlaps the work of the next
     stream = torch.cuda.Stream()
     comm = torch.cuda.Stream()
     filled = [torch.cuda.Event() for _ in range(2)]      # the kernels have written matrix b
@@ -403,8 +465,9 @@ def main():
     for e in reduced:
         e.record(stream)
     nstep = [0]
+    layout_kernels = []                                  # per step: HIP-event times of the layout's kernels
 
-    def step():
+    def launch():
         b = nstep[0] & 1
         nstep[0] += 1
         if use_dist:
@@ -419,6 +482,36 @@ def main():
                 dist.all_reduce(mats[b], op=dist.ReduceOp.SUM)
                 reduced[b].record(comm)
 
+    def step(record=False):
+        if per_set:
+            # the query set from its device arrays to "resident" (keys, regrouping, tiles, items; the
+            # library's own stream, the call returns when the layout is complete), ...
+            if routed:
+                lay_out()
+            else:
+                h.set_queries_device(view)
+            if record:
+                layout_kernels.append(layout_kernel_times(h))
+        launch()                               # ... then once over the reference index
+
+    def timed(fn, k):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()               # (every stream: the last all-reduce included)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        el = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
     with torch.cuda.stream(stream):
         for k in range(args.warmup):
             step()
@@ -426,27 +519,22 @@ def main():
                 # (a positives buffer that the first launch overflowed grows when a later launch finds that
                 # launch finished: let that be the second warm-up launch, not the first timed step)
                 torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()               # (every stream: the last all-reduce included)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-    matrix = mats[(nstep[0] - 1) & 1]
-    st = h.stats()
-    # HIP events recorded by the library on the kernels' stream, one set per step of
-    # the timed region (ring of the last 64 launches: no synchronisation inside the loop)
-    kernel_ms, probe_ms = h.kernel_times(args.steps)
+        elapsed = timed(lambda: step(True), args.steps)
+        matrix = mats[(nstep[0] - 1) & 1]
+        st = h.stats()
+        # HIP events recorded by the library on the kernels' stream, one set per step of
+        # the timed region (ring of the last 64 launches: no synchronisation inside the loop)
+        kernel_ms, probe_ms = h.kernel_times(args.steps)
+        # the launches alone over the resident layout (the headline of rounds 1-5)
+        for _ in range(2):
+            launch()
+        resident_steps = max(args.steps, 10)
+        elapsed_resident = elapsed if not per_set else timed(launch, resident_steps)
+        if per_set:
+            matrix_resident = mats[(nstep[0] - 1) & 1]
+            same_resident = bool(torch.equal(matrix_resident, matrix))
+        else:
+            same_resident = True
 
     total_queries = args.queries if strong else args.queries * world
     value = total_queries * args.steps / elapsed
@@ -456,14 +544,10 @@ def main():
     result_matrix = matrix.cpu().numpy().astype(np.uint64).reshape(R1, R2)
     checksum = synth.checksum(result_matrix)
 
-    # Two more rates of the same workload (one GPU): the query set handed over as DEVICE arrays
-    # (cmpr_set_queries_device: layout kernels + step, nothing on PCIe) -- what compares with
-    # the reference's in-memory 'Analysing:' phase -- and the step as a synchronous call that
-    # ends with the matrix in host memory.
+    # One more rate of the same workload (one GPU): the launch as a synchronous call that ends with
+    # the matrix in host memory, and the layout call on its own.
     device_soa = None
-    if world == 1 and not use_dist:
-        view, keep = h.device_view(qry)
-        h.set_queries_device(view)                         # (warm: allocations kept)
+    if world == 1 and not use_dist and view is not None:
         torch.cuda.synchronize()
         t = time.perf_counter()
         h.set_queries_device(view)
@@ -475,13 +559,15 @@ def main():
             got = h.overlap_matrix()
         t_sync = (time.perf_counter() - t) / 10
         device_soa = {"set_queries_device_ms": t_dev * 1e3,
-                      "value_from_device_soa": total_queries / (t_dev + elapsed / args.steps),
+                      "value_from_device_soa": total_queries / (t_dev + elapsed_resident / resident_steps
+                                                                if per_set else t_dev + elapsed / args.steps),
                       "step_ms_incl_d2h": t_sync * 1e3,
                       "value_incl_d2h": total_queries / t_sync,
                       "same_matrix": bool(np.array_equal(first, result_matrix) and
                                           np.array_equal(got, result_matrix))}
-        del keep
+    del keep
 
+    failed = []
     if rank == 0:
         wl = workload_name(args)
         baseline = None
@@ -503,6 +589,7 @@ def main():
             if not parity:
                 print("PARITY FAILURE: HIP matrix differs from the CPU %s on the sample"
                       % baseline["kind"], file=sys.stderr)
+                failed.append("parity_on_cpu_sample")
         rec = recorded_workload(args)
         parity_full = None
         if rec is not None:
@@ -512,12 +599,36 @@ def main():
             if why:
                 print("PARITY FAILURE: the (reduced) matrix differs from the reference's "
                       "(tests/golden/full_size.json %s): %s" % (rec["name"], why), file=sys.stderr)
+                failed.append("parity_vs_reference_full_size")
+        if not same_resident:
+            print("PARITY FAILURE: the launches over the resident layout give another matrix than the "
+                  "timed steps", file=sys.stderr)
+            failed.append("same_matrix_resident")
+        if device_soa and not device_soa["same_matrix"]:
+            print("PARITY FAILURE: the synchronous call gives another matrix than the timed steps",
+                  file=sys.stderr)
+            failed.append("same_matrix_sync")
+        # every kernel that is a tenth of the step or more against its roofline; `roofline` = the one that
+        # takes the longest (the dominant kernel of the timed step)
+        step_ms = dict({k: float(np.mean([x[k] for x in layout_kernels])) for k in LAYOUT_PARTS}
+                       if layout_kernels else {})
+        roofs = layout_rooflines(wl, int(st.queries), int(qry.offsets[-1]) if qry.n else 0,
+                                 int(layout["query_slots"]), int(h_items), args.indels, step_ms) if per_set else {}
+        roofs["probe"] = roofline(wl, st, p_avg_ms, k_avg_ms,
+                                  "probe_pairs2_kernel" if layout.get("d2_pairs") else
+                                  {0: "probe_kernel", 1: "probe_sliced_kernel", 2: "probe_rows_kernel"}[layout["variant"]])
+        dominant = max(roofs, key=lambda k: roofs[k]["kernel_ms"])
+        roof = dict(roofs[dominant], dominant_of=sorted(roofs))
         out = {
             "metric": "query sequences/sec for --matrix d=%d%s, %s-vs-%s %s" % (
                 args.differences, " --indels" if args.indels else "",
                 human(args.queries), human(args.refs),
                 "nucleotide" if args.nucleotides else "CDR3aa"),
             "value": value,
+            "step": ("one query set: cmpr_set_queries_device (layout from device arrays) + one launch over the "
+                     "reference index" + (" + all-reduce" if use_dist else "")) if per_set and not routed else
+                    ("one query set: route + all-to-all + layout of what arrived + one launch + all-reduce"
+                     if per_set else "one launch over the resident layout"),
             "unit": "query sequences/s",
             "n_gpus": world,
             "ranks_seen": dist.get_world_size() if use_dist else 1,
@@ -556,8 +667,16 @@ def main():
             # (warm: a context that has laid out a set of this size before and keeps its
             #  allocations; cold: the first call of a context, allocations included -- the
             #  definition BENCH_r01 / r02 used for "value_incl_layout")
-            "value_incl_layout": total_queries / (t_layout + elapsed / args.steps),
-            "value_incl_layout_cold": total_queries / (t_layout_first + elapsed / args.steps),
+            "value_incl_layout": total_queries / (t_layout + elapsed_resident / resident_steps),
+            "value_incl_layout_cold": total_queries / (t_layout_first + elapsed_resident / resident_steps),
+            # the launches alone over one laid-out query set (what rounds 1-5 reported as `value`)
+            "value_resident_step": total_queries * resident_steps / elapsed_resident,
+            "resident_step_ms": elapsed_resident / resident_steps * 1e3,
+            "resident_steps_same_matrix": same_resident,
+            # HIP-event times inside the timed steps (means): the layout's kernels, then probe and resolve
+            "step_kernels_ms": dict(
+                {k: float(np.mean([x[k] for x in layout_kernels])) for k in LAYOUT_PARTS} if layout_kernels else {},
+                probe=p_avg_ms, resolve=k_avg_ms - p_avg_ms),
             # from DEVICE arrays to the matrix (no PCIe), and the synchronous step that ends
             # with the matrix on the host
             "value_from_device_soa": device_soa and device_soa["value_from_device_soa"],
@@ -566,9 +685,8 @@ def main():
             # the whole result of the timed steps against the matrix the reference binary
             # printed for this very workload (tests/golden/full_size.json), at every N
             "parity_vs_reference_full_size": parity_full,
-            "roofline": roofline(wl, st, p_avg_ms, k_avg_ms,
-                                 "probe_pairs2_kernel" if layout.get("d2_pairs") else
-                                 {0: "probe_kernel", 1: "probe_sliced_kernel", 2: "probe_rows_kernel"}[layout["variant"]]),
+            "roofline": roof,
+            "roofline_kernels": roofs,
             "cpu_baseline": baseline,
             "parity_on_cpu_sample": parity,
         }
@@ -577,6 +695,9 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        # a number whose matrix is not the reference's is no number: the run fails
+        sys.exit(1)
 
 
 def human(n):

@@ -220,6 +220,8 @@ extern "C" int cmpr_create(const cmpr_options *options, cmpr_context **out)
   CREATE_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     CREATE_TRY(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
+  for (hipEvent_t &e : c->ev_layout)
+    CREATE_TRY(hipEventCreateWithFlags(&e, tflags));
 
 #undef CREATE_TRY
   /* environment overrides of the tunables (for the CLI, which has no flag) */
@@ -274,6 +276,8 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+  for (hipEvent_t e : c->ev_layout)
+    if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -390,6 +394,12 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     if (value < -1 || value > 1)
       return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
     c->narrow_upload = value;
+    affects_plan = false;
+  } else if (n == "item_wg" || n == "layout_recompute" || n == "layout_timing" || n == "layout_zob_lds") {
+    if (value < 0 || value > 1)
+      return fail(c, CMPR_EINVAL, n + " must be 0 or 1");
+    (n == "item_wg" ? c->item_wg : n == "layout_recompute" ? c->layout_recompute :
+     n == "layout_zob_lds" ? c->layout_zob_lds : c->layout_timing) = value;
     affects_plan = false;
   } else if (n == "assume_never_overflows") {
     /* TEST ONLY: the next launch runs without redo pass as if the margin had been
@@ -517,6 +527,14 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "layout_upload_us") *value = (int64_t)(c->layout_upload_ms * 1e3);
   else if (n == "layout_tail_us") *value = (int64_t)(c->layout_tail_ms * 1e3);
   else if (n == "layout_total_us") *value = (int64_t)(c->layout_total_ms * 1e3);
+  else if (n == "item_wg") *value = c->item_wg;
+  else if (n == "layout_recompute") *value = c->layout_recompute;
+  else if (n == "layout_timing") *value = c->layout_timing;
+  else if (n == "layout_keys_us") *value = (int64_t)(c->layout_kernel_ms[0] * 1e3);
+  else if (n == "layout_sizes_us") *value = (int64_t)(c->layout_kernel_ms[1] * 1e3);
+  else if (n == "layout_scatter_us") *value = (int64_t)(c->layout_kernel_ms[2] * 1e3);
+  else if (n == "layout_tiles_us") *value = (int64_t)(c->layout_kernel_ms[3] * 1e3);
+  else if (n == "layout_order_us") *value = (int64_t)(c->layout_kernel_ms[4] * 1e3);
   else if (n == "never_overflows") *value = c->never_overflows ? 1 : 0;
   else if (n == "debug") *value = c->debug;
   else if (n == "heavy_threshold") *value = c->heavy_threshold;
@@ -551,6 +569,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "pos_grow") *value = c->pos_grow;
   else if (n == "resolve_blocks_per_cu") *value = c->resolve_blocks_per_cu;
   else if (n == "query_slots") *value = (int64_t)c->ntiles * WAVE;
+  else if (n == "items") *value = (int64_t)c->items.n;       /* variant 2 / sub2: item slots, padding included */
 #ifdef CMPR_PHASE_TIMING
   else if (n.size() == 3 && n[0] == 'p' && n[1] == 't' && n[2] >= '0' && n[2] <= '7') {
     /* diagnostic build: wave cycles of phase n of the last launch (kernels_rows.h PT_*) */
@@ -1537,6 +1556,10 @@ extern "C" int cmpr_warm_up(const cmpr_options *o)
       fns[2] = select_probe_v2_inline_nw16(A, D, i, g);
     } else if (A == 4 && D == 2) {
       fns[1] = select_probe_pairs2(g);
+    } else if (D == 0) {
+      /* d = 0 runs on variant 0, no filter: probe -> reduce, no resolve_kernel */
+      fns[0] = nullptr;
+      fns[1] = select_probe_v0(A, D, i, g);
     } else {
       fns[1] = select_probe_v1_nw8(A, D, i, g);
       fns[2] = select_probe_v1_nw4(A, D, i, g);

@@ -263,6 +263,14 @@ struct cmpr_context {
   /* of the last cmpr_set_queries: host time inside the copies, from the last copy to the
      end (the device work the upload did not hide), and in all */
   double                     layout_upload_ms = 0, layout_tail_ms = 0, layout_total_ms = 0;
+  /* tunables of the query layout (query_layout.hip): item counters per workgroup in LDS, hashes worked out
+     from the records by fill_tiles_kernel (both 1 = default; 0 = round 5's form, kept for A/B and the
+     parity suite), and HIP events around its big kernels (tunable "layout_timing", default 0) */
+  int64_t                    item_wg = 1, layout_recompute = 1, layout_timing = 0;
+  int64_t                    layout_zob_lds = 1;          /* keys_kernel keeps the Zobrist keys in LDS when they fit */
+  hipEvent_t                 ev_layout[6] = {};
+  uint32_t                   layout_marks = 0;
+  float                      layout_kernel_ms[5] = {};    /* keys | sizes, slices | scatter | tiles | chunk order */
   StepPlan                   plan;
   unsigned long long        *d_stats = nullptr;        /* inside pos_ctr's allocation */
   uint32_t                  *d_tile_counter = nullptr; /* likewise */

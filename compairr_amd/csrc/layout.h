@@ -160,7 +160,10 @@ __host__ __device__ inline uint32_t row_slice(const SliceGeom &g, uint32_t key, 
 
 __host__ __device__ inline uint32_t class_pos(uint32_t len, uint32_t i, uint32_t c0)
 {
-  return len ? (c0 + i) % len : 0;
+  /* (no division where the position does not wrap -- every sequence of at least c0 + K residues: an integer
+     modulo is ~40 instructions on this chip, and the layout kernels ask a dozen times per query) */
+  const uint32_t x = c0 + i;
+  return x < len ? x : len ? x % len : 0;
 }
 
 /* Pair rows: the class PART of a pair that holds class positions is keyed by what is left of

@@ -65,9 +65,8 @@ constexpr uint32_t MAXP = 1 + MAX_CLASS_RES;     /* passes with a layout of thei
    tiles of 2^FOREIGN_SLICES_LOG2 pseudo-slices behind the real ones (no chunk lists them) */
 constexpr uint32_t FOREIGN_SLICES_LOG2 = 12;
 
-constexpr uint32_t KEYS_STAGE_BYTES = 16384;   /* keys_kernel: residues of a batch of 256 queries staged in LDS */
 enum : uint32_t { VERR_OFFSETS = 1, VERR_LONG = 2, VERR_REP = 3, VERR_GENE = 4, VERR_COUNT = 5,
-                  VERR_RESIDUE = 6, VERR_TOO_LONG = 7 };
+                  VERR_RESIDUE = 6, VERR_TOO_LONG = 7, VERR_OFFSETS0 = 8 };
 
 struct SliceTot {
   uint32_t tiles, chunks, small, list;
@@ -179,6 +178,24 @@ struct QL {
      and gives each copy its share of the (class part, slice)'s items (rbase). */
   uint32_t *ccnt_r, *cfill_r, *rbase;               /* [item_reps][nitem_slices] */
   uint32_t  item_reps;
+  /* item_wg (round 6; few counters -- <= ITEM_WG_MAX --, no routing): the items are counted per WORKGROUP in
+     LDS, nothing per query goes to memory.  keys_kernel and scatter_kernel are launched with the same grid
+     over the same query range, so workgroup w sees the same queries in both: keys_kernel counts w's items per
+     counter in LDS and claims a run for them with ONE answered atomic per non-empty counter (on padded
+     counters, one per 64 bytes: ccnt_r is then [nitem_slices][ITEM_PAD]), leaving the run's start in
+     rbase[row][k] (row = row0 of the launch + w); scatter_kernel loads its row into LDS and hands out the
+     places with LDS atomics.  (Round 5: 32 replicas of the counters in memory, one atomic per query in each
+     of the two kernels: 0.30 ms of keys_kernel's 1.23 and an answered atomic + two reads of scatter_kernel's
+     seven scattered operations per query.) */
+  uint32_t  item_wg;
+  uint32_t  recompute;                    /* fill_tiles_kernel works the hashes and the class key out from the
+                                             record (no QAux is scattered): every query fits its record */
+  uint32_t  total_on_device;              /* the residue total is off[n], read where the offsets lie */
+  uint32_t  zob_lds, zob_words;           /* keys_kernel keeps the Zobrist keys (zob_words of them, gene keys
+                                             included) in LDS; scatter_kernel those of the positions */
+  uint32_t  zob_pos_words;
+  uint32_t  ctab_lds;                     /* ... and both the class tables in front of the heavy bitmap
+                                             (geom.off_hv words) */
   uint32_t  cchunk0;                      /* first item chunk in the chunk list */
   cmpr::ItemRec *items;
   cmpr::ResPack *cpk;
@@ -188,14 +205,27 @@ struct QL {
   unsigned long long *alg_bytes;
 };
 
+constexpr uint32_t ITEM_WG_MAX = 4096;       /* counters a workgroup keeps in LDS (16 KiB) */
+constexpr uint32_t ITEM_PAD = 16;            /* ... and claims runs from: one counter per 64 bytes */
+
 /* keys_kernel with parts left out (the "debug" tunable's bits 16.., -DCMPR_ABLATION builds only) */
 enum : uint32_t { LDBG_NO_RANK = 1u << 16, LDBG_NO_ITEM_COUNT = 1u << 17, LDBG_NO_HASH = 1u << 18,
-                  LDBG_NO_TOTALS = 1u << 19, LDBG_NO_CLASSKEY = 1u << 20, LDBG_NO_TMP_WRITES = 1u << 21 };
+                  LDBG_NO_TOTALS = 1u << 19, LDBG_NO_CLASSKEY = 1u << 20, LDBG_NO_TMP_WRITES = 1u << 21,
+                  /* scatter_kernel: no record written | no items at all | the record to slot i (sequential) |
+                     items worked out, not written | no group base read (slot = i) */
+                  LDBG_S_NO_REC = 1u << 22, LDBG_S_NO_ITEMS = 1u << 23, LDBG_S_SEQ_REC = 1u << 24,
+                  LDBG_S_NO_ITEM_WRITE = 1u << 25, LDBG_S_NO_BASE = 1u << 26 };
 #ifdef CMPR_ABLATION
 #define LDBG(Q, bit) (((Q).dbg & (bit)) != 0)
 #else
 #define LDBG(Q, bit) false
 #endif
+
+/* the residues of the set: offsets[n] (read on the device when the host never saw the offsets) */
+__device__ inline uint64_t total_of(const QL &Q)
+{
+  return Q.total_on_device ? Q.off[Q.n] : Q.total;
+}
 
 /* Work sharding (tunables work_shard_index / _count): which context of `step` takes
    the work filed under a slice in a pass.  By slice, not by position in the work
@@ -313,32 +343,62 @@ validate_res_kernel(const uint8_t *res, uint64_t total, uint32_t A, uint32_t *ve
 
 /* ---- keys ---------------------------------------------------------------- */
 
-/* The residues of queries base .. base + 255 lie side by side: copied to LDS in whole dwords, read there
-   (a byte per load from where they lie, every load of a loop waiting for the one before, was most of
-   what keys_kernel and scatter_kernel took).  Returns false when they cannot be staged (a set whose
-   residues are not dword-aligned, a batch of very long sequences). */
-__device__ inline bool stage_residues(const QL &Q, uint64_t base, uint64_t last, uint32_t *res_lds, uint64_t &a0,
-                                      uint64_t &sb, uint64_t &se)
+/* A thread's OWN copy of its query's residues (round 6): the up to three aligned 16-byte pieces that hold
+   them go to the thread's words of LDS (OWN_DW each: an odd stride, so that the lanes' byte reads fall on
+   different banks) and are read there a byte at a time -- no barrier, no load that another thread's
+   address depends on: a wave runs on as soon as ITS loads are back.  (Rounds 4-5 staged a batch's residues
+   for the whole workgroup: two barriers and two dependent scalar loads per batch of
+   256 queries.)  Sequences that do not fit the three pieces, or a set whose residues are not 16-byte
+   aligned: read where they lie.  The caller has checked b <= e <= total. */
+constexpr uint32_t OWN_DW = 13;
+__device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t *mine)
 {
-  sb = Q.off[base];
-  se = Q.off[last];
-  a0 = sb & ~3ull;
-  const bool stage = ((uintptr_t)Q.res & 3u) == 0 && se >= sb && se <= Q.total && se - a0 <= KEYS_STAGE_BYTES;
-  if (stage)
-    for (uint64_t k = threadIdx.x; 4 * k < se - a0; k += 256) {
-      const uint64_t at = a0 + 4 * k;
-      uint32_t d = 0;
-      if (at + 4 <= Q.total) {
-        d = *(const uint32_t *)(Q.res + at);
-      } else {
-        for (uint32_t x = 0; x < 4 && at + x < Q.total; x++)
-          d |= (uint32_t)Q.res[at + x] << (8 * x);
+  const uint64_t a0 = b & ~15ull;
+  if (((uintptr_t)Q.res & 15u) != 0 || e - a0 > 48u)
+    return Q.res + b;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    const uint64_t at = a0 + 16u * k;
+    if (at < e) {
+      uint4 w = make_uint4(0u, 0u, 0u, 0u);
+      if (at + 16u <= total) {
+        w = *(const uint4 *)(Q.res + at);
+      } else {                                   /* (the last bytes of the set) */
+        uint64_t lo = 0, hi = 0;                 /* (no array: an index the compiler cannot see is scratch) */
+        for (uint32_t x = 0; x < 16u && at + x < total; x++) {
+          const uint64_t r = Q.res[at + x];
+          if (x < 8u)
+            lo |= r << (8u * x);
+          else
+            hi |= r << (8u * (x - 8u));
+        }
+        w = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
       }
-      res_lds[k] = d;
+      mine[4 * k + 0] = w.x;
+      mine[4 * k + 1] = w.y;
+      mine[4 * k + 2] = w.z;
+      mine[4 * k + 3] = w.w;
     }
-  return stage;
+  }
+  return (const uint8_t *)mine + (b - a0);
 }
 
+/* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that seed the rolling indel
+   enumeration (:90-104, :122-136); `z` = the Zobrist keys, in memory or the workgroup's copy in LDS */
+template <typename ZP>
+__device__ inline void hashes_of(ZP z, uint32_t A, bool indels, const uint8_t *s, uint32_t L, uint64_t &h,
+                                 uint64_t &hins, uint64_t &hdel)
+{
+  for (uint32_t p = 0; p < L; p++) {
+    const uint32_t r = s[p];
+    h ^= z[A * p + r];
+    if (indels) {
+      hins ^= z[A * (p + 1) + r];
+      if (p > 0)
+        hdel ^= z[A * (p - 1) + r];
+    }
+  }
+}
 
 /* number of variants the reference enumerates for one query
    (generate_variants, variants.cc:260-428) */
@@ -379,9 +439,12 @@ __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
    false: the hash argument is not computed) and once to place, so both see the
    same items. */
 template <bool HASH, typename F>
-__device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, uint32_t L, uint32_t ck, bool heavy, F f)
+__device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint64_t *zt, uint64_t i, const uint8_t *s,
+                                     uint32_t L, uint32_t ck, bool heavy, F f)
 {
-  /* (s: the query's residues -- where the set lies, or the caller's staged copy in LDS) */
+  /* (s: the query's residues -- where the set lies, or the thread's copy in LDS; ct, zt: the class tables in
+     front of the heavy bitmap and the Zobrist keys -- where they lie, or the workgroup's copies in LDS: a
+     lookup in memory with 64 different addresses per wave is the dear kind, round 6) */
   const SliceGeom &g = Q.geom;
   const uint32_t K = g.k, A = Q.A;
   if (L == 0 || K == 0 || Q.differences < 1)
@@ -395,7 +458,7 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
         const uint32_t pos = g.c0 + ci, r = s[pos];
         for (uint32_t kp = 1; kp < A; kp++) {
           const uint32_t v = (r + kp) % A;
-          const uint32_t key = ck ^ g.ctab[g.off_cr + ci * A + r] ^ g.ctab[g.off_cr + ci * A + v];
+          const uint32_t key = ck ^ ct[g.off_cr + ci * A + r] ^ ct[g.off_cr + ci * A + v];
           /* (counters slice-major: the blocks of all groups of a slice lie side by side
              and make one chunk -- the slice is staged once for them) */
           f((key & g.smask) * Q.ngroups + (ci * (A - 1) + kp - 1), 0ull, kp | (pos << 8) | (ITEM_SUB2 << 24));
@@ -424,16 +487,16 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
           if ((mk & ~1u) == p) {
             if (k < ci)
               first = false;
-            key ^= g.ctab[g.off_cr + k * A + s[mk]];
+            key ^= ct[g.off_cr + k * A + s[mk]];
           }
         }
         if (first) {
           const uint32_t ra = s[p], rb = p + 1 < L ? (uint32_t)s[p + 1] : A;
           uint64_t w = 0;
           if (HASH) {
-            w = h ^ Q.zob[A * p + ra];
+            w = h ^ zt[A * p + ra];
             if (p + 1 < L)
-              w ^= Q.zob[A * (p + 1) + rb];
+              w ^= zt[A * (p + 1) + rb];
           }
           uint32_t fl = 0;
           if (Q.indels && L > 1) {
@@ -442,7 +505,7 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
             if (p + 1 < L && s[p + 1] != s[p])
               fl |= ITEM_DEL2_COUNTS;
           }
-          key ^= pair_part_terms(g.ctab, g, A, L, p, [&](uint32_t pos) -> uint32_t { return s[pos]; });
+          key ^= pair_part_terms(ct, g, A, L, p, [&](uint32_t pos) -> uint32_t { return s[pos]; });
           f(Q.goff[ci] + (key & g.cmask), w, ra | (rb << 5) | (p << 10) | (ITEM_PAIR << 24) | fl);
         }
       }
@@ -457,8 +520,8 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
     uint32_t base = ck;
     if (heavy)
       for (uint32_t k = 0; k < K; k++)
-        base ^= g.ctab[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
-    const uint32_t base_i = base ^ g.ctab[L] ^ g.ctab[L + 1];
+        base ^= ct[g.off_cr + k * A + s[class_pos(L, k, g.c0)]];
+    const uint32_t base_i = base ^ ct[L] ^ ct[L + 1];
     if (!class_is_heavy(g.ctab, g, base_i))
       return;
     const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull;
@@ -473,15 +536,15 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
             if (ci < 0)
               ci = (int)k;
           } else {
-            key ^= g.ctab[g.off_cr + k * A + s[mk < x ? mk : mk - 1]];
+            key ^= ct[g.off_cr + k * A + s[mk < x ? mk : mk - 1]];
           }
         }
         if (ci >= 0) {
-          key ^= pair_part_terms(g.ctab, g, A, L + 1, x,
+          key ^= pair_part_terms(ct, g, A, L + 1, x,
                                  [&](uint32_t pos) -> uint32_t { return s[pos < x ? pos : pos - 1]; });
           uint64_t w = P0 ^ hins ^ Pp;           /* gap at x */
           if (HASH && x < L)
-            w ^= Q.zob[A * (x + 1) + s[x]];      /* ... and q[x], one position up, blanked */
+            w ^= zt[A * (x + 1) + s[x]];      /* ... and q[x], one position up, blanked */
           f(Q.goff[ci] + (key & g.cmask), w,
             (x < L ? (uint32_t)s[x] : A) | ((x > 0 ? (uint32_t)s[x - 1] : 31u) << 5) | (x << 10) | (ITEM_INS << 24));
         }
@@ -489,8 +552,8 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
       if (x == L)
         break;
       if (HASH) {
-        P0 ^= Q.zob[A * x + s[x]];
-        Pp ^= Q.zob[A * (x + 1) + s[x]];
+        P0 ^= zt[A * x + s[x]];
+        Pp ^= zt[A * (x + 1) + s[x]];
       }
     }
     return;
@@ -505,11 +568,11 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
         if (class_pos(L, k, g.c0) == pos) {
           if (k < ci)
             first = false;
-          key ^= g.ctab[g.off_cr + k * A + s[pos]];
+          key ^= ct[g.off_cr + k * A + s[pos]];
         }
       /* (single rows: d = 2 -- with -i, which goes with d = 1 only, the filter holds pair rows) */
       if (first)
-        f(Q.goff[ci] + (key & g.cmask), HASH ? h ^ Q.zob[A * pos + s[pos]] : 0ull,
+        f(Q.goff[ci] + (key & g.cmask), HASH ? h ^ zt[A * pos + s[pos]] : 0ull,
           (uint32_t)s[pos] | (pos << 8) | (ITEM_SUB << 24));
     }
   }
@@ -518,39 +581,48 @@ __device__ inline void for_each_item(const QL &Q, uint64_t i, const uint8_t *s, 
 /* One thread per query of [q0, q1): first what a host pass over the set would check,
    then -- for a sound query -- its keys. */
 __global__ void __launch_bounds__(256)
-keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
+keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
-  extern __shared__ double tot_lds[];          /* n_rep doubles when they fit */
+  /* dynamic LDS: n_rep doubles when they fit | the Zobrist keys when they fit (zob_lds) | (item_wg) the item
+     counters | OWN_DW words per thread */
+  extern __shared__ double tot_lds[];
   __shared__ uint32_t dest_lds[64];            /* route: this workgroup's records per destination */
   const bool lds_tot = Q.n_rep <= 2048;
+  uint64_t *const zl = (uint64_t *)(tot_lds + (lds_tot ? Q.n_rep : 0u));
+  uint32_t *const ctl = (uint32_t *)(zl + (Q.zob_lds ? Q.zob_words : 0u));
+  uint32_t *const ihist = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
+  uint32_t *const mine = ihist + (Q.item_wg ? Q.nitem_slices : 0u) + threadIdx.x * OWN_DW;
+  const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   if (lds_tot) {
     for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
       tot_lds[r] = 0.0;
   }
+  if (Q.zob_lds)
+    for (uint32_t k = threadIdx.x; k < Q.zob_words; k += 256)
+      zl[k] = Q.zob[k];
+  if (Q.ctab_lds)
+    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += 256)
+      ctl[k] = Q.geom.ctab[k];
+  if (Q.item_wg)
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256)
+      ihist[k] = 0;
   if (threadIdx.x < 64)
     dest_lds[threadIdx.x] = 0;
+  /* (a set whose offsets the host never saw: what cmpr_layout_queries checks of them) */
+  if (Q.total_on_device && blockIdx.x == 0 && threadIdx.x == 0 && q0 == 0 && Q.off[0] != 0)
+    atomicCAS(Q.verr, 0u, (uint32_t)VERR_OFFSETS0);
+  const uint64_t total = total_of(Q);
   __syncthreads();
   /* (a workgroup takes every gridDim.x-th batch of 256 queries: its sums leave it once, not once
      per batch -- 39 000 workgroups adding to the same few words and the repertoire totals' one
      line took 2.4 ms per 10M queries where the kernel's own work takes a fifth of that) */
-  /* The residues of a batch lie side by side: they are copied to LDS in whole dwords and the loops
-     below read them there.  (Read where they lie, a byte per load and every load of a loop waiting for
-     the one before, a query's thread spent 86 us in this kernel -- 1.9 ms per 10M queries.) */
-  __shared__ uint32_t res_lds[KEYS_STAGE_BYTES / 4];
   unsigned long long alg = 0;
   uint32_t err_all = 0, Lmax = 0;
-  for (uint64_t base = q0 + (uint64_t)blockIdx.x * 256; base < q1; base += (uint64_t)gridDim.x * 256) {
-    const uint64_t i = base + threadIdx.x;
-    uint64_t a0, sb, se;
-    __syncthreads();                           /* (the batch before is through with the buffer) */
-    const bool stage = stage_residues(Q, base, min(base + 256, q1), res_lds, a0, sb, se);
-    __syncthreads();
-    if (i >= q1)
-      continue;
+  for (uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * 256) {
     uint32_t err = 0;
     const uint64_t b = Q.off[i], e = Q.off[i + 1];
     uint32_t L = 0;
-    if (e < b || e > Q.total)
+    if (e < b || e > total)
       err = VERR_OFFSETS;
     else if (e - b > 0xffffu)
       err = VERR_LONG;
@@ -565,7 +637,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       err = VERR_GENE;
     if (!err && Q.counts && Q.cnt[i] < 1)
       err = VERR_COUNT;
-    const uint8_t *s = (stage && b >= sb && e <= se) ? (const uint8_t *)res_lds + (b - a0) : Q.res + b;
+    const uint8_t *s = err ? Q.res : own_residues(Q, b, e, total, mine);
     if (!err) {
       bool bad = false;
       for (uint32_t p = 0; p < L; p++)
@@ -586,28 +658,33 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       const uint32_t vg = Q.genes ? Q.v[i] : 0u, jg = Q.genes ? Q.j[i] : 0u;
       uint32_t ck = 0;
       bool heavy = false;
-      if (Q.sliced && !LDBG(Q, LDBG_NO_CLASSKEY))
-        ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, vg, jg, &heavy);
-      else if (Q.sliced)
+      if (Q.sliced && !LDBG(Q, LDBG_NO_CLASSKEY)) {
+        /* (class_key_of, layout.h, with the tables in front of the heavy bitmap read from LDS) */
+        ck = class_base(ct, Q.geom, Q.genes != 0, L, vg, jg);
+        heavy = Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, ck);
+        if (heavy && L > 0)
+          for (uint32_t k = 0; k < Q.geom.k; k++)
+            ck ^= ct[Q.geom.off_cr + k * Q.A + s[class_pos(L, k, Q.geom.c0)]];
+      } else if (Q.sliced)
         ck = (uint32_t)i * 2654435761u;
       if (Q.rows || Q.direct) {
         /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that
            seed the rolling indel enumeration (:90-104, :122-136) */
         uint64_t h = 0;
         if (Q.genes) {
-          const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-          h = gk[vg] ^ gk[Q.n_v + jg];
-        }
-        uint64_t hins = h, hdel = h;
-        for (uint32_t p = 0; p < (LDBG(Q, LDBG_NO_HASH) ? 0u : L); p++) {
-          const uint32_t r = s[p];
-          h ^= Q.zob[Q.A * p + r];
-          if (Q.indels) {
-            hins ^= Q.zob[Q.A * (p + 1) + r];
-            if (p > 0)
-              hdel ^= Q.zob[Q.A * (p - 1) + r];
+          if (Q.zob_lds) {
+            const uint64_t *gk = zl + Q.A * Q.zpos;
+            h = gk[vg] ^ gk[Q.n_v + jg];
+          } else {
+            const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+            h = gk[vg] ^ gk[Q.n_v + jg];
           }
         }
+        uint64_t hins = h, hdel = h;
+        if (Q.zob_lds)
+          hashes_of((const uint64_t *)zl, Q.A, Q.indels != 0, s, LDBG(Q, LDBG_NO_HASH) ? 0u : L, h, hins, hdel);
+        else
+          hashes_of(Q.zob, Q.A, Q.indels != 0, s, LDBG(Q, LDBG_NO_HASH) ? 0u : L, h, hins, hdel);
         if (Q.direct) {
           /* d = 0 without a filter: no slices to group by -- the pseudo-slice only spreads the group
              counters (one per length would take every query's atomic) and names the work shard */
@@ -630,7 +707,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
            record where the positive is resolved) */
         unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : (ck & DIRECT_OWNER_MASK), 0u, Q.wstep);
         if (Q.ngroups)
-          for_each_item<false>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+          for_each_item<false>(Q, ct, Q.zob, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
             mask |= 1ull << item_owner(Q, k, Q.wstep);
           });
         if (Q.route == 2u)
@@ -643,9 +720,12 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       /* the items of the query that this context works on */
       bool any_item = false;
       if (Q.ngroups && !Q.route && !LDBG(Q, LDBG_NO_ITEM_COUNT))
-        for_each_item<false>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+        for_each_item<false>(Q, ct, Q.zob, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
           if (item_owned(Q, k)) {
-            atomicAdd(Q.ccnt_r + (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k, 1u);
+            if (Q.item_wg)
+              atomicAdd(&ihist[k], 1u);
+            else
+              atomicAdd(Q.ccnt_r + (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k, 1u);
             any_item = true;
           }
         });
@@ -665,9 +745,11 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
       if (bucket != ~0ull && !Q.route) {
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
-        Q.rank[i] = LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u);
+        /* (its top bit: the query's class is split -- scatter_kernel need not ask the tables again) */
+        Q.rank[i] = (LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u)) | (heavy ? 0x80000000u : 0u);
       }
-      if (Q.alg_step <= 1u || work_owner(slice, 0u, Q.alg_step) == Q.alg_first)
+      /* (the same key as owned() above: ADVICE r5) */
+      if (Q.alg_step <= 1u || work_owner(Q.sliced ? slice : (ck & DIRECT_OWNER_MASK), 0u, Q.alg_step) == Q.alg_first)
         alg += LDBG(Q, LDBG_NO_TOTALS) ? 0ull : (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
   }
@@ -691,6 +773,15 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1)
   }
   if (Q.route && threadIdx.x < 64 && dest_lds[threadIdx.x])
     atomicAdd(Q.dest_cnt + threadIdx.x, (unsigned long long)dest_lds[threadIdx.x]);
+  /* item_wg: a run for this workgroup's items of every counter it met (QL::item_wg) */
+  if (Q.item_wg) {
+    uint32_t *const row = Q.rbase + (size_t)(row0 + blockIdx.x) * Q.nitem_slices;
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256) {
+      const uint32_t cn = ihist[k];
+      if (cn)
+        row[k] = atomicAdd(Q.ccnt_r + (size_t)k * ITEM_PAD, cn);
+    }
+  }
 }
 
 /* ---- narrowed upload: back to the caller's types -------------------------- */
@@ -882,123 +973,197 @@ slices_kernel(const QL Q, uint32_t pi)
 
 /* ---- placement ------------------------------------------------------------ */
 
-/* One thread per query: its record and its hashes to slot = group base + rank, as two
-   whole pieces of memory (64 + 32 bytes) -- the only scattered writes of the layout --, and
-   its items (variant 2 / sub2: the flat items of kernels_rows.h, 16 bytes each; a pass of their
-   own over the queries until round 5). */
+/* One thread per query: its 64-byte record to slot = group base + rank -- a whole piece of memory, the only
+   scattered write per query -- and its items (variant 2 / sub2: the flat items of kernels_rows.h, 16 bytes
+   each; a pass of their own over the queries until round 5).  The records leave the wave TRANSPOSED (round 6):
+   a lane's sixteen dwords go through its words of LDS, and four adjacent lanes write the four 16-byte pieces of
+   one record -- 64 contiguous bytes, one request to the memory system where a lane writing its own record in
+   four instructions made four (6.5 write requests per query in all, 0.23 ms of the kernel's 1.0 even with every
+   record sent to consecutive slots).  (Sets with sequences beyond the record's 36 residues, and the residue
+   packs of kernels_pairs2.h, also leave a QAux beside the record: QL::recompute.) */
 __global__ void __launch_bounds__(256)
-scatter_kernel(const QL Q)
+scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
-  __shared__ uint32_t res_lds[KEYS_STAGE_BYTES / 4 + 16];
-  const uint64_t base = (uint64_t)blockIdx.x * 256;
-  const uint64_t i = base + threadIdx.x;
-  uint64_t a0, sb, se;
-  const bool stage = stage_residues(Q, base, min(base + 256, Q.n), res_lds, a0, sb, se);
-  __syncthreads();
-  if (i >= Q.n)
-    return;
-  const uint32_t g = Q.grp[0][i];
-  if (g == 0xffffffffu) {                    /* not worked on by this context (no item of it either) */
-    Q.slot_of[i] = 0xffffffffu;
-    return;
+  /* dynamic LDS: (item_wg) where this workgroup's items of counter k go next | SCAT_DW words per thread */
+  extern __shared__ uint64_t scat_lds[];
+  uint64_t *const zl = scat_lds;
+  uint32_t *const ctl = (uint32_t *)(zl + (Q.zob_lds ? Q.zob_pos_words : 0u));
+  uint32_t *const ibase = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
+  uint32_t *const wave_words = ibase + (Q.item_wg ? Q.nitem_slices : 0u) + (threadIdx.x & ~63u) * OWN_DW;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t *const mine = wave_words + lane * OWN_DW;
+  const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
+  const uint64_t *const zt = Q.zob_lds ? zl : Q.zob;
+  if (Q.zob_lds)                             /* (the keys of the positions; the gene keys are not asked here) */
+    for (uint32_t k = threadIdx.x; k < Q.zob_pos_words; k += 256)
+      zl[k] = Q.zob[k];
+  if (Q.ctab_lds)
+    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += 256)
+      ctl[k] = Q.geom.ctab[k];
+  if (Q.zob_lds || Q.ctab_lds)
+    __syncthreads();
+  if (Q.item_wg) {
+    /* (the run keys_kernel's workgroup of the same number claimed for the same queries; a counter it did not
+       meet holds whatever the arena held -- nobody asks) */
+    const uint32_t *const row = Q.rbase + (size_t)(row0 + blockIdx.x) * Q.nitem_slices;
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256)
+      ibase[k] = Q.cbase[k] + row[k];
+    __syncthreads();
   }
-  const uint32_t slot = Q.base_g[0][g] + Q.rank[i];
-  Q.slot_of[i] = slot;
-  const uint64_t b = Q.off[i], e = Q.off[i + 1];
-  const uint32_t L = (uint32_t)(e - b);
-  const bool in_lds = stage && b >= sb && e <= se;
-  const uint8_t *s = in_lds ? (const uint8_t *)res_lds + (b - a0) : Q.res + b;
-  QueryRec qr;
-  qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
-  qr.v = Q.genes ? Q.v[i] : 0u;
-  qr.j = Q.genes ? Q.j[i] : 0u;
-  const uint32_t orig = Q.orig ? Q.orig[i] : (uint32_t)i;
-  qr.rep = Q.existence ? orig : Q.rep[i];           /* -x: the row is the sequence itself */
-  qr.len = L;
-  qr.orig = orig;
-  if (in_lds) {
-    /* nine dwords from ten aligned ones (the staged copy keeps the set's byte phase) */
-    const uint32_t o = (uint32_t)(b - a0), w0 = o >> 2, sh = o & 3u;
-    uint32_t lo = res_lds[w0];
+  const uint64_t total = total_of(Q);
+  /* (the same queries as keys_kernel's workgroup of this number: QL::item_wg; a wave stays together to the
+     end of its last batch: the records are written by the wave, not by the lane) */
+  for (uint64_t i0 = q0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < q1; i0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = i0 + lane;
+    uint32_t slot = 0xffffffffu;
+    QueryRec qr;
+    qr.cnt = 0;
+    qr.v = qr.j = qr.rep = qr.len = qr.orig = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 9; w++) {
-      const uint32_t hi = res_lds[w0 + w + 1u];          /* (within the array's slack; masked below) */
-      const uint32_t d = __builtin_amdgcn_alignbyte(hi, lo, sh);
-      const int n = (int)L - (int)(4u * w);
-      qr.res[w] = d & (n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
-      lo = hi;
-    }
-  } else {
+    for (uint32_t w = 0; w < 9; w++)
+      qr.res[w] = 0;
+    const uint32_t g = i < q1 ? Q.grp[0][i] : 0xffffffffu;
+    if (i < q1 && g == 0xffffffffu)            /* not worked on by this context (no item of it either) */
+      Q.slot_of[i] = 0xffffffffu;
+    if (g != 0xffffffffu) {
+      const uint32_t rk = Q.rank[i];               /* (rank in the group | class split << 31: keys_kernel) */
+      slot = LDBG(Q, LDBG_S_NO_BASE) ? (uint32_t)i : Q.base_g[0][g] + (rk & 0x7fffffffu);
+      Q.slot_of[i] = slot;
+      const uint64_t b = Q.off[i], e = Q.off[i + 1];
+      const uint32_t L = (uint32_t)(e - b);
+      const uint8_t *s = own_residues(Q, b, e, total, mine);
+      const bool in_lds = s != Q.res + b;
+      qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
+      qr.v = Q.genes ? Q.v[i] : 0u;
+      qr.j = Q.genes ? Q.j[i] : 0u;
+      const uint32_t orig = Q.orig ? Q.orig[i] : (uint32_t)i;
+      qr.rep = Q.existence ? orig : Q.rep[i];           /* -x: the row is the sequence itself */
+      qr.len = L;
+      qr.orig = orig;
+      if (in_lds) {
+        /* nine dwords from ten aligned ones (the thread's copy keeps the set's byte phase) */
+        const uint32_t o = (uint32_t)(b & 15u), w0 = o >> 2, sh = o & 3u;
+        uint32_t lo = mine[w0];
 #pragma unroll
-    for (uint32_t w = 0; w < 9; w++) {
-      uint32_t d = 0;
+        for (uint32_t w = 0; w < 9; w++) {
+          const uint32_t hi = mine[w0 + w + 1u];             /* (at most the thread's 13th word; masked below) */
+          const uint32_t d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+          const int n = (int)L - (int)(4u * w);
+          qr.res[w] = d & (n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
+          lo = hi;
+        }
+      } else {
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
-        if (4 * w + k < L)
-          d |= (uint32_t)s[4 * w + k] << (8 * k);
-      qr.res[w] = d;
+        for (uint32_t w = 0; w < 9; w++) {
+          uint32_t d = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++)
+            if (4 * w + k < L)
+              d |= (uint32_t)s[4 * w + k] << (8 * k);
+          qr.res[w] = d;
+        }
+      }
+      if (!Q.recompute) {
+        QAux a;
+        a.h = a.hins = a.hdel = 0;
+        a.ck = 0;
+        a.src = (uint32_t)i;
+        if (Q.rows) {
+          a.h = Q.h_tmp[i];
+          a.ck = Q.ck_tmp[i];
+          if (Q.indels) {
+            a.hins = Q.hins_tmp[i];
+            a.hdel = Q.hdel_tmp[i];
+          }
+        } else if (Q.direct) {
+          a.h = Q.h_tmp[i];
+        } else if (Q.genes) {
+          const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+          a.h = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
+        }
+        Q.aux[slot] = a;
+      }
+      if (Q.ngroups != 0 && !LDBG(Q, LDBG_S_NO_ITEMS)) {
+        /* ---- the query's items: the row's (variant's) hash, what to exclude / where / what kind, and
+                the query's slot in pass 0 ---- */
+        const uint32_t ck = (Q.rows || Q.sub2_items) ? Q.ck_tmp[i] : 0u;
+        const bool heavy = (rk >> 31) != 0;
+        uint64_t hq = 0;
+        cmpr::ResPack pk{};
+        if (Q.pairs2 && heavy)
+          for (uint32_t x = 0; x < L && x < RESPACK_MAX; x++)
+            pk.w[x >> 4] |= ((uint32_t)s[x] & 3u) << ((x & 15u) * 2u);
+        if (Q.sub2_items && heavy && L <= RESPACK_MAX) {
+          if (Q.genes) {
+            const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+            hq = gk[qr.v] ^ gk[Q.n_v + qr.j];
+          }
+          for (uint32_t x = 0; x < L; x++) {
+            const uint32_t r = s[x];
+            hq ^= Q.zob[Q.A * x + r];
+            pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
+          }
+        }
+        for_each_item<true>(Q, ct, zt, i, s, L, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
+          if (!item_owned(Q, k))
+            return;
+          uint32_t item;
+          if (Q.item_wg) {
+            item = atomicAdd(&ibase[k], 1u);
+          } else {
+            const size_t rk = (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k;
+            item = Q.cbase[k] + Q.rbase[rk] + atomicAdd(Q.cfill_r + rk, 1u);
+          }
+          if (Q.sub2_items) {
+            w = hq;                                   /* the query's hash and residues travel with the item */
+            Q.cpk[item] = pk;
+          } else if (Q.pairs2) {
+            Q.cpk[item] = pk;                         /* (beside the pair-blanked hash) */
+          }
+          ItemRec it;
+          it.w = w;
+          it.main = slot;
+          it.rp = crp;
+          if (!LDBG(Q, LDBG_S_NO_ITEM_WRITE))
+            Q.items[item] = it;
+        });
+      }
     }
+    /* ---- the wave's records, transposed through LDS: half a wave at a time -- 32 records of 17 words fit the
+            wave's 64 x 13 words, whose residue pieces have been read ---- */
+    if (LDBG(Q, LDBG_S_NO_REC))
+      continue;
+    static_assert(sizeof(QueryRec) == 64, "the record is four 16-byte pieces");
+    static_assert(32 * 17 <= 64 * OWN_DW, "half a wave's records in the wave's words");
+    const uint32_t out_slot = LDBG(Q, LDBG_S_SEQ_REC) && slot != 0xffffffffu ? (uint32_t)i : slot;
+#pragma unroll
+    for (uint32_t half = 0; half < 2; half++) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if ((lane >> 5) == half) {
+        uint32_t *const dst = wave_words + (lane & 31u) * 17u;
+        const uint32_t *q = (const uint32_t *)&qr;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++)
+          dst[w] = q[w];
+        dst[16] = out_slot;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (uint32_t r = 0; r < 2; r++) {
+        const uint32_t *src = wave_words + (16u * r + (lane >> 2)) * 17u;
+        const uint32_t part = lane & 3u;
+        const uint32_t sl = src[16];
+        const uint4 v = make_uint4(src[4 * part], src[4 * part + 1], src[4 * part + 2], src[4 * part + 3]);
+        if (sl != 0xffffffffu)
+          *(uint4 *)((char *)(Q.qrec + sl) + 16u * part) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  Q.qrec[slot] = qr;
-  QAux a;
-  a.h = a.hins = a.hdel = 0;
-  a.ck = 0;
-  a.src = (uint32_t)i;
-  if (Q.rows) {
-    a.h = Q.h_tmp[i];
-    a.ck = Q.ck_tmp[i];
-    if (Q.indels) {
-      a.hins = Q.hins_tmp[i];
-      a.hdel = Q.hdel_tmp[i];
-    }
-  } else if (Q.direct) {
-    a.h = Q.h_tmp[i];
-  } else if (Q.genes) {
-    const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-    a.h = gk[Q.v[i]] ^ gk[Q.n_v + Q.j[i]];
-  }
-  Q.aux[slot] = a;
-  if (Q.ngroups == 0)
-    return;
-
-  /* ---- the query's items: the row's (variant's) hash, what to exclude / where / what kind, and
-          the query's slot in pass 0 ---- */
-  const uint32_t ck = (Q.rows || Q.sub2_items) ? Q.ck_tmp[i] : 0u;
-  const bool heavy = Q.geom.k > 0 &&
-                     class_is_heavy(Q.geom.ctab, Q.geom, class_base(Q.geom.ctab, Q.geom, Q.genes != 0, L, qr.v, qr.j));
-  uint64_t hq = 0;
-  cmpr::ResPack pk{};
-  if (Q.pairs2 && heavy)
-    for (uint32_t x = 0; x < L && x < RESPACK_MAX; x++)
-      pk.w[x >> 4] |= ((uint32_t)s[x] & 3u) << ((x & 15u) * 2u);
-  if (Q.sub2_items && heavy && L <= RESPACK_MAX) {
-    if (Q.genes) {
-      const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
-      hq = gk[qr.v] ^ gk[Q.n_v + qr.j];
-    }
-    for (uint32_t x = 0; x < L; x++) {
-      const uint32_t r = s[x];
-      hq ^= Q.zob[Q.A * x + r];
-      pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
-    }
-  }
-  for_each_item<true>(Q, i, s, L, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
-    if (!item_owned(Q, k))
-      return;
-    const size_t rk = (size_t)((uint32_t)(i >> 8) % Q.item_reps) * Q.nitem_slices + k;
-    const uint32_t item = Q.cbase[k] + Q.rbase[rk] + atomicAdd(Q.cfill_r + rk, 1u);
-    if (Q.sub2_items) {
-      w = hq;                                   /* the query's hash and residues travel with the item */
-      Q.cpk[item] = pk;
-    } else if (Q.pairs2) {
-      Q.cpk[item] = pk;                         /* (beside the pair-blanked hash) */
-    }
-    ItemRec it;
-    it.w = w;
-    it.main = slot;
-    it.rp = crp;
-    Q.items[item] = it;
-  });
 }
 
 /* One wave per tile, one lane per slot: the records scatter_kernel left, read in slot
@@ -1015,20 +1180,55 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
   const TileDesc td = Q.tiles[t];
   const uint32_t slot = t * WAVE + lane;
   const bool valid = lane < td.nvalid;
+  __shared__ uint32_t rl[256 * 9];           /* recompute: a lane's residues, read a byte at a time */
   QueryRec qr;
   QAux a;
+  a.h = a.hins = a.hdel = 0;
+  a.ck = a.src = 0;
   if (valid) {
     qr = Q.qrec[slot];
-    a = Q.aux[slot];
+    if (!Q.recompute)
+      a = Q.aux[slot];
   } else {
     qr.cnt = 0;
     qr.v = qr.j = qr.rep = qr.len = qr.orig = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 9; w++)
       qr.res[w] = 0;
-    a.h = a.hins = a.hdel = 0;
-    a.ck = a.src = 0;
     Q.qrec[slot] = qr;
+  }
+  if (Q.recompute && valid) {
+    /* what keys_kernel worked out for this query, once more from its record (every residue is in it):
+       the hashes and the class key are not scattered beside the record (32 bytes per query to a random
+       place; round 6) -- zobrist_hash and the two shifted hashes, zobrist.cc:74-136 */
+    uint32_t *const mine = rl + threadIdx.x * 9;
+#pragma unroll
+    for (uint32_t w = 0; w < 9; w++)
+      mine[w] = qr.res[w];
+    const uint8_t *s = (const uint8_t *)mine;
+    const uint32_t L = qr.len;
+    uint64_t h = 0;
+    if (Q.genes) {
+      const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+      h = gk[qr.v] ^ gk[Q.n_v + qr.j];
+    }
+    if (Q.rows || Q.direct) {
+      uint64_t hins = h, hdel = h;
+      for (uint32_t p = 0; p < L; p++) {
+        const uint32_t r = s[p];
+        h ^= Q.zob[Q.A * p + r];
+        if (Q.indels) {
+          hins ^= Q.zob[Q.A * (p + 1) + r];
+          if (p > 0)
+            hdel ^= Q.zob[Q.A * (p - 1) + r];
+        }
+      }
+      a.hins = hins;
+      a.hdel = hdel;
+      if (Q.rows)
+        a.ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, qr.v, qr.j, nullptr);
+    }
+    a.h = h;
   }
   Q.qlen[slot] = (uint16_t)qr.len;
   Q.qorig[slot] = qr.orig;
@@ -1097,6 +1297,10 @@ item_replicas_kernel(const QL Q)
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= (uint64_t)Q.nitem_slices)
     return;
+  if (Q.item_wg) {                           /* (counted per workgroup: the padded counters hold the sums) */
+    Q.ccnt[k] = Q.ccnt_r[(size_t)k * ITEM_PAD];
+    return;
+  }
   uint32_t run = 0;
   for (uint32_t r = 0; r < Q.item_reps; r++) {
     const size_t rk = (size_t)r * Q.nitem_slices + k;
@@ -1487,6 +1691,7 @@ const char *verr_message(uint32_t e)
   case VERR_REP:     return "repertoire number out of range";
   case VERR_GENE:    return "gene number out of range";
   case VERR_COUNT:   return "duplicate_count must be >= 1";
+  case VERR_OFFSETS0: return "offsets[0] must be 0";
   default:           return "residue code out of range";
   }
 }
@@ -1673,17 +1878,13 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     total = n ? s->offsets[n] : 0;
   } else if (from_records) {
     total = n * (uint64_t)Lcap;                           /* (an upper bound sizes the arena; the scan gives the sum) */
-  } else if (n) {
-    uint64_t ends[2] = {0, 0};
-    HIP_TRY(c, hipMemcpy(&ends[0], s->offsets, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(&ends[1], s->offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (ends[0] != 0)
-      return fail(c, CMPR_EINVAL, "offsets[0] must be 0");
-    total = ends[1];
   }
+  /* (device arrays: the offsets stay where they are -- the keys kernel reads offsets[n] there, checks
+     offsets[0] and every sequence's length; until round 6 two blocking copies fetched the two ends first) */
+  const bool total_on_device = src.kind == LayoutSource::DEVICE && n > 0;
   if (n > 0x7fffffffull)                                  /* (hipCUB item counts are int) */
     return fail(c, CMPR_EUNSUPPORTED, "more than 2^31-1 sequences in one set");
-  if (total > 0xffffull * n)
+  if (!total_on_device && total > 0xffffull * n)
     return fail(c, CMPR_EINVAL, verr_message(VERR_OFFSETS));
   /* the caller's arrays on the device: copied there (host), unpacked there (records), or
      where the caller has them (device; an empty set still needs its one offset) */
@@ -1772,15 +1973,66 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const bool mixed_ok = c->sliced && (!c->opt.indels || c->rows);
   const uint64_t n2s = indel_passes ? 2 * nslices : 0;
 
+  /* ---- the query ranges keys_kernel and scatter_kernel are launched over (host arrays: up to four, a
+          range's keys run under the copy of the next; few and large: every copy call costs ~20 us of host
+          time, and the last range -- the smallest -- is what the upload does not hide) ---- */
+  struct Range { uint64_t q0, q1; uint32_t grid, row0; };
+  std::vector<Range> ranges;
+  /* few item counters: counted per workgroup in LDS (QL::item_wg) */
+  const bool item_wg = ncs > 0 && ncs <= ITEM_WG_MAX && !routing && c->item_wg != 0;
+  /* the Zobrist keys (gene keys behind them) in keys_kernel's LDS when they are few: CDR3 lengths, not 1 000-
+     nucleotide sequences */
+  const uint64_t zob_words = (uint64_t)A * c->zpos + (c->opt.ignore_genes ? 0 : c->opt.n_v_genes + c->opt.n_j_genes);
+  const bool zob_lds = c->layout_zob_lds != 0 && zob_words * sizeof(uint64_t) <= 12288;
+  const uint64_t zob_pos_words = (uint64_t)A * c->zpos;
+  const bool ctab_lds = c->layout_zob_lds != 0 && c->sliced && c->geom.off_hv <= 2048;
+  const size_t own_lds = 256 * OWN_DW * sizeof(uint32_t);
+  const size_t ctab_bytes = ctab_lds ? (size_t)c->geom.off_hv * sizeof(uint32_t) : 0;
+  const size_t keys_lds = (n_rep <= 2048 ? n_rep * sizeof(double) : 0) + (zob_lds ? zob_words * sizeof(uint64_t) : 0) +
+                          ctab_bytes + (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + own_lds;
+  const size_t scatter_lds = (zob_lds ? zob_pos_words * sizeof(uint64_t) : 0) + ctab_bytes +
+                             (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + own_lds;
+  if (keys_lds > 48 * 1024)
+    HIP_TRY(c, hipFuncSetAttribute((const void *)keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds));
+  /* Both kernels loop over their queries: the grid is what is RESIDENT at once (LDS and registers decide), no
+     more -- with 2 048 workgroups of which 6 or 7 per CU fit, the eighth ran alone behind the others, a second
+     round at a seventh of the occupancy for as long as the first (round 6: keys 0.80 -> .., scatter 1.01 -> ..).
+     The same grid for both (QL::item_wg). */
+  uint32_t resident = 2048;
+  {
+    int ok = 0, os = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ok, (const void *)keys_kernel, 256, keys_lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&os, (const void *)scatter_kernel, 256, scatter_lds) == hipSuccess &&
+        ok > 0 && os > 0)
+      resident = (uint32_t)c->cus * (uint32_t)std::min(ok, os);
+    (void)hipGetLastError();
+  }
+  {
+    const uint64_t min_range = 1u << 18;
+    const uint64_t nr = from_host ? std::max<uint64_t>(1, std::min<uint64_t>(4, n / min_range)) : 1;
+    static const uint32_t cut4[5] = {0, 30, 60, 86, 100};
+    uint32_t row = 0;
+    for (uint64_t r = 0; r < nr; r++) {
+      Range g;
+      g.q0 = nr == 4 ? n * cut4[r] / 100 : n * r / nr;
+      g.q1 = nr == 4 ? n * cut4[r + 1] / 100 : n * (r + 1) / nr;
+      g.grid = std::min<uint32_t>(blocks_for(g.q1 - g.q0), resident);
+      g.row0 = row;
+      row += g.grid;
+      ranges.push_back(g);
+    }
+  }
+  const uint64_t item_rows = (uint64_t)ranges.back().row0 + ranges.back().grid;
+
   /* ---- arena A: everything whose size the host knows now ---- */
   ArenaCut cut;
   /* (the counters that start at zero lie side by side: one memset) */
   const size_t o_gcnt = cut.take(G * npass * sizeof(uint32_t));
-  const uint32_t item_reps = ncs > 0 && ncs <= 65536 ? 32u : 1u;
+  const uint32_t item_reps = item_wg ? ITEM_PAD : ncs > 0 && ncs <= 65536 ? 32u : 1u;
   const size_t o_ccnt = cut.take(ncs * sizeof(uint32_t));
   const size_t o_cfill = cut.take(ncs * sizeof(uint32_t));
   const size_t o_ccnt_r = cut.take(ncs * item_reps * sizeof(uint32_t));
-  const size_t o_cfill_r = cut.take(ncs * item_reps * sizeof(uint32_t));
+  const size_t o_cfill_r = cut.take(item_wg ? 0 : ncs * item_reps * sizeof(uint32_t));
   const size_t o_sibcnt = cut.take(n2s * sizeof(uint32_t));
   const size_t o_sibfill = cut.take(n2s * sizeof(uint32_t));
   const size_t o_alg = cut.take(sizeof(unsigned long long));
@@ -1806,7 +2058,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_v16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_j16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_cnt32 = cut.take(narrow && !c->opt.ignore_counts ? (size_t)n * sizeof(uint32_t) : 0);
-  const size_t o_rbase = cut.take(ncs * item_reps * sizeof(uint32_t));
+  const size_t o_rbase = cut.take(ncs * (item_wg ? item_rows : (uint64_t)item_reps) * sizeof(uint32_t));
   const size_t o_gbase = cut.take(G * npass * sizeof(uint32_t));
   const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
@@ -1949,6 +2201,11 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.cfill_r = (uint32_t *)at(o_cfill_r);
   Q.rbase = (uint32_t *)at(o_rbase);
   Q.item_reps = item_reps;
+  Q.item_wg = item_wg ? 1u : 0u;
+  /* every query fits its 64-byte record (36 residues): the tiles' hashes and class keys are worked out from
+     the records, nothing else is scattered (kernels_pairs2.h's residue packs are built where the set lies) */
+  Q.recompute = Lcap <= 36u && !c->d2pairs && c->layout_recompute != 0 ? 1u : 0u;
+  Q.total_on_device = total_on_device ? 1u : 0u;
   Q.cnch = (uint32_t *)at(o_cnch);
   Q.cchpre = (uint32_t *)at(o_cchpre);
   uint32_t *const cpad = (uint32_t *)at(o_cpad);
@@ -1969,9 +2226,24 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
           not fit (a count >= 2^32, an id >= 2^16, offsets that are no CDR3 lengths) sends
           the whole set the wide way, where the keys kernel names the error if it is one. ---- */
   double upload_ms = 0;
+  Q.zob_lds = zob_lds ? 1u : 0u;
+  Q.zob_words = (uint32_t)zob_words;
+  Q.zob_pos_words = (uint32_t)zob_pos_words;
+  Q.ctab_lds = ctab_lds ? 1u : 0u;
+  /* HIP events around the big kernels when the caller asks for their times (tunable "layout_timing";
+     an event record is a packet the stream waits ~4.5 us for) */
+  const bool timing = c->layout_timing != 0 && !from_host && c->ev_layout[0] != nullptr;
+  c->layout_marks = 0;
+#define LAYOUT_MARK(k)                                                      \
+  do {                                                                      \
+    if (timing) {                                                           \
+      HIP_TRY(c, hipEventRecord(c->ev_layout[k], c->stream));               \
+      c->layout_marks |= 1u << (k);                                         \
+    }                                                                       \
+  } while (0)
   if (!from_host) {
     static const uint64_t zero_off1[1] = {0};
-    const size_t lds = n_rep <= 2048 ? n_rep * sizeof(double) : 0;
+    const size_t lds = keys_lds;
     if (n == 0) {
       HIP_TRY(c, hipMemcpyAsync(at(o_off), zero_off1, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     } else {
@@ -1993,26 +2265,27 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                            c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), (uint32_t *)at(o_orig));
         HIP_TRY(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(keys_kernel, dim3(blocks_looping(n)), dim3(256), lds, c->stream, Q, (uint64_t)0, n);
+      LAYOUT_MARK(0);
+      hipLaunchKernelGGL(keys_kernel, dim3(ranges[0].grid), dim3(256), lds, c->stream, Q, (uint64_t)0, n, 0u);
       HIP_TRY(c, hipGetLastError());
+      LAYOUT_MARK(1);
     }
   } else
   for (int attempt = 0;; attempt++) {
     /* (few, large ranges: every copy call costs ~20 us of host time, and the keys kernel of
        the last range is what the upload does not hide) */
-    const uint64_t min_range = 1u << 18;
-    const uint64_t nranges = std::max<uint64_t>(1, std::min<uint64_t>(4, n / min_range));
-    const size_t lds = n_rep <= 2048 ? n_rep * sizeof(double) : 0;
+    const uint64_t nranges = ranges.size();
+    const size_t lds = keys_lds;
     HIP_TRY(c, hipEventRecord(c->ev_copy[0], c->stream));            /* (the memset above) */
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0));
     static const uint64_t zero_off[1] = {0};
     if (n == 0)
       HIP_TRY(c, hipMemcpyAsync(at(o_off), zero_off, sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
-    /* (the last range is the smallest: its keys kernel is what the upload does not hide) */
-    static const uint32_t cut4[5] = {0, 30, 60, 86, 100};
     uint64_t rq[5] = {0, 0, 0, 0, 0};
-    for (uint64_t r = 0; r <= nranges; r++)
-      rq[r] = nranges == 4 ? n * cut4[r] / 100 : n * r / nranges;
+    for (uint64_t r = 0; r < nranges; r++) {
+      rq[r] = ranges[r].q0;
+      rq[r + 1] = ranges[r].q1;
+    }
 
     /* the narrowing threads: thread t takes the t-th part of every range, range by range */
     /* (a thread per >= 128k queries: starting 32 threads costs more than a 1M-query share's narrowing) */
@@ -2143,7 +2416,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                            c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), q0, q1);
         HIP_TRY(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(keys_kernel, dim3(blocks_looping(q1 - q0)), dim3(256), lds, c->stream, Q, q0, q1);
+      hipLaunchKernelGGL(keys_kernel, dim3(ranges[r].grid), dim3(256), lds, c->stream, Q, q0, q1, ranges[r].row0);
       HIP_TRY(c, hipGetLastError());
     }
     if (n == 0) {
@@ -2324,7 +2597,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                                                        (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                                        (int)nsmall, 0, 17, c->stream);
   ArenaCut cb;
-  const size_t o_aux = cb.take(std::max<size_t>(slots, 1) * sizeof(QAux));
+  const size_t o_aux = cb.take(std::max<size_t>(Q.recompute ? 1 : slots, 1) * sizeof(QAux));
   const size_t o_chunks_u = cb.take((size_t)nchunks * sizeof(Chunk));
   const size_t o_wk = cb.take((size_t)nchunks * sizeof(uint32_t));
   const size_t o_wk2 = cb.take((size_t)nchunks * sizeof(uint32_t));
@@ -2426,15 +2699,21 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
 
   hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
   HIP_TRY(c, hipGetLastError());
+  LAYOUT_MARK(2);
   if (n) {
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
+    /* (the grid of every range's keys_kernel once more: QL::item_wg) */
+    for (const Range &g : ranges) {
+      hipLaunchKernelGGL(scatter_kernel, dim3(g.grid), dim3(256), scatter_lds, c->stream, Q, g.q0, g.q1, g.row0);
+      HIP_TRY(c, hipGetLastError());
+    }
   }
+  LAYOUT_MARK(3);
   if (ntiles) {
     hipLaunchKernelGGL(fill_tiles_kernel, dim3((uint32_t)((ntiles + 3) / 4)), dim3(256), 0, c->stream, Q,
                        (uint32_t)ntiles);
     HIP_TRY(c, hipGetLastError());
   }
+  LAYOUT_MARK(4);
   if (ngroups) {
     hipLaunchKernelGGL(class_chunks_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
@@ -2509,8 +2788,17 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->nsmall = (uint32_t)mine;
   }
+  LAYOUT_MARK(5);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const auto t_end = std::chrono::steady_clock::now();
+#undef LAYOUT_MARK
+  for (float &x : c->layout_kernel_ms)
+    x = 0.0f;
+  if (c->layout_marks == 0x3fu) {
+    /* keys | sizes (per-slice needs, scans, the host's round trip) | slices + scatter | tiles | chunk order */
+    for (int k = 0; k < 5; k++)
+      (void)hipEventElapsedTime(&c->layout_kernel_ms[k], c->ev_layout[k], c->ev_layout[k + 1]);
+  }
   c->layout_upload_ms = upload_ms;
   c->layout_tail_ms = std::chrono::duration<double, std::milli>(t_end - t_uploaded).count();
   c->layout_total_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();

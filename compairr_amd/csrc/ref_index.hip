@@ -653,6 +653,11 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
   }
   if (c->slots > (1ull << 30))
     return fail(c, CMPR_EUNSUPPORTED, "reference set too large for a 32-bit record table");
+  /* d = 0 on the un-sliced kernel looks every query up where its bucket lies (kernels.h probe_kernel, D == 0):
+     no filter is read, none is built (it was sized, cleared and filled for nothing) */
+  const bool no_filter = !c->sliced && c->opt.differences == 0;
+  if (no_filter)
+    c->bloom_words = 1;
   if ((rc = dev_alloc(c, c->bloom, (size_t)c->bloom_words))) return rc;
   /* inverted polarity (bloompat.cc:54-57) for variants 0, 1; the row filter sets bits */
   HIP_TRY(c, hipMemsetAsync(c->bloom.p, c->rows ? 0 : 0xff, c->bloom_words * sizeof(uint64_t), c->stream));
@@ -739,7 +744,7 @@ int cmpr_build_reference(cmpr_context *c, const cmpr_set_view *s, uint32_t longe
     if (c->rows) {
       B.bloom = c->bloom.p;
       hipLaunchKernelGGL(build_rows_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
-    } else {
+    } else if (!no_filter) {
       /* (variants 0, 1: the per-variant filter; no table) */
       hipLaunchKernelGGL(build_index_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, c->stream, B);
     }

@@ -144,12 +144,26 @@ def spawn_ranks(script: str, argv, n: int, env=None, timeout: Optional[float] = 
     e.setdefault("MASTER_ADDR", "127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT"):
         e.pop(k, None)
-    p = subprocess.Popen(launcher_command(script, argv, n), env=e, stdout=subprocess.PIPE)
+    # (a session of its own: the launcher and its N ranks are one process group, known exactly)
+    p = subprocess.Popen(launcher_command(script, argv, n), env=e, stdout=subprocess.PIPE, start_new_session=True)
     try:
         out, _ = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
-        p.kill()                                        # (the exact child started here, nothing by pattern)
-        out, _ = p.communicate()
+        # SIGTERM to the group first: torch.distributed.run forwards it to its workers (a SIGKILL of the
+        # launcher alone would orphan them with their GPUs and the rendezvous port); then the group is killed
+        import signal
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            out, _ = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
         sys.stdout.write(out.decode(errors="replace"))
         sys.stdout.flush()
         return 124

@@ -89,10 +89,16 @@ public:
       (void)api_.warm_up(&co);
       return;
     }
+    /* (--devices: one thread per device, as overlap() then creates their contexts side by side -- warmed one
+       after the other, eight devices and a small input would wait for the start-up they were to hide) */
+    std::vector<std::thread> th;
     for (size_t g = 0; g < o.devices.size(); g++) {
-      co.device = o.devices[g];
-      (void)api_.warm_up(&co);
+      cmpr_options cg = co;
+      cg.device = o.devices[g];
+      th.emplace_back([this, cg]() { (void)api_.warm_up(&cg); });
     }
+    for (auto &t : th)
+      t.join();
   }
 
   bool overlap(const Options &o, const GeneTables &genes, const RepertoireSet &set1,

@@ -237,11 +237,11 @@ int compairr_main(int argc, char **argv, OverlapBackend &backend)
       if (log2_text)
         fwrite(log2_text, 1, log2_len, log);
       free(log2_text);
-      if (exit2.failed) {
-        fputs(exit2.text.c_str(), stderr);
-        fflush(NULL);
-        exit(1);
-      }
+      if (exit2.failed)
+        /* (the HIP start-up may still be running on `warm`: exit_with_message leaves through _exit while a
+           helper thread is active -- no static destructor of the runtime under a thread that initialises it;
+           ADVICE r5) */
+        exit_with_message(stderr, false, exit2.text);
       /* file 2's genes join file 1's in the order they first appeared (db.cc:121-125) */
       std::vector<uint32_t> mv(genes2.v.names.size()), mj(genes2.j.names.size());
       for (size_t k = 0; k < mv.size(); k++)

@@ -41,13 +41,23 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
                 "cpu_baseline", "value_incl_layout", "value_incl_layout_cold", "value_from_device_soa",
-                "step_ms_incl_d2h", "parity_vs_reference_full_size"):
+                "step_ms_incl_d2h", "parity_vs_reference_full_size", "value_resident_step", "step_kernels_ms",
+                "roofline_kernels", "step"):
         assert key in plain, key
     assert plain["n_gpus"] == 1 and plain["ranks_seen"] == 1 and plain["steps"] == 3 and plain["value"] > 0
     assert plain["scaling"] == "strong" and plain["dtype"] == "u64"
     assert set(plain["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert plain["device_resident_inputs"]["same_matrix"] is True
-    assert plain["value_from_device_soa"] > plain["value_incl_layout"] > 0
+    assert plain["resident_steps_same_matrix"] is True
+    # a step is a query set from its device arrays to the matrix: the launches alone are faster, the set
+    # from host buffers slower
+    assert plain["value_resident_step"] > plain["value"] > plain["value_incl_layout"] > 0
+    assert set(plain["step_kernels_ms"]) >= {"keys", "scatter", "tiles", "probe", "resolve"}
+    assert set(plain["roofline_kernels"]) >= {"keys", "scatter", "tiles", "probe"}
+    # ... `--step resident` is rounds 1-5's definition
+    res = _run([sys.executable, "bench.py", "--gpus", "1", "--step", "resident"] + SMALL)
+    assert res["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    assert res["value"] > plain["value"]
     # the same workload through torch.distributed.run: process group on nccl (= RCCL),
     # all-reduce of the matrix inside every step
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
@@ -55,12 +65,18 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
                  "bench.py", "--gpus", "1"] + SMALL)
     assert dist["n_gpus"] == 1
     assert dist["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
-    # ... and the queries went through compairr_amd.dist.exchange_queries (route, pack, all-to-all, receive)
-    ex = dist["config"]["query_layout_ms"]["exchange"]
+    assert dist["config"]["query_layout_ms"]["exchange"] is None       # (query shards: nothing but the matrix moves)
+    # ... the work-shard split: the queries go through compairr_amd.dist.exchange_queries (route, pack,
+    # all-to-all, receive) in every step
+    work = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                 "bench.py", "--gpus", "1", "--shard-by", "work"] + SMALL)
+    assert work["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
+    ex = work["config"]["query_layout_ms"]["exchange"]
     assert ex["records_sent"] == ex["records_received"] == 300000 and ex["record_bytes"] == 64
     rep = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                "bench.py", "--gpus", "1", "--layout", "replicated"] + SMALL)
+                "bench.py", "--gpus", "1", "--shard-by", "work", "--layout", "replicated"] + SMALL)
     assert rep["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
     assert rep["config"]["query_layout_ms"]["exchange"] is None
     # ... and the way the driver starts N > 1 (`python3 bench.py --gpus N`, no launcher around it): bench.py starts
@@ -68,7 +84,6 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
     own = _run([sys.executable, "bench.py", "--gpus", "1", "--launcher", "always"] + SMALL)
     assert own["n_gpus"] == 1 and own["ranks_seen"] == 1
     assert own["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
-    assert own["config"]["query_layout_ms"]["exchange"]["records_sent"] == 300000
     # weak scaling keeps the same shard at N = 1
     weak = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "weak"] + SMALL)
     assert weak["scaling"] == "weak"

@@ -10,7 +10,6 @@ import pytest
 import _full_size
 import _oracle
 from _routed import routed_contexts
-from _routed import routed_contexts
 from compairr_amd import HipOverlap, Options, synth
 from compairr_amd import hip as hipmod
 from conftest import (expected_of, expected_pairs_of, load_manifest, run_cli, sorted_pairs,
@@ -120,6 +119,16 @@ LAYOUTS = {
     # for sets of a million and more) and widened again on the device
     "rows_narrow": {"variant": 2, "narrow_upload": 1},
     "lds_narrow": {"variant": 1, "narrow_upload": 1, "slice_words_log2": 5},
+    # round 5's form of the query layout (every other layout runs round 6's: the item counters of variant 2
+    # kept per workgroup in LDS, hashes and class keys worked out from the records by fill_tiles_kernel):
+    # item counters in memory, hashes scattered beside the records
+    "rows_layout_r5": {"variant": 2, "item_wg": 0, "layout_recompute": 0},
+    "rows_tiny_k3_layout_r5": {"variant": 2, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
+                               "heavy_threshold": 0, "item_wg": 0, "layout_recompute": 0},
+    "rows_items_in_memory": {"variant": 2, "item_wg": 0},
+    "rows_hashes_scattered": {"variant": 2, "layout_recompute": 0, "class_residues": 2, "heavy_threshold": 2},
+    "lds_layout_r5": {"variant": 1, "layout_recompute": 0},
+    "hbm_layout_r5": {"variant": 0, "layout_recompute": 0},
 }
 
 
@@ -230,6 +239,33 @@ def test_cli_sharded_over_devices(case, devices, tmp_path):
     if case.get("pairs"):
         assert sorted_pairs(pairs) == expected_pairs_of(case)
     assert p.stdout == expected_of(case)
+
+
+def test_cli_broken_second_file_exits_1_while_the_runtime_starts(tmp_path):
+    """A missing or broken file 2 fails within milliseconds, while the helper thread is still inside the HIP
+    start-up (cmpr_warm_up): the program prints the reference's message and leaves with status 1 -- through
+    _exit, not through the runtime's static destructors under a thread that is initialising it."""
+    import os
+    import subprocess
+    from conftest import GOLDEN_INPUTS, ROOT
+    good = os.path.join(GOLDEN_INPUTS, "seta.tsv")
+    with open(good) as fh:
+        lines = fh.read().splitlines()
+    header = lines[0].split("\t")
+    vi = header.index("v_call")
+    bad2 = str(tmp_path / "bad2.tsv")
+    with open(bad2, "w") as fh:                      # (no v_call column)
+        fh.write("\n".join("\t".join(c for k, c in enumerate(l.split("\t")) if k != vi) for l in lines) + "\n")
+    for second, msg in ((str(tmp_path / "absent.tsv"), b"Unable to open input data file"),
+                        (bad2, b"Missing essential column(s)")):
+        for _ in range(3):
+            log = str(tmp_path / "log.txt")
+            p = subprocess.run([os.path.join(ROOT, "bin", "compairr"), "-m", good, second, "-d", "1", "-l", log],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert p.returncode == 1, (p.returncode, p.stderr)
+            assert p.stdout == b""
+            text = p.stderr + open(log, "rb").read()
+            assert msg in text, text
 
 
 # ---- HIP vs oracle on seeded inputs, option matrix ----
