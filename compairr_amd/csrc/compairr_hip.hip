@@ -274,6 +274,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->arena_a.release();
   c->arena_b.release();
   if (c->stage_host) (void)hipHostFree(c->stage_host);
+  if (c->h_sizes) (void)hipHostFree(c->h_sizes);
   for (uint32_t i = 0; i < cmpr_context::NCOPY_EV; i++)
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   for (hipEvent_t e : c->ev_layout)
@@ -728,8 +729,9 @@ static int retire_queries(cmpr_context *c)
   return CMPR_OK;
 }
 
-static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
+static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src_in)
 {
+  LayoutSource src = src_in;
   if (!c)
     return CMPR_EINVAL;
   if (!c->have_ref)
@@ -751,11 +753,9 @@ static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
   if ((rc = retire_queries(c)))
     return rc;
 
-  /* upload, validation, grouping by slice, tiles, chunks: all on the device
-     (query_layout.hip) */
-  if ((rc = cmpr_layout_queries(c, src)))
-    return rc;
-
+  /* the per-launch scratch, queued behind the layout's kernels (LayoutSource::finish) */
+  src.finish = [c]() -> int {
+  int rc;
   /* (kept from call to call when large enough: no hipMalloc / hipFree in the steady state) */
   const size_t cells = (size_t)c->R1 * c->R2;
   if ((rc = dev_reserve(c, c->matrix, cells))) return rc;
@@ -792,7 +792,13 @@ static int cmpr_set_queries_impl(cmpr_context *c, const LayoutSource &src)
     HIP_TRY(c, hipMemsetAsync(c->part.p, 0, (size_t)NPART * c->part_stride * sizeof(unsigned long long),
                               c->stream));
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CMPR_OK;
+  };
+
+  /* upload, validation, grouping by slice, tiles, chunks: all on the device
+     (query_layout.hip); returns with the stream drained */
+  if ((rc = cmpr_layout_queries(c, src)))
+    return rc;
   if ((rc = make_plan(c))) return rc;
   c->have_q = true;
   return CMPR_OK;
@@ -828,6 +834,7 @@ void invalidate_plan(cmpr_context *c)
    every kernel argument that does not change from launch to launch. */
 int make_plan(cmpr_context *c)
 {
+  int rc;
   invalidate_plan(c);
   StepPlan &S = c->plan;
   S = StepPlan();
@@ -953,8 +960,7 @@ int make_plan(cmpr_context *c)
     if (lds2 > 160 * 1024)
       return fail(c, CMPR_EUNSUPPORTED, "the pair-row kernel of d = 2 does not fit the 160 KiB LDS");
     ProbeFn fn = select_probe_pairs2(!c->opt.ignore_genes);
-    if (lds2 > 48 * 1024)
-      HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    if ((rc = raise_lds_limit(c, (const void *)fn, lds2))) return rc;
     P.chunk_cap = c->chunk_cap;
     uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->cus, (uint64_t)c->nchunks));
     S.fn = fn;
@@ -989,17 +995,15 @@ int make_plan(cmpr_context *c)
                        : c->sliced ? select_sliced_kernel(c->opt, nw) : select_kernel(c->opt);
   if (fn == nullptr)
     return fail(c, CMPR_EUNSUPPORTED, "no kernel for this layout (class residues)");
-  if (lds > 48 * 1024)
-    HIP_TRY(c, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((rc = raise_lds_limit(c, (const void *)fn, lds))) return rc;
   /* resident workgroups per CU: LDS- and wave-limited, at most the tunable */
   uint64_t per_cu = std::min<uint64_t>((160 * 1024) / lds, 32 / (uint64_t)nw);
   if (c->rows || direct) {
     /* variant 2 deals its chunks out statically over the workgroups of the grid:
        exactly as many as are resident at once (registers count too); so does the d = 0
        kernel its tiles (a second round of workgroups would start when the first is through) */
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, nw * WAVE, lds) ==
-            hipSuccess && occ > 0)
+    const int occ = occupancy_of(c, (const void *)fn, nw * WAVE, lds);
+    if (occ > 0)
       per_cu = std::min<uint64_t>(per_cu, (uint64_t)occ);
   }
   per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (uint64_t)c->blocks_per_cu));
@@ -1023,8 +1027,7 @@ int make_plan(cmpr_context *c)
   if (S.redo_kind) {
     /* the redo pass (issue_step) */
     S.fn2 = select_rows_kernel(c->opt, nw, true, wide);
-    if (lds > 48 * 1024)
-      HIP_TRY(c, hipFuncSetAttribute((const void *)S.fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((rc = raise_lds_limit(c, (const void *)S.fn2, lds))) return rc;
   }
   S.valid = true;
   return CMPR_OK;

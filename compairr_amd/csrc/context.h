@@ -12,6 +12,9 @@
 
 #include "select.h"
 
+#include <functional>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -89,6 +92,9 @@ struct LayoutSource {
   /* cmpr_route_queries: key the share, count the records per destination, keep it for cmpr_route_pack */
   bool          route = false;
   uint64_t      first_index = 0;
+  /* what the caller has to queue on the context's stream behind the layout (its per-launch scratch): run just
+     before the layout's last wait, so that the call waits once at its end, not twice */
+  std::function<int()> finish;
 };
 
 /* the keyed share cmpr_route_queries leaves in arena A for cmpr_route_pack */
@@ -268,6 +274,12 @@ struct cmpr_context {
      parity suite), and HIP events around its big kernels (tunable "layout_timing", default 0) */
   int64_t                    item_wg = 1, layout_recompute = 1, layout_timing = 0;
   int64_t                    layout_zob_lds = 1;          /* keys_kernel keeps the Zobrist keys in LDS when they fit */
+  /* what the runtime said about a kernel with a given dynamic LDS size (asked once: a plan is made per query
+     set): workgroups per CU, and whether its LDS limit has been raised */
+  std::map<std::pair<const void *, size_t>, int> occupancy_seen;
+  std::set<std::pair<const void *, size_t>>      lds_raised;
+  void                      *h_sizes = nullptr;           /* pinned: the layout's SizesBlock arrives here */
+  size_t                     h_sizes_bytes = 0;
   hipEvent_t                 ev_layout[6] = {};
   uint32_t                   layout_marks = 0;
   float                      layout_kernel_ms[5] = {};    /* keys | sizes, slices | scatter | tiles | chunk order */
@@ -351,6 +363,29 @@ int dev_upload(cmpr_context *c, DevBuf<T> &b, const T *src, size_t n)
   if (n)
     HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
   return CMPR_OK;
+}
+
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) / hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered */
+inline int raise_lds_limit(cmpr_context *c, const void *fn, size_t lds)
+{
+  if (lds <= 48 * 1024 || c->lds_raised.count({fn, lds}))
+    return CMPR_OK;
+  HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  c->lds_raised.insert({fn, lds});
+  return CMPR_OK;
+}
+
+inline int occupancy_of(cmpr_context *c, const void *fn, int threads, size_t lds)
+{
+  auto it = c->occupancy_seen.find({fn, lds});
+  if (it != c->occupancy_seen.end())
+    return it->second;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds) != hipSuccess)
+    occ = 0;
+  (void)hipGetLastError();
+  c->occupancy_seen[{fn, lds}] = occ;
+  return occ;
 }
 
 inline bool is_f64_score(const cmpr_options &o)

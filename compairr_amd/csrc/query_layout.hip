@@ -205,7 +205,7 @@ struct QL {
   unsigned long long *alg_bytes;
 };
 
-constexpr uint32_t ITEM_WG_MAX = 4096;       /* counters a workgroup keeps in LDS (16 KiB) */
+constexpr uint32_t ITEM_WG_MAX = 16384;      /* counters a workgroup keeps in LDS (at most 64 KiB) */
 constexpr uint32_t ITEM_PAD = 16;            /* ... and claims runs from: one counter per 64 bytes */
 
 /* keys_kernel with parts left out (the "debug" tunable's bits 16.., -DCMPR_ABLATION builds only) */
@@ -351,6 +351,9 @@ validate_res_kernel(const uint8_t *res, uint64_t total, uint32_t A, uint32_t *ve
    256 queries.)  Sequences that do not fit the three pieces, or a set whose residues are not 16-byte
    aligned: read where they lie.  The caller has checked b <= e <= total. */
 constexpr uint32_t OWN_DW = 13;
+/* (threads of a workgroup of keys_kernel / scatter_kernel: 256, 512 or 1024 -- the more share one copy of the
+   tables (Zobrist keys, class tables, item counters: 22 KiB at 10M queries, 54 KiB with -i), the more waves
+   fit a CU beside them; chosen per call, cmpr_layout_queries) */
 __device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t *mine)
 {
   const uint64_t a0 = b & ~15ull;
@@ -580,7 +583,8 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
 
 /* One thread per query of [q0, q1): first what a host pass over the set would check,
    then -- for a sound query -- its keys. */
-__global__ void __launch_bounds__(256)
+template <uint32_t LAYOUT_WG>
+__global__ void __launch_bounds__(LAYOUT_WG)
 keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
   /* dynamic LDS: n_rep doubles when they fit | the Zobrist keys when they fit (zob_lds) | (item_wg) the item
@@ -594,17 +598,17 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   uint32_t *const mine = ihist + (Q.item_wg ? Q.nitem_slices : 0u) + threadIdx.x * OWN_DW;
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   if (lds_tot) {
-    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
+    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += LAYOUT_WG)
       tot_lds[r] = 0.0;
   }
   if (Q.zob_lds)
-    for (uint32_t k = threadIdx.x; k < Q.zob_words; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.zob_words; k += LAYOUT_WG)
       zl[k] = Q.zob[k];
   if (Q.ctab_lds)
-    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += LAYOUT_WG)
       ctl[k] = Q.geom.ctab[k];
   if (Q.item_wg)
-    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += LAYOUT_WG)
       ihist[k] = 0;
   if (threadIdx.x < 64)
     dest_lds[threadIdx.x] = 0;
@@ -618,7 +622,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
      line took 2.4 ms per 10M queries where the kernel's own work takes a fifth of that) */
   unsigned long long alg = 0;
   uint32_t err_all = 0, Lmax = 0;
-  for (uint64_t i = q0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * 256) {
+  for (uint64_t i = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * LAYOUT_WG) {
     uint32_t err = 0;
     const uint64_t b = Q.off[i], e = Q.off[i + 1];
     uint32_t L = 0;
@@ -767,7 +771,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     atomicAdd(Q.alg_bytes, alg);
   __syncthreads();
   if (lds_tot) {
-    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 256)
+    for (uint32_t r = threadIdx.x; r < Q.n_rep; r += LAYOUT_WG)
       if (tot_lds[r] != 0.0)
         unsafeAtomicAdd(Q.rep_total + r, tot_lds[r]);
   }
@@ -776,7 +780,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   /* item_wg: a run for this workgroup's items of every counter it met (QL::item_wg) */
   if (Q.item_wg) {
     uint32_t *const row = Q.rbase + (size_t)(row0 + blockIdx.x) * Q.nitem_slices;
-    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256) {
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += LAYOUT_WG) {
       const uint32_t cn = ihist[k];
       if (cn)
         row[k] = atomicAdd(Q.ccnt_r + (size_t)k * ITEM_PAD, cn);
@@ -981,7 +985,8 @@ slices_kernel(const QL Q, uint32_t pi)
    four instructions made four (6.5 write requests per query in all, 0.23 ms of the kernel's 1.0 even with every
    record sent to consecutive slots).  (Sets with sequences beyond the record's 36 residues, and the residue
    packs of kernels_pairs2.h, also leave a QAux beside the record: QL::recompute.) */
-__global__ void __launch_bounds__(256)
+template <uint32_t LAYOUT_WG>
+__global__ void __launch_bounds__(LAYOUT_WG)
 scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
   /* dynamic LDS: (item_wg) where this workgroup's items of counter k go next | SCAT_DW words per thread */
@@ -995,10 +1000,10 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   const uint64_t *const zt = Q.zob_lds ? zl : Q.zob;
   if (Q.zob_lds)                             /* (the keys of the positions; the gene keys are not asked here) */
-    for (uint32_t k = threadIdx.x; k < Q.zob_pos_words; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.zob_pos_words; k += LAYOUT_WG)
       zl[k] = Q.zob[k];
   if (Q.ctab_lds)
-    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += LAYOUT_WG)
       ctl[k] = Q.geom.ctab[k];
   if (Q.zob_lds || Q.ctab_lds)
     __syncthreads();
@@ -1006,14 +1011,14 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     /* (the run keys_kernel's workgroup of the same number claimed for the same queries; a counter it did not
        meet holds whatever the arena held -- nobody asks) */
     const uint32_t *const row = Q.rbase + (size_t)(row0 + blockIdx.x) * Q.nitem_slices;
-    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += 256)
+    for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += LAYOUT_WG)
       ibase[k] = Q.cbase[k] + row[k];
     __syncthreads();
   }
   const uint64_t total = total_of(Q);
   /* (the same queries as keys_kernel's workgroup of this number: QL::item_wg; a wave stays together to the
      end of its last batch: the records are written by the wave, not by the lane) */
-  for (uint64_t i0 = q0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < q1; i0 += (uint64_t)gridDim.x * 256) {
+  for (uint64_t i0 = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + (threadIdx.x & ~63u); i0 < q1; i0 += (uint64_t)gridDim.x * LAYOUT_WG) {
     const uint64_t i = i0 + lane;
     uint32_t slot = 0xffffffffu;
     QueryRec qr;
@@ -1308,6 +1313,55 @@ item_replicas_kernel(const QL Q)
     run += Q.ccnt_r[rk];
   }
   Q.ccnt[k] = run;
+}
+
+/* What the host waits for between the two halves of the layout, in ONE piece of device memory (one copy, one
+   wait: until round 6 six small copies, ~20 us of stream time each): the layout's totals, the first error of
+   the validation, the algorithmic bytes, the sums of the item and sibling lists, the count totals per
+   repertoire behind it. */
+struct SizesBlock {
+  SliceTot last_tot, last_pre;
+  unsigned long long alg, sums[4];
+  uint32_t verr[2];
+};
+
+/* One workgroup: the two exclusive sums over the item counters (padded items -> first item, chunks -> first
+   chunk; 32-bit prefixes, 64-bit totals) that four hipCUB calls made, then the SizesBlock. */
+__global__ void __launch_bounds__(1024)
+sizes_kernel(const QL Q, const uint32_t *cpad, uint64_t ncs, unsigned long long *sums, SizesBlock *blk)
+{
+  typedef hipcub::BlockScan<uint32_t, 1024> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  unsigned long long run0 = 0, run1 = 0;
+  for (uint64_t base = 0; base < ncs; base += 1024) {
+    const uint64_t k = base + threadIdx.x;
+    const uint32_t a = k < ncs ? cpad[k] : 0u, b = k < ncs ? Q.cnch[k] : 0u;
+    uint32_t ea, eb, ta, tb;
+    Scan(tmp).ExclusiveSum(a, ea, ta);
+    __syncthreads();
+    Scan(tmp).ExclusiveSum(b, eb, tb);
+    __syncthreads();
+    if (k < ncs) {
+      Q.cbase[k] = (uint32_t)run0 + ea;
+      Q.cchpre[k] = (uint32_t)run1 + eb;
+    }
+    run0 += ta;
+    run1 += tb;
+  }
+  if (threadIdx.x == 0) {
+    blk->last_tot = Q.tot[0][Q.nslices - 1];
+    blk->last_pre = Q.pre[0][Q.nslices - 1];
+    blk->alg = *Q.alg_bytes;
+    blk->sums[0] = run0;
+    blk->sums[1] = run1;
+    blk->sums[2] = sums[2];
+    blk->sums[3] = sums[3];
+    blk->verr[0] = Q.verr[0];
+    blk->verr[1] = Q.verr[1];
+  }
+  double *rt = (double *)(blk + 1);
+  for (uint32_t r = threadIdx.x; r < Q.n_rep; r += 1024)
+    rt[r] = Q.rep_total[r];
 }
 
 /* the slice of the filter the items of counter k are filed under, and its pages (layout.h SliceGeom):
@@ -1986,26 +2040,55 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const bool zob_lds = c->layout_zob_lds != 0 && zob_words * sizeof(uint64_t) <= 12288;
   const uint64_t zob_pos_words = (uint64_t)A * c->zpos;
   const bool ctab_lds = c->layout_zob_lds != 0 && c->sliced && c->geom.off_hv <= 2048;
-  const size_t own_lds = 256 * OWN_DW * sizeof(uint32_t);
   const size_t ctab_bytes = ctab_lds ? (size_t)c->geom.off_hv * sizeof(uint32_t) : 0;
-  const size_t keys_lds = (n_rep <= 2048 ? n_rep * sizeof(double) : 0) + (zob_lds ? zob_words * sizeof(uint64_t) : 0) +
-                          ctab_bytes + (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + own_lds;
-  const size_t scatter_lds = (zob_lds ? zob_pos_words * sizeof(uint64_t) : 0) + ctab_bytes +
-                             (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + own_lds;
-  if (keys_lds > 48 * 1024)
-    HIP_TRY(c, hipFuncSetAttribute((const void *)keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds));
+  const size_t keys_shared = (n_rep <= 2048 ? n_rep * sizeof(double) : 0) + (zob_lds ? zob_words * sizeof(uint64_t) : 0) +
+                             ctab_bytes + (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0);
+  const size_t scatter_shared = (zob_lds ? zob_pos_words * sizeof(uint64_t) : 0) + ctab_bytes +
+                                (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0);
+  typedef void (*LayoutFn)(const QL, uint64_t, uint64_t, uint32_t);
+  static const uint32_t wg_sizes[3] = {256, 512, 1024};
+  static const LayoutFn keys_fns[3] = {keys_kernel<256>, keys_kernel<512>, keys_kernel<1024>};
+  static const LayoutFn scatter_fns[3] = {scatter_kernel<256>, scatter_kernel<512>, scatter_kernel<1024>};
   /* Both kernels loop over their queries: the grid is what is RESIDENT at once (LDS and registers decide), no
      more -- with 2 048 workgroups of which 6 or 7 per CU fit, the eighth ran alone behind the others, a second
      round at a seventh of the occupancy for as long as the first (round 6: keys 0.80 -> .., scatter 1.01 -> ..).
      The same grid for both (QL::item_wg). */
   uint32_t resident = 2048;
+  uint32_t LAYOUT_WG = 256;
+  size_t keys_lds = 0, scatter_lds = 0;
+  LayoutFn keys_fn = keys_fns[0], scatter_fn = scatter_fns[0];
   {
-    int ok = 0, os = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ok, (const void *)keys_kernel, 256, keys_lds) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&os, (const void *)scatter_kernel, 256, scatter_lds) == hipSuccess &&
-        ok > 0 && os > 0)
-      resident = (uint32_t)c->cus * (uint32_t)std::min(ok, os);
-    (void)hipGetLastError();
+    /* the workgroup size that leaves the most waves per CU resident (both kernels: the same grid) */
+    uint32_t best_waves = 0;
+    int bk = 0, bs = 0;
+    for (int w = 0; w < 3; w++) {
+      const size_t own = (size_t)wg_sizes[w] * OWN_DW * sizeof(uint32_t);
+      const size_t kl = keys_shared + own, sl = scatter_shared + own;
+      if (kl > 160 * 1024 - 512 || sl > 160 * 1024 - 512)
+        continue;
+      if ((rc = raise_lds_limit(c, (const void *)keys_fns[w], kl))) return rc;
+      if ((rc = raise_lds_limit(c, (const void *)scatter_fns[w], sl))) return rc;
+      const int ok = occupancy_of(c, (const void *)keys_fns[w], (int)wg_sizes[w], kl);
+      const int os = occupancy_of(c, (const void *)scatter_fns[w], (int)wg_sizes[w], sl);
+      const uint32_t waves = (uint32_t)std::max(0, std::min(ok, os)) * wg_sizes[w] / WAVE;
+      if (waves > best_waves) {
+        best_waves = waves;
+        LAYOUT_WG = wg_sizes[w];
+        keys_lds = kl;
+        scatter_lds = sl;
+        keys_fn = keys_fns[w];
+        scatter_fn = scatter_fns[w];
+        resident = (uint32_t)c->cus * (uint32_t)std::min(ok, os);
+        bk = ok;
+        bs = os;
+      }
+    }
+    if (best_waves == 0)
+      return fail(c, CMPR_EUNSUPPORTED, "the layout kernels' tables do not fit the 160 KiB LDS");
+    if (getenv("COMPAIRR_HIP_DEBUG"))
+      fprintf(stderr, "compairr_hip: layout kernels: workgroups of %u; keys %zu B of LDS, %d per CU; scatter %zu B, %d; "
+                      "grid %u; %llu item counters in %u groups (%s)\n", LAYOUT_WG, keys_lds, bk, scatter_lds, bs,
+              resident, (unsigned long long)ncs, ngroups, item_wg ? "per workgroup in LDS" : "replicas in memory");
   }
   {
     const uint64_t min_range = 1u << 18;
@@ -2016,7 +2099,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
       Range g;
       g.q0 = nr == 4 ? n * cut4[r] / 100 : n * r / nr;
       g.q1 = nr == 4 ? n * cut4[r + 1] / 100 : n * (r + 1) / nr;
-      g.grid = std::min<uint32_t>(blocks_for(g.q1 - g.q0), resident);
+      g.grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (g.q1 - g.q0 + LAYOUT_WG - 1) / LAYOUT_WG), resident);
       g.row0 = row;
       row += g.grid;
       ranges.push_back(g);
@@ -2041,6 +2124,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_dest = cut.take(2 * 64 * sizeof(unsigned long long));     /* route: counts | fill */
   const size_t o_sums = cut.take(8 * sizeof(unsigned long long));
   const size_t zero_bytes = cut.used;
+  const size_t blk_bytes = sizeof(SizesBlock) + (size_t)n_rep * sizeof(double);
+  const size_t o_blk = cut.take(blk_bytes);
   const size_t o_res = cut.take(soa_in_arena ? (size_t)total + 16 : 0);
   const size_t o_off = cut.take(soa_in_arena ? (size_t)(n + 1) * sizeof(uint64_t) : 0);
   const size_t o_v = cut.take(c->opt.ignore_genes || !soa_in_arena ? 0 : (size_t)n * sizeof(uint32_t));
@@ -2266,7 +2351,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
         HIP_TRY(c, hipGetLastError());
       }
       LAYOUT_MARK(0);
-      hipLaunchKernelGGL(keys_kernel, dim3(ranges[0].grid), dim3(256), lds, c->stream, Q, (uint64_t)0, n, 0u);
+      hipLaunchKernelGGL(keys_fn, dim3(ranges[0].grid), dim3(LAYOUT_WG), lds, c->stream, Q, (uint64_t)0, n, 0u);
       HIP_TRY(c, hipGetLastError());
       LAYOUT_MARK(1);
     }
@@ -2416,7 +2501,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                            c->opt.ignore_counts ? nullptr : (uint64_t *)at(o_cnt), q0, q1);
         HIP_TRY(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(keys_kernel, dim3(ranges[r].grid), dim3(256), lds, c->stream, Q, q0, q1, ranges[r].row0);
+      hipLaunchKernelGGL(keys_fn, dim3(ranges[r].grid), dim3(LAYOUT_WG), lds, c->stream, Q, q0, q1, ranges[r].row0);
       HIP_TRY(c, hipGetLastError());
     }
     if (n == 0) {
@@ -2498,14 +2583,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(class_pad_kernel, dim3(blocks_for(ncs)), dim3(256), 0, c->stream, Q, cpad);
     HIP_TRY(c, hipGetLastError());
-    size_t b = cub_bytes;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, cpad, Q.cbase, (int)ncs, c->stream));
-    b = cub_bytes;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, Q.cnch, Q.cchpre, (int)ncs, c->stream));
-    b = cub_bytes;
-    HIP_TRY(c, sum64(cub_tmp, b, cpad, sums + 0, (int)ncs, c->stream));
-    b = cub_bytes;
-    HIP_TRY(c, sum64(cub_tmp, b, Q.cnch, sums + 1, (int)ncs, c->stream));
+    /* (their two prefix sums and totals: sizes_kernel, below) */
   }
   if (indel_passes) {
     hipLaunchKernelGGL(sibling_count_kernel, dim3(blocks_for(G)), dim3(256), 0, c->stream, Q, G, sib_cnt);
@@ -2522,19 +2600,29 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     b = cub_bytes;
     HIP_TRY(c, sum64(cub_tmp, b, sib_nch, sums + 3, (int)n2s, c->stream));
   }
-  SliceTot last_tot, last_pre;
-  uint32_t hv[2] = {0, 0};
-  unsigned long long alg_bytes = 0, hsums[4] = {0, 0, 0, 0};
-  c->tot1.assign(n_rep, 0.0);
-  HIP_TRY(c, hipMemcpyAsync(&last_tot, Q.tot[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&last_pre, Q.pre[0] + (nslices - 1), sizeof(SliceTot), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(hv, Q.verr, sizeof hv, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&alg_bytes, Q.alg_bytes, sizeof alg_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(hsums, sums, sizeof hsums, hipMemcpyDeviceToHost, c->stream));
-  if (n_rep)
-    HIP_TRY(c, hipMemcpyAsync(c->tot1.data(), Q.rep_total, n_rep * sizeof(double),
-                              hipMemcpyDeviceToHost, c->stream));
+  /* the item lists' prefix sums, and everything the host waits for in one block, one copy (pinned) */
+  hipLaunchKernelGGL(sizes_kernel, dim3(1), dim3(1024), 0, c->stream, Q, cpad, ngroups ? ncs : (uint64_t)0, sums,
+                     (SizesBlock *)at(o_blk));
+  HIP_TRY(c, hipGetLastError());
+  if (c->h_sizes_bytes < blk_bytes) {
+    if (c->h_sizes)
+      (void)hipHostFree(c->h_sizes);
+    c->h_sizes = nullptr;
+    c->h_sizes_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_sizes, blk_bytes + 65536, hipHostMallocDefault));
+    c->h_sizes_bytes = blk_bytes + 65536;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_sizes, at(o_blk), blk_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const SizesBlock hb = *(const SizesBlock *)c->h_sizes;
+  const SliceTot last_tot = hb.last_tot, last_pre = hb.last_pre;
+  const uint32_t hv[2] = {hb.verr[0], hb.verr[1]};
+  const unsigned long long alg_bytes = hb.alg;
+  const unsigned long long hsums[4] = {hb.sums[0], hb.sums[1], hb.sums[2], hb.sums[3]};
+  {
+    const double *rt = (const double *)((const SizesBlock *)c->h_sizes + 1);
+    c->tot1.assign(rt, rt + n_rep);
+  }
   const auto t_sizes = std::chrono::steady_clock::now();
   if (hv[0] == VERR_TOO_LONG)
     return fail(c, CMPR_EINVAL, "query longer than the longest_query given to cmpr_set_reference");
@@ -2703,7 +2791,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   if (n) {
     /* (the grid of every range's keys_kernel once more: QL::item_wg) */
     for (const Range &g : ranges) {
-      hipLaunchKernelGGL(scatter_kernel, dim3(g.grid), dim3(256), scatter_lds, c->stream, Q, g.q0, g.q1, g.row0);
+      hipLaunchKernelGGL(scatter_fn, dim3(g.grid), dim3(LAYOUT_WG), scatter_lds, c->stream, Q, g.q0, g.q1, g.row0);
       HIP_TRY(c, hipGetLastError());
     }
   }
@@ -2789,6 +2877,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     c->nsmall = (uint32_t)mine;
   }
   LAYOUT_MARK(5);
+  if (src.finish && (rc = src.finish()))
+    return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const auto t_end = std::chrono::steady_clock::now();
 #undef LAYOUT_MARK
