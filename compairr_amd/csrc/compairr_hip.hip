@@ -258,7 +258,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   c->bloom.release(); c->v2.release(); c->j2.release(); c->rep2.release();
   c->rec2.release(); c->voff2.release(); c->bmap2.release();
   c->tiles.release(); c->qres.release(); c->qv.release(); c->qj.release(); c->qgh.release();
-  c->qrep.release(); c->qcnt.release(); c->qlen.release(); c->qorig.release(); c->qck.release();
+  c->qlen.release(); c->qck.release();
   c->qhins.release(); c->qhdel.release(); c->items.release(); c->cpk.release(); c->qpk.release(); c->slice_items.release(); c->qrec.release();
   c->matrix.release(); c->matrix_f64.release();
   c->pos_buf.release(); c->pos_ctr.release(); c->d_ctab.release(); c->chunks.release(); c->tile_refs.release(); c->small_tiles.release();
@@ -880,10 +880,7 @@ int make_plan(cmpr_context *c)
   P.qv = c->qv.p;
   P.qgh = c->qgh.p;
   P.qj = c->qj.p;
-  P.qrep = c->qrep.p;
-  P.qcnt = c->qcnt.p;
   P.qlen = c->qlen.p;
-  P.qorig = c->qorig.p;
   P.qck = c->qck.p;
   P.qrec = c->qrec.p;
   P.qhins = c->qhins.p;

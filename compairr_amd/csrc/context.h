@@ -210,15 +210,14 @@ struct cmpr_context {
   uint32_t          R1 = 0, ntiles = 0;
   DevBuf<TileDesc>  tiles;
   uint32_t          nmain_tiles = 0;     /* tiles of pass 0: slot = tile * 64 + lane */
-  DevBuf<uint32_t>  qres, qv, qj, qrep;
+  DevBuf<uint32_t>  qres, qv, qj;    /* qv, qj: variants 0 and 1 (their tiles read them) */
   DevBuf<uint64_t>  qgh;            /* per slot: V key ^ J key (variants 0, 1: one load, not
                                        two dependent ones) / the query's Zobrist hash
                                        (variant 2; db_hash, db.cc:903-916) */
   DevBuf<uint64_t>  qhins, qhdel;   /* variant 2 with -i: the two shifted hashes
                                        (zobrist.cc:90-104, 122-136) */
-  DevBuf<uint64_t>  qcnt;
   DevBuf<uint16_t>  qlen;
-  DevBuf<uint32_t>  qorig, qck;
+  DevBuf<uint32_t>  qck;
   DevBuf<cmpr::QueryRec> qrec;     /* per slot: what verification reads, 64 bytes */
   /* variant 2, class rows: per item the row's blanked hash, the query's slot in
      pass 0 (~0: padding) and its residue at the class position | position << 8 */

@@ -430,7 +430,7 @@ __device__ __forceinline__ void score_match(const ProbeParams &P, uint32_t qs, u
     /* pairs mode (overlap.cc:232-245) */
     const unsigned long long k = atomicAdd(P.pair_count, 1ull);
     if (k < P.pair_cap) {
-      P.pair_q[k] = P.qorig[qs];
+      P.pair_q[k] = P.qrec[qs].orig;
       P.pair_h[k] = hit;
     }
   } else if (P.score == 1 /* ratio */ && !P.ignore_counts) {
@@ -463,10 +463,13 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
   const uint32_t bk = dir_bucket(key, P.dir_mask);
   const TileDesc td = P.tiles[qs >> 6];
   const uint32_t ql = qs & 63u;
-  const uint32_t q_v = GENES ? P.qv[qs] : 0u, q_j = GENES ? P.qj[qs] : 0u;
-  const uint32_t q_rep = P.qrep[qs];
+  /* (from the query's record: the per-slot arrays of genes, repertoire and count are laid out only for the
+     kernels whose tiles read them -- variants 0 and 1) */
+  const QueryRec *const qrec = P.qrec + qs;
+  const uint32_t q_v = GENES ? qrec->v : 0u, q_j = GENES ? qrec->j : 0u;
+  const uint32_t q_rep = qrec->rep;
   const uint32_t q_len = P.qlen[qs];           /* own length (tiles may mix lengths) */
-  const unsigned long long q_cnt = P.ignore_counts ? 1ull : P.qcnt[qs];
+  const unsigned long long q_cnt = P.ignore_counts ? 1ull : qrec->cnt;
   for (uint32_t piece = bk;; piece++) {
     RefRec rec = *((const RefRec *)P.rec2 + piece);
     if (rec.idx == REC_EMPTY)

@@ -85,7 +85,7 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
       W.st.hash_eq++;
       bool ok = true;
       if (GENES)
-        ok = P.qv[qs] == rec->v && P.qj[qs] == rec->j;
+        ok = P.qrec[qs].v == rec->v && P.qrec[qs].j == rec->j;
       if (ok) {
         const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
         const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
@@ -109,8 +109,8 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
         }
         if (ok) {
           W.st.matches++;
-          score_match(P, qs, ri, (uint64_t)P.R2 * P.qrep[qs] + rec->rep,
-                      P.ignore_counts ? 1ull : P.qcnt[qs], rec->cnt, W.mat_lds);
+          score_match(P, qs, ri, (uint64_t)P.R2 * P.qrec[qs].rep + rec->rep,
+                      P.ignore_counts ? 1ull : P.qrec[qs].cnt, rec->cnt, W.mat_lds);
         }
       }
     }

@@ -363,10 +363,10 @@ struct ProbeParams {
                                       (<= RESPACK_MAX positions); ItemRec::w then holds the query's hash.
                                       kernels_pairs2.h items: the same residues beside the pair-blanked hash */
   const ResPack  *qpk;             /* kernels_pairs2.h: per slot, the query's residues, 2 bits each */
-  const uint32_t *qrep;
-  const uint64_t *qcnt;
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
-  const uint32_t *qorig;           /* per slot: index in the caller's set 1       */
+  /* (repertoire, count and the query's number in the caller's set are read from its QueryRec, by the
+     kernels that resolve a positive -- no per-slot arrays of them since round 6: 16 bytes per slot less for
+     the layout to write) */
   const uint32_t *qck;             /* per slot: class key (variant 2)             */
   const QueryRec *qrec;            /* per slot: what verification reads            */
   uint32_t        ntiles;

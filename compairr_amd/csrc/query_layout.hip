@@ -145,8 +145,8 @@ struct QL {
   Chunk    *chunks;
   TileRef  *tile_refs;
   uint32_t *small_tiles, *chunk_work;
-  uint32_t *qres, *qv, *qj, *qrep, *qorig, *qck;
-  uint64_t *qgh, *qhins, *qhdel, *qcnt;
+  uint32_t *qres, *qv, *qj, *qck;
+  uint64_t *qgh, *qhins, *qhdel;
   uint16_t *qlen;
   QueryRec *qrec;
   /* variant 2: rows that cannot be answered from the slice staged for their tile
@@ -354,18 +354,25 @@ constexpr uint32_t OWN_DW = 13;
 /* (threads of a workgroup of keys_kernel / scatter_kernel: 256, 512 or 1024 -- the more share one copy of the
    tables (Zobrist keys, class tables, item counters: 22 KiB at 10M queries, 54 KiB with -i), the more waves
    fit a CU beside them; chosen per call, cmpr_layout_queries) */
-__device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t *mine)
+/* ... in two steps, so that the caller can ask for the NEXT query's fields between them: the loads of the
+   pieces (own_load), and their way into LDS (own_commit: waits for them) */
+struct OwnPieces {
+  uint4 w[3];
+  bool  fits;
+};
+
+__device__ inline OwnPieces own_load(const QL &Q, uint64_t b, uint64_t e, uint64_t total)
 {
+  OwnPieces o;
   const uint64_t a0 = b & ~15ull;
-  if (((uintptr_t)Q.res & 15u) != 0 || e - a0 > 48u)
-    return Q.res + b;
+  o.fits = ((uintptr_t)Q.res & 15u) == 0 && e - a0 <= 48u;
 #pragma unroll
   for (uint32_t k = 0; k < 3; k++) {
+    o.w[k] = make_uint4(0u, 0u, 0u, 0u);
     const uint64_t at = a0 + 16u * k;
-    if (at < e) {
-      uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (o.fits && at < e) {
       if (at + 16u <= total) {
-        w = *(const uint4 *)(Q.res + at);
+        o.w[k] = *(const uint4 *)(Q.res + at);
       } else {                                   /* (the last bytes of the set) */
         uint64_t lo = 0, hi = 0;                 /* (no array: an index the compiler cannot see is scratch) */
         for (uint32_t x = 0; x < 16u && at + x < total; x++) {
@@ -375,15 +382,32 @@ __device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t 
           else
             hi |= r << (8u * (x - 8u));
         }
-        w = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        o.w[k] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
       }
-      mine[4 * k + 0] = w.x;
-      mine[4 * k + 1] = w.y;
-      mine[4 * k + 2] = w.z;
-      mine[4 * k + 3] = w.w;
     }
   }
+  return o;
+}
+
+__device__ inline const uint8_t *own_commit(const QL &Q, const OwnPieces &o, uint64_t b, uint64_t e, uint32_t *mine)
+{
+  if (!o.fits)
+    return Q.res + b;
+  const uint64_t a0 = b & ~15ull;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++)
+    if (a0 + 16u * k < e) {
+      mine[4 * k + 0] = o.w[k].x;
+      mine[4 * k + 1] = o.w[k].y;
+      mine[4 * k + 2] = o.w[k].z;
+      mine[4 * k + 3] = o.w[k].w;
+    }
   return (const uint8_t *)mine + (b - a0);
+}
+
+__device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t *mine)
+{
+  return own_commit(Q, own_load(Q, b, e, total), b, e, mine);
 }
 
 /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that seed the rolling indel
@@ -442,9 +466,10 @@ __device__ inline uint32_t class_base_of(const QL &Q, uint64_t i)
    false: the hash argument is not computed) and once to place, so both see the
    same items. */
 template <bool HASH, typename F>
-__device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint64_t *zt, uint64_t i, const uint8_t *s,
-                                     uint32_t L, uint32_t ck, bool heavy, F f)
+__device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint64_t *zt, uint64_t h_of_q,
+                                     uint64_t hins_of_q, const uint8_t *s, uint32_t L, uint32_t ck, bool heavy, F f)
 {
+  /* (h_of_q, hins_of_q: the query's hash and, with -i, its insert-first hash -- asked only with HASH) */
   /* (s: the query's residues -- where the set lies, or the thread's copy in LDS; ct, zt: the class tables in
      front of the heavy bitmap and the Zobrist keys -- where they lie, or the workgroup's copies in LDS: a
      lookup in memory with 64 different addresses per wave is the dear kind, round 6) */
@@ -480,7 +505,7 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
        two deletion variants exist (the first position of a run of equal residues,
        variants.cc:301-325; none for a query of one residue). */
     if (heavy) {
-      const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
+      const uint64_t h = HASH ? h_of_q : 0ull;
       for (uint32_t ci = 0; ci < K; ci++) {
         const uint32_t p = class_pos(L, ci, g.c0) & ~1u;
         bool first = true;
@@ -527,7 +552,7 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
     const uint32_t base_i = base ^ ct[L] ^ ct[L + 1];
     if (!class_is_heavy(g.ctab, g, base_i))
       return;
-    const uint64_t hins = HASH ? Q.hins_tmp[i] : 0ull;
+    const uint64_t hins = HASH ? hins_of_q : 0ull;
     uint64_t P0 = 0, Pp = 0;                     /* XOR_{y<x} Z[y][q[y]],  XOR_{y<x} Z[y+1][q[y]] */
     for (uint32_t x = 0; x <= L; x++) {
       if ((x & 1u) == 0) {
@@ -562,7 +587,7 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
     return;
   }
   if (heavy) {
-    const uint64_t h = HASH ? Q.h_tmp[i] : 0ull;
+    const uint64_t h = HASH ? h_of_q : 0ull;
     for (uint32_t ci = 0; ci < K; ci++) {
       const uint32_t pos = class_pos(L, ci, g.c0);
       bool first = true;
@@ -583,10 +608,38 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
 
 /* One thread per query of [q0, q1): first what a host pass over the set would check,
    then -- for a sound query -- its keys. */
-template <uint32_t LAYOUT_WG>
-__global__ void __launch_bounds__(LAYOUT_WG)
+/* What an instantiation of keys_kernel / scatter_kernel may take for granted about the flags of QL (the host
+   picks the instantiation by them): MODE 1 = amino acids or nucleotides on pair rows without -i (the headline
+   workload), 2 = pair rows with -i, 0 = anything.  The branches of the other layouts -- the insertion pairs'
+   rolling hashes, residue packs, routing -- then cost no registers: scatter_kernel needs 80 for six waves per
+   SIMD and took 90 with every path compiled in. */
+template <int MODE>
+__device__ inline void layout_mode_assume(const QL &Q)
+{
+  if (MODE != 0) {
+    __builtin_assume(Q.rows != 0);
+    __builtin_assume(Q.pairs != 0);
+    __builtin_assume(Q.sliced != 0);
+    __builtin_assume(Q.pairs2 == 0);
+    __builtin_assume(Q.sub2_items == 0);
+    __builtin_assume(Q.direct == 0);
+    __builtin_assume(Q.route == 0);
+    __builtin_assume(Q.differences == 1);
+    __builtin_assume(Q.recompute != 0);
+    __builtin_assume(Q.wstep <= 1);
+    __builtin_assume(Q.dbg == 0);
+  }
+  if (MODE == 1)
+    __builtin_assume(Q.indels == 0);
+  if (MODE == 2)
+    __builtin_assume(Q.indels != 0);
+}
+
+template <uint32_t LAYOUT_WG, int MODE>
+__global__ void __launch_bounds__(LAYOUT_WG, LAYOUT_WG == 1024 ? 4 : 6)
 keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
+  layout_mode_assume<MODE>(Q);
   /* dynamic LDS: n_rep doubles when they fit | the Zobrist keys when they fit (zob_lds) | (item_wg) the item
      counters | OWN_DW words per thread */
   extern __shared__ double tot_lds[];
@@ -622,9 +675,40 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
      line took 2.4 ms per 10M queries where the kernel's own work takes a fifth of that) */
   unsigned long long alg = 0;
   uint32_t err_all = 0, Lmax = 0;
-  for (uint64_t i = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + threadIdx.x; i < q1; i += (uint64_t)gridDim.x * LAYOUT_WG) {
+  /* The loop is pipelined by hand (round 6: a wave of this kernel waits four fifths of its time, every load and
+     the rank's atomic one behind the other): the fields of the thread's NEXT query are asked for while this
+     one's residue pieces are on their way, and the rank of a query -- the answer of its atomic -- is written
+     an iteration later, when the wait for newer loads has covered it. */
+  struct Fields {
+    uint64_t b, e, cn;
+    uint32_t rp, vg, jg;
+  };
+  auto fetch = [&](uint64_t i) -> Fields {
+    Fields f;
+    f.b = f.e = 0;
+    f.cn = 1;
+    f.rp = f.vg = f.jg = 0;
+    if (i < q1) {
+      f.b = Q.off[i];
+      f.e = Q.off[i + 1];
+      f.rp = Q.rep[i];
+      if (Q.genes) {
+        f.vg = Q.v[i];
+        f.jg = Q.j[i];
+      }
+      if (Q.counts)
+        f.cn = Q.cnt[i];
+    }
+    return f;
+  };
+  const uint64_t stride = (uint64_t)gridDim.x * LAYOUT_WG;
+  uint64_t i = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + threadIdx.x;
+  Fields cur = fetch(i);
+  uint64_t pend_i = ~0ull;
+  uint32_t pend_rank = 0;
+  for (; i < q1; i += stride) {
     uint32_t err = 0;
-    const uint64_t b = Q.off[i], e = Q.off[i + 1];
+    const uint64_t b = cur.b, e = cur.e;
     uint32_t L = 0;
     if (e < b || e > total)
       err = VERR_OFFSETS;
@@ -634,14 +718,26 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       err = VERR_TOO_LONG;
     else
       L = (uint32_t)(e - b);
-    const uint32_t rp = Q.rep[i];
+    const uint32_t rp = cur.rp;
     if (!err && rp >= Q.n_rep)
       err = VERR_REP;
-    if (!err && Q.genes && (Q.v[i] >= Q.n_v_max || Q.j[i] >= Q.n_j_max))
+    if (!err && Q.genes && (cur.vg >= Q.n_v_max || cur.jg >= Q.n_j_max))
       err = VERR_GENE;
-    if (!err && Q.counts && Q.cnt[i] < 1)
+    if (!err && Q.counts && cur.cn < 1)
       err = VERR_COUNT;
-    const uint8_t *s = err ? Q.res : own_residues(Q, b, e, total, mine);
+    OwnPieces pieces;
+    pieces.fits = false;
+    if (!err)
+      pieces = own_load(Q, b, e, total);
+    const Fields nxt = fetch(i + stride);
+    const uint8_t *s = err ? Q.res : own_commit(Q, pieces, b, e, mine);
+    if (pend_i != ~0ull) {
+      Q.rank[pend_i] = pend_rank;
+      pend_i = ~0ull;
+    }
+    const uint64_t cnt_i = cur.cn;
+    const uint32_t vg = cur.vg, jg = cur.jg;
+    cur = nxt;
     if (!err) {
       bool bad = false;
       for (uint32_t p = 0; p < L; p++)
@@ -654,12 +750,11 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       err_all = err;
     if (!err) {
       Lmax = max(Lmax, L);
-      const double x = Q.counts ? (double)Q.cnt[i] : 1.0;
+      const double x = Q.counts ? (double)cnt_i : 1.0;
       if (lds_tot)
         unsafeAtomicAdd(tot_lds + rp, x);
       else
         unsafeAtomicAdd(Q.rep_total + rp, x);
-      const uint32_t vg = Q.genes ? Q.v[i] : 0u, jg = Q.genes ? Q.j[i] : 0u;
       uint32_t ck = 0;
       bool heavy = false;
       if (Q.sliced && !LDBG(Q, LDBG_NO_CLASSKEY)) {
@@ -711,7 +806,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
            record where the positive is resolved) */
         unsigned long long mask = 1ull << work_owner(Q.sliced ? (ck & Q.geom.smask) : (ck & DIRECT_OWNER_MASK), 0u, Q.wstep);
         if (Q.ngroups)
-          for_each_item<false>(Q, ct, Q.zob, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+          for_each_item<false>(Q, ct, Q.zob, 0ull, 0ull, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
             mask |= 1ull << item_owner(Q, k, Q.wstep);
           });
         if (Q.route == 2u)
@@ -724,7 +819,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       /* the items of the query that this context works on */
       bool any_item = false;
       if (Q.ngroups && !Q.route && !LDBG(Q, LDBG_NO_ITEM_COUNT))
-        for_each_item<false>(Q, ct, Q.zob, i, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
+        for_each_item<false>(Q, ct, Q.zob, 0ull, 0ull, s, L, ck, heavy, [&](uint32_t k, uint64_t, uint32_t) {
           if (item_owned(Q, k)) {
             if (Q.item_wg)
               atomicAdd(&ihist[k], 1u);
@@ -750,13 +845,16 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
         /* (its top bit: the query's class is split -- scatter_kernel need not ask the tables again) */
-        Q.rank[i] = (LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u)) | (heavy ? 0x80000000u : 0u);
+        pend_rank = (LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u)) | (heavy ? 0x80000000u : 0u);
+        pend_i = i;                              /* (written when the next iteration has waited for newer loads) */
       }
       /* (the same key as owned() above: ADVICE r5) */
       if (Q.alg_step <= 1u || work_owner(Q.sliced ? slice : (ck & DIRECT_OWNER_MASK), 0u, Q.alg_step) == Q.alg_first)
         alg += LDBG(Q, LDBG_NO_TOTALS) ? 0ull : (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
   }
+  if (pend_i != ~0ull)
+    Q.rank[pend_i] = pend_rank;
   if (err_all)
     atomicCAS(Q.verr, 0u, err_all);
   /* longest: one atomic per wave */
@@ -985,10 +1083,14 @@ slices_kernel(const QL Q, uint32_t pi)
    four instructions made four (6.5 write requests per query in all, 0.23 ms of the kernel's 1.0 even with every
    record sent to consecutive slots).  (Sets with sequences beyond the record's 36 residues, and the residue
    packs of kernels_pairs2.h, also leave a QAux beside the record: QL::recompute.) */
-template <uint32_t LAYOUT_WG>
-__global__ void __launch_bounds__(LAYOUT_WG)
+/* (six waves per SIMD -- three workgroups of 512 per CU beside the shared tables -- is worth more than the
+   registers a seventh loop-carried field would like: at 109 registers, four waves per SIMD, the kernel took
+   0.63 ms per 10M queries where it takes 0.53) */
+template <uint32_t LAYOUT_WG, int MODE>
+__global__ void __launch_bounds__(LAYOUT_WG, LAYOUT_WG == 1024 ? 4 : 6)
 scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
+  layout_mode_assume<MODE>(Q);
   /* dynamic LDS: (item_wg) where this workgroup's items of counter k go next | SCAT_DW words per thread */
   extern __shared__ uint64_t scat_lds[];
   uint64_t *const zl = scat_lds;
@@ -1018,56 +1120,69 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   const uint64_t total = total_of(Q);
   /* (the same queries as keys_kernel's workgroup of this number: QL::item_wg; a wave stays together to the
      end of its last batch: the records are written by the wave, not by the lane) */
-  for (uint64_t i0 = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + (threadIdx.x & ~63u); i0 < q1; i0 += (uint64_t)gridDim.x * LAYOUT_WG) {
+  /* (pipelined by hand like keys_kernel: the NEXT query's fields are asked for while this one's group base and
+     residue pieces are on their way) */
+  struct Fields {                            /* (what the loads of an iteration depend on; the rest is asked
+                                                for with them, not ahead: registers -- 80 for six waves per SIMD) */
+    uint64_t b, e;
+    uint32_t g, rk;
+  };
+  const bool want_h = Q.ngroups != 0 && Q.rows, want_ck = Q.ngroups != 0 && (Q.rows || Q.sub2_items);
+  auto fetch = [&](uint64_t i) -> Fields {
+    Fields f;
+    f.b = f.e = 0;
+    f.g = 0xffffffffu;
+    f.rk = 0;
+    if (i < q1) {
+      f.g = Q.grp[0][i];
+      f.rk = Q.rank[i];
+      f.b = Q.off[i];
+      f.e = Q.off[i + 1];
+    }
+    return f;
+  };
+  const uint64_t stride = (uint64_t)gridDim.x * LAYOUT_WG;
+  uint64_t i0 = q0 + (uint64_t)blockIdx.x * LAYOUT_WG + (threadIdx.x & ~63u);
+  Fields cur = fetch(i0 + lane);
+  for (; i0 < q1; i0 += stride) {
     const uint64_t i = i0 + lane;
     uint32_t slot = 0xffffffffu;
     QueryRec qr;
     qr.cnt = 0;
     qr.v = qr.j = qr.rep = qr.len = qr.orig = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 9; w++)
-      qr.res[w] = 0;
-    const uint32_t g = i < q1 ? Q.grp[0][i] : 0xffffffffu;
-    if (i < q1 && g == 0xffffffffu)            /* not worked on by this context (no item of it either) */
+    const uint32_t g = cur.g;                    /* (all ones: not worked on by this context, no item of it either --
+                                                    or behind the end of the range) */
+    if (i < q1 && g == 0xffffffffu)
       Q.slot_of[i] = 0xffffffffu;
+    const uint64_t b = cur.b, e = cur.e;
+    const uint32_t rk = cur.rk;                  /* (rank in the group | class split << 31: keys_kernel) */
+    uint32_t gbase = 0, ck = 0;
+    uint64_t h_q = 0, hins_q = 0;
+    OwnPieces pieces;
+    pieces.fits = false;
     if (g != 0xffffffffu) {
-      const uint32_t rk = Q.rank[i];               /* (rank in the group | class split << 31: keys_kernel) */
-      slot = LDBG(Q, LDBG_S_NO_BASE) ? (uint32_t)i : Q.base_g[0][g] + (rk & 0x7fffffffu);
-      Q.slot_of[i] = slot;
-      const uint64_t b = Q.off[i], e = Q.off[i + 1];
-      const uint32_t L = (uint32_t)(e - b);
-      const uint8_t *s = own_residues(Q, b, e, total, mine);
-      const bool in_lds = s != Q.res + b;
+      gbase = LDBG(Q, LDBG_S_NO_BASE) ? 0u : Q.base_g[0][g];
+      pieces = own_load(Q, b, e, total);
       qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
       qr.v = Q.genes ? Q.v[i] : 0u;
       qr.j = Q.genes ? Q.j[i] : 0u;
-      const uint32_t orig = Q.orig ? Q.orig[i] : (uint32_t)i;
-      qr.rep = Q.existence ? orig : Q.rep[i];           /* -x: the row is the sequence itself */
-      qr.len = L;
-      qr.orig = orig;
-      if (in_lds) {
-        /* nine dwords from ten aligned ones (the thread's copy keeps the set's byte phase) */
-        const uint32_t o = (uint32_t)(b & 15u), w0 = o >> 2, sh = o & 3u;
-        uint32_t lo = mine[w0];
-#pragma unroll
-        for (uint32_t w = 0; w < 9; w++) {
-          const uint32_t hi = mine[w0 + w + 1u];             /* (at most the thread's 13th word; masked below) */
-          const uint32_t d = __builtin_amdgcn_alignbyte(hi, lo, sh);
-          const int n = (int)L - (int)(4u * w);
-          qr.res[w] = d & (n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
-          lo = hi;
-        }
-      } else {
-#pragma unroll
-        for (uint32_t w = 0; w < 9; w++) {
-          uint32_t d = 0;
-#pragma unroll
-          for (uint32_t k = 0; k < 4; k++)
-            if (4 * w + k < L)
-              d |= (uint32_t)s[4 * w + k] << (8 * k);
-          qr.res[w] = d;
-        }
+      qr.orig = Q.orig ? Q.orig[i] : (uint32_t)i;
+      qr.rep = Q.existence ? qr.orig : Q.rep[i];      /* -x: the row is the sequence itself */
+      if (want_h) {
+        h_q = Q.h_tmp[i];
+        if (Q.indels)
+          hins_q = Q.hins_tmp[i];
       }
+      if (want_ck)
+        ck = Q.ck_tmp[i];
+    }
+    cur = fetch(i + stride);
+    if (g != 0xffffffffu) {
+      slot = LDBG(Q, LDBG_S_NO_BASE) ? (uint32_t)i : gbase + (rk & 0x7fffffffu);
+      Q.slot_of[i] = slot;
+      const uint32_t L = (uint32_t)(e - b);
+      const uint8_t *s = own_commit(Q, pieces, b, e, mine);
+      qr.len = L;
       if (!Q.recompute) {
         QAux a;
         a.h = a.hins = a.hdel = 0;
@@ -1091,7 +1206,6 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       if (Q.ngroups != 0 && !LDBG(Q, LDBG_S_NO_ITEMS)) {
         /* ---- the query's items: the row's (variant's) hash, what to exclude / where / what kind, and
                 the query's slot in pass 0 ---- */
-        const uint32_t ck = (Q.rows || Q.sub2_items) ? Q.ck_tmp[i] : 0u;
         const bool heavy = (rk >> 31) != 0;
         uint64_t hq = 0;
         cmpr::ResPack pk{};
@@ -1109,7 +1223,7 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
             pk.w[x >> 4] |= (r & 3u) << ((x & 15u) * 2u);
           }
         }
-        for_each_item<true>(Q, ct, zt, i, s, L, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
+        for_each_item<true>(Q, ct, zt, h_q, hins_q, s, L, ck, heavy, [&](uint32_t k, uint64_t w, uint32_t crp) {
           if (!item_owned(Q, k))
             return;
           uint32_t item;
@@ -1133,6 +1247,38 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
             Q.items[item] = it;
         });
       }
+    }
+    /* (the record's residue dwords last: nine registers that need not live through the items) */
+    if (slot != 0xffffffffu) {
+      const uint32_t L = (uint32_t)(e - b);
+      if (pieces.fits) {
+        /* nine dwords from ten aligned ones (the thread's copy keeps the set's byte phase) */
+        const uint32_t o = (uint32_t)(b & 15u), w0 = o >> 2, sh = o & 3u;
+        uint32_t lo = mine[w0];
+#pragma unroll
+        for (uint32_t w = 0; w < 9; w++) {
+          const uint32_t hi = mine[w0 + w + 1u];             /* (at most the thread's 13th word; masked below) */
+          const uint32_t d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+          const int n = (int)L - (int)(4u * w);
+          qr.res[w] = d & (n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u);
+          lo = hi;
+        }
+      } else {
+        const uint8_t *s = Q.res + b;
+#pragma unroll
+        for (uint32_t w = 0; w < 9; w++) {
+          uint32_t d = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++)
+            if (4 * w + k < L)
+              d |= (uint32_t)s[4 * w + k] << (8 * k);
+          qr.res[w] = d;
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t w = 0; w < 9; w++)
+        qr.res[w] = 0;
     }
     /* ---- the wave's records, transposed through LDS: half a wave at a time -- 32 records of 17 words fit the
             wave's 64 x 13 words, whose residue pieces have been read ---- */
@@ -1178,14 +1324,29 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 __global__ void __launch_bounds__(256)
 fill_tiles_kernel(const QL Q, uint32_t ntiles)
 {
-  const uint32_t t = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
-  if (t >= ntiles)
-    return;
+  /* dynamic LDS (recompute): the Zobrist keys and the class tables in front of the heavy bitmap, when they fit
+     (QL::zob_lds, ctab_lds: a lookup in memory with 64 addresses per wave is the dear kind) */
+  extern __shared__ uint64_t fill_lds[];
+  __shared__ uint32_t rl[256 * 9];           /* recompute: a lane's residues, read a byte at a time */
+  const bool tabs = Q.recompute != 0;
+  uint64_t *const zl = fill_lds;
+  uint32_t *const ctl = (uint32_t *)(zl + (tabs && Q.zob_lds ? Q.zob_words : 0u));
+  if (tabs && Q.zob_lds)
+    for (uint32_t k = threadIdx.x; k < Q.zob_words; k += 256)
+      zl[k] = Q.zob[k];
+  if (tabs && Q.ctab_lds)
+    for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += 256)
+      ctl[k] = Q.geom.ctab[k];
+  if (tabs && (Q.zob_lds || Q.ctab_lds))
+    __syncthreads();
+  const uint64_t *const zt = tabs && Q.zob_lds ? zl : Q.zob;
+  const uint32_t *const ct = tabs && Q.ctab_lds ? ctl : Q.geom.ctab;
   const uint32_t lane = threadIdx.x % WAVE;
+  /* (a wave per tile, the grid what is resident: the tables are copied once per workgroup) */
+  for (uint32_t t = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE; t < ntiles; t += gridDim.x * (256 / WAVE)) {
   const TileDesc td = Q.tiles[t];
   const uint32_t slot = t * WAVE + lane;
   const bool valid = lane < td.nvalid;
-  __shared__ uint32_t rl[256 * 9];           /* recompute: a lane's residues, read a byte at a time */
   QueryRec qr;
   QAux a;
   a.h = a.hins = a.hdel = 0;
@@ -1214,36 +1375,30 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
     const uint32_t L = qr.len;
     uint64_t h = 0;
     if (Q.genes) {
-      const uint64_t *gk = Q.zob + (uint64_t)Q.A * Q.zpos;
+      const uint64_t *gk = zt + (uint64_t)Q.A * Q.zpos;
       h = gk[qr.v] ^ gk[Q.n_v + qr.j];
     }
     if (Q.rows || Q.direct) {
       uint64_t hins = h, hdel = h;
-      for (uint32_t p = 0; p < L; p++) {
-        const uint32_t r = s[p];
-        h ^= Q.zob[Q.A * p + r];
-        if (Q.indels) {
-          hins ^= Q.zob[Q.A * (p + 1) + r];
-          if (p > 0)
-            hdel ^= Q.zob[Q.A * (p - 1) + r];
-        }
-      }
+      hashes_of(zt, Q.A, Q.indels != 0, s, L, h, hins, hdel);
       a.hins = hins;
       a.hdel = hdel;
-      if (Q.rows)
-        a.ck = class_key_of(Q.geom.ctab, Q.geom, Q.A, Q.genes != 0, s, L, qr.v, qr.j, nullptr);
+      if (Q.rows) {
+        /* (class_key_of, layout.h, with the tables in front of the heavy bitmap read from LDS) */
+        uint32_t ck = class_base(ct, Q.geom, Q.genes != 0, L, qr.v, qr.j);
+        if (Q.geom.k > 0 && class_is_heavy(Q.geom.ctab, Q.geom, ck) && L > 0)
+          for (uint32_t k = 0; k < Q.geom.k; k++)
+            ck ^= ct[Q.geom.off_cr + k * Q.A + s[class_pos(L, k, Q.geom.c0)]];
+        a.ck = ck;
+      }
     }
     a.h = h;
   }
   Q.qlen[slot] = (uint16_t)qr.len;
-  Q.qorig[slot] = qr.orig;
-  Q.qrep[slot] = qr.rep;
-  if (Q.genes) {
+  if (Q.genes && !Q.rows) {                  /* (variants 0 and 1: their tiles hash / key by the genes) */
     Q.qv[slot] = qr.v;
     Q.qj[slot] = qr.j;
   }
-  if (Q.counts)
-    Q.qcnt[slot] = qr.cnt;
   if (Q.rows) {
     Q.qgh[slot] = a.h;
     Q.qck[slot] = a.ck;
@@ -1291,6 +1446,7 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
           d |= (uint32_t)s[4 * w + k] << (8 * k);
       dst[(size_t)w * WAVE] = padded(d, w);
     }
+  }
   }
 }
 
@@ -2047,8 +2203,19 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                                 (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0);
   typedef void (*LayoutFn)(const QL, uint64_t, uint64_t, uint32_t);
   static const uint32_t wg_sizes[3] = {256, 512, 1024};
-  static const LayoutFn keys_fns[3] = {keys_kernel<256>, keys_kernel<512>, keys_kernel<1024>};
-  static const LayoutFn scatter_fns[3] = {scatter_kernel<256>, scatter_kernel<512>, scatter_kernel<1024>};
+  static const LayoutFn keys_all[3][3] = {{keys_kernel<256, 0>, keys_kernel<512, 0>, keys_kernel<1024, 0>},
+                                          {keys_kernel<256, 1>, keys_kernel<512, 1>, keys_kernel<1024, 1>},
+                                          {keys_kernel<256, 2>, keys_kernel<512, 2>, keys_kernel<1024, 2>}};
+  static const LayoutFn scatter_all[3][3] = {{scatter_kernel<256, 0>, scatter_kernel<512, 0>, scatter_kernel<1024, 0>},
+                                             {scatter_kernel<256, 1>, scatter_kernel<512, 1>, scatter_kernel<1024, 1>},
+                                             {scatter_kernel<256, 2>, scatter_kernel<512, 2>, scatter_kernel<1024, 2>}};
+  /* (layout_mode_assume: what the instantiation may take for granted) */
+  const bool recompute_on = Lcap <= 36u && !c->d2pairs && c->layout_recompute != 0;
+  const int lmode = (c->rows && pair_rows(c) && !c->d2pairs && !sub2_items && !direct && !routing && wstep <= 1 &&
+                     c->opt.differences == 1 && recompute_on && c->debug == 0)
+                        ? (c->opt.indels ? 2 : 1)
+                        : 0;
+  const LayoutFn *const keys_fns = keys_all[lmode], *const scatter_fns = scatter_all[lmode];
   /* Both kernels loop over their queries: the grid is what is RESIDENT at once (LDS and registers decide), no
      more -- with 2 048 workgroups of which 6 or 7 per CU fit, the eighth ran alone behind the others, a second
      round at a seventh of the occupancy for as long as the first (round 6: keys 0.80 -> .., scatter 1.01 -> ..).
@@ -2071,7 +2238,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
       const int ok = occupancy_of(c, (const void *)keys_fns[w], (int)wg_sizes[w], kl);
       const int os = occupancy_of(c, (const void *)scatter_fns[w], (int)wg_sizes[w], sl);
       const uint32_t waves = (uint32_t)std::max(0, std::min(ok, os)) * wg_sizes[w] / WAVE;
-      if (waves > best_waves) {
+      if (waves >= best_waves && waves > 0) {      /* (a tie: the larger workgroup -- fewer runs of items to claim) */
         best_waves = waves;
         LAYOUT_WG = wg_sizes[w];
         keys_lds = kl;
@@ -2289,7 +2456,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.item_wg = item_wg ? 1u : 0u;
   /* every query fits its 64-byte record (36 residues): the tiles' hashes and class keys are worked out from
      the records, nothing else is scattered (kernels_pairs2.h's residue packs are built where the set lies) */
-  Q.recompute = Lcap <= 36u && !c->d2pairs && c->layout_recompute != 0 ? 1u : 0u;
+  Q.recompute = recompute_on ? 1u : 0u;
   Q.total_on_device = total_on_device ? 1u : 0u;
   Q.cnch = (uint32_t *)at(o_cnch);
   Q.cchpre = (uint32_t *)at(o_cchpre);
@@ -2712,12 +2879,10 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   if ((rc = dev_reserve(c, c->small_tiles, (size_t)nsmall))) return rc;
   /* + 9 rows: slack behind the last tile for readers that fetch nine dwords per query */
   if ((rc = dev_reserve(c, c->qres, (size_t)res_words + 9 * WAVE))) return rc;
-  if ((rc = dev_reserve(c, c->qrep, slots))) return rc;
   if ((rc = dev_reserve(c, c->qlen, slots))) return rc;
-  if ((rc = dev_reserve(c, c->qorig, slots))) return rc;
   if ((rc = dev_reserve(c, c->qrec, slots))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->qres.p + res_words, 0, 9 * WAVE * sizeof(uint32_t), c->stream));
-  if (!c->opt.ignore_genes) {
+  if (!c->opt.ignore_genes && !c->rows) {
     if ((rc = dev_reserve(c, c->qv, slots))) return rc;
     if ((rc = dev_reserve(c, c->qj, slots))) return rc;
   } else {
@@ -2728,11 +2893,6 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     if ((rc = dev_reserve(c, c->qgh, slots))) return rc;
   } else {
     c->qgh.release();
-  }
-  if (!c->opt.ignore_counts) {
-    if ((rc = dev_reserve(c, c->qcnt, slots))) return rc;
-  } else {
-    c->qcnt.release();
   }
   if (c->rows) {
     if ((rc = dev_reserve(c, c->qck, slots))) return rc;
@@ -2780,9 +2940,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.cpk = c->cpk.p;
   Q.qpk = c->qpk.p;
   Q.slice_items = (uint2 *)c->slice_items.p;
-  Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p; Q.qrep = c->qrep.p;
-  Q.qorig = c->qorig.p; Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
-  Q.qhdel = c->qhdel.p; Q.qcnt = c->qcnt.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
+  Q.qres = c->qres.p; Q.qv = c->qv.p; Q.qj = c->qj.p;
+  Q.qck = c->qck.p; Q.qgh = c->qgh.p; Q.qhins = c->qhins.p;
+  Q.qhdel = c->qhdel.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
   Q.items = c->items.p;
 
   hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
@@ -2797,8 +2957,10 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   }
   LAYOUT_MARK(3);
   if (ntiles) {
-    hipLaunchKernelGGL(fill_tiles_kernel, dim3((uint32_t)((ntiles + 3) / 4)), dim3(256), 0, c->stream, Q,
-                       (uint32_t)ntiles);
+    const size_t fill_lds = Q.recompute ? (zob_lds ? zob_words * sizeof(uint64_t) : 0) + ctab_bytes : 0;
+    const int fo = occupancy_of(c, (const void *)fill_tiles_kernel, 256, fill_lds);
+    const uint32_t fgrid = (uint32_t)std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)c->cus * (uint64_t)std::max(fo, 1));
+    hipLaunchKernelGGL(fill_tiles_kernel, dim3(fgrid), dim3(256), fill_lds, c->stream, Q, (uint32_t)ntiles);
     HIP_TRY(c, hipGetLastError());
   }
   LAYOUT_MARK(4);
