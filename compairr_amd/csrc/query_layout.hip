@@ -196,6 +196,13 @@ struct QL {
   uint32_t  zob_pos_words;
   uint32_t  ctab_lds;                     /* ... and both the class tables in front of the heavy bitmap
                                              (geom.off_hv words) */
+  /* group_wg: few (slice, length) groups -- the direct layout of d = 0, whose groups are pseudo-slices x lengths,
+     a thousand counters that every query's answered atomic met in memory (0.29 of the 0.5 ms a 1M-query set
+     took from device arrays to the matrix) --: ranked per workgroup in LDS like the items (item_wg): keys_kernel
+     ranks a query among its workgroup's queries of the group and claims a run of the group for them once,
+     gbase_w[row][g]; scatter_kernel adds it to the group's base. */
+  uint32_t  group_wg, G;
+  uint32_t *gbase_w;
   uint32_t  cchunk0;                      /* first item chunk in the chunk list */
   cmpr::ItemRec *items;
   cmpr::ResPack *cpk;
@@ -207,6 +214,7 @@ struct QL {
 
 constexpr uint32_t ITEM_WG_MAX = 16384;      /* counters a workgroup keeps in LDS (at most 64 KiB) */
 constexpr uint32_t ITEM_PAD = 16;            /* ... and claims runs from: one counter per 64 bytes */
+constexpr uint32_t GROUP_WG_MAX = 8192;      /* (slice, length) groups a workgroup ranks its queries in, in LDS */
 
 /* keys_kernel with parts left out (the "debug" tunable's bits 16.., -DCMPR_ABLATION builds only) */
 enum : uint32_t { LDBG_NO_RANK = 1u << 16, LDBG_NO_ITEM_COUNT = 1u << 17, LDBG_NO_HASH = 1u << 18,
@@ -628,6 +636,7 @@ __device__ inline void layout_mode_assume(const QL &Q)
     __builtin_assume(Q.recompute != 0);
     __builtin_assume(Q.wstep <= 1);
     __builtin_assume(Q.dbg == 0);
+    __builtin_assume(Q.group_wg == 0);
   }
   if (MODE == 1)
     __builtin_assume(Q.indels == 0);
@@ -648,7 +657,8 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   uint64_t *const zl = (uint64_t *)(tot_lds + (lds_tot ? Q.n_rep : 0u));
   uint32_t *const ctl = (uint32_t *)(zl + (Q.zob_lds ? Q.zob_words : 0u));
   uint32_t *const ihist = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
-  uint32_t *const mine = ihist + (Q.item_wg ? Q.nitem_slices : 0u) + threadIdx.x * OWN_DW;
+  uint32_t *const ghist = ihist + (Q.item_wg ? Q.nitem_slices : 0u);
+  uint32_t *const mine = ghist + (Q.group_wg ? Q.G : 0u) + threadIdx.x * OWN_DW;
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   if (lds_tot) {
     for (uint32_t r = threadIdx.x; r < Q.n_rep; r += LAYOUT_WG)
@@ -663,6 +673,9 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   if (Q.item_wg)
     for (uint32_t k = threadIdx.x; k < Q.nitem_slices; k += LAYOUT_WG)
       ihist[k] = 0;
+  if (Q.group_wg)
+    for (uint32_t k = threadIdx.x; k < Q.G; k += LAYOUT_WG)
+      ghist[k] = 0;
   if (threadIdx.x < 64)
     dest_lds[threadIdx.x] = 0;
   /* (a set whose offsets the host never saw: what cmpr_layout_queries checks of them) */
@@ -845,7 +858,8 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
         Q.grp[0][i] = g;
         /* (its top bit: the query's class is split -- scatter_kernel need not ask the tables again) */
-        pend_rank = (LDBG(Q, LDBG_NO_RANK) ? 0u : atomicAdd(Q.cnt_g[0] + g, 1u)) | (heavy ? 0x80000000u : 0u);
+        pend_rank = (LDBG(Q, LDBG_NO_RANK) ? 0u : Q.group_wg ? atomicAdd(&ghist[g], 1u) : atomicAdd(Q.cnt_g[0] + g, 1u)) |
+                    (heavy ? 0x80000000u : 0u);
         pend_i = i;                              /* (written when the next iteration has waited for newer loads) */
       }
       /* (the same key as owned() above: ADVICE r5) */
@@ -875,6 +889,15 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   }
   if (Q.route && threadIdx.x < 64 && dest_lds[threadIdx.x])
     atomicAdd(Q.dest_cnt + threadIdx.x, (unsigned long long)dest_lds[threadIdx.x]);
+  /* group_wg: a run of every group this workgroup met, for its queries of the group (QL::group_wg) */
+  if (Q.group_wg) {
+    uint32_t *const row = Q.gbase_w + (size_t)(row0 + blockIdx.x) * Q.G;
+    for (uint32_t g = threadIdx.x; g < Q.G; g += LAYOUT_WG) {
+      const uint32_t cn = ghist[g];
+      if (cn)
+        row[g] = atomicAdd(Q.cnt_g[0] + g, cn);
+    }
+  }
   /* item_wg: a run for this workgroup's items of every counter it met (QL::item_wg) */
   if (Q.item_wg) {
     uint32_t *const row = Q.rbase + (size_t)(row0 + blockIdx.x) * Q.nitem_slices;
@@ -1096,7 +1119,9 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   uint64_t *const zl = scat_lds;
   uint32_t *const ctl = (uint32_t *)(zl + (Q.zob_lds ? Q.zob_pos_words : 0u));
   uint32_t *const ibase = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
-  uint32_t *const wave_words = ibase + (Q.item_wg ? Q.nitem_slices : 0u) + (threadIdx.x & ~63u) * OWN_DW;
+  uint32_t *const gb = ibase + (Q.item_wg ? Q.nitem_slices : 0u);        /* group_wg: first slot of this workgroup's
+                                                                          queries of group g */
+  uint32_t *const wave_words = gb + (Q.group_wg ? Q.G : 0u) + (threadIdx.x & ~63u) * OWN_DW;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t *const mine = wave_words + lane * OWN_DW;
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
@@ -1107,7 +1132,13 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   if (Q.ctab_lds)
     for (uint32_t k = threadIdx.x; k < Q.geom.off_hv; k += LAYOUT_WG)
       ctl[k] = Q.geom.ctab[k];
-  if (Q.zob_lds || Q.ctab_lds)
+  if (Q.group_wg) {
+    /* (a group this workgroup did not meet holds whatever the arena held -- nobody asks) */
+    const uint32_t *const row = Q.gbase_w + (size_t)(row0 + blockIdx.x) * Q.G;
+    for (uint32_t g = threadIdx.x; g < Q.G; g += LAYOUT_WG)
+      gb[g] = Q.base_g[0][g] + row[g];
+  }
+  if (Q.zob_lds || Q.ctab_lds || Q.group_wg)
     __syncthreads();
   if (Q.item_wg) {
     /* (the run keys_kernel's workgroup of the same number claimed for the same queries; a counter it did not
@@ -1161,7 +1192,7 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     OwnPieces pieces;
     pieces.fits = false;
     if (g != 0xffffffffu) {
-      gbase = LDBG(Q, LDBG_S_NO_BASE) ? 0u : Q.base_g[0][g];
+      gbase = LDBG(Q, LDBG_S_NO_BASE) ? 0u : Q.group_wg ? gb[g] : Q.base_g[0][g];
       pieces = own_load(Q, b, e, total);
       qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
       qr.v = Q.genes ? Q.v[i] : 0u;
@@ -2197,10 +2228,12 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const uint64_t zob_pos_words = (uint64_t)A * c->zpos;
   const bool ctab_lds = c->layout_zob_lds != 0 && c->sliced && c->geom.off_hv <= 2048;
   const size_t ctab_bytes = ctab_lds ? (size_t)c->geom.off_hv * sizeof(uint32_t) : 0;
+  /* few groups (the direct layout of d = 0): ranked per workgroup in LDS (QL::group_wg) */
+  const bool group_wg = G <= GROUP_WG_MAX && !routing && c->item_wg != 0;
   const size_t keys_shared = (n_rep <= 2048 ? n_rep * sizeof(double) : 0) + (zob_lds ? zob_words * sizeof(uint64_t) : 0) +
-                             ctab_bytes + (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0);
+                             ctab_bytes + (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + (group_wg ? G * sizeof(uint32_t) : 0);
   const size_t scatter_shared = (zob_lds ? zob_pos_words * sizeof(uint64_t) : 0) + ctab_bytes +
-                                (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0);
+                                (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + (group_wg ? G * sizeof(uint32_t) : 0);
   typedef void (*LayoutFn)(const QL, uint64_t, uint64_t, uint32_t);
   static const uint32_t wg_sizes[3] = {256, 512, 1024};
   static const LayoutFn keys_all[3][3] = {{keys_kernel<256, 0>, keys_kernel<512, 0>, keys_kernel<1024, 0>},
@@ -2212,7 +2245,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   /* (layout_mode_assume: what the instantiation may take for granted) */
   const bool recompute_on = Lcap <= 36u && !c->d2pairs && c->layout_recompute != 0;
   const int lmode = (c->rows && pair_rows(c) && !c->d2pairs && !sub2_items && !direct && !routing && wstep <= 1 &&
-                     c->opt.differences == 1 && recompute_on && c->debug == 0)
+                     c->opt.differences == 1 && recompute_on && c->debug == 0 && !group_wg)
                         ? (c->opt.indels ? 2 : 1)
                         : 0;
   const LayoutFn *const keys_fns = keys_all[lmode], *const scatter_fns = scatter_all[lmode];
@@ -2311,6 +2344,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_j16 = cut.take(narrow && !c->opt.ignore_genes ? (size_t)n * sizeof(uint16_t) : 0);
   const size_t o_cnt32 = cut.take(narrow && !c->opt.ignore_counts ? (size_t)n * sizeof(uint32_t) : 0);
   const size_t o_rbase = cut.take(ncs * (item_wg ? item_rows : (uint64_t)item_reps) * sizeof(uint32_t));
+  const size_t o_gbase_w = cut.take(group_wg ? (size_t)G * item_rows * sizeof(uint32_t) : 0);
   const size_t o_gbase = cut.take(G * npass * sizeof(uint32_t));
   const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
@@ -2454,6 +2488,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.rbase = (uint32_t *)at(o_rbase);
   Q.item_reps = item_reps;
   Q.item_wg = item_wg ? 1u : 0u;
+  Q.group_wg = group_wg ? 1u : 0u;
+  Q.G = (uint32_t)G;
+  Q.gbase_w = (uint32_t *)at(o_gbase_w);
   /* every query fits its 64-byte record (36 residues): the tiles' hashes and class keys are worked out from
      the records, nothing else is scattered (kernels_pairs2.h's residue packs are built where the set lies) */
   Q.recompute = recompute_on ? 1u : 0u;
