@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -249,6 +250,7 @@ extern "C" void cmpr_destroy(cmpr_context *c)
   if (!c)
     return;
   (void)hipSetDevice(c->device);
+  cmpr_release_reservations();              /* (what cmpr_warm_up_sized reserved and nobody took) */
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
   invalidate_plan(c);
@@ -1569,6 +1571,92 @@ extern "C" int cmpr_warm_up(const cmpr_options *o)
         (void)hipFuncGetAttributes(&fa, (const void *)f);
   }
   (void)hipGetLastError();
+  return CMPR_OK;
+}
+
+/* ---- cmpr_warm_up_sized: the reservations (context.h WarmReservation) ---- */
+namespace {
+std::mutex g_warm_mu;
+WarmReservation g_warm;
+}
+
+void *cmpr_take_reserved_host(size_t need, size_t *got_bytes)
+{
+  std::lock_guard<std::mutex> lock(g_warm_mu);
+  if (!g_warm.host || g_warm.host_bytes < need)
+    return nullptr;
+  void *p = g_warm.host;
+  *got_bytes = g_warm.host_bytes;
+  g_warm.host = nullptr;
+  g_warm.host_bytes = 0;
+  return p;
+}
+
+char *cmpr_take_reserved_device(int device, size_t need, size_t *got_bytes)
+{
+  std::lock_guard<std::mutex> lock(g_warm_mu);
+  if (!g_warm.dev || g_warm.device != device || g_warm.dev_bytes < need)
+    return nullptr;
+  char *p = g_warm.dev;
+  *got_bytes = g_warm.dev_bytes;
+  g_warm.dev = nullptr;
+  g_warm.dev_bytes = 0;
+  return p;
+}
+
+void cmpr_release_reservations()
+{
+  std::lock_guard<std::mutex> lock(g_warm_mu);
+  if (g_warm.host)
+    (void)hipHostFree(g_warm.host);
+  if (g_warm.dev)
+    (void)hipFree(g_warm.dev);
+  g_warm = WarmReservation();
+}
+
+extern "C" int cmpr_warm_up_sized(const cmpr_options *o, uint64_t n_queries_hint, uint64_t n_refs_hint,
+                                  uint64_t residue_bytes_hint)
+{
+  int rc = cmpr_warm_up(o);
+  if (rc)
+    return rc;
+  (void)n_refs_hint;                      /* (the index build's temporaries come and go: nothing to keep for it) */
+  int device = o->device;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess)
+    return CMPR_EDEVICE;
+  /* what the first cmpr_set_queries of a set of that size allocates: the pinned staging buffer of the narrowed
+     upload (lengths, 16-bit ids, 32-bit counts: 12 bytes per query -- page-locking 100+ MB is what a cold layout
+     call waited for) and arena A (the caller's arrays on the device + ~60 bytes of temporaries per query) */
+  void *host = nullptr;
+  size_t host_bytes = 0;
+  if (n_queries_hint >= (1u << 20)) {
+    const size_t need = (size_t)(n_queries_hint + 1) * 2 + (size_t)n_queries_hint * (2 + 2 + 2 + 4) + 64;
+    host_bytes = need + need / 16;
+    if (hipHostMalloc(&host, host_bytes, hipHostMallocDefault) != hipSuccess) {
+      host = nullptr;
+      host_bytes = 0;
+    }
+  }
+  char *dev = nullptr;
+  size_t dev_bytes = 0;
+  if (n_queries_hint) {
+    dev_bytes = (size_t)n_queries_hint * 96 + (size_t)residue_bytes_hint + (64u << 20);
+    if (hipMalloc((void **)&dev, dev_bytes) != hipSuccess) {
+      dev = nullptr;
+      dev_bytes = 0;
+    }
+  }
+  (void)hipGetLastError();
+  std::lock_guard<std::mutex> lock(g_warm_mu);
+  if (g_warm.host)
+    (void)hipHostFree(g_warm.host);
+  if (g_warm.dev)
+    (void)hipFree(g_warm.dev);
+  g_warm.host = host;
+  g_warm.host_bytes = host_bytes;
+  g_warm.dev = dev;
+  g_warm.dev_bytes = dev_bytes;
+  g_warm.device = device;
   return CMPR_OK;
 }
 

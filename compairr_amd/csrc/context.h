@@ -303,6 +303,21 @@ struct cmpr_context {
 };
 
 
+/* What cmpr_warm_up_sized() reserved before any context existed (ABI v5): the pinned staging buffer of the
+   narrowed upload and one block of device memory per device, taken over by the first context that needs them
+   (query_layout.hip), released by the first cmpr_destroy() if nobody did.  Process-wide, under a mutex. */
+struct WarmReservation {
+  void  *host = nullptr;
+  size_t host_bytes = 0;
+  char  *dev = nullptr;
+  size_t dev_bytes = 0;
+  int    device = -1;
+};
+/* take what fits (nullptr: nothing reserved, or too small) */
+void *cmpr_take_reserved_host(size_t need, size_t *got_bytes);
+char *cmpr_take_reserved_device(int device, size_t need, size_t *got_bytes);
+void cmpr_release_reservations();
+
 /* message of a failed cmpr_create() (no context yet), per thread */
 std::string &cmpr_create_error();
 

@@ -2067,6 +2067,13 @@ static int arena_fit(cmpr_context *c, DevArena &A, size_t bytes)
   if (A.base && A.cap >= bytes)
     return CMPR_OK;
   A.release();
+  /* (a block cmpr_warm_up_sized reserved on this device while the caller still read its input) */
+  size_t got = 0;
+  if (char *p = cmpr_take_reserved_device(c->device, bytes, &got)) {
+    A.base = p;
+    A.cap = got;
+    return CMPR_OK;
+  }
   const size_t want = bytes + bytes / 16 + 4096;
   HIP_TRY(c, hipMalloc((void **)&A.base, want));
   A.cap = want;
@@ -2597,8 +2604,14 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
           (void)hipHostFree(c->stage_host);
         c->stage_host = nullptr;
         c->stage_host_bytes = 0;
-        HIP_TRY(c, hipHostMalloc(&c->stage_host, need + need / 16, hipHostMallocDefault));
-        c->stage_host_bytes = need + need / 16;
+        size_t got = 0;
+        if (void *p = cmpr_take_reserved_host(need, &got)) {       /* (cmpr_warm_up_sized page-locked it ahead) */
+          c->stage_host = p;
+          c->stage_host_bytes = got;
+        } else {
+          HIP_TRY(c, hipHostMalloc(&c->stage_host, need + need / 16, hipHostMallocDefault));
+          c->stage_host_bytes = need + need / 16;
+        }
       }
       char *hp = (char *)c->stage_host;
       h_len16 = (uint16_t *)hp; hp += (((size_t)(n + 1) * 2) + 15) & ~(size_t)15;

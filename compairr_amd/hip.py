@@ -26,7 +26,7 @@ EXPORTS = [
     "cmpr_count_duplicates", "cmpr_overlap_pairs",
     "cmpr_set_reference_device", "cmpr_set_queries_device",
     "cmpr_route_queries", "cmpr_route_pack", "cmpr_set_queries_routed",
-    "cmpr_warm_up",
+    "cmpr_warm_up", "cmpr_warm_up_sized",
 ]
 
 
@@ -149,7 +149,9 @@ def load_library() -> C.CDLL:
     lib.cmpr_cols.restype = C.c_uint32
     lib.cmpr_set_tunable.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cmpr_get_tunable.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
-    if lib.cmpr_abi_version() != 4:
+    lib.cmpr_warm_up.argtypes = [C.POINTER(_Options)]
+    lib.cmpr_warm_up_sized.argtypes = [C.POINTER(_Options), C.c_uint64, C.c_uint64, C.c_uint64]
+    if lib.cmpr_abi_version() != 5:
         raise RuntimeError("libcompairr_hip.so ABI version mismatch")
     _lib = lib
     return lib

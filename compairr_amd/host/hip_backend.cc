@@ -7,6 +7,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -33,6 +34,7 @@ struct Api {
   int (*count_duplicates)(cmpr_context *, const cmpr_set_view *, uint64_t *) = nullptr;
   int (*overlap_pairs)(cmpr_context *, uint64_t, uint32_t *, uint32_t *, uint64_t *) = nullptr;
   int (*warm_up)(const cmpr_options *) = nullptr;
+  int (*warm_up_sized)(const cmpr_options *, uint64_t, uint64_t, uint64_t) = nullptr;
 };
 
 template <typename F>
@@ -86,7 +88,16 @@ public:
     co.alphabet_size = o.alphabet_size;
     if (o.devices.empty()) {
       co.device = (int32_t)o.device;
-      (void)api_.warm_up(&co);
+      /* how large the query set will be, from the size of its file (the program knows it before it parses a
+         line): an AIRR line of the columns this program reads is ~35 bytes and up, ~15 of them residues --
+         a hint: the library reserves its page-locked upload buffer and layout arena meanwhile (ABI v5) */
+      uint64_t nq = 0, nres = 0;
+      struct stat st;
+      if (o.input1 && strcmp(o.input1, "-") != 0 && stat(o.input1, &st) == 0 && S_ISREG(st.st_mode)) {
+        nq = (uint64_t)st.st_size / 34;
+        nres = (uint64_t)st.st_size / 2;
+      }
+      (void)api_.warm_up_sized(&co, nq, 0, nres);
       return;
     }
     /* (--devices: one thread per device, as overlap() then creates their contexts side by side -- warmed one
@@ -371,7 +382,8 @@ OverlapBackend *make_hip_backend(const char *argv0, std::string &error)
       !bind(api.handle, "cmpr_get_stats", api.get_stats, error) ||
       !bind(api.handle, "cmpr_count_duplicates", api.count_duplicates, error) ||
       !bind(api.handle, "cmpr_overlap_pairs", api.overlap_pairs, error) ||
-      !bind(api.handle, "cmpr_warm_up", api.warm_up, error)) {
+      !bind(api.handle, "cmpr_warm_up", api.warm_up, error) ||
+      !bind(api.handle, "cmpr_warm_up_sized", api.warm_up_sized, error)) {
     dlclose(api.handle);
     return nullptr;
   }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CMPR_ABI_VERSION 4
+#define CMPR_ABI_VERSION 5
 
 enum {
   CMPR_OK          = 0,
@@ -136,6 +136,13 @@ const char *cmpr_last_error(const cmpr_context *ctx);
  * will be submitted (the Zobrist table needs max(longest1, longest2) + 3
  * positions, overlap.cc:840); pass 0 to size it from this set alone, in which
  * case later longer queries make cmpr_set_queries() fail with CMPR_EINVAL.
+ *
+ * Footprint: the record table holds one 64-byte slot per BUCKET, buckets = 2^table_log2_delta x the
+ * smallest power of two >= n / 0.7 (hashtable.cc:24, 36-38) -- 183 to 366 bytes per reference sequence at
+ * the default delta of 1 (10M: 2 GiB; 100M: 32 GiB) --, the row filter 2 bytes per residue position + 2 per
+ * sequence (twice that with -i), the set itself ~45 bytes per sequence.  At most 2^30 buckets: sets beyond
+ * ~375M sequences (187M at delta 1 ... 750M at delta 0) return CMPR_EUNSUPPORTED; "table_log2_delta" = 0
+ * halves the table.
  */
 int cmpr_set_reference(cmpr_context *ctx, const cmpr_set_view *set2,
                        uint32_t longest_query);
@@ -280,6 +287,20 @@ int cmpr_count_duplicates(cmpr_context *ctx, const cmpr_set_view *set, uint64_t 
  * nothing the caller has to free.  Thread-safe against every other entry point.
  */
 int cmpr_warm_up(const cmpr_options *options);
+
+/*
+ * (ABI v5)  cmpr_warm_up() for a caller that knows roughly how large its sets will be -- the host program
+ * knows both file sizes before it parses a line (compairr_amd/host/overlap_host.cc) --: additionally
+ * reserves what the first cmpr_set_queries() of a set of `n_queries_hint` sequences with
+ * `residue_bytes_hint` residues would otherwise allocate while the caller waits (the page-locked staging
+ * buffer of its upload, 12 bytes per query, and the device arena of the layout's temporaries).  The first
+ * context that needs them takes them over; what nobody took is released by the first cmpr_destroy().
+ * `n_refs_hint` is accepted for symmetry (the index build keeps nothing that could be reserved).  Hints
+ * are hints: too small, and the call allocates as before; too large, and memory is held until taken or
+ * released.  The reference has no counterpart (overlap.cc:840-887 allocates in microseconds).
+ */
+int cmpr_warm_up_sized(const cmpr_options *options, uint64_t n_queries_hint, uint64_t n_refs_hint,
+                       uint64_t residue_bytes_hint);
 
 /* Statistics of the last overlap call (synchronises the context's events). */
 int cmpr_get_stats(cmpr_context *ctx, cmpr_stats *out);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.cmpr_abi_version() == 4
+    assert lib.cmpr_abi_version() == 5
 
 
 def test_struct_sizes_match_header():
