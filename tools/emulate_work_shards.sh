@@ -1,14 +1,17 @@
 #!/bin/bash
-# per-rank step of an N-GPU strong-scaling run (--shard-by work), emulated on one GPU
+# per-rank cost of an N-GPU strong-scaling run by WORK shards (`bench.py --shard-by work --layout replicated`: every rank
+# holds the whole query set in HBM, lays out and works on what is filed under its share of the filter slices), one rank
+# emulated on one GPU: the query set per rank (layout + launch) and the launch alone over the resident layout.
+# usage (GPU box): tools/emulate_work_shards.sh <gpurun_out subdir> [bench args]
 cd "$(dirname "$0")/.." || exit 1
-O=gpurun_out/${1:-r02w}; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "work_shards or debug_switches" 2>&1 | tail -3
+O=${1:-gpurun_out/work_shards}; shift; mkdir -p $O
 for n in 1 2 4 8; do
-  python bench.py --steps 20 --warmup 5 --cpu-sample -1 --tunable work_shard_count=$n --tunable work_shard_index=0 > $O/w$n.json 2> $O/w$n.err
-  python - $O/w$n.json $n <<'PY'
+  python3 bench.py --steps 20 --warmup 5 --cpu-sample -1 --tunable work_shard_count=$n --tunable work_shard_index=0 "$@" > $O/w$n.json 2> $O/w$n.err
+  python3 - $O/w$n.json $n <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-r=d["roofline"]
-print("work shard 1/%s: step %.3f ms probe %.3f resolve %.3f chunks %s" % (sys.argv[2], d["ms_per_step"], r["kernel_ms"], r["resolve_kernel_ms"], d["config"]["layout"]["chunks"]))
+k=d["step_kernels_ms"]
+print("work shard 1/%s: query set %.3f ms %s | launch alone (resident) %.4f ms | chunks %s" % (
+    sys.argv[2], d["ms_per_step"], {a: round(b, 3) for a, b in k.items()}, d["resident_step_ms"], d["config"]["layout"]["chunks"]))
 PY
 done

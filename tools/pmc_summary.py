@@ -60,15 +60,20 @@ for f in glob.glob(os.path.join(src, "prof_stats", "**", "*kernel_stats.csv"), r
 else:
     stats = locals().get("stats", {})
 
-for k in ("probe", "resolve"):
-    b = pick(k)
+# the step's kernels: the layout's three (round 6: a step is a query set from its device arrays to the matrix),
+# then probe and resolve
+WORDS = {"probe": "probe", "resolve": "resolve", "keys": "keys_kernel", "scatter": "scatter_kernel",
+         "tiles": "fill_tiles_kernel"}
+for k in ("keys", "scatter", "tiles", "probe", "resolve"):
+    b = pick(WORDS[k])
     if not b:
         continue
     name, mean_us = b
     d = per[name]
     e = {"name": name, "dispatch": d["dispatch"], "pmc_pass_mean_duration_us": mean_us,
-         "counters": {c: {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+         "counters": {c: {"per_launch_mean": sum(v) / len(v), "per_launch_max": max(v), "launches": len(v)}
                       for c, v in d["ctr"].items()}}
+    e["longest_launch_us"] = max(d["dur"])
     if name in stats:
         r = stats[name]
         e["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
@@ -82,11 +87,15 @@ for k in ("probe", "resolve"):
         # its raw figure stands
         # ... and so does the filterless d = 0 kernel's (probe_kernel<A, 0, ..>: one random slot per query;
         # its coalesced reads of the queries' records are then undercounted, not the slots doubled)
+        # (the layout kernels stream their inputs 4 to 16 bytes per lane, coalesced: doubled like the probe kernel's;
+        #  the guide calls widths other than 16 bytes per lane uncalibrated -- the raw figures stand beside it)
         direct = re.search(r"probe_kernel<\d+, 0,", name) is not None
         e["fetch_factor"] = 1 if (k == "resolve" or direct) else 2
         e["hbm_bytes_per_launch"] = e["fetch_factor"] * fetch + write
         e["raw_fetch_bytes"] = fetch
         e["raw_write_bytes"] = write
+        e["hbm_bytes_per_launch_longest"] = (e["fetch_factor"] * c["FETCH_SIZE"]["per_launch_max"] +
+                                             c["WRITE_SIZE"]["per_launch_max"]) * 1024
     # issue-side utilisation straight from the counters: SQ_ACTIVE_INST_* count in units
     # of 4 cycles per SIMD, SQ_BUSY_CU_CYCLES in cycles per CU (4 SIMDs): their ratio is
     # the fraction of SIMD cycles in which the unit was executing an instruction
@@ -97,7 +106,7 @@ for k in ("probe", "resolve"):
                                            ("lds", "SQ_ACTIVE_INST_LDS")) if n in c}
     out["kernels"][k] = e
 
-tot = [e.get("hbm_bytes_per_launch") for e in out["kernels"].values()]
+tot = [e.get("hbm_bytes_per_launch") for k, e in out["kernels"].items() if k in ("probe", "resolve")]
 if tot and all(x is not None for x in tot):
     out["hbm_bytes_per_step"] = sum(tot)
     out["hbm_bytes_note"] = ("sum over the step's kernels of (f x FETCH_SIZE + WRITE_SIZE) x 1024: f = 2 for the probe "
@@ -175,8 +184,13 @@ if "probe" in out["kernels"] and os.path.exists(cal_path):
         "mix_cycles_per_valu_inst": mix["mean_cycles_per_instruction"] if mix else None,
         "mix": mix,
         # work of the profiled (N = 1) launch: a shard's share is priced against these
-        "filter_reads": (bench.get("roofline") or {}).get("filter_reads_per_launch"),
-        "variants": (bench.get("roofline") or {}).get("variants_per_launch"),
+        "filter_reads": ((bench.get("roofline_kernels") or {}).get("probe") or bench.get("roofline") or {}).get("filter_reads_per_launch"),
+        "variants": ((bench.get("roofline_kernels") or {}).get("probe") or bench.get("roofline") or {}).get("variants_per_launch"),
+        # the layout's kernels (bench.py layout_rooflines): counted HBM bytes per launch of the 10M-query call
+        # (the longest launch of the kernel in the profile: the device path lays the whole set out in one)
+        "layout_kernels": {WORDS[k]: {"hbm_bytes": out["kernels"][k].get("hbm_bytes_per_launch_longest"),
+                                      "us_in_profile": out["kernels"][k].get("longest_launch_us")}
+                           for k in ("keys", "scatter", "tiles") if k in out["kernels"]},
     }
     with open(inp_path, "w") as fh:
         json.dump(inputs, fh, indent=1)
