@@ -284,13 +284,13 @@ def layout_rooflines(workload, n, residues, slots, items, indels, times):
       keys_kernel     per query: reads its residues, offset 8, v 4, j 4, repertoire 4, count 8; writes group 4,
                       rank 4, hash 8 (24 with -i), class key 4; one 4-byte counter read-modify-write (8)
       scatter_kernel  per query: the same reads + group, rank, hash(es), class key, group base 4; writes the
-                      64-byte record and its slot number 4; per item 16
+                      64-byte record; per item 16
       fill_tiles      per slot (padding lanes included): reads the 64-byte record; writes residues (position-
                       major, ~the query's length rounded up to 4), length 2, hash 8 (24 with -i), class key 4
                       (amino acids on the row filter: genes, repertoire and count stay in the record)"""
     hb = 24 if indels else 8
     alg = {"keys": residues + n * (28 + 8 + hb + 4 + 8),
-           "scatter": residues + n * (28 + 8 + hb + 4 + 4 + 64 + 4) + items * 16,
+           "scatter": residues + n * (28 + 8 + hb + 4 + 4 + 64) + items * 16,
            "tiles": slots * (64 + 2 + hb + 4) + (residues + 2 * n) * slots // max(n, 1)}
     path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     try:

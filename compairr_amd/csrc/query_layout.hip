@@ -138,7 +138,7 @@ struct QL {
   uint32_t *tfirst_g;                /* pass 0: first tile of every group */
   /* per query */
   uint64_t *h_tmp, *hins_tmp, *hdel_tmp;
-  uint32_t *ck_tmp, *slot_of;
+  uint32_t *ck_tmp;
   struct QAux *aux;                  /* per slot: what the record has no room for */
   /* outputs */
   TileDesc *tiles;
@@ -758,7 +758,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       if (bad)
         err = VERR_RESIDUE;
     }
-    Q.grp[0][i] = 0xffffffffu;
+    uint32_t grp_out = 0xffffffffu;               /* (one store of the query's group, at the end) */
     if (err && !err_all)
       err_all = err;
     if (!err) {
@@ -824,7 +824,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
           });
         if (Q.route == 2u)
           mask = Q.wstep >= 64u ? ~0ull : (1ull << Q.wstep) - 1ull;       /* (a layout every context holds in full) */
-        Q.grp[0][i] = (uint32_t)mask;
+        grp_out = (uint32_t)mask;
         Q.rank[i] = (uint32_t)(mask >> 32);
         for (unsigned long long m = mask; m; m &= m - 1ull)
           atomicAdd(&dest_lds[__builtin_ctzll(m)], 1u);
@@ -856,7 +856,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
         bucket = 2 * (Q.nslices_real + (((uint32_t)i * 2654435761u) >> (32 - FOREIGN_SLICES_LOG2)));
       if (bucket != ~0ull && !Q.route) {
         const uint32_t g = (uint32_t)(bucket * Q.per_slice + gl);
-        Q.grp[0][i] = g;
+        grp_out = g;
         /* (its top bit: the query's class is split -- scatter_kernel need not ask the tables again) */
         pend_rank = (LDBG(Q, LDBG_NO_RANK) ? 0u : Q.group_wg ? atomicAdd(&ghist[g], 1u) : atomicAdd(Q.cnt_g[0] + g, 1u)) |
                     (heavy ? 0x80000000u : 0u);
@@ -866,6 +866,7 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       if (Q.alg_step <= 1u || work_owner(Q.sliced ? slice : (ck & DIRECT_OWNER_MASK), 0u, Q.alg_step) == Q.alg_first)
         alg += LDBG(Q, LDBG_NO_TOTALS) ? 0ull : (uint64_t)L + 20 + 8 * variants_of(Q, s, L);
     }
+    Q.grp[0][i] = grp_out;
   }
   if (pend_i != ~0ull)
     Q.rank[pend_i] = pend_rank;
@@ -940,11 +941,23 @@ widen_kernel(const uint16_t *v16, const uint16_t *j16, const uint16_t *rep16, co
 
 /* One thread per slice and pass.  WRITE = 0: what the slice needs (counted);
    WRITE = 1: the same walk, writing at the slice's exclusive prefix. */
+constexpr uint32_t SLICES_WG = 128;
 template <int WRITE>
-__global__ void __launch_bounds__(256)
-slices_kernel(const QL Q, uint32_t pi)
+__global__ void __launch_bounds__(SLICES_WG)
+slices_kernel(const QL Q, uint32_t pi, uint32_t in_lds)
 {
-  const uint64_t sl = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  /* (the group counters of the workgroup's SLICES_WG slices lie side by side: one coalesced copy to LDS, and
+     the loops below -- every step of which waited for a counter from memory -- read them there; round 6) */
+  extern __shared__ uint32_t cnt_lds[];
+  const uint32_t per_sl = (Q.sliced ? 2u : 1u) * Q.per_slice;
+  const uint64_t sl0 = (uint64_t)blockIdx.x * SLICES_WG;
+  if (in_lds) {
+    const uint64_t first = sl0 * per_sl, end = min((sl0 + SLICES_WG) * (uint64_t)per_sl, Q.nslices * (uint64_t)per_sl);
+    for (uint64_t k = first + threadIdx.x; k < end; k += SLICES_WG)
+      cnt_lds[k - first] = Q.cnt_g[pi][k];
+    __syncthreads();
+  }
+  const uint64_t sl = sl0 + threadIdx.x;
   if (sl >= Q.nslices)
     return;
   const uint32_t pass = pi == 0 ? 0u : 2u + pi;          /* class-row pass i = pass 3 + i */
@@ -961,7 +974,8 @@ slices_kernel(const QL Q, uint32_t pi)
   for (uint32_t hv = 0; hv < (Q.sliced ? 2u : 1u); hv++) {
     const uint64_t bucket = Q.sliced ? 2 * sl + hv : sl;
     const uint32_t tile_k = hv ? Q.geom.k : 0u;
-    const uint32_t *c = cnt + bucket * Q.per_slice;
+    /* (the bucket's counters: in the workgroup's copy, or where they lie) */
+    const uint32_t *c = in_lds ? cnt_lds + (bucket * Q.per_slice - sl0 * per_sl) : cnt + bucket * Q.per_slice;
     /* lengths >= min_mixed share tiles: longest first, cut every 64 */
     uint64_t n_long = 0;
     uint32_t gl_end = 0;
@@ -1183,8 +1197,6 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     qr.v = qr.j = qr.rep = qr.len = qr.orig = 0;
     const uint32_t g = cur.g;                    /* (all ones: not worked on by this context, no item of it either --
                                                     or behind the end of the range) */
-    if (i < q1 && g == 0xffffffffu)
-      Q.slot_of[i] = 0xffffffffu;
     const uint64_t b = cur.b, e = cur.e;
     const uint32_t rk = cur.rk;                  /* (rank in the group | class split << 31: keys_kernel) */
     uint32_t gbase = 0, ck = 0;
@@ -1210,7 +1222,6 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     cur = fetch(i + stride);
     if (g != 0xffffffffu) {
       slot = LDBG(Q, LDBG_S_NO_BASE) ? (uint32_t)i : gbase + (rk & 0x7fffffffu);
-      Q.slot_of[i] = slot;
       const uint32_t L = (uint32_t)(e - b);
       const uint8_t *s = own_commit(Q, pieces, b, e, mine);
       qr.len = L;
@@ -1551,6 +1562,22 @@ sizes_kernel(const QL Q, const uint32_t *cpad, uint64_t ncs, unsigned long long 
     rt[r] = Q.rep_total[r];
 }
 
+/* the padding of the item lists: behind the items of counter k up to its whole blocks of 64, and one block
+   behind the last list (a block read past the end stays inside) -- all ones = "no item" (round 6: a memset of the
+   whole array, 160 MB per 10M queries, did this before every call) */
+__global__ void __launch_bounds__(256)
+item_padding_kernel(const QL Q, const uint32_t *padded, uint32_t total)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  ItemRec none;
+  memset(&none, 0xff, sizeof none);
+  if (k < (uint64_t)Q.nitem_slices)
+    for (uint32_t x = Q.cbase[k] + Q.ccnt[k]; x < Q.cbase[k] + padded[k]; x++)
+      Q.items[x] = none;
+  if (k < WAVE)
+    Q.items[total + k] = none;
+}
+
 /* the slice of the filter the items of counter k are filed under, and its pages (layout.h SliceGeom):
    returns e (0: no pages) */
 __device__ inline uint32_t item_slice_pages(const QL &Q, uint64_t k, uint32_t *slice, uint32_t *pt_out)
@@ -1714,13 +1741,59 @@ sibling_write_chunks_kernel(const QL Q, const uint32_t *sib_cnt, const uint32_t 
 
 /* ---- chunk order: heaviest first ------------------------------------------ */
 
+__device__ inline uint32_t chunk_work_of(const QL &Q, const Chunk &ck);
+
 __global__ void __launch_bounds__(256)
 chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
 {
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nchunks)
     return;
-  const Chunk ck = Q.chunks[k];
+  const uint32_t w = chunk_work_of(Q, Q.chunks[k]);
+  work[k] = w;
+  if (idx)
+    idx[k] = k;
+  else                                        /* (chunk_order_kernel's classes: the heaviest chunk) */
+    atomicMax(work + nchunks, w);
+}
+
+/* The chunk order in ONE launch (round 6; up to ORDER_MAX chunks): heaviest first is what the probe kernels' deal
+   wants, and it wants it roughly -- the tail of a launch is made of the light chunks -- so a counting sort by
+   1024 classes of weight (linear up to the heaviest chunk) does what a 32-bit radix sort of (weight, index) pairs
+   did in eight launches (0.05 ms of a 2 ms query set).  The weights and their maximum (work[nchunks]) come from
+   chunk_work_kernel; then one workgroup: the classes' histogram in LDS, its prefix sums from the heavy end, the
+   chunks to their places. */
+constexpr uint32_t ORDER_MAX = 1u << 18;
+constexpr uint32_t ORDER_CLASSES = 1024;
+__global__ void __launch_bounds__(1024)
+chunk_order_kernel(const QL Q, uint32_t nchunks, uint32_t *work, Chunk *out)
+{
+  __shared__ uint32_t hist[ORDER_CLASSES];
+  __shared__ uint32_t wmax;
+  typedef hipcub::BlockScan<uint32_t, 1024> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0)
+    wmax = max(work[nchunks], 1u);
+  __syncthreads();
+  const uint64_t top = wmax;
+  auto cls = [&](uint32_t w) -> uint32_t {          /* class 0 = the heaviest */
+    return (ORDER_CLASSES - 1u) - (uint32_t)(((uint64_t)w * (ORDER_CLASSES - 1u)) / top);
+  };
+  for (uint32_t k = threadIdx.x; k < nchunks; k += 1024)
+    atomicAdd(&hist[cls(work[k])], 1u);
+  __syncthreads();
+  uint32_t first = 0;
+  Scan(tmp).ExclusiveSum(hist[threadIdx.x], first);
+  __syncthreads();
+  hist[threadIdx.x] = first;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nchunks; k += 1024)
+    out[atomicAdd(&hist[cls(work[k])], 1u)] = Q.chunks[k];
+}
+
+__device__ inline uint32_t chunk_work_of(const QL &Q, const Chunk &ck)
+{
   const uint32_t cpass = ck.pass & 0xffu;
   /* (variant 2 at d = 2 on single rows: an item reads ~12 x 19 words of its slice, kernels_rows.h) */
   uint64_t w = cpass >= 3 ? (uint64_t)ck.ntiles * WAVE * (Q.sub2_items ? 48 : Q.pairs2 ? 5 : (Q.rows && Q.differences == 2) ? 230 : 2) : 0;
@@ -1735,8 +1808,7 @@ chunk_work_kernel(const QL Q, uint32_t nchunks, uint32_t *work, uint32_t *idx)
   }
   if (ck.pass & CHUNK_WITH_ITEMS)
     w += (uint64_t)Q.slice_items[ck.slice].y * WAVE * 48;
-  work[k] = (uint32_t)min(w, (uint64_t)0xffffffffu);
-  idx[k] = k;
+  return (uint32_t)min(w, (uint64_t)0xffffffffu);
 }
 
 __global__ void __launch_bounds__(256)
@@ -2356,7 +2428,6 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const size_t o_grp = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_rank = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_tfirst = cut.take(G * sizeof(uint32_t));
-  const size_t o_slotof = cut.take((size_t)n * sizeof(uint32_t));
   const size_t o_tot = cut.take(nslices * sizeof(SliceTot));
   const size_t o_pre = cut.take(nslices * sizeof(SliceTot));
   const bool need_ck = c->rows || sub2_items;
@@ -2483,7 +2554,6 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.hins_tmp = (uint64_t *)at(o_hins);
   Q.hdel_tmp = (uint64_t *)at(o_hdel);
   Q.ck_tmp = (uint32_t *)at(o_ck);
-  Q.slot_of = (uint32_t *)at(o_slotof);
   Q.alg_bytes = (unsigned long long *)at(o_alg);
   Q.verr = (uint32_t *)at(o_verr);
   Q.rep_total = (double *)at(o_reptot);
@@ -2784,12 +2854,16 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     return CMPR_OK;
   }
 
+  /* (slices_kernel: the counters of a workgroup's slices in LDS when they fit 48 KiB) */
+  const size_t slices_lds_want = (size_t)SLICES_WG * (c->sliced ? 2 : 1) * per_slice * sizeof(uint32_t);
+  const size_t slices_lds = slices_lds_want <= 48 * 1024 ? slices_lds_want : 0;
   /* ---- per slice: what it needs; exclusive scan; items per (group, slice) padded to
           blocks of 64; -i (variant 1): the sibling lists; all sizes in ONE round trip ---- */
   {
     SliceTot zero;
     memset(&zero, 0, sizeof zero);
-    hipLaunchKernelGGL(slices_kernel<0>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
+    hipLaunchKernelGGL(slices_kernel<0>, dim3((uint32_t)((nslices + SLICES_WG - 1) / SLICES_WG)), dim3(SLICES_WG),
+                       slices_lds, c->stream, Q, 0u, slices_lds ? 1u : 0u);
     HIP_TRY(c, hipGetLastError());
     size_t b = cub_bytes;
     HIP_TRY(c, hipcub::DeviceScan::ExclusiveScan(cub_tmp, b, Q.tot[0], Q.pre[0], SliceTotSum(), zero,
@@ -2904,7 +2978,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   ArenaCut cb;
   const size_t o_aux = cb.take(std::max<size_t>(Q.recompute ? 1 : slots, 1) * sizeof(QAux));
   const size_t o_chunks_u = cb.take((size_t)nchunks * sizeof(Chunk));
-  const size_t o_wk = cb.take((size_t)nchunks * sizeof(uint32_t));
+  const size_t o_wk = cb.take(((size_t)nchunks + 1) * sizeof(uint32_t));
   const size_t o_wk2 = cb.take((size_t)nchunks * sizeof(uint32_t));
   const size_t o_ix = cb.take((size_t)nchunks * sizeof(uint32_t));
   const size_t o_ix2 = cb.take((size_t)nchunks * sizeof(uint32_t));
@@ -2961,11 +3035,12 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     c->qhins.release();
     c->qhdel.release();
   }
+  bool pad_items = false;
   if (ngroups) {
     /* (+ 64: a block read past the last item stays inside; all ones = padding) */
     const size_t ni = (size_t)cslots + WAVE;
     if ((rc = dev_reserve(c, c->items, ni))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->items.p, 0xff, ni * sizeof(ItemRec), c->stream));
+    pad_items = true;                      /* (item_padding_kernel, once Q.items is known) */
     if (sub2_items) {
       if ((rc = dev_reserve(c, c->cpk, ni))) return rc;
       if ((rc = dev_reserve(c, c->slice_items, 2 * (size_t)nslices_real))) return rc;
@@ -2995,7 +3070,13 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.qhdel = c->qhdel.p; Q.qlen = c->qlen.p; Q.qrec = c->qrec.p;
   Q.items = c->items.p;
 
-  hipLaunchKernelGGL(slices_kernel<1>, dim3(blocks_for(nslices)), dim3(256), 0, c->stream, Q, 0u);
+  if (pad_items) {
+    hipLaunchKernelGGL(item_padding_kernel, dim3(blocks_for(std::max<uint64_t>(ncs, WAVE))), dim3(256), 0, c->stream, Q,
+                       cpad, (uint32_t)cslots);
+    HIP_TRY(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(slices_kernel<1>, dim3((uint32_t)((nslices + SLICES_WG - 1) / SLICES_WG)), dim3(SLICES_WG),
+                     slices_lds, c->stream, Q, 0u, slices_lds ? 1u : 0u);
   HIP_TRY(c, hipGetLastError());
   LAYOUT_MARK(2);
   if (n) {
@@ -3033,7 +3114,15 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const bool select_share = wstep > 1 && !place_mine;
   /* ---- heaviest chunks first: the tail of the launch is made of light ones;
           single-wave tiles longest first ---- */
-  if (nchunks) {
+  if (nchunks && nchunks <= ORDER_MAX && !select_share) {
+    uint32_t *wk = (uint32_t *)(bb + o_wk);
+    HIP_TRY(c, hipMemsetAsync(wk + nchunks, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(chunk_work_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream, Q,
+                       (uint32_t)nchunks, wk, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(chunk_order_kernel, dim3(1), dim3(1024), 0, c->stream, Q, (uint32_t)nchunks, wk, c->chunks.p);
+    HIP_TRY(c, hipGetLastError());
+    c->nchunks = (uint32_t)nchunks;
+  } else if (nchunks) {
     uint32_t *wk = (uint32_t *)(bb + o_wk), *wk2 = (uint32_t *)(bb + o_wk2);
     uint32_t *ix = (uint32_t *)(bb + o_ix), *ix2 = (uint32_t *)(bb + o_ix2);
     hipLaunchKernelGGL(chunk_work_kernel, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream, Q,
