@@ -194,6 +194,7 @@ struct QL {
   uint32_t  zob_lds, zob_words;           /* keys_kernel keeps the Zobrist keys (zob_words of them, gene keys
                                              included) in LDS; scatter_kernel those of the positions */
   uint32_t  zob_pos_words;
+  uint32_t  own_np;                       /* 16-byte pieces of a thread's own copy of its residues (own_load): 3 .. 7 */
   uint32_t  ctab_lds;                     /* ... and both the class tables in front of the heavy bitmap
                                              (geom.off_hv words) */
   /* group_wg: few (slice, length) groups -- the direct layout of d = 0, whose groups are pseudo-slices x lengths,
@@ -358,27 +359,32 @@ validate_res_kernel(const uint8_t *res, uint64_t total, uint32_t A, uint32_t *ve
    for the whole workgroup: two barriers and two dependent scalar loads per batch of
    256 queries.)  Sequences that do not fit the three pieces, or a set whose residues are not 16-byte
    aligned: read where they lie.  The caller has checked b <= e <= total. */
-constexpr uint32_t OWN_DW = 13;
+constexpr uint32_t OWN_DW = 13;           /* three pieces + 1: the CDR3 amino-acid modes */
+constexpr int OWN_NP_MAX = 7;                /* the general mode: sequences of up to 97 residues in a thread's LDS words */
 /* (threads of a workgroup of keys_kernel / scatter_kernel: 256, 512 or 1024 -- the more share one copy of the
    tables (Zobrist keys, class tables, item counters: 22 KiB at 10M queries, 54 KiB with -i), the more waves
    fit a CU beside them; chosen per call, cmpr_layout_queries) */
 /* ... in two steps, so that the caller can ask for the NEXT query's fields between them: the loads of the
    pieces (own_load), and their way into LDS (own_commit: waits for them) */
+/* (NP: the pieces an instantiation has registers for -- 3 for the CDR3 amino-acid modes, 7 for the general one;
+   np <= NP: the pieces the set's longest sequence needs, QL::own_np, and 4 np + 1 words of LDS per thread) */
+template <int NP>
 struct OwnPieces {
-  uint4 w[3];
+  uint4 w[NP];
   bool  fits;
 };
 
-__device__ inline OwnPieces own_load(const QL &Q, uint64_t b, uint64_t e, uint64_t total)
+template <int NP>
+__device__ inline OwnPieces<NP> own_load(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t np)
 {
-  OwnPieces o;
+  OwnPieces<NP> o;
   const uint64_t a0 = b & ~15ull;
-  o.fits = ((uintptr_t)Q.res & 15u) == 0 && e - a0 <= 48u;
+  o.fits = ((uintptr_t)Q.res & 15u) == 0 && e - a0 <= 16u * np;
 #pragma unroll
-  for (uint32_t k = 0; k < 3; k++) {
+  for (uint32_t k = 0; k < (uint32_t)NP; k++) {
     o.w[k] = make_uint4(0u, 0u, 0u, 0u);
     const uint64_t at = a0 + 16u * k;
-    if (o.fits && at < e) {
+    if (k < np && o.fits && at < e) {
       if (at + 16u <= total) {
         o.w[k] = *(const uint4 *)(Q.res + at);
       } else {                                   /* (the last bytes of the set) */
@@ -397,13 +403,14 @@ __device__ inline OwnPieces own_load(const QL &Q, uint64_t b, uint64_t e, uint64
   return o;
 }
 
-__device__ inline const uint8_t *own_commit(const QL &Q, const OwnPieces &o, uint64_t b, uint64_t e, uint32_t *mine)
+template <int NP>
+__device__ inline const uint8_t *own_commit(const QL &Q, const OwnPieces<NP> &o, uint64_t b, uint64_t e, uint32_t *mine)
 {
   if (!o.fits)
     return Q.res + b;
   const uint64_t a0 = b & ~15ull;
 #pragma unroll
-  for (uint32_t k = 0; k < 3; k++)
+  for (uint32_t k = 0; k < (uint32_t)NP; k++)
     if (a0 + 16u * k < e) {
       mine[4 * k + 0] = o.w[k].x;
       mine[4 * k + 1] = o.w[k].y;
@@ -411,11 +418,6 @@ __device__ inline const uint8_t *own_commit(const QL &Q, const OwnPieces &o, uin
       mine[4 * k + 3] = o.w[k].w;
     }
   return (const uint8_t *)mine + (b - a0);
-}
-
-__device__ inline const uint8_t *own_residues(const QL &Q, uint64_t b, uint64_t e, uint64_t total, uint32_t *mine)
-{
-  return own_commit(Q, own_load(Q, b, e, total), b, e, mine);
 }
 
 /* zobrist_hash (zobrist.cc:74-88) and, with -i, the two shifted hashes that seed the rolling indel
@@ -618,12 +620,17 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
    then -- for a sound query -- its keys. */
 /* What an instantiation of keys_kernel / scatter_kernel may take for granted about the flags of QL (the host
    picks the instantiation by them): MODE 1 = amino acids or nucleotides on pair rows without -i (the headline
-   workload), 2 = pair rows with -i, 0 = anything.  The branches of the other layouts -- the insertion pairs'
+   workload), 2 = pair rows with -i, 3 = any layout of sequences that fit three 16-byte pieces (CDR3 amino acids:
+   d = 0, d = 2, work shards), 0 = anything.  The branches of the other layouts -- the insertion pairs'
    rolling hashes, residue packs, routing -- then cost no registers: scatter_kernel needs 80 for six waves per
    SIMD and took 90 with every path compiled in. */
 template <int MODE>
 __device__ inline void layout_mode_assume(const QL &Q)
 {
+  if (MODE == 3) {                           /* any layout, sequences that fit three 16-byte pieces */
+    __builtin_assume(Q.own_np == 3);
+    return;
+  }
   if (MODE != 0) {
     __builtin_assume(Q.rows != 0);
     __builtin_assume(Q.pairs != 0);
@@ -637,6 +644,7 @@ __device__ inline void layout_mode_assume(const QL &Q)
     __builtin_assume(Q.wstep <= 1);
     __builtin_assume(Q.dbg == 0);
     __builtin_assume(Q.group_wg == 0);
+    __builtin_assume(Q.own_np == 3);
   }
   if (MODE == 1)
     __builtin_assume(Q.indels == 0);
@@ -645,7 +653,7 @@ __device__ inline void layout_mode_assume(const QL &Q)
 }
 
 template <uint32_t LAYOUT_WG, int MODE>
-__global__ void __launch_bounds__(LAYOUT_WG, LAYOUT_WG == 1024 ? 4 : 6)
+__global__ void __launch_bounds__(LAYOUT_WG, (LAYOUT_WG == 1024 || MODE == 0) ? 4 : 6)
 keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
   layout_mode_assume<MODE>(Q);
@@ -658,7 +666,9 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   uint32_t *const ctl = (uint32_t *)(zl + (Q.zob_lds ? Q.zob_words : 0u));
   uint32_t *const ihist = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
   uint32_t *const ghist = ihist + (Q.item_wg ? Q.nitem_slices : 0u);
-  uint32_t *const mine = ghist + (Q.group_wg ? Q.G : 0u) + threadIdx.x * OWN_DW;
+  constexpr int NP = MODE == 0 ? OWN_NP_MAX : 3;
+  const uint32_t own_np = MODE == 0 ? Q.own_np : 3u, own_dw = 4u * own_np + 1u;
+  uint32_t *const mine = ghist + (Q.group_wg ? Q.G : 0u) + threadIdx.x * own_dw;
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   if (lds_tot) {
     for (uint32_t r = threadIdx.x; r < Q.n_rep; r += LAYOUT_WG)
@@ -738,10 +748,10 @@ keys_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       err = VERR_GENE;
     if (!err && Q.counts && cur.cn < 1)
       err = VERR_COUNT;
-    OwnPieces pieces;
+    OwnPieces<NP> pieces;
     pieces.fits = false;
     if (!err)
-      pieces = own_load(Q, b, e, total);
+      pieces = own_load<NP>(Q, b, e, total, own_np);
     const Fields nxt = fetch(i + stride);
     const uint8_t *s = err ? Q.res : own_commit(Q, pieces, b, e, mine);
     if (pend_i != ~0ull) {
@@ -1124,7 +1134,7 @@ slices_kernel(const QL Q, uint32_t pi, uint32_t in_lds)
    registers a seventh loop-carried field would like: at 109 registers, four waves per SIMD, the kernel took
    0.63 ms per 10M queries where it takes 0.53) */
 template <uint32_t LAYOUT_WG, int MODE>
-__global__ void __launch_bounds__(LAYOUT_WG, LAYOUT_WG == 1024 ? 4 : 6)
+__global__ void __launch_bounds__(LAYOUT_WG, (LAYOUT_WG == 1024 || MODE == 0) ? 4 : 6)
 scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
 {
   layout_mode_assume<MODE>(Q);
@@ -1135,9 +1145,11 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
   uint32_t *const ibase = ctl + (Q.ctab_lds ? Q.geom.off_hv : 0u);
   uint32_t *const gb = ibase + (Q.item_wg ? Q.nitem_slices : 0u);        /* group_wg: first slot of this workgroup's
                                                                           queries of group g */
-  uint32_t *const wave_words = gb + (Q.group_wg ? Q.G : 0u) + (threadIdx.x & ~63u) * OWN_DW;
+  constexpr int NP = MODE == 0 ? OWN_NP_MAX : 3;
+  const uint32_t own_np = MODE == 0 ? Q.own_np : 3u, own_dw = 4u * own_np + 1u;
+  uint32_t *const wave_words = gb + (Q.group_wg ? Q.G : 0u) + (threadIdx.x & ~63u) * own_dw;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t *const mine = wave_words + lane * OWN_DW;
+  uint32_t *const mine = wave_words + lane * own_dw;
   const uint32_t *const ct = Q.ctab_lds ? ctl : Q.geom.ctab;
   const uint64_t *const zt = Q.zob_lds ? zl : Q.zob;
   if (Q.zob_lds)                             /* (the keys of the positions; the gene keys are not asked here) */
@@ -1201,11 +1213,11 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     const uint32_t rk = cur.rk;                  /* (rank in the group | class split << 31: keys_kernel) */
     uint32_t gbase = 0, ck = 0;
     uint64_t h_q = 0, hins_q = 0;
-    OwnPieces pieces;
+    OwnPieces<NP> pieces;
     pieces.fits = false;
     if (g != 0xffffffffu) {
       gbase = LDBG(Q, LDBG_S_NO_BASE) ? 0u : Q.group_wg ? gb[g] : Q.base_g[0][g];
-      pieces = own_load(Q, b, e, total);
+      pieces = own_load<NP>(Q, b, e, total, own_np);
       qr.cnt = Q.counts ? Q.cnt[i] : 1ull;
       qr.v = Q.genes ? Q.v[i] : 0u;
       qr.j = Q.genes ? Q.j[i] : 0u;
@@ -1327,7 +1339,7 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
     if (LDBG(Q, LDBG_S_NO_REC))
       continue;
     static_assert(sizeof(QueryRec) == 64, "the record is four 16-byte pieces");
-    static_assert(32 * 17 <= 64 * OWN_DW, "half a wave's records in the wave's words");
+    static_assert(32 * 17 <= 64 * OWN_DW, "half a wave's records in the wave's words (13 per lane at least)");
     const uint32_t out_slot = LDBG(Q, LDBG_S_SEQ_REC) && slot != 0xffffffffu ? (uint32_t)i : slot;
 #pragma unroll
     for (uint32_t half = 0; half < 2; half++) {
@@ -1455,9 +1467,36 @@ fill_tiles_kernel(const QL Q, uint32_t ntiles)
     /* kernels_pairs2.h reads a query's residues two bits each, one 24-byte piece per slot */
     cmpr::ResPack pk{};
     if (valid) {
-      const uint8_t *s = Q.res + Q.off[a.src];
-      for (uint32_t x = 0; x < qr.len && x < RESPACK_MAX; x++)
-        pk.w[x >> 4] |= ((uint32_t)s[x] & 3u) << ((x & 15u) * 2u);
+      /* (16 residues of the pack = one 16-byte piece of the set when it is aligned: a load per piece, not per
+         residue -- 5.5 ms per 12.5M nucleotide queries were spent here, a byte and a wait at a time) */
+      const uint64_t b0 = Q.off[a.src];
+      const uint32_t n = min(qr.len, (uint32_t)RESPACK_MAX);
+      const uint64_t total = total_of(Q);
+#pragma unroll
+      for (uint32_t k = 0; k < RESPACK_MAX / 16; k++) {
+        uint32_t word = 0;
+        if (16u * k < n) {
+          const uint64_t at = b0 + 16u * k;
+          if (at + 16u <= total) {
+            /* (two dwords at a time: the set's residues are at any byte phase) */
+            const uint8_t *s = Q.res + at;
+            uint64_t lo, hi;
+            __builtin_memcpy(&lo, s, 8);
+            __builtin_memcpy(&hi, s + 8, 8);
+#pragma unroll
+            for (uint32_t x = 0; x < 8; x++) {
+              if (16u * k + x < n)
+                word |= ((uint32_t)(lo >> (8u * x)) & 3u) << (x * 2u);
+              if (16u * k + 8u + x < n)
+                word |= ((uint32_t)(hi >> (8u * x)) & 3u) << ((8u + x) * 2u);
+            }
+          } else {
+            for (uint32_t x = 0; x < 16u && 16u * k + x < n; x++)
+              word |= ((uint32_t)Q.res[at + x] & 3u) << (x * 2u);
+          }
+        }
+        pk.w[k] = word;
+      }
     }
     Q.qpk[slot] = pk;
   }
@@ -2307,6 +2346,8 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   const uint64_t zob_pos_words = (uint64_t)A * c->zpos;
   const bool ctab_lds = c->layout_zob_lds != 0 && c->sliced && c->geom.off_hv <= 2048;
   const size_t ctab_bytes = ctab_lds ? (size_t)c->geom.off_hv * sizeof(uint32_t) : 0;
+  /* the 16-byte pieces that hold the longest sequence at any byte phase (own_load) */
+  const uint32_t own_np_want = std::min<uint32_t>((uint32_t)OWN_NP_MAX, std::max<uint32_t>(3u, (Lcap + 15u + 15u) / 16u));
   /* few groups (the direct layout of d = 0): ranked per workgroup in LDS (QL::group_wg) */
   const bool group_wg = G <= GROUP_WG_MAX && !routing && c->item_wg != 0;
   const size_t keys_shared = (n_rep <= 2048 ? n_rep * sizeof(double) : 0) + (zob_lds ? zob_words * sizeof(uint64_t) : 0) +
@@ -2315,19 +2356,22 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
                                 (item_wg ? (size_t)ncs * sizeof(uint32_t) : 0) + (group_wg ? G * sizeof(uint32_t) : 0);
   typedef void (*LayoutFn)(const QL, uint64_t, uint64_t, uint32_t);
   static const uint32_t wg_sizes[3] = {256, 512, 1024};
-  static const LayoutFn keys_all[3][3] = {{keys_kernel<256, 0>, keys_kernel<512, 0>, keys_kernel<1024, 0>},
+  static const LayoutFn keys_all[4][3] = {{keys_kernel<256, 0>, keys_kernel<512, 0>, keys_kernel<1024, 0>},
                                           {keys_kernel<256, 1>, keys_kernel<512, 1>, keys_kernel<1024, 1>},
-                                          {keys_kernel<256, 2>, keys_kernel<512, 2>, keys_kernel<1024, 2>}};
-  static const LayoutFn scatter_all[3][3] = {{scatter_kernel<256, 0>, scatter_kernel<512, 0>, scatter_kernel<1024, 0>},
+                                          {keys_kernel<256, 2>, keys_kernel<512, 2>, keys_kernel<1024, 2>},
+                                          {keys_kernel<256, 3>, keys_kernel<512, 3>, keys_kernel<1024, 3>}};
+  static const LayoutFn scatter_all[4][3] = {{scatter_kernel<256, 0>, scatter_kernel<512, 0>, scatter_kernel<1024, 0>},
                                              {scatter_kernel<256, 1>, scatter_kernel<512, 1>, scatter_kernel<1024, 1>},
-                                             {scatter_kernel<256, 2>, scatter_kernel<512, 2>, scatter_kernel<1024, 2>}};
+                                             {scatter_kernel<256, 2>, scatter_kernel<512, 2>, scatter_kernel<1024, 2>},
+                                             {scatter_kernel<256, 3>, scatter_kernel<512, 3>, scatter_kernel<1024, 3>}};
   /* (layout_mode_assume: what the instantiation may take for granted) */
   const bool recompute_on = Lcap <= 36u && !c->d2pairs && c->layout_recompute != 0;
   const int lmode = (c->rows && pair_rows(c) && !c->d2pairs && !sub2_items && !direct && !routing && wstep <= 1 &&
                      c->opt.differences == 1 && recompute_on && c->debug == 0 && !group_wg)
                         ? (c->opt.indels ? 2 : 1)
-                        : 0;
+                        : own_np_want == 3u ? 3 : 0;
   const LayoutFn *const keys_fns = keys_all[lmode], *const scatter_fns = scatter_all[lmode];
+  const uint32_t own_np = lmode ? 3u : own_np_want;
   /* Both kernels loop over their queries: the grid is what is RESIDENT at once (LDS and registers decide), no
      more -- with 2 048 workgroups of which 6 or 7 per CU fit, the eighth ran alone behind the others, a second
      round at a seventh of the occupancy for as long as the first (round 6: keys 0.80 -> .., scatter 1.01 -> ..).
@@ -2341,7 +2385,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
     uint32_t best_waves = 0;
     int bk = 0, bs = 0;
     for (int w = 0; w < 3; w++) {
-      const size_t own = (size_t)wg_sizes[w] * OWN_DW * sizeof(uint32_t);
+      const size_t own = (size_t)wg_sizes[w] * (4 * own_np + 1) * sizeof(uint32_t);
       const size_t kl = keys_shared + own, sl = scatter_shared + own;
       if (kl > 160 * 1024 - 512 || sl > 160 * 1024 - 512)
         continue;
@@ -2595,6 +2639,7 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.zob_lds = zob_lds ? 1u : 0u;
   Q.zob_words = (uint32_t)zob_words;
   Q.zob_pos_words = (uint32_t)zob_pos_words;
+  Q.own_np = own_np;
   Q.ctab_lds = ctab_lds ? 1u : 0u;
   /* HIP events around the big kernels when the caller asks for their times (tunable "layout_timing";
      an event record is a packet the stream waits ~4.5 us for) */

@@ -755,6 +755,40 @@ def test_device_resident_sets():
         assert e.value.code == 1
 
 
+def test_warm_up_sized_reservations_are_taken_over():
+    """cmpr_warm_up_sized (ABI v5) reserves the page-locked upload buffer and the layout arena for a query set
+    of the hinted size before any context exists; the first context that lays such a set out takes them over,
+    and the result is what it is without them.  Hints that are too small, zero, or never used are harmless."""
+    import ctypes as C
+    lib = hipmod.load_library()
+    o = hipmod._Options()
+    o.differences = 1
+    o.alphabet_size = 20
+    o.n_v_genes, o.n_j_genes = synth.N_V, synth.N_J
+    o.device = -1
+    n = (1 << 20) + 5000                               # (the narrowed upload -- the pinned buffer -- starts at 2^20)
+    a = synth.make_set(n, 61, prefix="A", pool_size=n // 4)
+    b = synth.make_set(200000, 62, prefix="B", pool_size=n // 4)
+    opt = Options(differences=1, **FULL)
+    with HipOverlap(opt) as h:
+        h.set_reference(b, a.longest)
+        h.set_queries(a)
+        want = h.overlap_matrix()
+    for hint_n, hint_res in ((n + 1000, 20 * n), (1000, 0), (0, 0)):
+        assert lib.cmpr_warm_up_sized(C.byref(o), hint_n, 0, hint_res) == 0
+        with HipOverlap(opt) as h:
+            h.set_reference(b, a.longest)
+            h.set_queries(a)
+            assert np.array_equal(h.overlap_matrix(), want)
+            h.set_queries(a)                           # (a second set on the same context: nothing left to take)
+            assert np.array_equal(h.overlap_matrix(), want)
+    assert lib.cmpr_warm_up_sized(C.byref(o), n, 0, 20 * n) == 0      # reserved and never used: released by
+    with HipOverlap(opt) as h:                                          # the next cmpr_destroy
+        pass
+    o.device = 99
+    assert lib.cmpr_warm_up_sized(C.byref(o), n, 0, 0) != 0           # no such device
+
+
 def test_repeated_launches_with_and_without_redo_pass():
     """Variant 2 drops its redo launch once a finished launch has shown that the
     positives buffer has room to spare: every launch of a series gives the same matrix,
