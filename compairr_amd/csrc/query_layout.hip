@@ -564,8 +564,19 @@ __device__ inline void for_each_item(const QL &Q, const uint32_t *ct, const uint
       return;
     const uint64_t hins = HASH ? hins_of_q : 0ull;
     uint64_t P0 = 0, Pp = 0;                     /* XOR_{y<x} Z[y][q[y]],  XOR_{y<x} Z[y+1][q[y]] */
+    /* (the pairs that hold a class position of the variants, as a bit set: every other pair is passed by
+       without a table lookup -- the loop asked the class tables K times per pair of every query, round 6) */
+    uint64_t cand = 0;
+    bool cand_far = false;
+    for (uint32_t k = 0; k < K; k++) {
+      const uint32_t mk = class_pos(L + 1, k, g.c0);
+      if (mk < 64u)
+        cand |= 1ull << (mk & ~1u);
+      else
+        cand_far = true;
+    }
     for (uint32_t x = 0; x <= L; x++) {
-      if ((x & 1u) == 0) {
+      if ((x & 1u) == 0 && (x < 64u ? ((cand >> x) & 1ull) != 0 : cand_far)) {
         int ci = -1;
         uint32_t key = base_i;
         for (uint32_t k = 0; k < K; k++) {

@@ -103,6 +103,14 @@ def random_case(rng):
         tun["host_threads"] = int(rng.integers(1, 9))
     if rng.random() < 0.3:
         tun["narrow_upload"] = 1                          # (by default only for sets of a million and more)
+    # round 6's query layout against round 5's form of it: item counters / group ranks per workgroup in LDS,
+    # hashes recomputed by fill_tiles_kernel, tables in LDS -- each switched off now and then
+    if rng.random() < 0.2:
+        tun["item_wg"] = 0
+    if rng.random() < 0.2:
+        tun["layout_recompute"] = 0
+    if rng.random() < 0.2:
+        tun["layout_zob_lds"] = 0
     same = rng.random() < 0.2
     return a, (a if same else b), o, tun
 
@@ -163,7 +171,13 @@ def main():
                     shards = 1                            # (long sequences fell back to the unsliced kernel)
                     h.set_tunable("work_shard_count", 1)
                     h.set_tunable("work_shard_index", 0)
-                h.set_queries(a)
+                # (every third case: the query set handed over as device arrays -- the path bench.py times)
+                if n % 3 == 1:
+                    view, keep = h.device_view(a)
+                    h.set_queries_device(view)
+                    del keep
+                else:
+                    h.set_queries(a)
                 m = h.overlap_matrix()
                 st = h.stats()
                 # repeated launches (the third may run without its redo pass) give the same
