@@ -398,11 +398,14 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
       return fail(c, CMPR_EINVAL, "narrow_upload must be -1 (auto), 0 or 1");
     c->narrow_upload = value;
     affects_plan = false;
-  } else if (n == "item_wg" || n == "layout_recompute" || n == "layout_timing" || n == "layout_zob_lds") {
+  } else if (n == "item_wg" || n == "layout_recompute" || n == "layout_timing" || n == "layout_zob_lds" ||
+             n == "record_tiles") {
     if (value < 0 || value > 1)
       return fail(c, CMPR_EINVAL, n + " must be 0 or 1");
+    if (n == "record_tiles" && c->have_q)
+      return fail(c, CMPR_ESTATE, "set record_tiles before cmpr_set_queries");
     (n == "item_wg" ? c->item_wg : n == "layout_recompute" ? c->layout_recompute :
-     n == "layout_zob_lds" ? c->layout_zob_lds : c->layout_timing) = value;
+     n == "layout_zob_lds" ? c->layout_zob_lds : n == "record_tiles" ? c->record_tiles : c->layout_timing) = value;
     affects_plan = false;
   } else if (n == "assume_never_overflows") {
     /* TEST ONLY: the next launch runs without redo pass as if the margin had been
@@ -533,6 +536,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "item_wg") *value = c->item_wg;
   else if (n == "layout_recompute") *value = c->layout_recompute;
   else if (n == "layout_timing") *value = c->layout_timing;
+  else if (n == "record_tiles") *value = c->have_q ? (c->rec_tiles ? 1 : 0) : c->record_tiles;
   else if (n == "layout_keys_us") *value = (int64_t)(c->layout_kernel_ms[0] * 1e3);
   else if (n == "layout_sizes_us") *value = (int64_t)(c->layout_kernel_ms[1] * 1e3);
   else if (n == "layout_scatter_us") *value = (int64_t)(c->layout_kernel_ms[2] * 1e3);
@@ -861,6 +865,8 @@ int make_plan(cmpr_context *c)
   P.zob = c->zob.p;
   P.zpos = c->zpos;
   P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
+  P.n_j_keys = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
+  P.rec_tiles = c->rec_tiles ? 1u : 0u;
   P.bloom = c->bloom.p;
   P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
   P.dir_mask = (uint32_t)(c->slots - 1);
@@ -940,7 +946,8 @@ int make_plan(cmpr_context *c)
     if (c->rows)
       b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
            (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) +
-           RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef));
+           RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef)) +
+           (c->rec_tiles && !c->opt.ignore_genes ? ((size_t)c->opt.n_v_genes + c->opt.n_j_genes) * sizeof(uint64_t) : 0);
     else if (c->sliced)
       b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
            MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +

@@ -380,8 +380,9 @@ __device__ __forceinline__ uint32_t query_residue(const ProbeParams &P,
    flight together (an early-exit loop costs one memory round trip per residue). */
 __device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
                                     uint32_t lane, uint32_t L, uint32_t ca, uint32_t cb,
-                                    const RefRec &rec, const unsigned char *t)
+                                    const RefRec &rec, const unsigned char *t, const QueryRec *qrec = nullptr)
 {
+  /* (qrec: the query's residues from its record -- ProbeParams::rec_tiles, no position-major copy exists) */
   const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
   const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
   const uint32_t M = rec.len;
@@ -409,7 +410,9 @@ __device__ bool variant_matches_hit(const ProbeParams &P, const TileDesc &td,
     }
     if (qp >= L)
       qp = L ? L - 1 : 0;                       /* only when is_new; keeps the load in range */
-    const uint32_t expect = is_new ? newres : query_residue(P, td, lane, qp);
+    const uint32_t expect = is_new ? newres
+                            : qrec   ? (qrec->res[qp >> 2] >> ((qp & 3u) * 8u)) & 0xffu
+                                     : query_residue(P, td, lane, qp);
     bad |= expect ^ (uint32_t)t[x];
   }
   return bad == 0;
@@ -468,7 +471,7 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
   const QueryRec *const qrec = P.qrec + qs;
   const uint32_t q_v = GENES ? qrec->v : 0u, q_j = GENES ? qrec->j : 0u;
   const uint32_t q_rep = qrec->rep;
-  const uint32_t q_len = P.qlen[qs];           /* own length (tiles may mix lengths) */
+  const uint32_t q_len = P.rec_tiles ? qrec->len : (uint32_t)P.qlen[qs];      /* own length (tiles may mix lengths) */
   const unsigned long long q_cnt = P.ignore_counts ? 1ull : qrec->cnt;
   for (uint32_t piece = bk;; piece++) {
     RefRec rec = *((const RefRec *)P.rec2 + piece);
@@ -482,7 +485,8 @@ __device__ void resolve_one(const ProbeParams &P, uint64_t hash, uint32_t qs, ui
       if (GENES)
         ok = (q_v == rec.v) && (q_j == rec.j);
       /* (the residues where the set lies: this is the rare path, and they are all there) */
-      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, P.res2 + P.off2[rec.idx])) {
+      if (ok && variant_matches_hit(P, td, ql, q_len, ca, cb, rec, P.res2 + P.off2[rec.idx],
+                                    P.rec_tiles ? qrec : nullptr)) {
         st.matches++;
         score_match(P, qs, rec.idx, (uint64_t)P.R2 * q_rep + rec.rep, q_cnt, rec.cnt, mat_lds);
       }

@@ -642,6 +642,11 @@ probe_rows_kernel(const ProbeParams P)
   RingSlot *ring = (RingSlot *)(hv_lds + (INDELS ? HEAVY_WORDS : 0u));
   TileRef *tref_lds = (TileRef *)(ring + RING);             /* RING x chunk_cap */
   const uint32_t chunk_cap = P.chunk_cap;
+  /* record tiles (ProbeParams::rec_tiles: amino acids, d = 1 without -i): a tile's lengths and residues come from
+     the queries' 64-byte records and the hashes are worked out here; the gene keys lie behind the tile references */
+  constexpr bool REC_OK = PAIRS && !INDELS && D == 1;
+  const bool rec_tiles = REC_OK && P.rec_tiles != 0u;
+  uint64_t *gk_lds = (uint64_t *)(tref_lds + RING * chunk_cap);
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT) {
     const uint32_t r = i % ZS;
@@ -654,6 +659,9 @@ probe_rows_kernel(const ProbeParams P)
       hv_lds[i] = P.geom.ctab[P.geom.off_hv + i];
   for (uint32_t i = threadIdx.x; i < RING * (uint32_t)(sizeof(RingSlot) / 4); i += NT)
     ((uint32_t *)ring)[i] = 0;
+  if (REC_OK && rec_tiles && GENES)
+    for (uint32_t i = threadIdx.x; i < P.n_v + P.n_j_keys; i += NT)
+      gk_lds[i] = P.zob[(size_t)A * P.zpos + i];
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
@@ -769,6 +777,7 @@ probe_rows_kernel(const ProbeParams P)
     uint64_t a;
     uint32_t b, c;
     uint32_t r0, r1, r2, r3, r4, r5;
+    uint32_t r6, r7;               /* record tiles: positions 24 .. 31 (never live in the other instantiations) */
   };
   auto load_tile_data = [&](uint32_t len, uint32_t nvalid, uint32_t res_base, uint32_t t,
                             uint32_t tpass) -> TileData {
@@ -776,6 +785,8 @@ probe_rows_kernel(const ProbeParams P)
     x.a = 0;
     x.b = x.c = 0;
     x.r0 = x.r1 = x.r2 = x.r3 = x.r4 = x.r5 = PADW;
+    if constexpr (REC_OK)
+      x.r6 = x.r7 = PADW;
     const bool valid = lane < nvalid;
     if (tpass >= 3) {
       /* a block of 64 class-row items, from item res_base on */
@@ -783,6 +794,18 @@ probe_rows_kernel(const ProbeParams P)
       x.a = it.w;
       x.b = it.main;
       x.c = it.rp;
+    } else if (REC_OK && rec_tiles) {
+      /* the query's record as scatter_kernel left it: {cnt, v, j | rep, len, res 0-7 | res 8-23 | res 24-35, orig};
+         gene numbers travel in `a` until the hash is worked out (tile_from_record) */
+      if (valid) {
+        const u32x4 *rq = (const u32x4 *)(P.qrec + (size_t)t * WAVE + lane);
+        const u32x4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
+        x.a = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+        x.b = q1.y;
+        x.r0 = q1.z; x.r1 = q1.w;
+        x.r2 = q2.x; x.r3 = q2.y; x.r4 = q2.z; x.r5 = q2.w;
+        x.r6 = q3.x; x.r7 = q3.y;
+      }
     } else {
       const uint32_t slot = t * WAVE + lane;
       if (valid) {
@@ -873,6 +896,7 @@ probe_rows_kernel(const ProbeParams P)
   cur.b = cur.c = nxt.b = nxt.c = 0;
   cur.r0 = cur.r1 = cur.r2 = cur.r3 = cur.r4 = cur.r5 = 0;
   nxt.r0 = nxt.r1 = nxt.r2 = nxt.r3 = nxt.r4 = nxt.r5 = 0;
+  cur.r6 = cur.r7 = nxt.r6 = nxt.r7 = 0;
 
   /* What is known of the tile at hand, all wave-uniform: `staged` = it came from a
      chunk (slice in LDS at sbase; pass and cslice are the chunk's), else one of the
@@ -1001,6 +1025,35 @@ probe_rows_kernel(const ProbeParams P)
                               (CMPR_DBG(P, DBG_SKIP_CLASS_TILES) && tpass_real >= 3) ||
                               (CMPR_DBG(P, DBG_SKIP_MAIN_TILES) && tpass_real < 3)) ? 0xffu : tpass_real;
       PT_MARK(PT_TILE_DATA);
+      if constexpr (REC_OK) {
+        if (rec_tiles && tpass_real < 3u) {
+          /* tile_from_record: what fill_tiles_kernel wrote for the other layouts -- the residues padded with code A
+             behind the query's end (its key is zero: a pair that hangs over the end hashes without a test), the
+             query's Zobrist hash (zobrist_hash, zobrist.cc:74-88; db_hash, db.cc:903-916) -- from the record */
+          const bool v_ = lane < nvalid;
+          const uint32_t len_ = v_ ? cur.b : 0u;
+          auto pad_ = [&](uint32_t d, uint32_t w) -> uint32_t {
+            const int n = (int)len_ - (int)(4u * w);
+            const uint32_t mk = n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
+            return (d & mk) | (PADW & ~mk);
+          };
+          cur.r0 = pad_(cur.r0, 0); cur.r1 = pad_(cur.r1, 1); cur.r2 = pad_(cur.r2, 2); cur.r3 = pad_(cur.r3, 3);
+          cur.r4 = pad_(cur.r4, 4); cur.r5 = pad_(cur.r5, 5); cur.r6 = pad_(cur.r6, 6); cur.r7 = pad_(cur.r7, 7);
+          uint64_t hq = 0;
+          if (GENES && v_)
+            hq = gk_lds[(uint32_t)cur.a] ^ gk_lds[P.n_v + (uint32_t)(cur.a >> 32)];
+          const uint32_t rw_[8] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5, cur.r6, cur.r7};
+#pragma unroll
+          for (uint32_t w = 0; w < 8; w++)
+            if (4u * w < L) {                          /* (wave-uniform: the tile's longest query) */
+#pragma unroll
+              for (uint32_t k = 0; k < 4; k++)
+                hq ^= lds_u64(zl_addr + (ZS * (4u * w + k) + ((rw_[w] >> (8u * k)) & 0xffu)) * 8u);
+            }
+          cur.a = v_ ? hq : 0ull;
+          cur.b = len_;
+        }
+      }
       /* the tile's counters (nvar further down), 32 bits wide -- a lane's variants of
          one tile fit -- and added to the 64-bit ones once per tile */
       uint32_t treads = 0;
@@ -1171,12 +1224,18 @@ probe_rows_kernel(const ProbeParams P)
           for (uint32_t p0 = 0; p0 < (CMPR_DBG(P, DBG_SKIP_LDS_ROWS) ? 0u : L); p0 += PP) {
             if (p0 && p0 % (4u * TDW) == 0) {
               const uint32_t w0 = p0 >> 2;
+              if (REC_OK && rec_tiles) {            /* (record tiles: positions 24 .. 31 came with the record) */
+                s0 = cur.r6;
+                s1 = cur.r7;
+                s2 = s3 = s4 = s5 = PADW;
+              } else {
               s0 = qr[w0 * WAVE];
               s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : PADW;
               s2 = w0 + 2u < nd ? qr[(w0 + 2u) * WAVE] : PADW;
               s3 = w0 + 3u < nd ? qr[(w0 + 3u) * WAVE] : PADW;
               s4 = w0 + 4u < nd ? qr[(w0 + 4u) * WAVE] : PADW;
               s5 = w0 + 5u < nd ? qr[(w0 + 5u) * WAVE] : PADW;
+              }
             }
             const uint64_t rr = ((uint64_t)s1 << 32) | s0;
             if constexpr (PP == 4) {

@@ -89,9 +89,11 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
       if (ok) {
         const uint32_t kind = ca & 7u, p1 = (ca >> 3) & 0xffffu, r1 = ca >> 24;
         const uint32_t p2 = cb & 0xffffu, r2 = cb >> 24;
-        const uint32_t L = P.qlen[qs], M = rl & 0xffffu;
+        /* (record tiles -- layout.h ProbeParams::rec_tiles --: length and residues from the query's record) */
+        const QueryRec *const qrec = P.qrec + qs;
+        const uint32_t L = P.rec_tiles ? qrec->len : (uint32_t)P.qlen[qs], M = rl & 0xffffu;
         ok = M == (kind == K_DEL ? L - 1 : (kind == K_INS ? L + 1 : L));
-        const uint32_t *qr = P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
+        const uint32_t *qr = P.rec_tiles ? nullptr : P.qres + P.tiles[qs >> 6].res_base + (qs & 63u);
 #pragma unroll 1
         for (uint32_t x = 0; ok && x < M; x++) {
           /* check_variant (variants.cc:166-240): residue the variant has at x */
@@ -103,7 +105,7 @@ __device__ __forceinline__ void resolve_inline_slow(SProber &W, int first, int n
           else {
             const uint32_t qp = kind == K_DEL ? (x < p1 ? x : x + 1)
                                               : (kind == K_INS ? (x < p1 ? x : x - 1) : x);
-            want = (qr[(size_t)(qp >> 2) * WAVE] >> ((qp & 3u) * 8)) & 0xffu;
+            want = ((P.rec_tiles ? qrec->res[qp >> 2] : qr[(size_t)(qp >> 2) * WAVE]) >> ((qp & 3u) * 8)) & 0xffu;
           }
           ok = want == (uint32_t)rp[x];
         }

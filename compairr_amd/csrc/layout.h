@@ -364,6 +364,13 @@ struct ProbeParams {
                                       kernels_pairs2.h items: the same residues beside the pair-blanked hash */
   const ResPack  *qpk;             /* kernels_pairs2.h: per slot, the query's residues, 2 bits each */
   const uint16_t *qlen;            /* per slot: own length (<= tile len)         */
+  uint32_t n_j_keys;               /* J-gene keys behind the V-gene keys of the Zobrist table (0 with -g) */
+  uint32_t rec_tiles;              /* (round 6) amino acids, d = 1 without -i, every sequence within the record's 36
+                                      residues: NO per-slot arrays are laid out -- probe_rows_kernel takes a tile's
+                                      lengths and residues from the 64-byte QueryRecs scatter_kernel wrote and works
+                                      the hashes out itself (the Zobrist keys are in its LDS anyway): fill_tiles_kernel,
+                                      0.29 ms per 10M queries of reading those records and writing them out again
+                                      position-major, does not run */
   /* (repertoire, count and the query's number in the caller's set are read from its QueryRec, by the
      kernels that resolve a positive -- no per-slot arrays of them since round 6: 16 bytes per slot less for
      the layout to write) */

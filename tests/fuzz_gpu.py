@@ -111,6 +111,8 @@ def random_case(rng):
         tun["layout_recompute"] = 0
     if rng.random() < 0.2:
         tun["layout_zob_lds"] = 0
+    if rng.random() < 0.3:
+        tun["record_tiles"] = 0                           # (amino acids, d = 1 without -i: per-slot arrays after all)
     same = rng.random() < 0.2
     return a, (a if same else b), o, tun
 
