@@ -947,7 +947,8 @@ int make_plan(cmpr_context *c)
       b += RING * (size_t)c->geom.rw_words * ROW_WORD_BYTES + MAX_CLASS_RES * A * sizeof(uint32_t) +
            (c->opt.indels ? HEAVY_WORDS * sizeof(uint32_t) : 0) +
            RING * (sizeof(RingSlot) + (size_t)c->chunk_cap * sizeof(TileRef)) +
-           (c->rec_tiles && !c->opt.ignore_genes ? ((size_t)c->opt.n_v_genes + c->opt.n_j_genes) * sizeof(uint64_t) : 0);
+           (c->rec_tiles && !c->opt.ignore_genes ? ((size_t)c->opt.n_v_genes + c->opt.n_j_genes) * sizeof(uint64_t) : 0) +
+           (c->rec_tiles && c->opt.indels ? (size_t)c->geom.off_cr * sizeof(uint32_t) : 0);
     else if (c->sliced)
       b += ((size_t)1 << c->geom.words_log2) * sizeof(uint64_t) +
            MAX_CLASS_RES * A * sizeof(uint32_t) + HEAVY_WORDS * sizeof(uint32_t) + 16 +

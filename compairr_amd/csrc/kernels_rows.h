@@ -464,8 +464,21 @@ __device__ __forceinline__ void drain_round(SProber &W, uint32_t zl_addr, int n,
     /* "the query without position lazy_p", from its first-deleted hash and its residues
        (zobrist_hash_delete_first + the rolling update, variants.cc:301-325) */
     const ProbeParams &P = W.P;
-    uint64_t hd = P.qhdel[slot];
     const QueryRec *qr = P.qrec + slot;
+    uint64_t hd;
+    if (P.rec_tiles) {
+      /* record tiles: zobrist_hash_delete_first (zobrist.cc:90-104) from the query's record -- once per deletion
+         variant that passed the filter, not once per query */
+      hd = 0;
+      if (GENES) {
+        const uint64_t *gk = P.zob + (size_t)A * P.zpos;
+        hd = gk[qr->v] ^ gk[P.n_v + qr->j];
+      }
+      for (uint32_t y = 1; y < qr->len; y++)
+        hd ^= lds_u64(zl_addr + (ZS * (y - 1u) + ((qr->res[y >> 2] >> ((y & 3u) * 8u)) & 0xffu)) * 8u);
+    } else {
+      hd = P.qhdel[slot];
+    }
     const uint32_t *far = P.qres + P.tiles[slot >> 6].res_base + (slot & 63u);
     auto res_of = [&](uint32_t y) -> uint32_t {
       const uint32_t w = y < 36u ? qr->res[y >> 2] : far[(size_t)(y >> 2) * WAVE];
@@ -644,9 +657,12 @@ probe_rows_kernel(const ProbeParams P)
   const uint32_t chunk_cap = P.chunk_cap;
   /* record tiles (ProbeParams::rec_tiles: amino acids, d = 1 without -i): a tile's lengths and residues come from
      the queries' 64-byte records and the hashes are worked out here; the gene keys lie behind the tile references */
-  constexpr bool REC_OK = PAIRS && !INDELS && D == 1;
+  constexpr bool REC_OK = PAIRS && D == 1;
   const bool rec_tiles = REC_OK && P.rec_tiles != 0u;
   uint64_t *gk_lds = (uint64_t *)(tref_lds + RING * chunk_cap);
+  /* (-i: the class tables in front of the class-residue rows -- CL | CV | CJ -- behind the gene keys: a record
+     tile works the query's class key out itself) */
+  uint32_t *cb_lds = (uint32_t *)(gk_lds + (GENES ? P.n_v + P.n_j_keys : 0u));
 
   for (uint32_t i = threadIdx.x; i < nz; i += NT) {
     const uint32_t r = i % ZS;
@@ -662,6 +678,9 @@ probe_rows_kernel(const ProbeParams P)
   if (REC_OK && rec_tiles && GENES)
     for (uint32_t i = threadIdx.x; i < P.n_v + P.n_j_keys; i += NT)
       gk_lds[i] = P.zob[(size_t)A * P.zpos + i];
+  if (REC_OK && INDELS && rec_tiles)
+    for (uint32_t i = threadIdx.x; i < P.geom.off_cr; i += NT)
+      cb_lds[i] = P.geom.ctab[i];
 
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE;
@@ -1025,6 +1044,8 @@ probe_rows_kernel(const ProbeParams P)
                               (CMPR_DBG(P, DBG_SKIP_CLASS_TILES) && tpass_real >= 3) ||
                               (CMPR_DBG(P, DBG_SKIP_MAIN_TILES) && tpass_real < 3)) ? 0xffu : tpass_real;
       PT_MARK(PT_TILE_DATA);
+      [[maybe_unused]] uint64_t rec_hins = 0;
+      [[maybe_unused]] uint32_t rec_ck = 0;
       if constexpr (REC_OK) {
         if (rec_tiles && tpass_real < 3u) {
           /* tile_from_record: what fill_tiles_kernel wrote for the other layouts -- the residues padded with code A
@@ -1040,18 +1061,47 @@ probe_rows_kernel(const ProbeParams P)
           cur.r0 = pad_(cur.r0, 0); cur.r1 = pad_(cur.r1, 1); cur.r2 = pad_(cur.r2, 2); cur.r3 = pad_(cur.r3, 3);
           cur.r4 = pad_(cur.r4, 4); cur.r5 = pad_(cur.r5, 5); cur.r6 = pad_(cur.r6, 6); cur.r7 = pad_(cur.r7, 7);
           uint64_t hq = 0;
+          const uint32_t gv_ = (uint32_t)cur.a, gj_ = (uint32_t)(cur.a >> 32);
           if (GENES && v_)
-            hq = gk_lds[(uint32_t)cur.a] ^ gk_lds[P.n_v + (uint32_t)(cur.a >> 32)];
+            hq = gk_lds[gv_] ^ gk_lds[P.n_v + gj_];
+          uint64_t hi_ = hq;                           /* (-i) zobrist_hash_insert_first, zobrist.cc:122-136 */
           const uint32_t rw_[8] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5, cur.r6, cur.r7};
 #pragma unroll
           for (uint32_t w = 0; w < 8; w++)
             if (4u * w < L) {                          /* (wave-uniform: the tile's longest query) */
 #pragma unroll
               for (uint32_t k = 0; k < 4; k++)
-                hq ^= lds_u64(zl_addr + (ZS * (4u * w + k) + ((rw_[w] >> (8u * k)) & 0xffu)) * 8u);
+                if (4u * w + k < L) {                  /* (the table ends three positions behind the longest) */
+                  const uint32_t r_ = (rw_[w] >> (8u * k)) & 0xffu;
+                  hq ^= lds_u64(zl_addr + (ZS * (4u * w + k) + r_) * 8u);
+                  if constexpr (INDELS)
+                    hi_ ^= lds_u64(zl_addr + (ZS * (4u * w + k + 1u) + r_) * 8u);
+                }
             }
           cur.a = v_ ? hq : 0ull;
           cur.b = len_;
+          if constexpr (INDELS) {
+            rec_hins = v_ ? hi_ : 0ull;
+            /* the query's class key (class_key_of, layout.h): base of its (V, J) class -- no length term with -i,
+               the table says -- and, where that class is split, its class residues (wave-uniform positions) */
+            uint32_t ck_ = cb_lds[len_];
+            if (GENES)
+              ck_ ^= cb_lds[P.geom.off_cv + gv_] ^ cb_lds[P.geom.off_cj + gj_];
+            const uint32_t hb_ = ck_ >> (32 - HEAVY_BUCKETS_LOG2);
+            if (KH > 0 && ((hv_lds[hb_ >> 5] >> (hb_ & 31u)) & 1u) && len_ > 0u) {
+#pragma unroll
+              for (uint32_t i = 0; i < MCR; i++)
+                if (i < KH) {
+                  const uint32_t pp_ = __builtin_amdgcn_readfirstlane(class_pos(L, i, P.geom.c0));
+                  uint32_t x_ = rw_[0];
+#pragma unroll
+                  for (uint32_t w = 1; w < 8; w++)
+                    x_ = (pp_ >> 2) == w ? rw_[w] : x_;
+                  ck_ ^= cr_lds[i * A + ((x_ >> ((pp_ & 3u) * 8u)) & 0xffu)];
+                }
+            }
+            rec_ck = v_ ? ck_ : 0u;
+          }
         }
       }
       /* the tile's counters (nvar further down), 32 bits wide -- a lane's variants of
@@ -1768,7 +1818,9 @@ probe_rows_kernel(const ProbeParams P)
         /* the shifted hash that seeds the rolling gap hashes of the insertion rows (the
            deletion variants were answered with the substitution rows, above) */
         uint64_t h_ins = 0;
-        if (valid)
+        if (rec_tiles)
+          h_ins = rec_hins;
+        else if (valid)
           h_ins = P.qhins[W.qslot];
         /* Indel variants change the length, hence the class.  t = the variant:
              base(t) = base(q) ^ CL[L] ^ CL[L'],  split iff heavy(base(t)),
@@ -1777,12 +1829,15 @@ probe_rows_kernel(const ProbeParams P)
            this pass; what does not is an item of a later pass (query_layout.hip
            for_each_item) or, rarely, read where it lies. */
         const uint32_t cl_L = P.geom.ctab[L];
-        const uint32_t qck = P.qck[W.qslot];     /* the query's class key */
+        const uint32_t qck = rec_tiles ? rec_ck : P.qck[W.qslot];     /* the query's class key */
         /* residue of a wave-uniform position: from the tile's data (a select chain kept
            opaque, or the compiler turns it into an indexed read of a scratch copy) */
         auto res_reg = [&](uint32_t pp) -> uint32_t {
-          if (pp >= 4u * TDW)
+          if (pp >= 4u * TDW) {
+            if (REC_OK && rec_tiles)               /* (record tiles: positions 24 .. 31 came with the record) */
+              return ((pp >= 28u ? cur.r7 : cur.r6) >> ((pp & 3u) * 8u)) & 0xffu;
             return res_at(pp);
+          }
           const uint32_t wq = pp >> 2;
           uint32_t x = cur.r0;
           asm volatile("" : "+v"(x));
@@ -1973,7 +2028,11 @@ probe_rows_kernel(const ProbeParams P)
             }
           };
           for (uint32_t g0 = 0; g0 <= L; g0 += PP) {
-            if (g0 && g0 % (4u * TDW) == 0) {
+            if (g0 && g0 % (4u * TDW) == 0 && REC_OK && rec_tiles) {
+              s0 = cur.r6;
+              s1 = cur.r7;
+              s2 = s3 = s4 = s5 = PADW;
+            } else if (g0 && g0 % (4u * TDW) == 0) {
               const uint32_t w0 = g0 >> 2;
               s0 = w0 < nd ? qr[w0 * WAVE] : PADW;
               s1 = w0 + 1u < nd ? qr[(w0 + 1u) * WAVE] : PADW;

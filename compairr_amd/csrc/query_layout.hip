@@ -3146,8 +3146,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   /* record tiles (layout.h ProbeParams::rec_tiles): amino acids on pair rows at d = 1 without -i, every sequence of
      both sets within 32 residues (a hit is verified from its 64-byte slot and the query's record alone) -- the probe
      kernel reads the records, no per-slot array is written */
-  c->rec_tiles = c->rows && pair_rows(c) && !c->d2pairs && c->opt.differences == 1 && !c->opt.indels && A == 20 &&
-                 Lcap <= 32u && c->record_tiles != 0 && !sub2_items;
+  /* (with -i a hit is one residue longer or shorter than the query: 31) */
+  c->rec_tiles = c->rows && pair_rows(c) && !c->d2pairs && c->opt.differences == 1 && A == 20 &&
+                 Lcap <= (c->opt.indels ? 31u : 32u) && c->record_tiles != 0 && !sub2_items;
   if (ntiles && !c->rec_tiles) {
     const size_t fill_lds = Q.recompute ? (zob_lds ? zob_words * sizeof(uint64_t) : 0) + ctab_bytes : 0;
     const int fo = occupancy_of(c, (const void *)fill_tiles_kernel, 256, fill_lds);
