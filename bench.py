@@ -452,6 +452,8 @@ def main():
     R1, R2 = h.shape
     layout = h.layout()
     h_items = h.get_tunable("items") if layout["variant"] == 2 else 0
+    rec_tiles = bool(h.get_tunable("record_tiles"))    # no per-slot arrays: the probe kernel reads the records
+    layout["record_tiles"] = int(rec_tiles)
     # every rank uses the same R1 x R2 (16 x 16 for the synthetic law).  Two matrices:
     # step i fills one while the all-reduce of step i - 1 still works on the other
     mats = [torch.zeros(R1 * R2, dtype=torch.int64, device="cuda") for _ in range(2)]
@@ -612,6 +614,8 @@ def main():
         # takes the longest (the dominant kernel of the timed step)
         step_ms = dict({k: float(np.mean([x[k] for x in layout_kernels])) for k in LAYOUT_PARTS}
                        if layout_kernels else {})
+        if rec_tiles:
+            step_ms.pop("tiles", None)             # (record tiles: fill_tiles_kernel does not run -- an empty interval)
         roofs = layout_rooflines(wl, int(st.queries), int(qry.offsets[-1]) if qry.n else 0,
                                  int(layout["query_slots"]), int(h_items), args.indels, step_ms) if per_set else {}
         roofs["probe"] = roofline(wl, st, p_avg_ms, k_avg_ms,
@@ -675,7 +679,8 @@ def main():
             "resident_steps_same_matrix": same_resident,
             # HIP-event times inside the timed steps (means): the layout's kernels, then probe and resolve
             "step_kernels_ms": dict(
-                {k: float(np.mean([x[k] for x in layout_kernels])) for k in LAYOUT_PARTS} if layout_kernels else {},
+                {k: float(np.mean([x[k] for x in layout_kernels])) for k in LAYOUT_PARTS
+                 if not (rec_tiles and k == "tiles")} if layout_kernels else {},
                 probe=p_avg_ms, resolve=k_avg_ms - p_avg_ms),
             # from DEVICE arrays to the matrix (no PCIe), and the synchronous step that ends
             # with the matrix on the host

@@ -52,8 +52,10 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
     # a step is a query set from its device arrays to the matrix: the launches alone are faster, the set
     # from host buffers slower
     assert plain["value_resident_step"] > plain["value"] > plain["value_incl_layout"] > 0
-    assert set(plain["step_kernels_ms"]) >= {"keys", "scatter", "tiles", "probe", "resolve"}
-    assert set(plain["roofline_kernels"]) >= {"keys", "scatter", "tiles", "probe"}
+    # (amino acids at d = 1 run on record tiles: fill_tiles_kernel -- "tiles" -- does not run)
+    assert set(plain["step_kernels_ms"]) >= {"keys", "scatter", "probe", "resolve"}
+    assert set(plain["roofline_kernels"]) >= {"keys", "scatter", "probe"}
+    assert plain["config"]["layout"]["record_tiles"] == 1 and "tiles" not in plain["step_kernels_ms"]
     # ... `--step resident` is rounds 1-5's definition
     res = _run([sys.executable, "bench.py", "--gpus", "1", "--step", "resident"] + SMALL)
     assert res["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]

@@ -18,7 +18,7 @@ d=int(sys.argv[2]); lab="+".join(n for b,n in names.items() if d&b) or "-"
 try:
     j=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     k=j["step_kernels_ms"]
-    print("%-60s keys %.3f scatter %.3f tiles %.3f" % (lab, k["keys"], k["scatter"], k["tiles"]))
+    print("%-60s keys %.3f scatter %.3f tiles %.3f" % (lab, k["keys"], k["scatter"], k.get("tiles", 0.0)))
 except Exception as e:
     print("%-60s FAILED %s" % (lab, e))
 PY
