@@ -400,8 +400,8 @@ static int set_tunable_value(cmpr_context *c, const std::string &n, int64_t valu
     affects_plan = false;
   } else if (n == "item_wg" || n == "layout_recompute" || n == "layout_timing" || n == "layout_zob_lds" ||
              n == "record_tiles") {
-    if (value < 0 || value > 1)
-      return fail(c, CMPR_EINVAL, n + " must be 0 or 1");
+    if (value < 0 || value > (n == "record_tiles" ? 2 : 1))
+      return fail(c, CMPR_EINVAL, n + (n == "record_tiles" ? " must be 0, 1 or 2" : " must be 0 or 1"));
     if (n == "record_tiles" && c->have_q)
       return fail(c, CMPR_ESTATE, "set record_tiles before cmpr_set_queries");
     (n == "item_wg" ? c->item_wg : n == "layout_recompute" ? c->layout_recompute :
@@ -536,7 +536,7 @@ extern "C" int cmpr_get_tunable(cmpr_context *c, const char *name, int64_t *valu
   else if (n == "item_wg") *value = c->item_wg;
   else if (n == "layout_recompute") *value = c->layout_recompute;
   else if (n == "layout_timing") *value = c->layout_timing;
-  else if (n == "record_tiles") *value = c->have_q ? (c->rec_tiles ? 1 : 0) : c->record_tiles;
+  else if (n == "record_tiles") *value = c->have_q ? (c->rec_tiles ? (c->rec_hash ? 1 : 2) : 0) : c->record_tiles;
   else if (n == "layout_keys_us") *value = (int64_t)(c->layout_kernel_ms[0] * 1e3);
   else if (n == "layout_sizes_us") *value = (int64_t)(c->layout_kernel_ms[1] * 1e3);
   else if (n == "layout_scatter_us") *value = (int64_t)(c->layout_kernel_ms[2] * 1e3);
@@ -866,7 +866,7 @@ int make_plan(cmpr_context *c)
   P.zpos = c->zpos;
   P.n_v = c->opt.ignore_genes ? 0 : c->opt.n_v_genes;
   P.n_j_keys = c->opt.ignore_genes ? 0 : c->opt.n_j_genes;
-  P.rec_tiles = c->rec_tiles ? 1u : 0u;
+  P.rec_tiles = c->rec_tiles ? (c->rec_hash ? 2u : 1u) : 0u;
   P.bloom = c->bloom.p;
   P.bloom_byte_mask = (uint32_t)((c->bloom_words - 1) << 3);
   P.dir_mask = (uint32_t)(c->slots - 1);

@@ -273,9 +273,11 @@ struct cmpr_context {
      parity suite), and HIP events around its big kernels (tunable "layout_timing", default 0) */
   int64_t                    item_wg = 1, layout_recompute = 1, layout_timing = 0;
   int64_t                    layout_zob_lds = 1;          /* keys_kernel keeps the Zobrist keys in LDS when they fit */
-  int64_t                    record_tiles = 1;            /* tunable: 1 = where the layout allows (layout.h rec_tiles) */
+  int64_t                    record_tiles = 1;            /* tunable: 1 = where the layout allows (layout.h rec_tiles), the hash in
+                                                             the record where the sequences leave room; 2 = never the hash (rows) */
   bool                       rec_tiles = false;           /* the resident layout has no per-slot arrays: the probe
                                                              kernel reads the queries' records (layout.h ProbeParams) */
+  bool                       rec_hash = false;            /* ... and the query's hash lies in the record (layout.h rec_tiles == 2) */
   /* what the runtime said about a kernel with a given dynamic LDS size (asked once: a plan is made per query
      set): workgroups per CU, and whether its LDS limit has been raised */
   std::map<std::pair<const void *, size_t>, int> occupancy_seen;

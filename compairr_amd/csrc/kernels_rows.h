@@ -659,6 +659,9 @@ probe_rows_kernel(const ProbeParams P)
      the queries' 64-byte records and the hashes are worked out here; the gene keys lie behind the tile references */
   constexpr bool REC_OK = PAIRS && D == 1;
   const bool rec_tiles = REC_OK && P.rec_tiles != 0u;
+  /* (rec_tiles == 2, every sequence within 28 residues: the query's hash came with the record, in the last two
+     residue words -- nothing is hashed here but, with -i, the insert-first hash) */
+  const bool rec_hash = rec_tiles && P.rec_tiles == 2u;
   uint64_t *gk_lds = (uint64_t *)(tref_lds + RING * chunk_cap);
   /* (-i: the class tables in front of the class-residue rows -- CL | CV | CJ -- behind the gene keys: a record
      tile works the query's class key out itself) */
@@ -824,6 +827,7 @@ probe_rows_kernel(const ProbeParams P)
         x.r0 = q1.z; x.r1 = q1.w;
         x.r2 = q2.x; x.r3 = q2.y; x.r4 = q2.z; x.r5 = q2.w;
         x.r6 = q3.x; x.r7 = q3.y;
+        x.c = q3.z;                              /* (rec_hash: the hash's high word; its low one is r7) */
       }
     } else {
       const uint32_t slot = t * WAVE + lane;
@@ -1053,6 +1057,8 @@ probe_rows_kernel(const ProbeParams P)
              query's Zobrist hash (zobrist_hash, zobrist.cc:74-88; db_hash, db.cc:903-916) -- from the record */
           const bool v_ = lane < nvalid;
           const uint32_t len_ = v_ ? cur.b : 0u;
+          const uint64_t h_rec = ((uint64_t)cur.c << 32) | cur.r7;     /* (rec_hash; r7 is padding from here on) */
+          cur.c = 0;
           auto pad_ = [&](uint32_t d, uint32_t w) -> uint32_t {
             const int n = (int)len_ - (int)(4u * w);
             const uint32_t mk = n <= 0 ? 0u : n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
@@ -1062,10 +1068,11 @@ probe_rows_kernel(const ProbeParams P)
           cur.r4 = pad_(cur.r4, 4); cur.r5 = pad_(cur.r5, 5); cur.r6 = pad_(cur.r6, 6); cur.r7 = pad_(cur.r7, 7);
           uint64_t hq = 0;
           const uint32_t gv_ = (uint32_t)cur.a, gj_ = (uint32_t)(cur.a >> 32);
-          if (GENES && v_)
+          if (GENES && v_ && (INDELS || !rec_hash))
             hq = gk_lds[gv_] ^ gk_lds[P.n_v + gj_];
           uint64_t hi_ = hq;                           /* (-i) zobrist_hash_insert_first, zobrist.cc:122-136 */
           const uint32_t rw_[8] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5, cur.r6, cur.r7};
+          if (!rec_hash) {
 #pragma unroll
           for (uint32_t w = 0; w < 8; w++)
             if (4u * w < L) {                          /* (wave-uniform: the tile's longest query) */
@@ -1078,6 +1085,22 @@ probe_rows_kernel(const ProbeParams P)
                     hi_ ^= lds_u64(zl_addr + (ZS * (4u * w + k + 1u) + r_) * 8u);
                 }
             }
+          } else {
+            /* the hash came with the record (keys_kernel's, gene keys included) */
+            if constexpr (INDELS) {
+#pragma unroll
+              for (uint32_t w = 0; w < 7; w++)         /* (rec_hash: 28 residues at most) */
+                if (4u * w < L) {
+#pragma unroll
+                  for (uint32_t k = 0; k < 4; k++)
+                    if (4u * w + k < L) {
+                      const uint32_t r_ = (rw_[w] >> (8u * k)) & 0xffu;
+                      hi_ ^= lds_u64(zl_addr + (ZS * (4u * w + k + 1u) + r_) * 8u);
+                    }
+                }
+            }
+            hq = h_rec;
+          }
           cur.a = v_ ? hq : 0ull;
           cur.b = len_;
           if constexpr (INDELS) {

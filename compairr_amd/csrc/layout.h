@@ -370,7 +370,9 @@ struct ProbeParams {
                                       lengths and residues from the 64-byte QueryRecs scatter_kernel wrote and works
                                       the hashes out itself (the Zobrist keys are in its LDS anyway): fill_tiles_kernel,
                                       0.29 ms per 10M queries of reading those records and writing them out again
-                                      position-major, does not run */
+                                      position-major, does not run.  2: every sequence within 28 residues -- the query's
+                                      Zobrist hash rides in the record's last two residue words (bytes 28 .. 35, where
+                                      scatter_kernel leaves what keys_kernel worked out): the kernel does not hash */
   /* (repertoire, count and the query's number in the caller's set are read from its QueryRec, by the
      kernels that resolve a positive -- no per-slot arrays of them since round 6: 16 bytes per slot less for
      the layout to write) */

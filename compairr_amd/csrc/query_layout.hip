@@ -122,6 +122,8 @@ struct QL {
   uint32_t        wfirst, wstep;     /* this context places what work shard wfirst of wstep works on (1: all) */
   uint32_t        direct;            /* d = 0 on the un-sliced kernel: the query's hash is computed here (qgh), the
                                         queries are grouped by pseudo-slice (bits of the hash & pmask) and length */
+  uint32_t        rec_hash;          /* record tiles, every sequence within 28 residues: scatter_kernel leaves the
+                                        query's Zobrist hash in the record's last two residue words (bytes 28 .. 35) */
   uint32_t        pmask;
   uint32_t        dbg;               /* -DCMPR_ABLATION builds: LDBG_* (timing experiments, results become wrong) */
   uint32_t        route;             /* 1: cmpr_route_queries -- the keys kernel names the contexts a query goes
@@ -1241,6 +1243,8 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
       }
       if (want_ck)
         ck = Q.ck_tmp[i];
+      if (Q.rec_hash && !want_h)
+        h_q = Q.h_tmp[i];
     }
     cur = fetch(i + stride);
     if (g != 0xffffffffu) {
@@ -1339,6 +1343,12 @@ scatter_kernel(const QL Q, uint64_t q0, uint64_t q1, uint32_t row0)
               d |= (uint32_t)s[4 * w + k] << (8 * k);
           qr.res[w] = d;
         }
+      }
+      if (Q.rec_hash) {
+        /* record tiles, every sequence within 28 residues: the hash keys_kernel worked out rides in the residue
+           words no sequence of the set reaches (bytes 28 .. 35) -- probe_rows_kernel does not hash the tile again */
+        qr.res[7] = (uint32_t)h_q;
+        qr.res[8] = (uint32_t)(h_q >> 32);
       }
     } else {
 #pragma unroll
@@ -2583,6 +2593,16 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
   Q.wfirst = place_mine ? wfirst : 0u;
   Q.wstep = place_mine ? wstep : 1u;
   Q.direct = direct ? 1u : 0u;
+  /* (the row filter at d = 1: layout.h ProbeParams::rec_tiles; decided here because scatter_kernel writes the
+     records, applied -- c->rec_tiles -- where fill_tiles_kernel would run) */
+  const bool rows_rec = c->rows && pair_rows(c) && !c->d2pairs && c->opt.differences == 1 && A == 20 &&
+                        Lcap <= (c->opt.indels ? 31u : 32u) && c->record_tiles != 0 && !sub2_items;
+  /* (d = 0 was tried on records too -- the hash in the record, no qgh, no fill_tiles_kernel: 0.23 ms of layout less
+     per 10M queries, but probe_kernel<A, 0> reading a 64-byte record per lane a tile ahead instead of 8 coalesced
+     bytes took 0.11 ms more and lost a wave per SIMD to the registers: per set -5 %, per launch +30 %; not kept,
+     profiles/r06/extra/d0_record_tiles.txt) */
+  const bool rec_hash = rows_rec && recompute_on && Lcap <= 28u && c->record_tiles != 2;
+  Q.rec_hash = rec_hash ? 1u : 0u;
   Q.pmask = (uint32_t)(pseudo - 1);
   if (routing) {                             /* (a layout every context holds in full: every record to everyone) */
     Q.route = place_mine || wstep == 1 ? 1u : 2u;
@@ -3147,8 +3167,9 @@ int cmpr_layout_queries(cmpr_context *c, const LayoutSource &src)
      both sets within 32 residues (a hit is verified from its 64-byte slot and the query's record alone) -- the probe
      kernel reads the records, no per-slot array is written */
   /* (with -i a hit is one residue longer or shorter than the query: 31) */
-  c->rec_tiles = c->rows && pair_rows(c) && !c->d2pairs && c->opt.differences == 1 && A == 20 &&
-                 Lcap <= (c->opt.indels ? 31u : 32u) && c->record_tiles != 0 && !sub2_items;
+  /* (d = 0: QL::direct == 2 -- scatter_kernel has stored the hashes) */
+  c->rec_tiles = rows_rec;
+  c->rec_hash = c->rec_tiles && rec_hash;
   if (ntiles && !c->rec_tiles) {
     const size_t fill_lds = Q.recompute ? (zob_lds ? zob_words * sizeof(uint64_t) : 0) + ctab_bytes : 0;
     const int fo = occupancy_of(c, (const void *)fill_tiles_kernel, 256, fill_lds);

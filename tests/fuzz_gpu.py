@@ -111,8 +111,9 @@ def random_case(rng):
         tun["layout_recompute"] = 0
     if rng.random() < 0.2:
         tun["layout_zob_lds"] = 0
-    if rng.random() < 0.3:
-        tun["record_tiles"] = 0                           # (amino acids, d = 1 without -i: per-slot arrays after all)
+    if rng.random() < 0.4:
+        # (amino acids at d = 1: 0 = per-slot arrays after all, 2 = records, hashed by the kernel)
+        tun["record_tiles"] = 0 if rng.random() < 0.6 else 2
     same = rng.random() < 0.2
     return a, (a if same else b), o, tun
 

@@ -133,6 +133,12 @@ LAYOUTS = {
     "rows_arrays_tiny_k3": {"variant": 2, "record_tiles": 0, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
                             "heavy_threshold": 0},
     "rows_arrays_inline": {"variant": 2, "record_tiles": 0, "deferred_resolve": 0},
+    # ... and where every sequence is within 28 residues the query's hash rides in the record (the kernel does not
+    # hash): these keep the records but have the kernel hash them (what sets with 29 .. 32 residues get)
+    "rows_records_hashed_here": {"variant": 2, "record_tiles": 2},
+    "rows_records_hashed_here_tiny_k3": {"variant": 2, "record_tiles": 2, "slice_words_log2": 2, "class_residues": 3,
+                                         "chunk_tiles": 2, "heavy_threshold": 0},
+    "rows_records_hashed_here_inline": {"variant": 2, "record_tiles": 2, "deferred_resolve": 0, "page_budget": 10},
     "lds_layout_r5": {"variant": 1, "layout_recompute": 0},
     "hbm_layout_r5": {"variant": 0, "layout_recompute": 0},
 }
