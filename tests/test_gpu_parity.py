@@ -127,7 +127,7 @@ LAYOUTS = {
                                "heavy_threshold": 0, "item_wg": 0, "layout_recompute": 0},
     "rows_items_in_memory": {"variant": 2, "item_wg": 0},
     "rows_hashes_scattered": {"variant": 2, "layout_recompute": 0, "class_residues": 2, "heavy_threshold": 2},
-    # amino acids at d = 1 without -i run on RECORD TILES (no per-slot arrays, the probe kernel reads the queries'
+    # amino acids at d = 1 (with or without -i) run on RECORD TILES (no per-slot arrays, the probe kernel reads the queries'
     # records and hashes them itself) wherever every sequence is within 32 residues: these keep the arrays
     "rows_arrays": {"variant": 2, "record_tiles": 0},
     "rows_arrays_tiny_k3": {"variant": 2, "record_tiles": 0, "slice_words_log2": 2, "class_residues": 3, "chunk_tiles": 2,
