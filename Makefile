@@ -124,8 +124,25 @@ tests/bin/compairr_oracle_cli: $(HOST_CORE) $(HOST_HDR) tests/oracle_cli_main.cc
 	$(CXX) $(CXXFLAGS) -Iinclude -Icompairr_amd/host -Ioracle -o $@ $(HOST_CORE) \
 	    tests/oracle_cli_main.cc tests/bin/compairr_oracle.o -lpthread
 
+# the microbenchmarks profiles/rNN/calibration.json and extra/lds_conflicts.txt come from (tools/reprofile.sh,
+# tools/r06_lds_conflicts.sh run them on the GPU box; the binaries travel with the snapshot)
+TOOL_BINS = tools/bin/calib tools/bin/lds_conflicts tools/bin/atom tools/bin/chase
+tools: $(TOOL_BINS)
+tools/bin/calib: tools/calib.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+tools/bin/lds_conflicts: tools/lds_conflicts.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+tools/bin/atom: tools/atomics_bench.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+tools/bin/chase: tools/chase_bench.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
 clean:
 	rm -rf compairr_amd/lib bin tests/bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle asan timing ablation clean
+.PHONY: all lib cli oracle asan timing ablation tools clean

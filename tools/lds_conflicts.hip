@@ -20,7 +20,7 @@
  * A bijection of a uniformly random index is a uniformly random index: MODE 2/3/4 can only differ
  * from MODE 1 if the hardware pairs the two instructions of a lane, which the counters then show.
  *
- * Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/lds_conflicts tools/lds_conflicts.hip */
+ * Build: make tools  (hipcc --offload-arch=gfx950 -O3 -o tools/bin/lds_conflicts tools/lds_conflicts.hip) */
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
