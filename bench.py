@@ -113,6 +113,10 @@ def parse_args():
     p.add_argument("--self", dest="self_cmp", action="store_true",
                    help="one-file mode: the queries are the reference set itself")
     p.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE")
+    p.add_argument("--skip-host-layout", action="store_true",
+                   help="do not measure cmpr_set_queries from HOST buffers (value_incl_layout becomes null): under "
+                        "rocprofv3 --kernel-trace --stats every launch of the layout's kernels is then a full-size one "
+                        "of a timed step, and the trace's averages are the bench line's per-kernel times")
     p.add_argument("--launcher", choices=["auto", "always", "never"], default="auto",
                    help="auto: `--gpus N` with N > 1 and no RANK in the environment starts its N ranks itself "
                         "(torch.distributed.run as a child process, before anything touches the GPU); always: "
@@ -430,9 +434,11 @@ def main():
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
             dt = float(x.item())
         return dt, m
-    t_layout_first, _ = timed_layout()
-    t_layout, moved = timed_layout()
-    layout_ms = {"total": t_layout * 1e3,
+    skip_host = args.skip_host_layout and not routed
+    t_layout_first, _ = (None, None) if skip_host else timed_layout()
+    t_layout, moved = (None, None) if skip_host else timed_layout()
+    layout_ms = None if skip_host else {
+                 "total": t_layout * 1e3,
                  "library_call_total": h.get_tunable("layout_total_us") / 1e3,
                  "host_time_in_copy_calls": h.get_tunable("layout_upload_us") / 1e3,
                  "after_last_copy": h.get_tunable("layout_tail_us") / 1e3,
@@ -660,8 +666,8 @@ def main():
                        "matrix_checksum": checksum,
                        "layout": layout,
                        "setup_seconds": {"generate": round(t_gen, 2), "index_build+upload": round(t_index, 3),
-                                         "query_layout+upload": round(t_layout, 4),
-                                         "query_layout+upload_first_call": round(t_layout_first, 4)},
+                                         "query_layout+upload": None if skip_host else round(t_layout, 4),
+                                         "query_layout+upload_first_call": None if skip_host else round(t_layout_first, 4)},
                        # cmpr_set_queries, warm context: upload of the caller's arrays in ranges
                        # (the keys kernel of a range runs under the copy of the next), then what
                        # the upload cannot hide (sizes, scatter, tiles, items, chunk order)
@@ -671,8 +677,9 @@ def main():
             # (warm: a context that has laid out a set of this size before and keeps its
             #  allocations; cold: the first call of a context, allocations included -- the
             #  definition BENCH_r01 / r02 used for "value_incl_layout")
-            "value_incl_layout": total_queries / (t_layout + elapsed_resident / resident_steps),
-            "value_incl_layout_cold": total_queries / (t_layout_first + elapsed_resident / resident_steps),
+            "value_incl_layout": None if skip_host else total_queries / (t_layout + elapsed_resident / resident_steps),
+            "value_incl_layout_cold": None if skip_host else
+                                      total_queries / (t_layout_first + elapsed_resident / resident_steps),
             # the launches alone over one laid-out query set (what rounds 1-5 reported as `value`)
             "value_resident_step": total_queries * resident_steps / elapsed_resident,
             "resident_step_ms": elapsed_resident / resident_steps * 1e3,

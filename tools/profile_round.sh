@@ -10,9 +10,13 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 python3 $R/tools/csrc_hash.py > $O/csrc_sha256.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err
+if [ "$STATS_ONLY" != 1 ]; then timeout 900 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err; fi
+if [ "$STATS_ONLY" = 1 ]; then rm -rf $O/prof_stats; fi
+# (--skip-host-layout: every launch of the layout's kernels in the trace is a full-size one of a step -- the trace's
+#  averages are then the bench line's per-kernel times)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o p --output-format csv -- \
-    python3 $R/bench.py --cpu-sample -1 "$@" > $O/stats_bench.json 2> $O/stats.err
+    python3 $R/bench.py --cpu-sample -1 --skip-host-layout "$@" > $O/stats_bench.json 2> $O/stats.err
+if [ "$STATS_ONLY" = 1 ]; then find $O -name '*agent_info*' -delete; find $O -name '*.csv' -size +8M -delete; exit 0; fi
 i=0
 # PMC_GROUPS=essential: the six groups the roofline needs (long workloads)
 CTR_GROUPS=("FETCH_SIZE" "WRITE_SIZE"
