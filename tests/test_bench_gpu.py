@@ -60,6 +60,10 @@ def test_bench_line_contract_and_rccl_path_at_world_1():
     res = _run([sys.executable, "bench.py", "--gpus", "1", "--step", "resident"] + SMALL)
     assert res["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"]
     assert res["value"] > plain["value"]
+    # ... `--skip-host-layout` (the profiling passes): no set from host buffers is laid out, nothing else changes
+    skip = _run([sys.executable, "bench.py", "--gpus", "1", "--skip-host-layout"] + SMALL)
+    assert skip["value_incl_layout"] is None and skip["config"]["query_layout_ms"] is None
+    assert skip["config"]["matrix_checksum"] == plain["config"]["matrix_checksum"] and skip["value"] > 0
     # the same workload through torch.distributed.run: process group on nccl (= RCCL),
     # all-reduce of the matrix inside every step
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
