@@ -30,6 +30,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.cmpr_abi_version() == 5
 
 
+def test_header_is_plain_c_and_a_c_program_links_the_library(tmp_path):
+    """The boundary is a C ABI: the header compiles as C11 (-pedantic), and a C translation unit that names every
+    entry point links against the shared library (sizes agree with the ctypes mirror)."""
+    calls = "\n".join("  p[%d] = (void *)%s;" % (i, n) for i, n in enumerate(declared_symbols()))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "compairr_hip.h"\n#include <stdio.h>\nint main(void) {\n  void *p[64];\n%s\n'
+                   '  printf("%%d %%zu %%zu %%zu %%d\\n", CMPR_ABI_VERSION, sizeof(cmpr_options), sizeof(cmpr_set_view), '
+                   'sizeof(cmpr_stats), p[0] != 0);\n  return 0;\n}\n' % calls)
+    lib = hip.library_path()
+    exe = tmp_path / "abi"
+    p = subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic",
+                        "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), lib,
+                        "-Wl,-rpath," + os.path.dirname(lib)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    # (the header alone, strictly: no extension a C compiler would have to forgive)
+    q = subprocess.run(["gcc", "-std=c11", "-pedantic-errors", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c",
+                        os.path.join(ROOT, "include", "compairr_hip.h")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode == 0, q.stderr.decode()[-2000:]
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().split() == ["5", "64", "64", "88", "1"]
+
+
 def test_struct_sizes_match_header():
     # cmpr_options: 9 x 4 + 7 x 4; cmpr_set_view: 8 + 6 x 8 + 2 x 4; cmpr_stats
     assert ctypes.sizeof(hip._Options) == 64
