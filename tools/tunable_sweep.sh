@@ -13,11 +13,12 @@ for cfg in "$@"; do
   python - "$cfg" $O/run$i.json <<'PY'
 import json,sys
 try:
-    d=json.loads(open(sys.argv[2]).read())
-    r=d["roofline"]; l=d["config"]["layout"]
-    print("%-60s step %.3f ms probe %.3f resolve %.3f | K=%s slices=%s tiles=%s chunks=%s small=%s pos=%s setup=%s cs=%s" % (
-        sys.argv[1], d["ms_per_step"], r["kernel_ms"], r["resolve_kernel_ms"], l.get("class_residues"), l.get("slices"),
-        l.get("tiles"), l.get("chunks"), l.get("small_tiles"), r["bloom_positive_per_launch"], d["config"]["setup_seconds"]["query_layout+upload"], d["config"]["matrix_checksum"][:8]))
+    d=json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+    l=d["config"]["layout"]
+    k=" ".join("%s %.3f" % (a, b) for a, b in d["step_kernels_ms"].items())
+    print("%-40s set %.3f ms  launch alone %.3f | %s | K=%s slices=%s tiles=%s chunks=%s cs=%s" % (
+        sys.argv[1] or "(defaults)", d["ms_per_step"], d["resident_step_ms"], k, l.get("class_residues"), l.get("slices"),
+        l.get("tiles"), l.get("chunks"), d["config"]["matrix_checksum"][:8]))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
