@@ -14,6 +14,7 @@
 
 #include <chrono>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -315,6 +316,33 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
   return true;
 }
 
+/* Transparent huge pages for the reader's large buffers (file text, parsed arrays): two 10M-sequence files are
+   ~2.5 GB of fresh memory, and faulting that in 4 KiB at a time -- 600 000 faults that 64 threads take under one lock --
+   was most of the "read" phase (measured apart: 2.5 GiB touched by 64 threads in 210-280 ms, in 9 ms on 2-MiB pages;
+   tools/dev/exit_cost.c).  Where the system offers them on request (transparent_hugepage = madvise) the 2-MiB-aligned
+   inside of a fresh allocation is asked for huge pages before it is touched; elsewhere this is a no-op. */
+static void advise_huge(void *p, size_t bytes)
+{
+#ifdef MADV_HUGEPAGE
+  static const bool off = getenv("COMPAIRR_NO_HUGEPAGES") != nullptr;      /* (measurement aid) */
+  if (off)
+    return;
+  const uintptr_t H = (uintptr_t)2 << 20;
+  const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
+  if (p && e > a)
+    (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+#else
+  (void)p;
+  (void)bytes;
+#endif
+}
+template <typename V>
+static void reserve_huge(V &v, size_t n)
+{
+  v.reserve(n);
+  advise_huge((void *)v.data(), v.capacity() * sizeof(typename V::value_type));
+}
+
 /* parses the lines of text[begin, end) (ends at a line end or at EOF) */
 void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
                  const Options &o, const Columns &c, const char *default_rep,
@@ -322,12 +350,12 @@ void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
 {
   /* (the lines of the range were counted for the error messages' sake: room for one sequence each, no vector
      grows -- and copies itself -- while the range is parsed) */
-  out.lengths.reserve(nlines);
-  out.v.reserve(nlines);
-  out.j.reserve(nlines);
-  out.rep.reserve(nlines);
-  out.count.reserve(nlines);
-  out.residues.reserve(nlines ? (end - begin) / 6 + 64 : 0);
+  reserve_huge(out.lengths, nlines);
+  reserve_huge(out.v, nlines);
+  reserve_huge(out.j, nlines);
+  reserve_huge(out.rep, nlines);
+  reserve_huge(out.count, nlines);
+  reserve_huge(out.residues, nlines ? (end - begin) / 6 + 64 : 0);
   std::vector<char *> fields;
   uint64_t lineno = first_lineno;
   size_t pos = begin;
@@ -367,6 +395,7 @@ bool read_whole_file(const char *filename, size_t threads, FileText &text)
     const size_t n = (size_t)sb.st_size;
     text.p = (char *)malloc(n + 1);
     if (text.p) {
+      advise_huge(text.p, n + 1);
       /* (two readers at most: with the second file being read beside this one, more of them only meet in the
          page cache's locks -- 64 readers per file took 0.40-0.56 s for what one takes 0.35-0.45 s, measured) */
       size_t parts = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(threads, 2), n / (4 << 20) + 1));
@@ -561,6 +590,12 @@ void read_airr_tsv(const char *filename, const Options &o, GeneTables &genes,
     d.ignored_unknown += p.ignored_unknown;
     d.ignored_empty += p.ignored_empty;
   }
+  reserve_huge(d.residues, nres);          /* (asked for huge pages before the resize touches -- zero-fills -- them) */
+  reserve_huge(d.offsets, n + 1);
+  reserve_huge(d.v_gene, n);
+  reserve_huge(d.j_gene, n);
+  reserve_huge(d.repertoire, n);
+  reserve_huge(d.count, n);
   d.residues.resize(nres);
   d.offsets.resize(n + 1);
   d.offsets[0] = 0;
