@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <new>
 #include <thread>
 #include <unordered_map>
 
@@ -169,17 +170,113 @@ struct LocalNames {
   }
 };
 
+/* Transparent huge pages for the reader's large buffers (file text, parsed arrays): two 10M-sequence files are
+   ~2.5 GB of fresh memory, and faulting that in 4 KiB at a time -- 600 000 faults that 64 threads take under one lock --
+   was most of the "read" phase (measured apart: 2.5 GiB touched by 64 threads in 210-280 ms, in 9 ms on 2-MiB pages;
+   tools/dev/exit_cost.c).  Where the system offers them on request (transparent_hugepage = madvise) the 2-MiB-aligned
+   inside of a fresh allocation is asked for huge pages before it is touched; elsewhere this is a no-op. */
+static void advise_huge(void *p, size_t bytes)
+{
+#ifdef MADV_HUGEPAGE
+  static const bool off = getenv("COMPAIRR_NO_HUGEPAGES") != nullptr;      /* (measurement aid) */
+  if (off)
+    return;
+  const uintptr_t H = (uintptr_t)2 << 20;
+  const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
+  if (p && e > a)
+    (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+#else
+  (void)p;
+  (void)bytes;
+#endif
+}
+template <typename V>
+static void reserve_huge(V &v, size_t n)
+{
+  v.reserve(n);
+  advise_huge((void *)v.data(), v.capacity() * sizeof(typename V::value_type));
+}
+
+/* A range's parsed arrays (RangeResult) live in ONE mapping per range, 2-MiB aligned and asked for huge pages: six
+   vectors of a megabyte or two each would sit in mappings of their own, too small and too oddly placed for a huge
+   page (64 ranges per file: 0.85 GiB in 4-KiB faults for two 10M-sequence files).  A bump allocator; what does not fit
+   (a vector that outgrows the estimate) comes from malloc. */
+struct HugeArena {
+  char  *map = nullptr, *base = nullptr;
+  size_t map_bytes = 0, cap = 0, used = 0;
+  HugeArena() {}
+  HugeArena(const HugeArena &) = delete;
+  HugeArena &operator=(const HugeArena &) = delete;
+  ~HugeArena()
+  {
+    if (map)
+      munmap(map, map_bytes);
+  }
+  void init(size_t bytes)
+  {
+    const size_t H = (size_t)2 << 20;
+    const size_t want = (bytes + H - 1) & ~(H - 1);
+    void *m = mmap(nullptr, want + H, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED)
+      return;                                  /* (everything from malloc then) */
+    map = (char *)m;
+    map_bytes = want + H;
+    base = (char *)(((uintptr_t)map + H - 1) & ~(uintptr_t)(H - 1));
+    cap = want;
+    advise_huge(base, cap);
+  }
+  void *take(size_t n)
+  {
+    n = (n + 63) & ~(size_t)63;
+    if (!base || n > cap - used)
+      return nullptr;
+    void *p = base + used;
+    used += n;
+    return p;
+  }
+  bool owns(const void *p) const { return base && (const char *)p >= base && (const char *)p < base + cap; }
+};
+template <typename T> struct ArenaAlloc {
+  typedef T value_type;
+  HugeArena *a;
+  ArenaAlloc(HugeArena *x = nullptr) : a(x) {}
+  template <typename U> ArenaAlloc(const ArenaAlloc<U> &o) : a(o.a) {}
+  T *allocate(size_t n)
+  {
+    void *p = a ? a->take(n * sizeof(T)) : nullptr;
+    if (!p && !(p = malloc(n * sizeof(T) + (n == 0))))
+      throw std::bad_alloc();
+    return (T *)p;
+  }
+  void deallocate(T *p, size_t)
+  {
+    if (!(a && a->owns(p)))
+      free(p);
+  }
+  template <typename U> bool operator==(const ArenaAlloc<U> &o) const { return a == o.a; }
+  template <typename U> bool operator!=(const ArenaAlloc<U> &o) const { return a != o.a; }
+};
+template <typename T> using ArenaVec = std::vector<T, ArenaAlloc<T> >;
+
 /* what one thread produces from its range */
 struct RangeResult {
-  std::vector<uint8_t>  residues;
-  std::vector<uint32_t> lengths, v, j, rep;   /* range-local string numbers */
-  std::vector<uint64_t> count;
+  HugeArena             arena;                /* (first: it outlives the vectors that live in it) */
+  ArenaVec<uint8_t>     residues;
+  ArenaVec<uint32_t>    lengths, v, j, rep;   /* range-local string numbers */
+  ArenaVec<uint64_t>    count;
   std::vector<std::string> ids;              /* sequence_id, when kept */
   std::vector<std::string> keep;             /* -k columns, tab-joined */
   LocalNames            reps, vs, js;
   uint64_t              ignored_unknown = 0, ignored_empty = 0;
   bool                  failed = false;
   std::string           error;                /* the message for the log */
+  RangeResult()
+      : residues(ArenaAlloc<uint8_t>(&arena)), lengths(ArenaAlloc<uint32_t>(&arena)), v(ArenaAlloc<uint32_t>(&arena)),
+        j(ArenaAlloc<uint32_t>(&arena)), rep(ArenaAlloc<uint32_t>(&arena)), count(ArenaAlloc<uint64_t>(&arena))
+  {
+  }
+  RangeResult(const RangeResult &) = delete;
+  RangeResult &operator=(const RangeResult &) = delete;
 };
 
 void fail_line(RangeResult &r, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -316,32 +413,6 @@ bool parse_line(char *line, uint64_t lineno, const Options &o, const Columns &c,
   return true;
 }
 
-/* Transparent huge pages for the reader's large buffers (file text, parsed arrays): two 10M-sequence files are
-   ~2.5 GB of fresh memory, and faulting that in 4 KiB at a time -- 600 000 faults that 64 threads take under one lock --
-   was most of the "read" phase (measured apart: 2.5 GiB touched by 64 threads in 210-280 ms, in 9 ms on 2-MiB pages;
-   tools/dev/exit_cost.c).  Where the system offers them on request (transparent_hugepage = madvise) the 2-MiB-aligned
-   inside of a fresh allocation is asked for huge pages before it is touched; elsewhere this is a no-op. */
-static void advise_huge(void *p, size_t bytes)
-{
-#ifdef MADV_HUGEPAGE
-  static const bool off = getenv("COMPAIRR_NO_HUGEPAGES") != nullptr;      /* (measurement aid) */
-  if (off)
-    return;
-  const uintptr_t H = (uintptr_t)2 << 20;
-  const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
-  if (p && e > a)
-    (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
-#else
-  (void)p;
-  (void)bytes;
-#endif
-}
-template <typename V>
-static void reserve_huge(V &v, size_t n)
-{
-  v.reserve(n);
-  advise_huge((void *)v.data(), v.capacity() * sizeof(typename V::value_type));
-}
 
 /* parses the lines of text[begin, end) (ends at a line end or at EOF) */
 void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
@@ -350,12 +421,14 @@ void parse_range(char *text, size_t begin, size_t end, uint64_t first_lineno,
 {
   /* (the lines of the range were counted for the error messages' sake: room for one sequence each, no vector
      grows -- and copies itself -- while the range is parsed) */
-  reserve_huge(out.lengths, nlines);
-  reserve_huge(out.v, nlines);
-  reserve_huge(out.j, nlines);
-  reserve_huge(out.rep, nlines);
-  reserve_huge(out.count, nlines);
-  reserve_huge(out.residues, nlines ? (end - begin) / 6 + 64 : 0);
+  const size_t nres_guess = nlines ? (end - begin) / 6 + 64 : 0;
+  out.arena.init(nlines * (4 * sizeof(uint32_t) + sizeof(uint64_t)) + nres_guess + 6 * 64);
+  out.lengths.reserve(nlines);
+  out.v.reserve(nlines);
+  out.j.reserve(nlines);
+  out.rep.reserve(nlines);
+  out.count.reserve(nlines);
+  out.residues.reserve(nres_guess);
   std::vector<char *> fields;
   uint64_t lineno = first_lineno;
   size_t pos = begin;
