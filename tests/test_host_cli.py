@@ -120,3 +120,38 @@ def test_errors_of_two_files_come_in_the_reference_order(tmp_path):
         if ref is not None:
             assert ref[0] == ours[0]
             assert _error_lines(ref[2].decode() + ref[3]) == _error_lines(text)
+
+
+def test_reader_on_a_file_large_enough_for_huge_pages(tmp_path):
+    """The reader keeps the file text, a range's parsed arrays and the merged arrays on 2-MiB pages where the system
+    gives them on request (airr_tsv.cc advise_huge / HugeArena): 300 000 sequences are several aligned 2-MiB pieces of
+    each.  Same output with the advice, without it (COMPAIRR_NO_HUGEPAGES), on 1 / 5 / 8 threads -- and as the
+    reference binary's, where that is built."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from compairr_amd import synth
+    a = synth.make_set(300000, 11, prefix="A", pool_size=2000)
+    b = synth.make_set(3000, 12, prefix="B", pool_size=2000)
+    fa, fb = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    a.write_tsv_fast(fa)
+    b.write_tsv_fast(fb)
+    ours = os.path.join(ROOT, "tests", "bin", "compairr_oracle_cli")
+    outs = []
+    for threads, env in (("1", {}), ("5", {}), ("8", {}), ("8", {"COMPAIRR_NO_HUGEPAGES": "1"})):
+        p = subprocess.run([ours, "-m", fa, fb, "-d", "0", "-t", threads, "-l", os.devnull],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        outs.append(p.stdout)
+    assert len(set(outs)) == 1 and len(outs[0]) > 100
+    # (the same host sources under AddressSanitizer + UBSan: the arena's bump allocation and the fall-back to malloc)
+    asan = os.path.join(ROOT, "tests", "bin", "compairr_oracle_cli_asan")
+    if os.path.exists(asan):
+        p = subprocess.run([asan, "-m", fa, fb, "-d", "0", "-t", "5", "-l", os.devnull],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        assert p.stdout == outs[0]
+    ref = os.path.join(ROOT, "oracle", "_ref", "compairr")
+    if os.path.exists(ref):
+        q = subprocess.run([ref, "-m", fa, fb, "-d", "0", "-t", "4", "-l", os.devnull],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert q.returncode == 0 and q.stdout == outs[0]
